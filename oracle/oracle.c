@@ -1,0 +1,842 @@
+/*
+ * oracle/oracle.c -- TEST INFRASTRUCTURE.  CPU restatement ("port") of the
+ * reference's CPU algorithms for the halo2 prover hot path.  NOT product code:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the shipped path (halo2-gpu-specific_amd/) never does.
+ *
+ * PARITY UNPINNED against reference bytes: the reference holds no golden
+ * vectors for this path and its arithmetic lives in the un-vendored crate
+ * pairing_bn256@30b052f (see bn254.h).  This file is pinned against an
+ * independent Python big-integer computation (tests/golden/) and against the
+ * reference's own relational tests restated with seeded inputs
+ * (tests/test_oracle_relational.py).
+ *
+ * Every function cites the reference file:line it follows; paths are relative
+ * to /root/reference/halo2_proofs/src/.
+ *
+ * Threading: OpenMP tasks mirror rayon's fork-join (`multicore::scope`,
+ * `rayon::join`, `par_chunks_mut`); `threads` plays `current_num_threads()`.
+ */
+#include "bn254.h"
+
+#include <math.h>
+#include <omp.h>
+#include <stdio.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* small exported field / group helpers (test plumbing)                */
+/* ------------------------------------------------------------------ */
+EXPORT void oracle_fr_mul(const u256 *a, const u256 *b, u256 *r) { fr_mul(r, a, b); }
+EXPORT void oracle_fr_add(const u256 *a, const u256 *b, u256 *r) { fr_add(r, a, b); }
+EXPORT void oracle_fr_sub(const u256 *a, const u256 *b, u256 *r) { fr_sub(r, a, b); }
+EXPORT void oracle_fr_inv(const u256 *a, u256 *r) { fr_inv(r, a); }
+EXPORT void oracle_fr_pow(const u256 *a, const uint64_t e[4], u256 *r) { fr_pow(r, a, e); }
+EXPORT void oracle_fq_mul(const u256 *a, const u256 *b, u256 *r) { fq_mul(r, a, b); }
+EXPORT void oracle_fq_add(const u256 *a, const u256 *b, u256 *r) { fq_add(r, a, b); }
+EXPORT void oracle_fq_sub(const u256 *a, const u256 *b, u256 *r) { fq_sub(r, a, b); }
+EXPORT void oracle_fq_inv(const u256 *a, u256 *r) { fq_inv(r, a); }
+
+/* canonical <-> Montgomery, in place over n elements; is_fq selects the field */
+EXPORT void oracle_from_repr_batch(u256 *a, size_t n, int is_fq) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        if (is_fq)
+            fq_from_repr(&a[i], &a[i]);
+        else
+            fr_from_repr(&a[i], &a[i]);
+    }
+}
+EXPORT void oracle_to_repr_batch(u256 *a, size_t n, int is_fq) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        if (is_fq)
+            fq_to_repr(&a[i], &a[i]);
+        else
+            fr_to_repr(&a[i], &a[i]);
+    }
+}
+
+EXPORT void oracle_g1_to_affine(const g1_jac *p, g1_affine *r) { g1j_to_affine(r, p); }
+EXPORT void oracle_g1_add(const g1_jac *p, const g1_jac *q, g1_jac *r) { g1j_add(r, p, q); }
+EXPORT void oracle_g1_add_affine(const g1_jac *p, const g1_affine *q, g1_jac *r) { g1j_add_affine(r, p, q); }
+EXPORT void oracle_g1_double(const g1_jac *p, g1_jac *r) { g1j_double(r, p); }
+EXPORT int oracle_g1_eq(const g1_jac *p, const g1_jac *q) { return g1j_eq(p, q); }
+EXPORT int oracle_g1_on_curve(const g1_affine *p) { return g1a_on_curve(p); }
+/* [k]P with k a Montgomery-form Fr */
+EXPORT void oracle_g1_mul(const g1_affine *p, const u256 *k_mont, g1_jac *r) {
+    u256 k;
+    fr_to_repr(&k, k_mont);
+    g1_jac pj;
+    g1j_from_affine(&pj, p);
+    g1j_mul_canon(r, &pj, &k);
+}
+
+/* ------------------------------------------------------------------ */
+/* deterministic synthetic inputs              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    uint64_t s[4];
+} xoshiro_t;
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t splitmix64(uint64_t *x) {
+    uint64_t z = (*x += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline void xo_seed(xoshiro_t *g, uint64_t seed) {
+    for (int i = 0; i < 4; i++) g->s[i] = splitmix64(&seed);
+}
+static inline uint64_t xo_next(xoshiro_t *g) { /* xoshiro256** */
+    uint64_t *s = g->s;
+    uint64_t result = rotl64(s[1] * 5, 7) * 9;
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+/* n uniform Fr elements in [0, r), Montgomery form.  Element i is drawn from its
+ * own stream seeded (seed, i) so generation is order- and thread-independent. */
+EXPORT void oracle_random_fr(uint64_t seed, size_t n, u256 *out) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        xoshiro_t g;
+        xo_seed(&g, seed ^ (0x9e3779b97f4a7c15ULL * (i + 1)));
+        u256 c;
+        do {
+            for (int k = 0; k < 4; k++) c.l[k] = xo_next(&g);
+            c.l[3] &= 0x3fffffffffffffffULL; /* 254 bits, then rejection-sample */
+        } while (fr_geq_mod(c.l));
+        fr_from_repr(&out[i], &c);
+    }
+}
+
+/* n G1 points by try-and-increment: x from the PRNG, y = (x^3+3)^((q+1)/4)
+ * (q = 3 mod 4; cofactor 1 so every curve point is in G1).  Affine Montgomery 64 B. */
+EXPORT void oracle_random_g1(uint64_t seed, size_t n, g1_affine *out) {
+    /* (q+1)/4 */
+    static const uint64_t E[4] = {0x4f082305b61f3f52ULL, 0x65e05aa45a1c72a3ULL, 0x6e14116da0605617ULL,
+                                  0x0c19139cb84c680aULL};
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t i = 0; i < n; i++) {
+        xoshiro_t g;
+        xo_seed(&g, seed ^ (0xd1342543de82ef95ULL * (i + 1)));
+        u256 three;
+        fq_from_u64(&three, 3);
+        for (;;) {
+            u256 c, x, rhs, y, y2;
+            for (int k = 0; k < 4; k++) c.l[k] = xo_next(&g);
+            c.l[3] &= 0x3fffffffffffffffULL;
+            if (fq_geq_mod(c.l)) continue;
+            fq_from_repr(&x, &c);
+            fq_sqr(&rhs, &x);
+            fq_mul(&rhs, &rhs, &x);
+            fq_add(&rhs, &rhs, &three);
+            fq_pow(&y, &rhs, E);
+            fq_sqr(&y2, &y);
+            if (!fq_eq(&y2, &rhs)) continue;
+            if (xo_next(&g) & 1) fq_neg(&y, &y);
+            out[i].x = x;
+            out[i].y = y;
+            break;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* MSM: arithmetic.rs:20-108 (multiexp_serial), :465-492 (best_multiexp) */
+/* ------------------------------------------------------------------ */
+
+/* arithmetic.rs:31-49 get_at: c-bit digit `segment` of the canonical LE repr */
+static inline size_t get_at(size_t segment, size_t c, const u256 *repr) {
+    size_t skip_bits = segment * c;
+    size_t skip_bytes = skip_bits / 8;
+    if (skip_bytes >= 32) return 0;
+    uint8_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t *bytes = (const uint8_t *)repr->l;
+    for (size_t i = 0; i < 8 && skip_bytes + i < 32; i++) v[i] = bytes[skip_bytes + i];
+    uint64_t tmp;
+    memcpy(&tmp, v, 8);
+    tmp >>= skip_bits - (skip_bytes * 8);
+    tmp = tmp % ((uint64_t)1 << c);
+    return (size_t)tmp;
+}
+
+/* arithmetic.rs:58-87 `enum Bucket { None, Affine, Projective }` */
+typedef struct {
+    int tag; /* 0 None, 1 Affine, 2 Projective */
+    g1_affine a;
+    g1_jac p;
+} bucket_t;
+
+static void multiexp_serial(const u256 *coeffs_mont, const g1_affine *bases, size_t n, g1_jac *acc) {
+    /* :21 coeffs.iter().map(|a| a.to_repr()) */
+    u256 *coeffs = (u256 *)malloc((n ? n : 1) * sizeof(u256));
+    for (size_t i = 0; i < n; i++) fr_to_repr(&coeffs[i], &coeffs_mont[i]);
+
+    /* :23-29 window size */
+    size_t c;
+    if (n < 4)
+        c = 1;
+    else if (n < 32)
+        c = 3;
+    else
+        c = (size_t)ceil(log((double)(uint32_t)n));
+
+    size_t segments = (256 / c) + 1; /* :51 */
+    size_t nb = ((size_t)1 << c) - 1;
+    bucket_t *buckets = (bucket_t *)malloc(nb * sizeof(bucket_t));
+
+    for (size_t seg = segments; seg-- > 0;) { /* :53 (0..segments).rev() */
+        for (size_t i = 0; i < c; i++) g1j_double(acc, acc); /* :54-56 */
+        for (size_t i = 0; i < nb; i++) buckets[i].tag = 0; /* :89 */
+        for (size_t i = 0; i < n; i++) {                    /* :91-96 */
+            size_t d = get_at(seg, c, &coeffs[i]);
+            if (d != 0) {
+                bucket_t *b = &buckets[d - 1];
+                if (b->tag == 0) { /* :68 */
+                    b->tag = 1;
+                    b->a = bases[i];
+                } else if (b->tag == 1) { /* :69 a + *other */
+                    g1_jac t;
+                    g1j_from_affine(&t, &b->a);
+                    g1j_add_affine(&b->p, &t, &bases[i]);
+                    b->tag = 2;
+                } else { /* :70-73 */
+                    g1j_add_affine(&b->p, &b->p, &bases[i]);
+                }
+            }
+        }
+        /* :98-106 summation by parts */
+        g1_jac running;
+        g1j_set_identity(&running);
+        for (size_t i = nb; i-- > 0;) {
+            bucket_t *b = &buckets[i];
+            if (b->tag == 1)
+                g1j_add_affine(&running, &running, &b->a);
+            else if (b->tag == 2)
+                g1j_add(&running, &running, &b->p);
+            g1j_add(acc, acc, &running);
+        }
+    }
+    free(buckets);
+    free(coeffs);
+}
+
+EXPORT void oracle_multiexp_serial(const u256 *coeffs, const g1_affine *bases, size_t n, g1_jac *acc) {
+    multiexp_serial(coeffs, bases, n, acc);
+}
+
+/* arithmetic.rs:465-492.  `threads` = multicore::current_num_threads() */
+EXPORT void oracle_best_multiexp(const u256 *coeffs, const g1_affine *bases, size_t n, int threads, g1_jac *out) {
+    if (threads < 1) threads = 1;
+    if (n > (size_t)threads) {
+        size_t chunk = n / (size_t)threads;
+        size_t num_chunks = (n + chunk - 1) / chunk;
+        g1_jac *results = (g1_jac *)malloc(num_chunks * sizeof(g1_jac));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (size_t ci = 0; ci < num_chunks; ci++) {
+            size_t lo = ci * chunk;
+            size_t len = (lo + chunk <= n) ? chunk : n - lo;
+            g1j_set_identity(&results[ci]);
+            multiexp_serial(coeffs + lo, bases + lo, len, &results[ci]);
+        }
+        g1_jac acc;
+        g1j_set_identity(&acc);
+        for (size_t ci = 0; ci < num_chunks; ci++) g1j_add(&acc, &acc, &results[ci]); /* :486 */
+        *out = acc;
+        free(results);
+    } else {
+        g1_jac acc;
+        g1j_set_identity(&acc);
+        multiexp_serial(coeffs, bases, n, &acc);
+        *out = acc;
+    }
+}
+
+/* arithmetic.rs:442-458 best_multiexp_gpu_cond, non-cuda branch */
+EXPORT void oracle_best_multiexp_gpu_cond(const u256 *coeffs, const g1_affine *bases, size_t n, int threads,
+                                          g1_jac *out) {
+    if (n == 0) {
+        g1j_set_identity(out);
+        return;
+    }
+    oracle_best_multiexp(coeffs, bases, n, threads, out);
+}
+
+/* arithmetic.rs:112-132 small_multiexp */
+EXPORT void oracle_small_multiexp(const u256 *coeffs_mont, const g1_affine *bases, size_t n, g1_jac *out) {
+    u256 *coeffs = (u256 *)malloc((n ? n : 1) * sizeof(u256));
+    for (size_t i = 0; i < n; i++) fr_to_repr(&coeffs[i], &coeffs_mont[i]);
+    g1_jac acc;
+    g1j_set_identity(&acc);
+    for (int byte_idx = 31; byte_idx >= 0; byte_idx--) {
+        for (int bit_idx = 7; bit_idx >= 0; bit_idx--) {
+            g1j_double(&acc, &acc);
+            for (size_t i = 0; i < n; i++) {
+                uint8_t byte = ((const uint8_t *)coeffs[i].l)[byte_idx];
+                if ((byte >> bit_idx) & 1) g1j_add_affine(&acc, &acc, &bases[i]);
+            }
+        }
+    }
+    *out = acc;
+    free(coeffs);
+}
+
+/* plonk/prover.rs:237-254 get_scalar_bits(max): bit length of the largest canonical scalar */
+EXPORT uint32_t oracle_find_max_scalar_bits(const u256 *a, size_t n) {
+    u256 best = {{0, 0, 0, 0}};
+    for (size_t i = 0; i < n; i++) {
+        u256 c;
+        fr_to_repr(&c, &a[i]);
+        for (int k = 3; k >= 0; k--) {
+            if (c.l[k] > best.l[k]) {
+                best = c;
+                break;
+            }
+            if (c.l[k] < best.l[k]) break;
+        }
+    }
+    for (int k = 3; k >= 0; k--)
+        if (best.l[k]) return (uint32_t)(64 * k + 64 - __builtin_clzll(best.l[k]));
+    return 0;
+}
+
+/* poly/commitment.rs:199-222 commit_lagrange_with_bound, non-cuda branch:
+ * drop zero scalars (and their bases), then best_multiexp_gpu_cond */
+EXPORT void oracle_commit_lagrange_with_bound(const u256 *scalars, const g1_affine *g_lagrange, size_t n,
+                                              int threads, g1_jac *out) {
+    u256 *s = (u256 *)malloc((n ? n : 1) * sizeof(u256));
+    g1_affine *b = (g1_affine *)malloc((n ? n : 1) * sizeof(g1_affine));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!fr_is_zero(&scalars[i])) {
+            s[m] = scalars[i];
+            b[m] = g_lagrange[i];
+            m++;
+        }
+    }
+    oracle_best_multiexp_gpu_cond(s, b, m, threads, out);
+    free(s);
+    free(b);
+}
+
+/* ------------------------------------------------------------------ */
+/* FFT: arithmetic.rs:556-705 (best_fft_cpu), :952-1009 (best_fft_cpu_st) */
+/* ------------------------------------------------------------------ */
+static inline size_t bitreverse(size_t n, size_t l) { /* :557-564 */
+    size_t r = 0;
+    for (size_t i = 0; i < l; i++) {
+        r = (r << 1) | (n & 1);
+        n >>= 1;
+    }
+    return r;
+}
+
+static inline void butterfly(u256 *a, u256 *b, const u256 *tw) {
+    /* :697-701  t = b*w; b = a; a += t; b -= t */
+    u256 t;
+    fr_mul(&t, b, tw);
+    *b = *a;
+    fr_add(a, a, &t);
+    fr_sub(b, b, &t);
+}
+
+static inline void butterfly_one(u256 *a, u256 *b) { /* :668-673 twiddle == 1 */
+    u256 t = *b;
+    *b = *a;
+    fr_add(a, a, &t);
+    fr_sub(b, b, &t);
+}
+
+/* :647-705 recursive_butterfly_arithmetic */
+static void recursive_butterfly_arithmetic(u256 *a, size_t n, size_t twiddle_chunk, const u256 *twiddles,
+                                           unsigned level, unsigned par_levels) {
+    if (n == 2) {
+        butterfly_one(&a[0], &a[1]);
+        return;
+    }
+    u256 *left = a, *right = a + n / 2;
+    if (level < par_levels) { /* rayon::join */
+#pragma omp task default(shared)
+        recursive_butterfly_arithmetic(left, n / 2, twiddle_chunk * 2, twiddles, level + 1, par_levels);
+        recursive_butterfly_arithmetic(right, n / 2, twiddle_chunk * 2, twiddles, level + 1, par_levels);
+#pragma omp taskwait
+    } else {
+        recursive_butterfly_arithmetic(left, n / 2, twiddle_chunk * 2, twiddles, level + 1, par_levels);
+        recursive_butterfly_arithmetic(right, n / 2, twiddle_chunk * 2, twiddles, level + 1, par_levels);
+    }
+    butterfly_one(&left[0], &right[0]);
+    left++;
+    right++;
+    size_t m = n / 2 - 1;
+    const size_t chunk_size = 512;
+    if (n > (chunk_size << 2) && level < 4) { /* :676-691 par_chunks_mut(512) */
+        size_t nchunks = (m + chunk_size - 1) / chunk_size;
+#pragma omp taskloop default(shared) grainsize(1)
+        for (size_t i = 0; i < nchunks; i++) {
+            size_t lo = i * chunk_size, hi = lo + chunk_size < m ? lo + chunk_size : m;
+            for (size_t j = lo; j < hi; j++) butterfly(&left[j], &right[j], &twiddles[(j + 1) * twiddle_chunk]);
+        }
+    } else { /* :693-702 */
+        for (size_t i = 0; i < m; i++) butterfly(&left[i], &right[i], &twiddles[(i + 1) * twiddle_chunk]);
+    }
+}
+
+static unsigned log2_floor(size_t num) { /* :796-806 */
+    unsigned pow = 0;
+    while (((size_t)1 << (pow + 1)) <= num) pow++;
+    return pow;
+}
+
+EXPORT void oracle_best_fft(u256 *a, const u256 *omega, uint32_t log_n, int threads) {
+    if (threads < 1) threads = 1;
+    unsigned log_threads = log2_floor((size_t)threads);
+    size_t n = (size_t)1 << log_n;
+
+    for (size_t k = 0; k < n; k++) { /* :571-576 */
+        size_t rk = bitreverse(k, log_n);
+        if (k < rk) {
+            u256 t = a[rk];
+            a[rk] = a[k];
+            a[k] = t;
+        }
+    }
+
+    /* :580-611 twiddles[i] = omega^i, i < n/2 (the reference builds them in 2^14
+     * chunks; the values are the plain powers) */
+    size_t half = n / 2;
+    u256 *twiddles = (u256 *)malloc((half ? half : 1) * sizeof(u256));
+    const size_t chunk = (size_t)1 << 14;
+    if (half > 0) {
+        twiddles[0] = fr_ONE;
+        size_t first = half < chunk ? half : chunk;
+        for (size_t i = 1; i < first; i++) fr_mul(&twiddles[i], &twiddles[i - 1], omega);
+        if (half > chunk) {
+            u256 base;
+            fr_mul(&base, &twiddles[chunk - 1], omega); /* omega^chunk */
+            for (size_t c0 = chunk; c0 < half; c0 += chunk) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+                for (size_t j = 0; j < chunk; j++) fr_mul(&twiddles[c0 + j], &base, &twiddles[c0 - chunk + j]);
+            }
+        }
+    }
+
+    if (log_n <= log_threads) { /* :613-641 */
+        size_t chunk_len = 2, twiddle_chunk = n / 2;
+        for (uint32_t s = 0; s < log_n; s++) {
+            for (size_t base = 0; base < n; base += chunk_len) {
+                u256 *left = a + base, *right = a + base + chunk_len / 2;
+                butterfly_one(&left[0], &right[0]);
+                for (size_t i = 1; i < chunk_len / 2; i++) butterfly(&left[i], &right[i], &twiddles[i * twiddle_chunk]);
+            }
+            chunk_len *= 2;
+            twiddle_chunk /= 2;
+        }
+    } else { /* :643 */
+#pragma omp parallel num_threads(threads)
+#pragma omp single
+        recursive_butterfly_arithmetic(a, n, 1, twiddles, 0, log_threads + 1);
+    }
+    free(twiddles);
+}
+
+/* :952-1009 best_fft_cpu_st */
+EXPORT void oracle_best_fft_st(u256 *a, const u256 *omega, uint32_t log_n) {
+    size_t n = (size_t)1 << log_n;
+    for (size_t k = 0; k < n; k++) {
+        size_t rk = bitreverse(k, log_n);
+        if (k < rk) {
+            u256 t = a[rk];
+            a[rk] = a[k];
+            a[k] = t;
+        }
+    }
+    size_t half = n / 2;
+    u256 *twiddles = (u256 *)malloc((half ? half : 1) * sizeof(u256));
+    u256 w = fr_ONE;
+    for (size_t i = 0; i < half; i++) {
+        twiddles[i] = w;
+        fr_mul(&w, &w, omega);
+    }
+    size_t chunk_len = 2, twiddle_chunk = n / 2;
+    for (uint32_t s = 0; s < log_n; s++) {
+        for (size_t base = 0; base < n; base += chunk_len) {
+            u256 *left = a + base, *right = a + base + chunk_len / 2;
+            butterfly_one(&left[0], &right[0]);
+            for (size_t i = 1; i < chunk_len / 2; i++) butterfly(&left[i], &right[i], &twiddles[i * twiddle_chunk]);
+        }
+        chunk_len *= 2;
+        twiddle_chunk /= 2;
+    }
+    free(twiddles);
+}
+
+/* arithmetic.rs:777-794 parallelize: contiguous chunks of n/threads */
+#define PARALLELIZE(n_, threads_, idxvar, body)                             \
+    do {                                                                    \
+        int par_nthr_ = (threads_);                                         \
+        _Pragma("omp parallel for schedule(static) num_threads(par_nthr_)") \
+        for (size_t idxvar = 0; idxvar < (n_); idxvar++) { body; }          \
+    } while (0)
+
+/* poly/domain.rs:400-410 ifft (non-cuda): best_fft(omega_inv) then scale by divisor */
+EXPORT void oracle_ifft(u256 *a, const u256 *omega_inv, uint32_t log_n, const u256 *divisor, int threads) {
+    if (threads < 1) threads = 1;
+    oracle_best_fft(a, omega_inv, log_n, threads);
+    size_t n = (size_t)1 << log_n;
+    PARALLELIZE(n, threads, i, fr_mul(&a[i], &a[i], divisor));
+}
+
+/* poly/domain.rs:382-398 distribute_powers_zeta */
+EXPORT void oracle_distribute_powers_zeta(u256 *a, size_t n, const u256 *g_coset, const u256 *g_coset_inv,
+                                          int into_coset, int threads) {
+    if (threads < 1) threads = 1;
+    const u256 *coset_powers[2];
+    if (into_coset) {
+        coset_powers[0] = g_coset;
+        coset_powers[1] = g_coset_inv;
+    } else {
+        coset_powers[0] = g_coset_inv;
+        coset_powers[1] = g_coset;
+    }
+    PARALLELIZE(n, threads, index, {
+        size_t i = index % 3;
+        if (i != 0) fr_mul(&a[index], &a[index], coset_powers[i - 1]);
+    });
+}
+
+/* poly/domain.rs:270-287 coeff_to_extended: zeta-distribute, zero-pad, FFT(extended_omega).
+ * `a` has n = 2^k coefficients (not modified), `out` has 2^extended_k slots. */
+EXPORT void oracle_coeff_to_extended(const u256 *a, uint32_t k, uint32_t extended_k, const u256 *g_coset,
+                                     const u256 *g_coset_inv, const u256 *extended_omega, u256 *out, int threads) {
+    size_t n = (size_t)1 << k, en = (size_t)1 << extended_k;
+    memcpy(out, a, n * sizeof(u256));
+    oracle_distribute_powers_zeta(out, n, g_coset, g_coset_inv, 1, threads);
+    memset(out + n, 0, (en - n) * sizeof(u256)); /* :280 resize(.., group_zero) */
+    oracle_best_fft(out, extended_omega, extended_k, threads);
+}
+
+/* poly/domain.rs:328-350 extended_to_coeff: iFFT, un-distribute, truncate to n*quotient_poly_degree.
+ * Works in place on `a` (2^extended_k); the first `out_len` entries are the result. */
+EXPORT size_t oracle_extended_to_coeff(u256 *a, uint32_t k, uint32_t extended_k, uint64_t quotient_poly_degree,
+                                       const u256 *g_coset, const u256 *g_coset_inv,
+                                       const u256 *extended_omega_inv, const u256 *extended_ifft_divisor,
+                                       int threads) {
+    size_t en = (size_t)1 << extended_k;
+    oracle_ifft(a, extended_omega_inv, extended_k, extended_ifft_divisor, threads);
+    oracle_distribute_powers_zeta(a, en, g_coset, g_coset_inv, 0, threads);
+    return ((size_t)1 << k) * (size_t)quotient_poly_degree;
+}
+
+/* poly/domain.rs:354-373 divide_by_vanishing_poly */
+EXPORT void oracle_divide_by_vanishing_poly(u256 *a, size_t en, const u256 *t_evaluations, size_t t_len,
+                                            int threads) {
+    if (threads < 1) threads = 1;
+    PARALLELIZE(en, threads, index, fr_mul(&a[index], &a[index], &t_evaluations[index % t_len]));
+}
+
+/* poly.rs:191-203 (+), :205-217 (-), :245-257 (* scalar) */
+EXPORT void oracle_poly_add(u256 *lhs, const u256 *rhs, size_t n, int threads) {
+    if (threads < 1) threads = 1;
+    PARALLELIZE(n, threads, i, fr_add(&lhs[i], &lhs[i], &rhs[i]));
+}
+EXPORT void oracle_poly_sub(u256 *lhs, const u256 *rhs, size_t n, int threads) {
+    if (threads < 1) threads = 1;
+    PARALLELIZE(n, threads, i, fr_sub(&lhs[i], &lhs[i], &rhs[i]));
+}
+EXPORT void oracle_poly_scale(u256 *lhs, const u256 *c, size_t n, int threads) {
+    if (threads < 1) threads = 1;
+    PARALLELIZE(n, threads, i, fr_mul(&lhs[i], &lhs[i], c));
+}
+
+/* ------------------------------------------------------------------ */
+/* EvaluationDomain::new -- poly/domain.rs:44-149                      */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    uint64_t n, k, extended_k, quotient_poly_degree, t_len;
+    u256 omega, omega_inv, extended_omega, extended_omega_inv;
+    u256 g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor, barycentric_weight;
+} oracle_domain_t;
+
+/* zeta: Montgomery-form `FieldExt::ZETA` (NULL -> the halo2curves value).
+ * t_evaluations must have room for 2^(extended_k - k) elements (<= t_cap). */
+EXPORT int oracle_domain_new(uint32_t j, uint32_t k, const u256 *zeta, oracle_domain_t *d, u256 *t_evaluations,
+                             size_t t_cap) {
+    uint64_t quotient_poly_degree = (uint64_t)(j - 1); /* :46 */
+    uint64_t n = (uint64_t)1 << k;
+    uint32_t extended_k = k;
+    while (((uint64_t)1 << extended_k) < n * quotient_poly_degree) extended_k++; /* :56-59 */
+
+    u256 extended_omega;
+    fr_from_repr(&extended_omega, &FR_ROOT_OF_UNITY_CANON); /* :61 */
+    for (uint32_t i = extended_k; i < FR_S; i++) fr_sqr(&extended_omega, &extended_omega); /* :66-68 */
+    u256 omega = extended_omega;
+    for (uint32_t i = k; i < extended_k; i++) fr_sqr(&omega, &omega); /* :77-80 */
+
+    u256 g_coset, g_coset_inv;
+    if (zeta)
+        g_coset = *zeta;
+    else
+        fr_from_repr(&g_coset, &FR_ZETA_CANON); /* :88 */
+    fr_sqr(&g_coset_inv, &g_coset);             /* :89 */
+
+    size_t t_len = (size_t)1 << (extended_k - k);
+    if (t_len > t_cap) return -1;
+    u256 orig, step, cur;
+    fr_pow_u64(&orig, &g_coset, n);        /* :95 */
+    fr_pow_u64(&step, &extended_omega, n); /* :96 */
+    cur = orig;
+    size_t cnt = 0;
+    for (;;) { /* :98-104 */
+        if (cnt >= t_len) return -2;
+        t_evaluations[cnt++] = cur;
+        fr_mul(&cur, &cur, &step);
+        if (fr_eq(&cur, &orig)) break;
+    }
+    if (cnt != t_len) return -3; /* :105 */
+    for (size_t i = 0; i < t_len; i++) fr_sub(&t_evaluations[i], &t_evaluations[i], &fr_ONE); /* :108-110 */
+
+    /* :116-131 one batch inversion over t_evaluations ++ [divisors, weight, omegas] */
+    size_t m = t_len + 5;
+    u256 *batch = (u256 *)malloc(m * sizeof(u256));
+    memcpy(batch, t_evaluations, t_len * sizeof(u256));
+    fr_from_u64(&batch[t_len + 0], (uint64_t)1 << k);
+    fr_from_u64(&batch[t_len + 1], (uint64_t)1 << extended_k);
+    fr_from_u64(&batch[t_len + 2], n);
+    batch[t_len + 3] = extended_omega;
+    batch[t_len + 4] = omega;
+    fr_batch_invert(batch, m);
+    memcpy(t_evaluations, batch, t_len * sizeof(u256));
+
+    d->n = n;
+    d->k = k;
+    d->extended_k = extended_k;
+    d->quotient_poly_degree = quotient_poly_degree;
+    d->t_len = t_len;
+    d->omega = omega;
+    d->omega_inv = batch[t_len + 4];
+    d->extended_omega = extended_omega;
+    d->extended_omega_inv = batch[t_len + 3];
+    d->g_coset = g_coset;
+    d->g_coset_inv = g_coset_inv;
+    d->ifft_divisor = batch[t_len + 0];
+    d->extended_ifft_divisor = batch[t_len + 1];
+    d->barycentric_weight = batch[t_len + 2];
+    free(batch);
+    return 0;
+}
+
+/* poly/domain.rs:458-468 rotate_omega */
+static void rotate_omega(const oracle_domain_t *d, const u256 *value, int32_t rotation, u256 *out) {
+    u256 p;
+    if (rotation >= 0)
+        fr_pow_u64(&p, &d->omega, (uint64_t)rotation);
+    else
+        fr_pow_u64(&p, &d->omega_inv, (uint64_t)(-(int64_t)rotation));
+    fr_mul(out, value, &p);
+}
+
+/* poly/domain.rs:497-522 l_i_range */
+EXPORT void oracle_l_i_range(const oracle_domain_t *d, const u256 *x, const u256 *xn, const int32_t *rotations,
+                             size_t nrot, u256 *results) {
+    for (size_t i = 0; i < nrot; i++) {
+        u256 w;
+        rotate_omega(d, &fr_ONE, rotations[i], &w);
+        fr_sub(&results[i], x, &w);
+    }
+    fr_batch_invert(results, nrot);
+    u256 common;
+    fr_sub(&common, xn, &fr_ONE);
+    fr_mul(&common, &common, &d->barycentric_weight);
+    for (size_t i = 0; i < nrot; i++) {
+        u256 t;
+        fr_mul(&t, &results[i], &common);
+        rotate_omega(d, &t, rotations[i], &results[i]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* adjacent numerics: arithmetic.rs:707-735, :754-773, :840-844, :849-903 */
+/* ------------------------------------------------------------------ */
+EXPORT void oracle_eval_polynomial(const u256 *poly, size_t n, const u256 *point, u256 *out) {
+    u256 acc = fr_ZERO; /* :707-711 Horner, from the top coefficient */
+    for (size_t i = n; i-- > 0;) {
+        fr_mul(&acc, &acc, point);
+        fr_add(&acc, &acc, &poly[i]);
+    }
+    *out = acc;
+}
+
+/* :754-773 kate_division: a(X) / (X - b), no remainder; q has n-1 coefficients */
+EXPORT void oracle_kate_division(const u256 *a, size_t n, const u256 *b_in, u256 *q) {
+    u256 b, tmp = fr_ZERO;
+    fr_neg(&b, b_in);
+    for (size_t i = n - 1; i-- > 0;) {
+        u256 lead;
+        fr_sub(&lead, &a[i + 1], &tmp);
+        q[i] = lead;
+        fr_mul(&tmp, &lead, &b);
+    }
+}
+
+EXPORT void oracle_batch_invert(u256 *f, size_t n) { fr_batch_invert(f, n); }
+
+/* :849-903 lagrange_interpolate */
+EXPORT void oracle_lagrange_interpolate(const u256 *points, const u256 *evals, size_t n, u256 *final_poly) {
+    if (n == 1) {
+        final_poly[0] = evals[0];
+        return;
+    }
+    u256 *denoms = (u256 *)malloc(n * (n - 1) * sizeof(u256));
+    for (size_t j = 0; j < n; j++) {
+        size_t c = 0;
+        for (size_t k = 0; k < n; k++)
+            if (k != j) fr_sub(&denoms[j * (n - 1) + c++], &points[j], &points[k]);
+        fr_batch_invert(&denoms[j * (n - 1)], n - 1);
+    }
+    for (size_t i = 0; i < n; i++) final_poly[i] = fr_ZERO;
+    u256 *tmp = (u256 *)malloc((n + 1) * sizeof(u256));
+    u256 *product = (u256 *)malloc((n + 1) * sizeof(u256));
+    for (size_t j = 0; j < n; j++) {
+        size_t len = 1;
+        tmp[0] = fr_ONE;
+        size_t c = 0;
+        for (size_t k = 0; k < n; k++) {
+            if (k == j) continue;
+            const u256 *denom = &denoms[j * (n - 1) + c++];
+            u256 ndx; /* -denom * x_k */
+            fr_mul(&ndx, denom, &points[k]);
+            fr_neg(&ndx, &ndx);
+            for (size_t i = 0; i <= len; i++) {
+                u256 a = (i < len) ? tmp[i] : fr_ZERO;
+                u256 b = (i > 0) ? tmp[i - 1] : fr_ZERO;
+                u256 t1, t2;
+                fr_mul(&t1, &a, &ndx);
+                fr_mul(&t2, &b, denom);
+                fr_add(&product[i], &t1, &t2);
+            }
+            len++;
+            u256 *sw = tmp;
+            tmp = product;
+            product = sw;
+        }
+        for (size_t i = 0; i < n; i++) {
+            u256 t;
+            fr_mul(&t, &tmp[i], &evals[j]);
+            fr_add(&final_poly[i], &final_poly[i], &t);
+        }
+    }
+    free(tmp);
+    free(product);
+    free(denoms);
+}
+
+/* ------------------------------------------------------------------ */
+/* Params::unsafe_setup with an injected `s` -- poly/commitment.rs:56-124 */
+/* ------------------------------------------------------------------ */
+EXPORT void oracle_unsafe_setup(uint32_t k, const u256 *s, g1_affine *g, g1_affine *g_lagrange) {
+    size_t n = (size_t)1 << k;
+    g1_affine gen; /* generator (1, 2) */
+    fq_from_u64(&gen.x, 1);
+    fq_from_u64(&gen.y, 2);
+    g1_jac genj;
+    g1j_from_affine(&genj, &gen);
+
+    /* :67-83 g[i] = [s^i] G */
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u256 si, c;
+        fr_pow_u64(&si, s, (uint64_t)i);
+        fr_to_repr(&c, &si);
+        g1_jac p;
+        g1j_mul_canon(&p, &genj, &c);
+        g1j_to_affine(&g[i], &p);
+    }
+
+    /* :85-112 g_lagrange[i] = [ (s^n - 1)/n * w^i / (s - w^i) ] G */
+    u256 root;
+    fr_from_repr(&root, &FR_ROOT_OF_UNITY_CANON);
+    for (uint32_t i = k; i < FR_S; i++) fr_sqr(&root, &root);
+    u256 n_inv, nn, multiplier;
+    fr_from_u64(&nn, (uint64_t)n);
+    fr_inv(&n_inv, &nn);
+    fr_pow_u64(&multiplier, s, (uint64_t)n);
+    fr_sub(&multiplier, &multiplier, &fr_ONE);
+    fr_mul(&multiplier, &multiplier, &n_inv);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u256 root_pow, d, scalar, c;
+        fr_pow_u64(&root_pow, &root, (uint64_t)i);
+        fr_sub(&d, s, &root_pow);
+        fr_inv(&d, &d);
+        fr_mul(&scalar, &multiplier, &root_pow);
+        fr_mul(&scalar, &scalar, &d);
+        fr_to_repr(&c, &scalar);
+        g1_jac p;
+        g1j_mul_canon(&p, &genj, &c);
+        g1j_to_affine(&g_lagrange[i], &p);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* elementwise kernels' CPU twins              */
+/* ------------------------------------------------------------------ */
+/* plonk/evaluation.rs:40-42 get_rotation_idx, as used with a signed element offset */
+static inline size_t rot_idx(size_t i, int64_t rot, size_t size) {
+    int64_t v = ((int64_t)i + rot) % (int64_t)size;
+    if (v < 0) v += (int64_t)size;
+    return (size_t)v;
+}
+
+enum {
+    OP_MUL_C = 0,    /* res[i] = l[i+lrot] * c            evaluation_gpu.rs:669,1034 */
+    OP_SUM_C = 1,    /* res[i] = l[i+lrot] + c            evaluation_gpu.rs:560,668  */
+    OP_SUM = 2,      /* res[i] = l[i+lrot] + r[i+rrot]    evaluation_gpu.rs:279-305  */
+    OP_MUL = 3,      /* res[i] = l[i+lrot] * r[i+rrot]                               */
+    OP_SUB = 4,      /* res[i] = l[i+lrot] - r[i+rrot]    (Polynomial - ; poly.rs:205-217) */
+    OP_LCTHETA = 5,  /* res = l*theta + r                 evaluation.rs:223-241      */
+    OP_LCBETA = 6,   /* res = (l + x) * r                 evaluation.rs:195-222      */
+    OP_ADDGAMMA = 7, /* res = l + x  (alias of SUM_C)     evaluation.rs:242-255      */
+    OP_CONSTANT = 8, /* res = c                           evaluation_gpu.rs:579-585  */
+};
+
+EXPORT void oracle_eval_op(int op, u256 *res, const u256 *l, const u256 *r, int64_t l_rot, int64_t r_rot,
+                           size_t size, const u256 *c) {
+    u256 *out = (u256 *)malloc(size * sizeof(u256)); /* res may alias an input */
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < size; i++) {
+        u256 lv = fr_ZERO, rv = fr_ZERO, t;
+        if (l) lv = l[rot_idx(i, l_rot, size)];
+        if (r) rv = r[rot_idx(i, r_rot, size)];
+        switch (op) {
+            case OP_MUL_C: fr_mul(&out[i], &lv, c); break;
+            case OP_SUM_C:
+            case OP_ADDGAMMA: fr_add(&out[i], &lv, c); break;
+            case OP_SUM: fr_add(&out[i], &lv, &rv); break;
+            case OP_MUL: fr_mul(&out[i], &lv, &rv); break;
+            case OP_SUB: fr_sub(&out[i], &lv, &rv); break;
+            case OP_LCTHETA:
+                fr_mul(&t, &lv, c);
+                fr_add(&out[i], &t, &rv);
+                break;
+            case OP_LCBETA:
+                fr_add(&t, &lv, c);
+                fr_mul(&out[i], &t, &rv);
+                break;
+            case OP_CONSTANT: out[i] = *c; break;
+            default: out[i] = fr_ZERO;
+        }
+    }
+    memcpy(res, out, size * sizeof(u256));
+    free(out);
+}
+
+EXPORT int oracle_version(void) { return 1; }
