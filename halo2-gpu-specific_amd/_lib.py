@@ -1,0 +1,84 @@
+"""ctypes loader for libhalo2_hip.so.  Fails loudly when the extension is missing."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class H2Error(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhalo2_hip.so")
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ -> libhalo2_hip.so (in-tree)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return lib_path()
+
+
+# name -> (restype, argtypes); every symbol include/halo2_hip.h declares
+_vp, _sz, _i32, _u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32
+_fp = ctypes.POINTER(ctypes.c_float)
+SYMBOLS = {
+    "h2_version": (ctypes.c_int, []),
+    "h2_device_count": (ctypes.c_int, []),
+    "h2_last_error": (ctypes.c_char_p, []),
+    "h2_synchronize": (ctypes.c_int, []),
+    "h2_ntt": (ctypes.c_int, [_vp, _vp, _u32]),
+    "h2_intt": (ctypes.c_int, [_vp, _vp, _vp, _u32]),
+    "h2_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "h2_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
+    "h2_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),
+    "h2_msm_multi": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),
+    "h2_msm_intt": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _u32, _vp]),
+    "h2_batch_mont": (ctypes.c_int, [_vp, _sz]),
+    "h2_batch_unmont": (ctypes.c_int, [_vp, _sz]),
+    "h2_eval_op": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i32, _i32, _sz, _vp]),
+    "h2_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz]),
+    "h2_dev_ntt": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    "h2_dev_intt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "h2_dev_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "h2_dev_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "h2_msm_scratch_bytes": (_sz, [_sz, _u32]),
+    "h2_dev_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
+    "h2_dev_eval_op": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i32, _i32, _sz, _vp, _vp]),
+    "h2_dev_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz, _vp]),
+    "h2_dev_batch_mont": (ctypes.c_int, [_vp, _sz, _vp]),
+    "h2_dev_batch_unmont": (ctypes.c_int, [_vp, _sz, _vp]),
+    "h2_timer_start": (ctypes.c_int, [_vp]),
+    "h2_timer_stop": (ctypes.c_int, [_vp, _fp]),
+}
+
+
+def lib():
+    """The loaded C-ABI library.  Raises H2Error if libhalo2_hip.so has not been built:
+    the product path never falls back to a CPU implementation."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise H2Error(
+                "libhalo2_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C halo2-gpu-specific_amd/csrc`; there is no CPU fallback" % path
+            )
+        L = ctypes.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().h2_last_error()
+        raise H2Error("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else ""))

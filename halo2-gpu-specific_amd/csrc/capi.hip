@@ -1,0 +1,399 @@
+// capi.hip -- the extern "C" boundary declared in include/halo2_hip.h.
+// Host-buffer entry points = the reference's gpu_* functions (arithmetic.rs:134-534) with the
+// per-call program creation removed: a pooled device context keeps streams, scratch and
+// twiddle plans alive across calls.  h2_dev_* = the same ops on device-resident data.
+#include <cstring>
+
+#include "common.hpp"
+#include "msm.hpp"
+#include "ntt.hpp"
+#include "poly.hpp"
+
+using namespace h2;
+
+namespace {
+
+hipStream_t pick_stream(DeviceCtx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+DeviceCtx* current_ctx() {
+    int dev = 0;
+    H2_HIP(hipGetDevice(&dev));
+    return ctx_for(dev);
+}
+
+int bad(const char* msg) {
+    set_last_error(msg);
+    return H2_ERR_INVALID;
+}
+
+// plan lookup is the only shared mutable state touched by the h2_dev_* paths
+NttPlan* plan_locked(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, bool have_lock) {
+    if (have_lock) return ntt_get_plan(ctx, log_n, omega, s);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return ntt_get_plan(ctx, log_n, omega, s);
+}
+
+int dev_ntt_impl(DeviceCtx* ctx, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const uint64_t omega[4],
+                 uint32_t log_n, const Fr* pre3, const Fr* post3, hipStream_t s, bool have_lock) {
+    if (log_n > 28) return bad("log_n exceeds the 2-adicity of Fr (S = 28)");
+    std::vector<uint32_t> bits;
+    ntt_split(log_n, bits);
+    if (bits.size() >= 2 && tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
+    NttPlan* pl = plan_locked(ctx, log_n, omega, s, have_lock);
+    ntt_run(ctx, pl, src, dst, tmp, in_len, pre3, post3, s);
+    return H2_OK;
+}
+
+int dev_extended_to_coeff_impl(DeviceCtx* ctx, Fr* d_a, Fr* d_tmp, uint32_t extended_k, const uint64_t g_coset[4],
+                               const uint64_t g_coset_inv[4], const uint64_t extended_omega_inv[4],
+                               const uint64_t extended_ifft_divisor[4], hipStream_t s, bool have_lock) {
+    // into_coset = false: coset_powers = [g_coset_inv, g_coset] (domain.rs:385-387), fused with the
+    // iFFT divisor: y[i] *= divisor * {1, g_coset_inv, g_coset}[i % 3].
+    Fr d = fr_from_u64x4(extended_ifft_divisor);
+    Fr gi = fr_from_u64x4(g_coset_inv), g = fr_from_u64x4(g_coset);
+    Fr post3[3] = {d, fp_mul(d, gi), fp_mul(d, g)};  // host-side Montgomery products
+    return dev_ntt_impl(ctx, d_a, d_a, d_tmp, 1u << extended_k, extended_omega_inv, extended_k, nullptr, post3, s,
+                        have_lock);
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2_version(void) { return 1; }
+
+int h2_device_count(void) { return device_count(); }
+
+const char* h2_last_error(void) { return get_last_error(); }
+
+int h2_synchronize(void) {
+    return guarded([&] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        for (int d = 0; d < n; d++) {
+            H2_HIP(hipSetDevice(d));
+            H2_HIP(hipDeviceSynchronize());
+        }
+        return (int)H2_OK;
+    });
+}
+
+// ------------------------------------------------------------------ NTT, host buffers
+int h2_ntt(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+    if (!a || !omega) return bad("h2_ntt: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t bytes = sizeof(Fr) << log_n;
+        Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(bytes);
+        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = dev_ntt_impl(ctx, d_a, d_a, d_t, 1u << log_n, omega, log_n, nullptr, nullptr, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_intt(uint64_t* a, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n) {
+    if (!a || !omega_inv || !divisor) return bad("h2_intt: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t bytes = sizeof(Fr) << log_n;
+        Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(bytes);
+        Fr d = fr_from_u64x4(divisor);
+        Fr post3[3] = {d, d, d};
+        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = dev_ntt_impl(ctx, d_a, d_a, d_t, 1u << log_n, omega_inv, log_n, nullptr, post3, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint32_t extended_k,
+                         const uint64_t g_coset[4], const uint64_t g_coset_inv[4], const uint64_t extended_omega[4]) {
+    if (!coeffs || !out || !g_coset || !g_coset_inv || !extended_omega) return bad("h2_coeff_to_extended: null argument");
+    if (extended_k < k) return bad("h2_coeff_to_extended: extended_k < k");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t in_bytes = sizeof(Fr) << k, ext_bytes = sizeof(Fr) << extended_k;
+        Fr* d_in = (Fr*)ctx->buf_a.get(ext_bytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
+        // into_coset = true: coset_powers = [g_coset, g_coset_inv] (domain.rs:383-385)
+        Fr pre3[3] = {fr_from_u64x4(g_coset), fr_from_u64x4(g_coset), fr_from_u64x4(g_coset_inv)};
+        H2_HIP(hipMemcpyAsync(d_in, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = dev_ntt_impl(ctx, d_in, d_in, d_t, 1u << k, extended_omega, extended_k, pre3, nullptr, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(out, d_in, ext_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_extended_to_coeff(const uint64_t* a, uint64_t* out, size_t out_len, uint32_t extended_k,
+                         const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                         const uint64_t extended_omega_inv[4], const uint64_t extended_ifft_divisor[4]) {
+    if (!a || !out || !g_coset || !g_coset_inv || !extended_omega_inv || !extended_ifft_divisor)
+        return bad("h2_extended_to_coeff: null argument");
+    if (out_len > ((size_t)1 << extended_k)) return bad("h2_extended_to_coeff: out_len exceeds the extended domain");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t ext_bytes = sizeof(Fr) << extended_k;
+        Fr* d_a = (Fr*)ctx->buf_a.get(ext_bytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
+        H2_HIP(hipMemcpyAsync(d_a, a, ext_bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = dev_extended_to_coeff_impl(ctx, d_a, d_t, extended_k, g_coset, g_coset_inv, extended_omega_inv,
+                                            extended_ifft_divisor, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(out, d_a, out_len * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+// ------------------------------------------------------------------ Montgomery conversion
+static int host_batch_mont(uint64_t* a, size_t n, bool to_mont) {
+    if (!a && n) return bad("h2_batch_mont: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t bytes = n * sizeof(Fr);
+        if (n == 0) return (int)H2_OK;
+        Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
+        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = batch_mont_launch(d_a, n, to_mont, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+int h2_batch_mont(uint64_t* a, size_t n) { return host_batch_mont(a, n, true); }
+int h2_batch_unmont(uint64_t* a, size_t n) { return host_batch_mont(a, n, false); }
+
+// ------------------------------------------------------------------ elementwise, host buffers
+int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int32_t l_rot, int32_t r_rot, size_t size,
+               const uint64_t c[4]) {
+    if (!res) return bad("h2_eval_op: null result");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t bytes = size * sizeof(Fr);
+        if (size == 0) return (int)H2_OK;
+        Fr* d_res = (Fr*)ctx->buf_a.get(bytes);
+        Fr* d_l = l ? (Fr*)ctx->buf_b.get(bytes) : nullptr;
+        Fr* d_r = r ? (Fr*)ctx->buf_c.get(bytes) : nullptr;
+        if (l) H2_HIP(hipMemcpyAsync(d_l, l, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (r) H2_HIP(hipMemcpyAsync(d_r, r, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = eval_op_launch(op, d_res, d_l, d_r, l_rot, r_rot, size, c, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_divide_by_vanishing_poly(uint64_t* a, size_t size, const uint64_t* t_evaluations, size_t t_len) {
+    if (!a || !t_evaluations) return bad("h2_divide_by_vanishing_poly: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        if (size == 0) return (int)H2_OK;
+        Fr* d_a = (Fr*)ctx->buf_a.get(size * sizeof(Fr));
+        Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
+        H2_HIP(hipMemcpyAsync(d_a, a, size * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = divide_by_vanishing_launch(d_a, size, d_t, t_len, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d_a, size * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+// ------------------------------------------------------------------ MSM, host buffers
+int h2_msm(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]) {
+    if (!out_xyz || (n && (!scalars || !bases))) return bad("h2_msm: null argument");
+    return guarded([&] {
+        if (max_bits == 0 || n == 0) {  // arithmetic.rs:346, :421
+            msm_identity(out_xyz);
+            return (int)H2_OK;
+        }
+        DeviceLease lease;
+        return msm_host(lease.ctx, scalars, bases, n, max_bits, out_xyz);
+    });
+}
+
+int h2_msm_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]) {
+    if (!out_xyz || (n && (!scalars || !bases))) return bad("h2_msm_multi: null argument");
+    return guarded([&] {
+        if (max_bits == 0 || n == 0) {
+            msm_identity(out_xyz);
+            return (int)H2_OK;
+        }
+        return msm_host_multi(scalars, bases, n, max_bits, out_xyz);
+    });
+}
+
+int h2_msm_intt(uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, const uint64_t omega_inv[4],
+                const uint64_t divisor[4], uint32_t log_n, uint64_t out_xyz[12]) {
+    if (!out_xyz || !scalars || !bases || !omega_inv || !divisor) return bad("h2_msm_intt: null argument");
+    if (n != ((size_t)1 << log_n)) return bad("h2_msm_intt: n != 2^log_n");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t sbytes = n * sizeof(Fr);
+        // one upload of the scalars feeds both the MSM and the iNTT (arithmetic.rs:402-404)
+        Fr* d_s = (Fr*)ctx->buf_a.get(sbytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(sbytes);
+        H2_HIP(hipMemcpyAsync(d_s, scalars, sbytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = H2_OK;
+        if (max_bits == 0)
+            msm_identity(out_xyz);
+        else
+            rc = msm_host_resident_scalars(ctx, d_s, bases, n, max_bits, out_xyz);
+        if (rc != H2_OK) return rc;
+        Fr d = fr_from_u64x4(divisor);
+        Fr post3[3] = {d, d, d};
+        rc = dev_ntt_impl(ctx, d_s, d_s, d_t, (uint32_t)n, omega_inv, log_n, nullptr, post3, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(scalars, d_s, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+// ------------------------------------------------------------------ device-resident entry points
+int h2_dev_ntt(void* d_a, void* d_tmp, const uint64_t omega[4], uint32_t log_n, void* stream) {
+    if (!d_a || !omega) return bad("h2_dev_ntt: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return dev_ntt_impl(ctx, (Fr*)d_a, (Fr*)d_a, (Fr*)d_tmp, 1u << log_n, omega, log_n, nullptr, nullptr,
+                            pick_stream(ctx, stream), false);
+    });
+}
+
+int h2_dev_intt(void* d_a, void* d_tmp, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n,
+                void* stream) {
+    if (!d_a || !omega_inv || !divisor) return bad("h2_dev_intt: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        Fr d = fr_from_u64x4(divisor);
+        Fr post3[3] = {d, d, d};
+        return dev_ntt_impl(ctx, (Fr*)d_a, (Fr*)d_a, (Fr*)d_tmp, 1u << log_n, omega_inv, log_n, nullptr, post3,
+                            pick_stream(ctx, stream), false);
+    });
+}
+
+int h2_dev_coeff_to_extended(const void* d_coeffs, void* d_out, void* d_tmp, uint32_t k, uint32_t extended_k,
+                             const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                             const uint64_t extended_omega[4], void* stream) {
+    if (!d_coeffs || !d_out || !g_coset || !g_coset_inv || !extended_omega)
+        return bad("h2_dev_coeff_to_extended: null argument");
+    if (extended_k < k) return bad("h2_dev_coeff_to_extended: extended_k < k");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        Fr pre3[3] = {fr_from_u64x4(g_coset), fr_from_u64x4(g_coset), fr_from_u64x4(g_coset_inv)};
+        if (d_coeffs == d_out && extended_k > 8 && d_tmp == nullptr) return bad("in-place extension needs d_tmp");
+        return dev_ntt_impl(ctx, (const Fr*)d_coeffs, (Fr*)d_out, (Fr*)d_tmp, 1u << k, extended_omega, extended_k,
+                            pre3, nullptr, pick_stream(ctx, stream), false);
+    });
+}
+
+int h2_dev_extended_to_coeff(void* d_a, void* d_tmp, uint32_t extended_k, const uint64_t g_coset[4],
+                             const uint64_t g_coset_inv[4], const uint64_t extended_omega_inv[4],
+                             const uint64_t extended_ifft_divisor[4], void* stream) {
+    if (!d_a || !g_coset || !g_coset_inv || !extended_omega_inv || !extended_ifft_divisor)
+        return bad("h2_dev_extended_to_coeff: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return dev_extended_to_coeff_impl(ctx, (Fr*)d_a, (Fr*)d_tmp, extended_k, g_coset, g_coset_inv,
+                                          extended_omega_inv, extended_ifft_divisor, pick_stream(ctx, stream), false);
+    });
+}
+
+size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits) { return msm_scratch_bytes(n, max_bits); }
+
+int h2_dev_msm(const void* d_scalars, const void* d_bases, size_t n, uint32_t max_bits, void* d_scratch,
+               size_t scratch_bytes, uint64_t out_xyz[12], void* stream) {
+    if (!out_xyz || (n && (!d_scalars || !d_bases))) return bad("h2_dev_msm: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return msm_device(ctx, (const Fr*)d_scalars, (const uint64_t*)d_bases, n, max_bits, d_scratch, scratch_bytes,
+                          out_xyz, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_eval_op(int op, void* d_res, const void* d_l, const void* d_r, int32_t l_rot, int32_t r_rot, size_t size,
+                   const uint64_t c[4], void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return eval_op_launch(op, (Fr*)d_res, (const Fr*)d_l, (const Fr*)d_r, l_rot, r_rot, size, c,
+                              pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_divide_by_vanishing_poly(void* d_a, size_t size, const void* d_t, size_t t_len, void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return divide_by_vanishing_launch((Fr*)d_a, size, (const Fr*)d_t, t_len, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_batch_mont(void* d_a, size_t n, void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return batch_mont_launch((Fr*)d_a, n, true, pick_stream(ctx, stream));
+    });
+}
+int h2_dev_batch_unmont(void* d_a, size_t n, void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return batch_mont_launch((Fr*)d_a, n, false, pick_stream(ctx, stream));
+    });
+}
+
+// ------------------------------------------------------------------ HIP-event timer for bench.py
+namespace {
+std::mutex g_timer_mu;
+std::map<void*, std::pair<hipEvent_t, hipEvent_t>> g_timers;
+}  // namespace
+
+int h2_timer_start(void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        hipStream_t s = pick_stream(ctx, stream);
+        std::lock_guard<std::mutex> g(g_timer_mu);
+        auto& t = g_timers[(void*)s];
+        if (!t.first) {
+            H2_HIP(hipEventCreate(&t.first));
+            H2_HIP(hipEventCreate(&t.second));
+        }
+        H2_HIP(hipEventRecord(t.first, s));
+        return (int)H2_OK;
+    });
+}
+
+int h2_timer_stop(void* stream, float* ms_out) {
+    if (!ms_out) return bad("h2_timer_stop: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        hipStream_t s = pick_stream(ctx, stream);
+        std::lock_guard<std::mutex> g(g_timer_mu);
+        auto it = g_timers.find((void*)s);
+        if (it == g_timers.end()) return bad("h2_timer_stop without h2_timer_start");
+        H2_HIP(hipEventRecord(it->second.second, s));
+        H2_HIP(hipEventSynchronize(it->second.second));
+        H2_HIP(hipEventElapsedTime(ms_out, it->second.first, it->second.second));
+        return (int)H2_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// common.hpp -- device context, error plumbing and grow-only device arenas shared by the
+// NTT / MSM / elementwise translation units of libhalo2_hip.so.
+//
+// Mirrors the reference's process-global device pool (`N_GPU`, `GPU_LOCK`, `GPU_COND_VAR`,
+// /root/reference/halo2_proofs/src/plonk/prover.rs:56-74; `acquire_gpu`/`release_gpu`,
+// arithmetic.rs:314-331): one in-flight host-API operation per device, callers on any thread.
+// Unlike the reference nothing is re-created per call: streams, scratch and twiddle plans are
+// cached per device for the life of the process.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/halo2_hip.h"
+#include "field.hpp"
+
+namespace h2 {
+
+void set_last_error(const std::string& msg);
+const char* get_last_error();
+
+struct HipError {
+    hipError_t code;
+    const char* expr;
+    const char* file;
+    int line;
+};
+
+#define H2_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t h2_e_ = (expr);                                          \
+        if (h2_e_ != hipSuccess) throw h2::HipError{h2_e_, #expr, __FILE__, __LINE__}; \
+    } while (0)
+
+// Grow-only device buffer (never shrinks; reused across calls).
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    void* get(size_t bytes);
+    void release();
+};
+
+struct NttPlan;  // ntt.hip
+
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;      // compute stream for host-API calls
+    hipStream_t copy_stream = nullptr; // H2D/D2H overlap
+    std::mutex mu;                     // one in-flight host-API op per device
+    DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
+    DevBuf msm_scratch;
+    std::map<std::string, NttPlan*> plans;
+    hipDeviceProp_t prop;
+};
+
+// Device pool (HALO2_PROOFS_N_GPU honoured, prover.rs:57-70).
+int device_count();
+DeviceCtx* ctx_for(int device);  // creates on first use; throws HipError
+int acquire_device();            // blocking free-list, arithmetic.rs:314-321
+void release_device(int idx);    // arithmetic.rs:324-331
+
+struct DeviceLease {
+    int idx;
+    DeviceCtx* ctx;
+    DeviceLease() : idx(acquire_device()), ctx(nullptr) {
+        try {
+            ctx = ctx_for(idx);
+        } catch (...) {
+            release_device(idx);
+            throw;
+        }
+        ctx->mu.lock();  // two pool slots may map onto one physical device (idx % devices.len())
+        hipSetDevice(ctx->device);
+    }
+    ~DeviceLease() {
+        ctx->mu.unlock();
+        release_device(idx);
+    }
+};
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP error %d (%s) in `%s` at %s:%d", (int)e.code, hipGetErrorString(e.code), e.expr,
+                 e.file, e.line);
+        set_last_error(buf);
+        return e.code == hipErrorOutOfMemory ? H2_ERR_OOM : H2_ERR_HIP;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return H2_ERR_INVALID;
+    }
+}
+
+}  // namespace h2

@@ -1,0 +1,114 @@
+// context.hip -- device pool, per-device context, error text.
+// Reference counterpart: N_GPU / GPU_LOCK / GPU_COND_VAR (plonk/prover.rs:56-74) and
+// acquire_gpu / release_gpu (arithmetic.rs:314-331).
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace h2 {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+void* DevBuf::get(size_t bytes) {
+    if (bytes <= cap) return ptr;
+    if (ptr) H2_HIP(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = bytes + (bytes >> 3);  // 12.5 % headroom so nearby sizes reuse the block
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        H2_HIP(hipMalloc(&ptr, want));
+    }
+    cap = want;
+    return ptr;
+}
+void DevBuf::release() {
+    if (ptr) hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> free_list;  // GPU_LOCK: Vec of free device indices
+    std::vector<DeviceCtx*> ctxs;
+    int n_gpu = -1;  // pool size (N_GPU)
+    int n_visible = 0;
+    bool inited = false;
+
+    void init() {
+        if (inited) return;
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess) cnt = 0;
+        n_visible = cnt;
+        n_gpu = cnt;
+        // HALO2_PROOFS_N_GPU overrides the pool size (prover.rs:57-70); indices wrap modulo the
+        // visible devices like `devices[gpu_idx % devices.len()]` (arithmetic.rs:355).
+        if (const char* env = std::getenv("HALO2_PROOFS_N_GPU")) {
+            int v = std::atoi(env);
+            if (v > 0) n_gpu = v;
+        }
+        if (cnt == 0) n_gpu = 0;
+        for (int i = n_gpu - 1; i >= 0; i--) free_list.push_back(i);
+        ctxs.assign(cnt > 0 ? cnt : 0, nullptr);
+        inited = true;
+    }
+};
+Pool& pool() {
+    static Pool p;
+    return p;
+}
+}  // namespace
+
+int device_count() {
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.init();
+    return p.n_gpu;
+}
+
+DeviceCtx* ctx_for(int idx) {
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.init();
+    if (p.n_visible == 0) throw HipError{hipErrorNoDevice, "no HIP device visible", __FILE__, __LINE__};
+    int dev = idx % p.n_visible;
+    if (!p.ctxs[dev]) {
+        DeviceCtx* c = new DeviceCtx();
+        c->device = dev;
+        H2_HIP(hipSetDevice(dev));
+        H2_HIP(hipGetDeviceProperties(&c->prop, dev));
+        H2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        H2_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        p.ctxs[dev] = c;
+    }
+    return p.ctxs[dev];
+}
+
+int acquire_device() {
+    Pool& p = pool();
+    std::unique_lock<std::mutex> lk(p.mu);
+    p.init();
+    if (p.n_gpu == 0) throw HipError{hipErrorNoDevice, "no HIP device visible", __FILE__, __LINE__};
+    p.cv.wait(lk, [&] { return !p.free_list.empty(); });
+    int idx = p.free_list.back();
+    p.free_list.pop_back();
+    return idx;
+}
+
+void release_device(int idx) {
+    Pool& p = pool();
+    {
+        std::lock_guard<std::mutex> g(p.mu);
+        p.free_list.push_back(idx);
+    }
+    p.cv.notify_one();
+}
+
+}  // namespace h2

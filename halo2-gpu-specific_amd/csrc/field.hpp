@@ -1,0 +1,234 @@
+// field.hpp -- BN254 Fr / Fq arithmetic for gfx950 (CDNA4), 8 x u32 limbs, Montgomery form.
+//
+// Replaces (device side) the arithmetic the reference gets from the un-vendored crates
+// pairing_bn256 (Fr/Fq, /root/reference/halo2_proofs/src/arithmetic.rs:16-17) and
+// ec-gpu-gen's generated FIELD_* CUDA source (/root/reference/halo2_proofs/build.rs:1-11).
+//
+// In-memory layout is the reference's: 32 B = 4 x u64 LE limbs in Montgomery form with
+// R = 2^256 (prover.rs:176,183; helpers.rs:185-194) -- identical bytes to 8 x u32 LE.
+//
+// The multiplier is a product-scanning (Comba) Montgomery multiplication built on
+// v_mad_u64_u32 with its carry-out routed through an SGPR pair into one v_addc_co_u32,
+// i.e. 1 quarter-rate multiply-add + 1 full-rate add per 32x32 partial product
+// (136 mads per modular multiplication).  No MFMA: there is no dense contraction here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace h2 {
+
+struct FrParams {
+    static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
+    static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                        0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod r
+    static constexpr uint32_t RR[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                       0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};  // R^2 mod r
+};
+
+struct FqParams {
+    static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
+    static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                        0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod q
+    static constexpr uint32_t RR[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                       0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};  // R^2 mod q
+};
+
+template <class P>
+struct alignas(16) Fp {
+    uint32_t l[8];
+};
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+#define H2_DEV __host__ __device__ __forceinline__
+
+// ---- 32-byte vector load/store (two global_load_dwordx4) -------------------------------
+template <class P>
+H2_DEV Fp<P> fp_load(const Fp<P>* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fp<P> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <class P>
+H2_DEV void fp_store(Fp<P>* p, const Fp<P>& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+template <class P>
+H2_DEV Fp<P> fp_zero() {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+}
+template <class P>
+H2_DEV Fp<P> fp_one() {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = P::ONE[i];
+    return r;
+}
+template <class P>
+H2_DEV bool fp_is_zero(const Fp<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i];
+    return o == 0;
+}
+template <class P>
+H2_DEV bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class P>
+H2_DEV Fp<P> fp_reduce_once(const Fp<P>& a) {
+    Fp<P> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - P::MOD[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+    return r;
+}
+
+template <class P>
+H2_DEV Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        s.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return fp_reduce_once(s);  // p < 2^254: a + b < 2^255, no carry out of limb 7
+}
+
+template <class P>
+H2_DEV Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    uint32_t mask = borrow ? 0xffffffffu : 0u;
+    uint64_t c = 0;
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.l[i] + (P::MOD[i] & mask);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <class P>
+H2_DEV Fp<P> fp_neg(const Fp<P>& a) {
+    return fp_sub(fp_zero<P>(), a);
+}
+template <class P>
+H2_DEV Fp<P> fp_dbl(const Fp<P>& a) {
+    return fp_add(a, a);
+}
+
+// acc(96 bit = lo64 : hi32) += a * b.
+// v_mad_u64_u32 D, carry(SGPR pair), a, b, D ; v_addc_co_u32 hi, carry, hi, 0, carry
+H2_DEV void mad_acc(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+#if defined(H2_PORTABLE_MUL) || !defined(__HIP_DEVICE_COMPILE__)
+    uint64_t p = (uint64_t)a * b;
+    uint64_t s = lo + p;
+    hi += (s < p) ? 1u : 0u;
+    lo = s;
+#else
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(carry) : "v"(a), "v"(b));
+    asm("v_addc_co_u32 %0, %1, %0, 0, %1" : "+v"(hi), "+s"(carry));
+#endif
+}
+
+// Montgomery product a*b*R^-1 mod p, product scanning (FIPS) form.
+template <class P>
+H2_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+    uint32_t m[8];
+    Fp<P> r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) mad_acc(lo, hi, a.l[j], b.l[i - j]);
+#pragma unroll
+        for (int j = 0; j < i; j++) mad_acc(lo, hi, m[j], P::MOD[i - j]);
+        m[i] = (uint32_t)lo * P::INV;
+        mad_acc(lo, hi, m[i], P::MOD[0]);  // low word becomes 0
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+#pragma unroll
+    for (int i = 8; i < 16; i++) {
+#pragma unroll
+        for (int j = i - 7; j < 8; j++) mad_acc(lo, hi, a.l[j], b.l[i - j]);
+#pragma unroll
+        for (int j = i - 7; j < 8; j++) mad_acc(lo, hi, m[j], P::MOD[i - j]);
+        r.l[i - 8] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    // a, b < p  =>  result < 2p < 2^255, so the word above r.l[7] is zero here
+    return fp_reduce_once(r);
+}
+
+template <class P>
+H2_DEV Fp<P> fp_sqr(const Fp<P>& a) {
+    return fp_mul(a, a);
+}
+
+// canonical integer <-> Montgomery (`batch_mont` / `batch_unmont`, arithmetic.rs:235-241,280-286)
+template <class P>
+H2_DEV Fp<P> fp_to_mont(const Fp<P>& canon) {
+    Fp<P> rr;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rr.l[i] = P::RR[i];
+    return fp_mul(canon, rr);
+}
+template <class P>
+H2_DEV Fp<P> fp_from_mont(const Fp<P>& a) {
+    Fp<P> one = fp_zero<P>();
+    one.l[0] = 1;
+    return fp_mul(a, one);
+}
+
+// a^e for a 32-bit exponent (square-and-multiply, MSB first)
+template <class P>
+H2_DEV Fp<P> fp_pow_u32(const Fp<P>& a, uint32_t e) {
+    Fp<P> acc = fp_one<P>();
+    for (int i = 31; i >= 0; i--) {
+        acc = fp_sqr(acc);
+        if ((e >> i) & 1) acc = fp_mul(acc, a);
+    }
+    return acc;
+}
+
+}  // namespace h2

@@ -1,0 +1,17 @@
+// msm.hpp -- MSM drivers (msm.hip)
+#pragma once
+#include "common.hpp"
+
+namespace h2 {
+size_t msm_scratch_bytes(size_t n, uint32_t max_bits);
+void msm_identity(uint64_t out_xyz[12]);
+// device-resident scalars + bases; result to host memory (synchronises `stream` for the final
+// W*G-point read-back and the host-side window combine)
+int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, size_t n, uint32_t max_bits,
+               void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
+int msm_host(DeviceCtx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
+             uint64_t out_xyz[12]);
+int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n,
+                              uint32_t max_bits, uint64_t out_xyz[12]);
+int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+}  // namespace h2

@@ -1,0 +1,311 @@
+// ntt.hip -- radix-2^B multi-pass NTT over BN254 Fr for gfx950.
+//
+// Replaces ec-gpu-gen's `SingleFftKernel::{radix_fft, radix_ifft}` (called from
+// /root/reference/halo2_proofs/src/arithmetic.rs:495-534) and the device-resident driver
+// `do_fft_core` (plonk/evaluation_gpu.rs:976-1052); semantics are those of the CPU twin
+// `best_fft_cpu` (arithmetic.rs:556-645): natural order in, natural order out,
+// X[k] = sum_j x[j] * omega^(j*k).
+//
+// Decomposition (not the reference's): n = R_0 * R_1 * ... * R_{P-1}, R_p = 2^{B_p} <= 2^9.
+//   input index   j = sum_p j_p * S_p,   S_p = 2^(L - B_0 - ... - B_p)   (j_0 most significant)
+//   output index  k = sum_p k_p * T_p,   T_p = 2^(B_0 + ... + B_{p-1})   (k_0 least significant)
+// Pass p replaces digit j_p by k_p *in place* (an R_p-point DFT along stride S_p) after
+// multiplying element j_p by omega^(j_p * S_p * K_{p-1}), K_{p-1} = sum_{q<p} k_q T_q.
+// The last pass reads R_{P-1} contiguous elements per DFT and scatters to the natural output
+// order, so it is out of place; tiles hold C DFTs with consecutive K so both the loads
+// (contiguous rows) and the stores (C consecutive outputs) are coalesced.
+// One workgroup = one LDS tile of R_p x C elements (32 B each); butterflies are radix-2
+// DIT on bit-reversed rows, twiddles w_R^e from a per-pass LDS table.
+//
+// Fused into the passes (so the reference's separate kernels/loops disappear):
+//   * zero padding  (eval_fft_prepare, evaluation_gpu.rs:890-900; domain.rs:280)
+//   * zeta-power coset pre-scale (distribute_powers_zeta, domain.rs:382-398)
+//   * 1/n and zeta^-1 post-scale (domain.rs:404-409, :341)
+#include "common.hpp"
+#include "ntt.hpp"
+
+namespace h2 {
+
+static constexpr int NTT_MAX_B = 9;
+static constexpr int LO_BITS = 12;  // two-level twiddle tables: w^e = lo[e & 4095] * hi[e >> 12]
+
+// ---------------------------------------------------------------- table generation
+// out[i] = base^(i * mul)   (i < count)
+__global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, uint32_t mul, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // base^(i*mul): exponent < 2^28 always (order of omega divides 2^28)
+    fp_store(out + i, fp_pow_u32(base, i * mul));
+}
+
+// ---------------------------------------------------------------- the pass kernel
+struct PassArgs {
+    const Fr* in;
+    Fr* out;
+    const Fr* tw_bfly;  // R/2 entries: (w^(n/R))^e
+    const Fr* tw_lo;    // min(n, 4096) entries: w^i
+    const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
+    Fr pre3[3];         // has_pre3: x *= pre3[idx % 3] on the first-pass load (idx % 3 == 0 skipped)
+    Fr post3[3];        // has_post3: y *= post3[idx % 3] on the final store
+    uint32_t has_pre3, has_post3;
+    uint32_t log_n, B, s_log, t_log;
+    uint32_t nprev;       // number of earlier passes
+    uint32_t prevB[4];    // their bit widths
+    uint32_t prevT[4];    // their T_q logs
+    uint32_t is_last, in_len, log_c;
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
+    return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+}
+
+// hi (digits k_0..k_{p-1}, k_0 most significant) -> K = sum k_q << T_q
+__device__ __forceinline__ uint32_t hi_to_K(uint32_t hi, const PassArgs& a) {
+    uint32_t K = 0;
+    for (int q = (int)a.nprev - 1; q >= 0; q--) {
+        uint32_t d = hi & ((1u << a.prevB[q]) - 1);
+        hi >>= a.prevB[q];
+        K |= d << a.prevT[q];
+    }
+    return K;
+}
+__device__ __forceinline__ uint32_t K_to_hi(uint32_t K, const PassArgs& a) {
+    uint32_t hi = 0;
+    for (uint32_t q = 0; q < a.nprev; q++) {
+        uint32_t d = (K >> a.prevT[q]) & ((1u << a.prevB[q]) - 1);
+        hi = (hi << a.prevB[q]) | d;
+    }
+    return hi;
+}
+
+__device__ __forceinline__ Fr twiddle_pow(const PassArgs& a, uint32_t e) {
+    if (a.log_n <= LO_BITS) return fp_load(a.tw_lo + e);
+    Fr lo = fp_load(a.tw_lo + (e & ((1u << LO_BITS) - 1)));
+    Fr hi = fp_load(a.tw_hi + (e >> LO_BITS));
+    return fp_mul(lo, hi);
+}
+
+extern __shared__ __attribute__((aligned(16))) uint4 h2_smem[];
+
+__global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
+    Fr* tile = reinterpret_cast<Fr*>(h2_smem);
+    const uint32_t B = a.B, R = 1u << B, log_c = a.log_c, C = 1u << log_c;
+    Fr* twb = tile + (R << log_c);  // R/2 butterfly twiddles
+    const uint32_t nthreads = blockDim.x;  // == max(R/2 * C, 1)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
+
+    for (uint32_t i = tid; i < (R >> 1); i += nthreads) twb[i] = fp_load(a.tw_bfly + i);
+
+    const uint32_t tile_id = blockIdx.x;
+    const uint32_t total = R << log_c;
+
+    // ---- tile geometry
+    uint32_t base = 0, K_uniform = 0;
+    const uint32_t S = 1u << a.s_log;
+    if (!a.is_last) {
+        // tiles: for each hi, for each chunk of C consecutive low positions
+        uint32_t chunks_per_hi = S >> log_c;
+        uint32_t hi = tile_id / chunks_per_hi, lo0 = (tile_id % chunks_per_hi) << log_c;
+        base = (hi << (B + a.s_log)) + lo0;
+        K_uniform = hi_to_K(hi, a);
+    }
+
+    // ---- load (+ zero pad, coset pre-scale, inter-pass twiddle), bit-reversed rows into LDS
+    for (uint32_t e = tid; e < total; e += nthreads) {
+        uint32_t rho, c, idx, K;
+        if (!a.is_last) {
+            c = e & (C - 1);
+            rho = e >> log_c;
+            idx = base + (rho << a.s_log) + c;
+            K = K_uniform;
+        } else {
+            rho = e & (R - 1);
+            c = e >> B;
+            K = (tile_id << log_c) + c;
+            idx = (K_to_hi(K, a) << B) + rho;
+        }
+        Fr x = (idx < a.in_len) ? fp_load(a.in + idx) : fp_zero<FrParams>();
+        if (a.has_pre3) {
+            uint32_t m = idx % 3;
+            if (m != 0) x = fp_mul(x, m == 1 ? a.pre3[1] : a.pre3[2]);
+        }
+        if (a.nprev != 0) {
+            // omega^(rho * S * K)
+            uint32_t ex = (uint32_t)(((uint64_t)rho * K) << a.s_log) & n_mask;
+            if (ex != 0) x = fp_mul(x, twiddle_pow(a, ex));
+        }
+        tile[(bitrev(rho, B) << log_c) + c] = x;
+    }
+    __syncthreads();
+
+    // ---- B radix-2 DIT stages in LDS
+    const uint32_t nbf = total >> 1;
+    for (uint32_t s = 0; s < B; s++) {
+        const uint32_t h = 1u << s;
+        for (uint32_t t = tid; t < nbf; t += nthreads) {
+            uint32_t c = t & (C - 1), b = t >> log_c;
+            uint32_t r = b & (h - 1);
+            uint32_t i = ((b >> s) << (s + 1)) | r;
+            Fr* pu = tile + ((i << log_c) + c);
+            Fr* pv = tile + (((i + h) << log_c) + c);
+            Fr u = *pu, v = *pv;
+            if (s != 0) v = fp_mul(v, twb[r << (B - 1 - s)]);
+            *pu = fp_add(u, v);
+            *pv = fp_sub(u, v);
+        }
+        __syncthreads();
+    }
+
+    // ---- store (+ post-scale on the final pass)
+    for (uint32_t e = tid; e < total; e += nthreads) {
+        uint32_t c = e & (C - 1), k = e >> log_c;
+        uint32_t idx;
+        if (!a.is_last)
+            idx = base + (k << a.s_log) + c;
+        else
+            idx = ((tile_id << log_c) + c) + (k << a.t_log);
+        Fr y = tile[(k << log_c) + c];
+        if (a.is_last && a.has_post3) {
+            uint32_t m = idx % 3;
+            y = fp_mul(y, m == 0 ? a.post3[0] : (m == 1 ? a.post3[1] : a.post3[2]));
+        }
+        fp_store(a.out + idx, y);
+    }
+}
+
+// ---------------------------------------------------------------- plans
+static std::string plan_key(uint32_t log_n, const uint64_t omega[4]) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "%u:%016llx%016llx%016llx%016llx", log_n, (unsigned long long)omega[3],
+             (unsigned long long)omega[2], (unsigned long long)omega[1], (unsigned long long)omega[0]);
+    return buf;
+}
+
+Fr fr_from_u64x4(const uint64_t v[4]) {
+    Fr r;
+    for (int i = 0; i < 4; i++) {
+        r.l[2 * i] = (uint32_t)v[i];
+        r.l[2 * i + 1] = (uint32_t)(v[i] >> 32);
+    }
+    return r;
+}
+
+void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits) {
+    bits.clear();
+    if (log_n == 0) return;
+    uint32_t P = (log_n + 7) / 8;  // <= 8 bits per pass on average
+    uint32_t base = log_n / P, extra = log_n % P;
+    for (uint32_t p = 0; p < P; p++) bits.push_back(base + (p < extra ? 1 : 0));
+}
+
+NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream) {
+    std::string key = plan_key(log_n, omega);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) return it->second;
+
+    NttPlan* pl = new NttPlan();
+    pl->log_n = log_n;
+    ntt_split(log_n, pl->bits);
+    Fr w = fr_from_u64x4(omega);
+    const uint32_t n = 1u << log_n;
+    uint32_t lo_count = n < (1u << LO_BITS) ? n : (1u << LO_BITS);
+    uint32_t hi_count = log_n > LO_BITS ? (n >> LO_BITS) : 0;
+    size_t total = lo_count + hi_count;
+    std::vector<uint32_t> bf_off;
+    for (uint32_t b : pl->bits) {
+        bf_off.push_back((uint32_t)total);
+        total += (1u << b) >> 1 ? (1u << b) >> 1 : 1;
+    }
+    H2_HIP(hipMalloc(&pl->tables, total * sizeof(Fr)));
+    pl->tw_lo = pl->tables;
+    pl->tw_hi = pl->tables + lo_count;
+    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, pl->tables, w, 1u, lo_count);
+    if (hi_count)
+        hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, pl->tables + lo_count, w,
+                           1u << LO_BITS, hi_count);
+    for (size_t p = 0; p < pl->bits.size(); p++) {
+        uint32_t R = 1u << pl->bits[p], half = R >> 1;
+        pl->tw_bfly.push_back(pl->tables + bf_off[p]);
+        if (half)
+            hipLaunchKernelGGL(k_pow_table, dim3((half + 255) / 256), dim3(256), 0, stream, pl->tables + bf_off[p], w,
+                               n >> pl->bits[p], half);
+    }
+    H2_HIP(hipGetLastError());
+    ctx->plans[key] = pl;
+    return pl;
+}
+
+// Runs the transform.  `src` (in_len valid elements, zero-extended to n) -> result in `dst`.
+// `tmp` is an n-element scratch; src may equal dst (then tmp must be distinct from both).
+static void set_scale3(PassArgs& a, const Fr* pre3, const Fr* post3) {
+    a.has_pre3 = pre3 != nullptr;
+    a.has_post3 = post3 != nullptr;
+    for (int i = 0; i < 3; i++) {
+        if (pre3) a.pre3[i] = pre3[i];
+        if (post3) a.post3[i] = post3[i];
+    }
+}
+
+void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const Fr* pre3,
+             const Fr* post3, hipStream_t stream) {
+    const uint32_t L = pl->log_n;
+    if (L == 0) {
+        // n = 1: X[0] = x[0] (times post3[0])
+        PassArgs a{};
+        a.in = src; a.out = dst; a.tw_bfly = pl->tables; a.tw_lo = pl->tw_lo; a.tw_hi = pl->tw_hi;
+        set_scale3(a, pre3, post3); a.log_n = 0; a.B = 0; a.s_log = 0; a.t_log = 0; a.nprev = 0;
+        a.is_last = 1; a.in_len = in_len; a.log_c = 0;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(64), 2 * sizeof(Fr), stream, a);
+        H2_HIP(hipGetLastError());
+        return;
+    }
+    const size_t P = pl->bits.size();
+    // buffer chain: pass 0 reads src; intermediate passes run in place on `work`; last pass writes dst.
+    // With P == 1 the single (last) pass goes src -> dst through LDS (safe in place: one tile per DFT...
+    // but tiles of other DFTs do not exist when P == 1, so src == dst is fine).
+    Fr* work = (P >= 2) ? tmp : nullptr;
+    uint32_t consumed = 0;
+    for (size_t p = 0; p < P; p++) {
+        PassArgs a{};
+        const uint32_t B = pl->bits[p];
+        const bool last = (p + 1 == P);
+        a.in = (p == 0) ? src : work;
+        a.out = last ? dst : work;
+        a.tw_bfly = pl->tw_bfly[p];
+        a.tw_lo = pl->tw_lo;
+        a.tw_hi = pl->tw_hi;
+        set_scale3(a, (p == 0) ? pre3 : nullptr, last ? post3 : nullptr);
+        a.log_n = L;
+        a.B = B;
+        a.s_log = L - consumed - B;
+        a.t_log = consumed;
+        a.nprev = (uint32_t)p;
+        uint32_t t = 0;
+        for (size_t q = 0; q < p; q++) {
+            a.prevB[q] = pl->bits[q];
+            a.prevT[q] = t;
+            t += pl->bits[q];
+        }
+        a.is_last = last ? 1 : 0;
+        a.in_len = (p == 0) ? in_len : (1u << L);
+        // columns per tile: 4 (128 B segments) when the geometry allows it
+        uint32_t log_c = 2;
+        if (!last) {
+            if (a.s_log < log_c) log_c = a.s_log;
+        } else {
+            if (consumed < log_c) log_c = consumed;  // number of DFTs = 2^consumed
+        }
+        a.log_c = log_c;
+        uint32_t R = 1u << B, C = 1u << log_c;
+        uint32_t threads = (R >> 1) * C;
+        if (threads < 64) threads = 64;
+        uint32_t ntiles = (1u << L) / (R * C);
+        size_t lds = ((size_t)R * C + (R >> 1) + 1) * sizeof(Fr);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(ntiles), dim3(threads), lds, stream, a);
+        consumed += B;
+    }
+    H2_HIP(hipGetLastError());
+}
+
+}  // namespace h2

@@ -1,0 +1,137 @@
+/*
+ * halo2_hip.h -- C ABI of libhalo2_hip.so: the MI355X (gfx950) drop-in for the `cuda`
+ * feature of halo2_proofs (DelphinusLab/halo2-gpu-specific).
+ *
+ * Every entry point replaces one `#[cfg(feature = "cuda")]` call site of the reference
+ * (file:line under /root/reference/halo2_proofs/src/, cited per function).  The Rust side
+ * keeps its generic signatures and forwards the transmuted slices (exactly what it hands to
+ * ec-gpu-gen today, arithmetic.rs:156-161,351-352,391-394,507-508); see INTEGRATION.md.
+ *
+ * Conventions
+ *   Fr            32 B = 4 x u64 little-endian limbs, Montgomery form (R = 2^256)
+ *   G1Affine      64 B = {x: Fq, y: Fq} Montgomery, identity = (0, 0)
+ *   G1 (result)   96 B = Jacobian {x, y, z: Fq} Montgomery, identity has z = 0
+ *   return value  0 = H2_OK, non-zero = error; h2_last_error() gives the text.  The
+ *                 reference unwrap()s its GPU Results (arithmetic.rs:358,360,509), so the
+ *                 Rust shim panics on non-zero.
+ *   threading     every function may be called concurrently from any thread (rayon workers);
+ *                 host-buffer calls take a device from the blocking pool sized by
+ *                 HALO2_PROOFS_N_GPU (plonk/prover.rs:56-74; arithmetic.rs:314-331).
+ *   h2_dev_*      operate on HIP device pointers on the caller's stream (void* = hipStream_t,
+ *                 NULL = the library's stream for the current device) and do not synchronise.
+ */
+#ifndef HALO2_HIP_H
+#define HALO2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    H2_OK = 0,
+    H2_ERR_INVALID = 1,
+    H2_ERR_NO_DEVICE = 2,
+    H2_ERR_HIP = 3,
+    H2_ERR_OOM = 4
+};
+
+/* ---- library / device pool ------------------------------------------------------------ */
+int h2_version(void);
+/* Device::all().len() clipped by HALO2_PROOFS_N_GPU -- plonk/prover.rs:57-70 */
+int h2_device_count(void);
+const char *h2_last_error(void);
+/* blocks until all work queued by this library on every pooled device has finished */
+int h2_synchronize(void);
+
+/* ---- NTT (host buffers) ---------------------------------------------------------------- */
+/* best_fft -> gpu_fft: arithmetic.rs:546-554, :495-512.  a: 2^log_n Fr, in place. */
+int h2_ntt(uint64_t *a, const uint64_t omega[4], uint32_t log_n);
+/* gpu_ifft: arithmetic.rs:515-534 (EvaluationDomain::ifft, poly/domain.rs:400-414).
+ * a <- NTT(a, omega_inv) * divisor. */
+int h2_intt(uint64_t *a, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n);
+/* EvaluationDomain::coeff_to_extended: poly/domain.rs:270-287 (+ distribute_powers_zeta :382-398).
+ * coeffs: 2^k Fr (read only); out: 2^extended_k Fr. */
+int h2_coeff_to_extended(const uint64_t *coeffs, uint64_t *out, uint32_t k, uint32_t extended_k,
+                         const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                         const uint64_t extended_omega[4]);
+/* EvaluationDomain::extended_to_coeff: poly/domain.rs:328-350.  a: 2^extended_k Fr (read only);
+ * out: out_len = n * quotient_poly_degree Fr (the truncation of :346-347). */
+int h2_extended_to_coeff(const uint64_t *a, uint64_t *out, size_t out_len, uint32_t extended_k,
+                         const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                         const uint64_t extended_omega_inv[4], const uint64_t extended_ifft_divisor[4]);
+
+/* ---- MSM (host buffers) ---------------------------------------------------------------- */
+/* gpu_multiexp_single_gpu_with_bound: arithmetic.rs:334-367 (kern.multiexp_bound :360).
+ * Only the low max_bits bits of each canonical scalar are used (callers guarantee the rest
+ * are zero: plonk/prover.rs:237-254).  max_bits == 0 or n == 0 -> identity (:346, :421). */
+int h2_msm(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+/* gpu_multiexp_bound: arithmetic.rs:413-440 -- contiguous ceil(n/N_GPU) chunks, one pooled
+ * device each, partial points summed on the host. */
+int h2_msm_multi(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+/* gpu_multiexp_bound_and_fft: arithmetic.rs:375-410 (Params::commit_lagrange_and_ifft,
+ * poly/commitment.rs:148-170): MSM over `bases` and, sharing the one upload, scalars <-
+ * NTT(scalars, omega_inv) * divisor. */
+int h2_msm_intt(uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max_bits,
+                const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n, uint64_t out_xyz[12]);
+
+/* ---- Montgomery conversion (host buffers) ------------------------------------------------ */
+/* gpu_mont / gpu_unmont: arithmetic.rs:263-306, :218-261 (kernels batch_mont / batch_unmont) */
+int h2_batch_mont(uint64_t *a, size_t n);
+int h2_batch_unmont(uint64_t *a, size_t n);
+
+/* ---- elementwise polynomial kernels (host buffers) ---------------- */
+enum {
+    H2_OP_MUL_C = 0,    /* res[i] = l[i+l_rot] * c          eval_mul_c   evaluation_gpu.rs:669,1034 */
+    H2_OP_SUM_C = 1,    /* res[i] = l[i+l_rot] + c          eval_sum_c   evaluation_gpu.rs:560,668  */
+    H2_OP_SUM = 2,      /* res[i] = l[i+l_rot] + r[i+r_rot] eval_sum     evaluation_gpu.rs:279-305  */
+    H2_OP_MUL = 3,      /* res[i] = l[i+l_rot] * r[i+r_rot] eval_mul     evaluation_gpu.rs:622-648  */
+    H2_OP_SUB = 4,      /* res[i] = l[i+l_rot] - r[i+r_rot] Polynomial - poly.rs:205-217            */
+    H2_OP_LCTHETA = 5,  /* res = l*c + r                    eval_lctheta evaluation_gpu.rs:148-163  */
+    H2_OP_LCBETA = 6,   /* res = (l + c) * r                eval_lcbeta  evaluation_gpu.rs:202-217  */
+    H2_OP_ADDGAMMA = 7, /* res = l + c                      eval_addgamma evaluation_gpu.rs:246-259 */
+    H2_OP_CONSTANT = 8  /* res = c                          eval_constant evaluation_gpu.rs:579-585 */
+};
+/* Rotations are signed element offsets taken modulo size (evaluation.rs:40-42).  res may alias
+ * l or r when that operand's rotation is 0 (evaluation_gpu.rs:631-639).  Unused operands NULL. */
+int h2_eval_op(int op, uint64_t *res, const uint64_t *l, const uint64_t *r, int32_t l_rot, int32_t r_rot,
+               size_t size, const uint64_t c[4]);
+/* EvaluationDomain::divide_by_vanishing_poly: poly/domain.rs:354-373: a[i] *= t_evals[i % t_len] */
+int h2_divide_by_vanishing_poly(uint64_t *a, size_t size, const uint64_t *t_evaluations, size_t t_len);
+
+/* ---- device-resident entry points ---------------------------------------------------------- */
+/* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for
+ * log_n <= 8).  Results land in d_a (in place from the caller's view). */
+int h2_dev_ntt(void *d_a, void *d_tmp, const uint64_t omega[4], uint32_t log_n, void *stream);
+int h2_dev_intt(void *d_a, void *d_tmp, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n,
+                void *stream);
+int h2_dev_coeff_to_extended(const void *d_coeffs, void *d_out, void *d_tmp, uint32_t k, uint32_t extended_k,
+                             const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                             const uint64_t extended_omega[4], void *stream);
+int h2_dev_extended_to_coeff(void *d_a, void *d_tmp, uint32_t extended_k, const uint64_t g_coset[4],
+                             const uint64_t g_coset_inv[4], const uint64_t extended_omega_inv[4],
+                             const uint64_t extended_ifft_divisor[4], void *stream);
+/* MSM over device-resident scalars and bases.  d_scratch/scratch_bytes: device workspace sized by
+ * h2_msm_scratch_bytes(n, max_bits).  out_xyz is HOST memory: the call synchronises `stream` to
+ * read back the per-window partial sums (<= a few KB) and finishes the window combine on the host. */
+size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits);
+int h2_dev_msm(const void *d_scalars, const void *d_bases, size_t n, uint32_t max_bits, void *d_scratch,
+               size_t scratch_bytes, uint64_t out_xyz[12], void *stream);
+int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,
+                   const uint64_t c[4], void *stream);
+int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);
+int h2_dev_batch_mont(void *d_a, size_t n, void *stream);
+int h2_dev_batch_unmont(void *d_a, size_t n, void *stream);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
+/* Wall time in ms of the last timed region recorded with HIP events on `stream`:
+ * h2_timer_start / h2_timer_stop bracket any sequence of h2_dev_* calls on that stream. */
+int h2_timer_start(void *stream);
+int h2_timer_stop(void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO2_HIP_H */

@@ -1,0 +1,284 @@
+"""GPU parity: the HIP path (through the C ABI, libhalo2_hip.so) against the CPU oracle and
+the committed golden vectors.  Bit-exact: everything here is integer / finite-field work.
+MSM results are compared after affine normalisation (the reference's own `==` on C::Curve is
+projective-aware, poly/commitment.rs:494)."""
+import numpy as np
+import pytest
+
+import halo2_gpu_specific_amd as h2
+from halo2_gpu_specific_amd import arithmetic as ar
+from h2util import (
+    Q_MOD,
+    R_MOD,
+    arr_to_points,
+    from_mont,
+    fr_mont,
+    golden_points,
+    h2i,
+    ints_to_arr,
+    load_golden,
+    points_to_arr,
+    to_mont,
+)
+
+pytestmark = pytest.mark.gpu
+
+S = 28
+ROOT = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+
+
+def omega_for(log_n):
+    return pow(ROOT, 1 << (S - log_n), R_MOD)
+
+
+def test_device_visible():
+    assert h2.lib().h2_device_count() >= 1
+
+
+# ------------------------------------------------------------------ Montgomery conversion
+def test_batch_mont_unmont():
+    vals = [0, 1, 2, R_MOD - 1, R_MOD - 2, (1 << 253) + 12345, 0xDEADBEEF << 100] + [
+        (i * 0x9E3779B97F4A7C15F39CC0605CEDC834) % R_MOD for i in range(1, 300)
+    ]
+    a = ints_to_arr(vals)
+    ar.gpu_mont(a)
+    assert from_mont(a) == vals
+    assert np.array_equal(a, to_mont(vals))
+    ar.gpu_unmont(a)
+    assert np.array_equal(a, ints_to_arr(vals))
+
+
+# ------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("size", [1, 7, 256, 1000, 1 << 14])
+def test_eval_ops(oracle, size):
+    l = oracle.random_fr(11, size)
+    r = oracle.random_fr(12, size)
+    c = oracle.random_fr(13, 1)[0]
+    rots = [(0, 0), (1, -1), (-3, 5), (size - 1, -(size - 1))]
+    for op in range(9):
+        for l_rot, r_rot in rots:
+            l_rot, r_rot = (l_rot % size if l_rot > 0 else -((-l_rot) % size)), (r_rot % size if r_rot > 0 else -((-r_rot) % size))
+            want = oracle.eval_op(op, l, r, l_rot, r_rot, c)
+            need_r = op in (ar.OP_SUM, ar.OP_MUL, ar.OP_SUB, ar.OP_LCTHETA, ar.OP_LCBETA)
+            got = ar.eval_op(op, l if op != ar.OP_CONSTANT else None, r if need_r else None, l_rot, r_rot, c, size=size)
+            assert np.array_equal(got, want), (op, l_rot, r_rot)
+
+
+def test_eval_op_edge_values(oracle):
+    vals = [0, 1, R_MOD - 1, R_MOD - 2, 2, (R_MOD + 1) // 2]
+    l = to_mont(vals)
+    r = to_mont(list(reversed(vals)))
+    for op in (ar.OP_SUM, ar.OP_SUB, ar.OP_MUL):
+        assert np.array_equal(ar.eval_op(op, l, r), oracle.eval_op(op, l, r, 0, 0, None))
+
+
+def test_divide_by_vanishing(oracle):
+    d, t = oracle.domain(5, 6)
+    a = oracle.random_fr(21, 1 << d.extended_k)
+    want = a.copy()
+    oracle.lib.oracle_divide_by_vanishing_poly(want.ctypes.data, len(want), t.ctypes.data, len(t), 4)
+    got = ar.divide_by_vanishing_poly(a.copy(), t)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ NTT
+def test_ntt_golden():
+    for case in load_golden("ntt_kat.json"):
+        log_n = case["log_n"]
+        x = to_mont([h2i(v) for v in case["input"]])
+        out = ar.best_fft(x.copy(), fr_mont(h2i(case["omega"])), log_n)
+        assert from_mont(out) == [h2i(v) for v in case["output"]], log_n
+        back = ar.gpu_ifft(out, fr_mont(h2i(case["omega_inv"])), log_n, fr_mont(h2i(case["n_inv"])))
+        assert np.array_equal(back, x), log_n
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 21)))
+def test_ntt_vs_oracle(oracle, log_n):
+    n = 1 << log_n
+    x = oracle.random_fr(100 + log_n, n)
+    w = fr_mont(omega_for(log_n))
+    want = oracle.best_fft(x, w, log_n)
+    got = ar.best_fft(x.copy(), w, log_n)
+    assert np.array_equal(got, want)
+
+
+def test_ntt_edge_inputs(oracle):
+    log_n = 10
+    n = 1 << log_n
+    w = fr_mont(omega_for(log_n))
+    zeros = np.zeros((n, 4), dtype=np.uint64)
+    assert not ar.best_fft(zeros.copy(), w, log_n).any()
+    delta = zeros.copy()
+    delta[0] = fr_mont(1)
+    out = ar.best_fft(delta, w, log_n)  # DFT of a delta is all ones
+    assert np.array_equal(out, np.tile(fr_mont(1), (n, 1)))
+    big = to_mont([R_MOD - 1] * n)
+    assert np.array_equal(ar.best_fft(big.copy(), w, log_n), oracle.best_fft(big, w, log_n))
+
+
+def test_ntt_linearity(oracle):
+    log_n = 16
+    n = 1 << log_n
+    w = fr_mont(omega_for(log_n))
+    a, b = oracle.random_fr(1, n), oracle.random_fr(2, n)
+    c = oracle.random_fr(3, 1)[0]
+    fa, fb = ar.best_fft(a.copy(), w, log_n), ar.best_fft(b.copy(), w, log_n)
+    comb = oracle.eval_op(ar.OP_LCTHETA, a, b, 0, 0, c)  # a*c + b
+    want = oracle.eval_op(ar.OP_LCTHETA, fa, fb, 0, 0, c)
+    assert np.array_equal(ar.best_fft(comb, w, log_n), want)
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_ntt_full_size(oracle, log_n):
+    """BASELINE config 3: 2^24 forward + inverse; forward output == oracle on all elements."""
+    n = 1 << log_n
+    x = oracle.random_fr(0x48414C4F32 + 1, n)
+    w = fr_mont(omega_for(log_n))
+    want = oracle.best_fft(x, w, log_n)
+    got = ar.best_fft(x.copy(), w, log_n)
+    assert np.array_equal(got, want)
+    back = ar.gpu_ifft(got, fr_mont(pow(omega_for(log_n), -1, R_MOD)), log_n, fr_mont(pow(n, -1, R_MOD)))
+    assert np.array_equal(back, x)
+
+
+def test_coset_golden(oracle):
+    for case in load_golden("coset_kat.json"):
+        d, _ = oracle.domain(case["j"], case["k"])
+        coeffs = to_mont([h2i(v) for v in case["coeffs"]])
+        ext = ar.coeff_to_extended(coeffs, d.k, d.extended_k, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega"))
+        assert from_mont(ext) == [h2i(v) for v in case["extended"]]
+        back = ar.extended_to_coeff(
+            ext, d.k, d.extended_k, d.quotient_poly_degree, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega_inv"),
+            d.fr("extended_ifft_divisor"),
+        )
+        assert np.array_equal(back[: 1 << d.k], coeffs) and not back[1 << d.k :].any()
+
+
+@pytest.mark.parametrize("j,k", [(3, 10), (5, 12), (4, 15), (2, 9), (9, 11)])
+def test_coset_vs_oracle(oracle, j, k):
+    d, _ = oracle.domain(j, k)
+    coeffs = oracle.random_fr(j * 100 + k, 1 << k)
+    want = oracle.coeff_to_extended(coeffs, d)
+    got = ar.coeff_to_extended(coeffs, d.k, d.extended_k, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega"))
+    assert np.array_equal(got, want)
+    ext = oracle.random_fr(j * 1000 + k, 1 << d.extended_k)  # arbitrary extended-domain values
+    want_c = oracle.extended_to_coeff(ext, d)
+    got_c = ar.extended_to_coeff(
+        ext, d.k, d.extended_k, d.quotient_poly_degree, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega_inv"),
+        d.fr("extended_ifft_divisor"),
+    )
+    assert np.array_equal(got_c, want_c)
+
+
+# ------------------------------------------------------------------ MSM
+def _affine(oracle, jac):
+    return arr_to_points(oracle.to_affine(jac))[0]
+
+
+def test_msm_golden(oracle):
+    for case in load_golden("msm_kat.json"):
+        scalars = to_mont([h2i(s) for s in case["scalars"]]).reshape(-1, 4)
+        pts = points_to_arr(golden_points(case["points"])).reshape(-1, 8)
+        want = golden_points([case["result"]])[0]
+        got = _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, 254))
+        assert got == want, case["name"]
+        got = _affine(oracle, ar.gpu_multiexp_bound(scalars, pts, 254))
+        assert got == want, case["name"] + " (multi)"
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 5, 10, 14, 16])
+def test_msm_vs_oracle(oracle, log_n):
+    n = 1 << log_n
+    scalars = oracle.random_fr(500 + log_n, n)
+    pts = oracle.random_g1(600 + log_n, n)
+    want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+    assert _affine(oracle, ar.best_multiexp(scalars, pts)) == want
+
+
+def test_msm_ragged_sizes(oracle):
+    for n in (3, 33, 1000, 4097, 70001):
+        scalars = oracle.random_fr(n, n)
+        pts = oracle.random_g1(n + 1, n)
+        want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+        assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, 254)) == want, n
+
+
+def test_msm_max_bits_bound(oracle):
+    """advice-column shape: all scalars < 2^16, max_bits = 16 (plonk/prover.rs:286,296-297)"""
+    n = 1 << 14
+    vals = [(i * 2654435761) % (1 << 16) for i in range(n)]
+    scalars = to_mont(vals)
+    pts = oracle.random_g1(77, n)
+    want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+    for bits in (16, 17, 64, 254):
+        assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, bits)) == want, bits
+    ident = ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, 0)  # arithmetic.rs:346
+    assert _affine(oracle, ident) == (0, 0)
+
+
+def test_msm_skewed_and_adversarial(oracle):
+    n = 1 << 13
+    pts = oracle.random_g1(88, n)
+    cases = {
+        "boolean": [i & 1 for i in range(n)],
+        "all_ones": [1] * n,
+        "all_same": [0x1234567] * n,
+        "zero_one_rm1": [(0, 1, R_MOD - 1)[i % 3] for i in range(n)],
+        "half_zero": [0 if i % 2 else (i * 0x9E3779B97F4A7C15F39CC0605CEDC835) % R_MOD for i in range(n)],
+    }
+    for name, vals in cases.items():
+        scalars = to_mont(vals)
+        want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+        assert _affine(oracle, ar.best_multiexp(scalars, pts)) == want, name
+    # repeated points and P / -P pairs
+    rep = np.tile(pts[:4], (n // 4, 1))
+    neg = rep.copy()
+    ys = [(-y) % Q_MOD for _, y in arr_to_points(rep[:4])]
+    neg_y = to_mont(ys, Q_MOD)
+    neg[1::2, 4:] = np.tile(neg_y[1::2], (n // 4, 1))[: len(neg[1::2])]
+    scalars = oracle.random_fr(99, n)
+    for name, b in (("repeated", rep), ("neg_pairs", neg)):
+        want = _affine(oracle, oracle.best_multiexp(scalars, b))
+        assert _affine(oracle, ar.best_multiexp(scalars, b)) == want, name
+    same = to_mont([5] * n)
+    assert _affine(oracle, ar.best_multiexp(same, neg)) == _affine(oracle, oracle.best_multiexp(same, neg))
+
+
+def test_msm_linearity(oracle):
+    """size-independent property: MSM(a + b, P) == MSM(a, P) + MSM(b, P)"""
+    n = 1 << 15
+    pts = oracle.random_g1(5, n)
+    a, b = oracle.random_fr(6, n), oracle.random_fr(7, n)
+    ab = oracle.eval_op(ar.OP_SUM, a, b, 0, 0, None)
+    ra, rb, rab = ar.best_multiexp(a, pts), ar.best_multiexp(b, pts), ar.best_multiexp(ab, pts)
+    s = np.zeros(12, dtype=np.uint64)
+    oracle.lib.oracle_g1_add(ra.ctypes.data, rb.ctypes.data, s.ctypes.data)
+    assert _affine(oracle, s) == _affine(oracle, rab)
+
+
+def test_msm_2_20(oracle):
+    """BASELINE config 2: 2^20 random scalars / points, bit-exact vs the oracle"""
+    n = 1 << 20
+    scalars = oracle.random_fr(0x48414C4F32, n)
+    pts = oracle.random_g1(0x48414C4F32, n)
+    want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+    assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, 254)) == want
+
+
+def test_commit_lagrange_and_ifft(oracle):
+    """gpu_multiexp_bound_and_fft (arithmetic.rs:375-410) + the relational KAT of
+    poly/commitment.rs:481-495: commit(ifft(a)) == commit_lagrange(a)."""
+    k = 8
+    n = 1 << k
+    case_s = fr_mont(0x1234567890ABCDEF1234567890ABCDEF)
+    g = np.zeros((n, 8), dtype=np.uint64)
+    gl = np.zeros((n, 8), dtype=np.uint64)
+    oracle.lib.oracle_unsafe_setup(k, case_s.ctypes.data, g.ctypes.data, gl.ctypes.data)
+    d, _ = oracle.domain(1, k)
+    a = to_mont(list(range(n)))  # commitment.rs:489-491
+    vals = a.copy()
+    c_lagrange = ar.gpu_multiexp_bound_and_fft(vals, gl, 254, d.fr("omega_inv"), d.fr("ifft_divisor"), k)
+    assert np.array_equal(vals, oracle.ifft(a, d.fr("omega_inv"), k, d.fr("ifft_divisor")))
+    c_coeff = ar.best_multiexp(vals, g)
+    assert _affine(oracle, c_lagrange) == _affine(oracle, c_coeff)
+    assert _affine(oracle, c_lagrange) == _affine(oracle, oracle.best_multiexp(a, gl))
