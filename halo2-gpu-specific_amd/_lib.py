@@ -38,6 +38,7 @@ SYMBOLS = {
     "h2_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
     "h2_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),
     "h2_msm_multi": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),
+    "h2_g1_sum": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_msm_intt": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _u32, _vp]),
     "h2_batch_mont": (ctypes.c_int, [_vp, _sz]),
     "h2_batch_unmont": (ctypes.c_int, [_vp, _sz]),
@@ -48,11 +49,13 @@ SYMBOLS = {
     "h2_dev_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "h2_dev_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "h2_msm_scratch_bytes": (_sz, [_sz, _u32]),
+    "h2_msm_shape": (ctypes.c_int, [_sz, _u32, _vp, _vp, _vp]),
     "h2_dev_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
     "h2_dev_eval_op": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i32, _i32, _sz, _vp, _vp]),
     "h2_dev_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "h2_dev_batch_mont": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_batch_unmont": (ctypes.c_int, [_vp, _sz, _vp]),
+    "h2_dev_random_points": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
     "h2_timer_start": (ctypes.c_int, [_vp]),
     "h2_timer_stop": (ctypes.c_int, [_vp, _fp]),
 }

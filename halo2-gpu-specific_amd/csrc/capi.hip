@@ -231,6 +231,12 @@ int h2_msm(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t ma
     });
 }
 
+int h2_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) {
+    if (!out_xyz || (count && !points_xyz)) return bad("h2_g1_sum: null argument");
+    g1_sum_host(points_xyz, count, out_xyz);
+    return H2_OK;
+}
+
 int h2_msm_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]) {
     if (!out_xyz || (n && (!scalars || !bases))) return bad("h2_msm_multi: null argument");
     return guarded([&] {
@@ -320,6 +326,10 @@ int h2_dev_extended_to_coeff(void* d_a, void* d_tmp, uint32_t extended_k, const 
 }
 
 size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits) { return msm_scratch_bytes(n, max_bits); }
+int h2_msm_shape(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
+    msm_shape_query(n, max_bits, c, windows, buckets_per_window);
+    return H2_OK;
+}
 
 int h2_dev_msm(const void* d_scalars, const void* d_bases, size_t n, uint32_t max_bits, void* d_scratch,
                size_t scratch_bytes, uint64_t out_xyz[12], void* stream) {
@@ -328,6 +338,14 @@ int h2_dev_msm(const void* d_scalars, const void* d_bases, size_t n, uint32_t ma
         DeviceCtx* ctx = current_ctx();
         return msm_device(ctx, (const Fr*)d_scalars, (const uint64_t*)d_bases, n, max_bits, d_scratch, scratch_bytes,
                           out_xyz, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
+    if (!d_out && n) return bad("h2_dev_random_points: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return random_points_launch(seed, n, (uint64_t*)d_out, pick_stream(ctx, stream));
     });
 }
 

@@ -96,6 +96,12 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
 }
 
 size_t msm_scratch_bytes(size_t n, uint32_t max_bits) { return msm_shape(n, max_bits).total; }
+void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
+    MsmShape s = msm_shape(n, max_bits);
+    if (c) *c = s.c;
+    if (windows) *windows = s.W;
+    if (buckets_per_window) *buckets_per_window = s.nb;
+}
 
 // ---------------------------------------------------------------- k_digits
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
@@ -316,6 +322,57 @@ __global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32
     if (tid == 0) xyzz_store(winpart + (size_t)w * G + g, sh[0]);
 }
 
+// ---------------------------------------------------------------- synthetic bases (bench / tests)
+// n deterministic G1 points by try-and-increment: x = mix(seed, i), y = (x^3 + 3)^((q+1)/4) when that
+// is a square root (q = 3 mod 4).  Cofactor 1: every curve point is in G1.  Not part of the prover
+// path; it exists so bench.py can build its workload without touching the CPU oracle.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_random_points(uint64_t seed, size_t n, Affine* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // (q + 1) / 4, little-endian u32 limbs
+    const uint32_t E[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u,
+                           0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    uint64_t st = seed ^ (0xd1342543de82ef95ull * (uint64_t)(i + 1));
+    Fq x;
+    for (int k = 0; k < 4; k++) {
+        uint64_t v = splitmix64(st);
+        x.l[2 * k] = (uint32_t)v;
+        x.l[2 * k + 1] = (uint32_t)(v >> 32);
+    }
+    x.l[7] &= 0x1fffffffu;  // < 2^253 < q: a valid Montgomery residue
+    Fq three = fp_add(fp_add(fp_one<FqParams>(), fp_one<FqParams>()), fp_one<FqParams>());
+    for (;;) {
+        Fq rhs = fp_add(fp_mul(fp_sqr(x), x), three);
+        Fq y = fp_one<FqParams>();
+        for (int bit = 253; bit >= 0; bit--) {
+            y = fp_sqr(y);
+            if ((E[bit >> 5] >> (bit & 31)) & 1) y = fp_mul(y, rhs);
+        }
+        if (fp_eq(fp_sqr(y), rhs)) {
+            if (splitmix64(st) & 1) y = fp_neg(y);
+            fp_store(&out[i].x, x);
+            fp_store(&out[i].y, y);
+            return;
+        }
+        x = fp_add(x, fp_one<FqParams>());
+    }
+}
+
+int random_points_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_random_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seed, n,
+                       (Affine*)d_out);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 // ---------------------------------------------------------------- drivers
 void msm_identity(uint64_t out_xyz[12]) {
     Jacobian j = xyzz_to_jacobian(xyzz_identity());
@@ -431,11 +488,18 @@ int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uin
             set_last_error(errs[p]);
             return rcs[p];
         }
-    // host fold of Jacobian partials (converted through XYZZ: ZZ = Z^2, ZZZ = Z^3)
+    g1_sum_host(parts[0].data(), nparts, out_xyz);
+    return H2_OK;
+}
+
+// host fold of `count` Jacobian points (12 x u64 each) -- the `reduce(|acc, x| acc + x)` of
+// arithmetic.rs:434 and the local add after an all-gather of per-rank partial points.
+// Jacobian (X, Y, Z) -> XYZZ (X, Y, Z^2, Z^3).
+void g1_sum_host(const uint64_t* points, size_t count, uint64_t out_xyz[12]) {
     XYZZ acc = xyzz_identity();
-    for (size_t p = 0; p < nparts; p++) {
+    for (size_t p = 0; p < count; p++) {
         Jacobian j;
-        memcpy(&j, parts[p].data(), 96);
+        memcpy(&j, points + 12 * p, 96);
         XYZZ q;
         q.x = j.x;
         q.y = j.y;
@@ -445,7 +509,6 @@ int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uin
     }
     Jacobian j = xyzz_to_jacobian(acc);
     memcpy(out_xyz, &j, 96);
-    return H2_OK;
 }
 
 }  // namespace h2

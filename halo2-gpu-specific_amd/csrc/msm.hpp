@@ -4,6 +4,8 @@
 
 namespace h2 {
 size_t msm_scratch_bytes(size_t n, uint32_t max_bits);
+void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window);
+void g1_sum_host(const uint64_t* points, size_t count, uint64_t out_xyz[12]);
 void msm_identity(uint64_t out_xyz[12]);
 // device-resident scalars + bases; result to host memory (synchronises `stream` for the final
 // W*G-point read-back and the host-side window combine)
@@ -14,4 +16,5 @@ int msm_host(DeviceCtx* ctx, const uint64_t* scalars, const uint64_t* bases, siz
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n,
                               uint32_t max_bits, uint64_t out_xyz[12]);
 int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+int random_points_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream);
 }  // namespace h2

@@ -71,6 +71,10 @@ int h2_msm(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t ma
 /* gpu_multiexp_bound: arithmetic.rs:413-440 -- contiguous ceil(n/N_GPU) chunks, one pooled
  * device each, partial points summed on the host. */
 int h2_msm_multi(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+/* Host-side fold of `count` partial results (12 x u64 Jacobian each): the
+ * `.reduce(|acc, x| acc + x)` of arithmetic.rs:433-435; also used after an all-gather of per-rank
+ * partial points when one MSM is split across processes (one process per GPU). */
+int h2_g1_sum(const uint64_t *points_xyz, size_t count, uint64_t out_xyz[12]);
 /* gpu_multiexp_bound_and_fft: arithmetic.rs:375-410 (Params::commit_lagrange_and_ifft,
  * poly/commitment.rs:148-170): MSM over `bases` and, sharing the one upload, scalars <-
  * NTT(scalars, omega_inv) * divisor. */
@@ -117,6 +121,8 @@ int h2_dev_extended_to_coeff(void *d_a, void *d_tmp, uint32_t extended_k, const 
  * h2_msm_scratch_bytes(n, max_bits).  out_xyz is HOST memory: the call synchronises `stream` to
  * read back the per-window partial sums (<= a few KB) and finishes the window combine on the host. */
 size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits);
+/* the Pippenger shape the library will use: window bits c, number of windows, buckets per window */
+int h2_msm_shape(size_t n, uint32_t max_bits, uint32_t *c, uint32_t *windows, uint32_t *buckets_per_window);
 int h2_dev_msm(const void *d_scalars, const void *d_bases, size_t n, uint32_t max_bits, void *d_scratch,
                size_t scratch_bytes, uint64_t out_xyz[12], void *stream);
 int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,
@@ -124,6 +130,10 @@ int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);
 int h2_dev_batch_mont(void *d_a, size_t n, void *stream);
 int h2_dev_batch_unmont(void *d_a, size_t n, void *stream);
+
+/* ---- synthetic workload (bench.py / tests; not a reference entry point) --------------------- */
+/* n deterministic valid G1Affine points (try-and-increment on y^2 = x^3 + 3) into d_out (n x 64 B). */
+int h2_dev_random_points(uint64_t seed, size_t n, void *d_out, void *stream);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
 /* Wall time in ms of the last timed region recorded with HIP events on `stream`:

@@ -1,0 +1,54 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the split-MSM exchange (all-gather of per-rank
+partial points + local fold, parallel.allgather_fold) and the per-column sharding plan.  The per-rank
+partial points come from the CPU oracle here (there is no GPU); on the GPU box the same code path is
+fed by h2_msm and runs over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+from h2util import ROOT
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from halo2_gpu_specific_amd import parallel
+from h2util import Oracle, arr_to_points
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+oracle = Oracle.get()
+n = 1000
+s, p = oracle.random_fr(5, n), oracle.random_g1(6, n)
+lo, hi = parallel.msm_split_range(n, world, rank)
+partial = oracle.best_multiexp(s[lo:hi], p[lo:hi], threads=1)
+full = parallel.allgather_fold(partial)
+want = arr_to_points(oracle.to_affine(oracle.best_multiexp(s, p, threads=2)))[0]
+assert arr_to_points(oracle.to_affine(full))[0] == want, "rank %%d: folded MSM differs" %% rank
+cols = parallel.shard_columns(7, world, rank)
+t = torch.zeros(7, dtype=torch.int64); t[cols] = 1
+dist.all_reduce(t)
+assert t.tolist() == [1] * 7
+# bench-style timing reduction: max over ranks
+m = torch.tensor([float(rank + 1)], dtype=torch.float64); dist.all_reduce(m, op=dist.ReduceOp.MAX)
+assert m.item() == world
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_split_msm_allgather_world2(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "OK %d" % rank in out
