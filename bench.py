@@ -220,16 +220,27 @@ def main():
         clog = min(log_n, 22)
         x = oracle.random_fr(7, 1 << clog)
         wc = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - clog), R_MOD))
-        oracle.best_fft(x, wc, clog, threads=cores)  # warm-up
+        # libgomp does not always scale to every hardware thread: probe a few team sizes once, then
+        # time the best one (`cores` in the report = the threads actually used)
+        best_t, best_th = None, cores
+        for th in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32)}, reverse=True):
+            c0 = time.perf_counter()
+            oracle.best_fft(x, wc, clog, threads=th)
+            dt = time.perf_counter() - c0
+            if best_t is None or dt < best_t:
+                best_t, best_th = dt, th
+            if time.perf_counter() - c0 > 20:
+                break
         reps, c0 = 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - c0 < 5.0 and reps < 20):
-            oracle.best_fft(x, wc, clog, threads=cores)
+        while reps < 3 and (time.perf_counter() - c0) < 15.0:
+            oracle.best_fft(x, wc, clog, threads=best_th)
             reps += 1
-        ct = (time.perf_counter() - c0) / reps
+        ct = (time.perf_counter() - c0) / max(reps, 1)
         out["cpu_baseline"] = {
             "value": 3 * ((1 << clog) // 2) * clog / ct,
             "unit": "Fr-ops/s",
-            "cores": cores,
+            "cores": best_th,
+            "host_threads_available": cores,
             "kind": "port",
             "sample": "oracle best_fft (C restatement of arithmetic.rs:556-705, OpenMP tasks ~ rayon) on one forward "
             "2^%d NTT, %d reps, %.3f s each (includes the oracle wrapper's input copy)" % (clog, reps, ct),

@@ -380,7 +380,11 @@ static void recursive_butterfly_arithmetic(u256 *a, size_t n, size_t twiddle_chu
     const size_t chunk_size = 512;
     if (n > (chunk_size << 2) && level < 4) { /* :676-691 par_chunks_mut(512) */
         size_t nchunks = (m + chunk_size - 1) / chunk_size;
-#pragma omp taskloop default(shared) grainsize(1)
+        /* rayon splits par_chunks_mut adaptively; libgomp's single task queue does not scale to
+         * 15-us tasks on 100+ threads, so hand it ~4 tasks per thread instead of one per chunk */
+        size_t ntasks = (size_t)omp_get_num_threads() * 4;
+        if (ntasks > nchunks) ntasks = nchunks;
+#pragma omp taskloop default(shared) num_tasks(ntasks)
         for (size_t i = 0; i < nchunks; i++) {
             size_t lo = i * chunk_size, hi = lo + chunk_size < m ? lo + chunk_size : m;
             for (size_t j = lo; j < hi; j++) butterfly(&left[j], &right[j], &twiddles[(j + 1) * twiddle_chunk]);
