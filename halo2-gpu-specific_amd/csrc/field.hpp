@@ -9,8 +9,8 @@
 //
 // The multiplier is a product-scanning (Comba) Montgomery multiplication built on
 // v_mad_u64_u32 with its carry-out routed through an SGPR pair into one v_addc_co_u32,
-// i.e. 1 quarter-rate multiply-add + 1 full-rate add per 32x32 partial product
-// (136 mads per modular multiplication).  No MFMA: there is no dense contraction here.
+// i.e. 1 half-rate multiply-add + 1 full-rate add per 32x32 partial product (136 mads per
+// modular multiplication; measured chip ceiling 1.31e11 multiplications/s, profiles/r1_mulbench.txt).  No MFMA: there is no dense contraction here.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -171,10 +171,10 @@ H2_DEV void mad_acc(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 // Montgomery product a*b*R^-1 mod p, product scanning (FIPS) form.
 template <class P>
 H2_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
-    uint32_t m[8];
     Fp<P> r;
     uint64_t lo = 0;
     uint32_t hi = 0;
+    uint32_t m[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll

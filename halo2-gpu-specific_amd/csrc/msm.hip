@@ -8,16 +8,21 @@
 //
 // Pipeline (one stream, no host round trip until the final 1-2 KB read-back):
 //   k_digits      scalar -> canonical (one Montgomery mul), signed c-bit digits, bucket histogram
-//   k_scan        exclusive scans: entries per bucket, 32-entry segments per bucket
+//   k_scan_*      3-launch exclusive scan of the histogram -> bucket start offsets
 //   k_scatter     counting sort of (point index, sign) by (window, bucket)
-//   k_acc_seg     one thread per (bucket, segment): <= 32 mixed XYZZ additions        [hot loop]
-//   k_finish      per bucket: fold its segment partials (serial when few, else queued)
+//   k_acc_slice   one thread per fixed-size SLICE of the sorted list: exactly S mixed XYZZ
+//                 additions per lane whatever the bucket sizes are; a partial sum is emitted at
+//                 every bucket boundary inside the slice                              [hot loop]
+//   k_finish      per bucket: fold its slice partials (serial when few, else queued)
 //   k_finish_heavy one workgroup per heavy bucket: strided fold + LDS tree
 //   k_reduce      per window: sum_b (b+1) * B_b by chunked running sums + small scalar mul + LDS tree
 //   host          adds the <= W*G partial window sums and runs the W*c doublings (Horner)
-// Splitting buckets into fixed 32-entry segments keeps the hot loop load-balanced for the
-// skewed digit distributions real witness columns have (boolean / small-valued columns put
-// most points into a handful of buckets -- SURVEY.md section 7 "hard parts (ii)").
+// Slicing the *sorted list* evenly (instead of giving each bucket to a thread) keeps every lane of
+// the hot loop busy for any digit distribution: Poisson-sized buckets of a uniform MSM as well as
+// the skewed columns real witnesses have (boolean / small-valued columns put most points into a
+// handful of buckets -- SURVEY.md section 7 "hard parts (ii)").  The partial of (bucket b, slice s)
+// lives in slot b + s: along the sorted list either b or s grows at every emission, so slots are
+// unique, a bucket's partials are contiguous, and no second prefix sum is needed.
 #include <algorithm>
 #include <array>
 #include <cstdlib>
@@ -30,18 +35,20 @@
 
 namespace h2 {
 
-static constexpr uint32_t SEG = 32;          // entries per accumulation segment
 static constexpr uint32_t FINISH_SERIAL = 8; // partials a single thread folds in k_finish
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 256;    // threads per k_reduce workgroup
 static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce thread
+static constexpr uint32_t SCAN_CHUNK = 4096;  // histogram entries per k_scan_local workgroup (256 threads x 16)
 
 struct MsmShape {
     uint32_t c, W, nb, nbt, G;  // window bits, windows, buckets/window, total buckets, reduce groups/window
+    uint32_t log_s;             // slice length S = 2^log_s entries
+    uint32_t scan_blocks;
     size_t n, entries, max_items;
     // scratch offsets (bytes)
-    size_t off_keys, off_sorted, off_counts, off_starts, off_cursor, off_segstarts, off_heavy, off_partials,
+    size_t off_keys, off_sorted, off_counts, off_starts, off_cursor, off_blocksums, off_heavy, off_partials,
         off_buckets, off_winpart, total;
 };
 
@@ -74,7 +81,15 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     uint32_t per_group = REDUCE_T * REDUCE_M;
     s.G = (s.nb + per_group - 1) / per_group;
     s.entries = n * s.W;
-    s.max_items = s.entries / SEG + s.nbt + 1;
+    // slice length: aim at >= 2^18 slices (one resident round of the chip at 4 waves/SIMD), 8 <= S <= 64
+    s.log_s = 6;
+    while (s.log_s > 3 && (s.entries >> s.log_s) < (1u << 18)) s.log_s--;
+    if (const char* env = getenv("H2_MSM_SLICE_LOG")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 10) s.log_s = (uint32_t)v;
+    }
+    s.scan_blocks = (s.nbt + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    s.max_items = (s.entries >> s.log_s) + s.nbt + 2;
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t r = o;
@@ -86,7 +101,7 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     s.off_counts = take(((size_t)s.nbt + 2) * 4);
     s.off_starts = take(((size_t)s.nbt + 2) * 4);
     s.off_cursor = take(((size_t)s.nbt + 2) * 4);
-    s.off_segstarts = take(((size_t)s.nbt + 2) * 4);
+    s.off_blocksums = take(((size_t)s.scan_blocks + 2) * 4);
     s.off_heavy = take(((size_t)s.nbt + 2) * 4);
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
@@ -103,12 +118,40 @@ void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows
     if (buckets_per_window) *buckets_per_window = s.nb;
 }
 
+// ---------------------------------------------------------------- wave-aggregated atomics
+// atomicAdd(&counter[key], 1) for every `valid` lane, returning the lane's slot.  Lanes of a wave that
+// share a key are served by ONE atomic (up to 4 distinct hot keys per call are aggregated, the rest fall
+// back to per-lane atomics): a column of equal / boolean scalars would otherwise serialise hundreds of
+// thousands of atomics on a single address.
+__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* counter, uint32_t key, bool valid) {
+    const uint32_t lane = __lane_id();
+    uint64_t todo = __ballot(valid);
+    uint32_t pos = 0;
+    bool done = !valid;
+#pragma unroll 1
+    for (int it = 0; it < 4 && todo != 0; it++) {
+        int leader = __ffsll((unsigned long long)todo) - 1;
+        uint32_t lkey = __shfl(key, leader, 64);
+        uint64_t same = __ballot(!done && key == lkey);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counter[lkey], (uint32_t)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (!done && key == lkey) {
+            pos = base + (uint32_t)__popcll(same & (((uint64_t)1 << lane) - 1));
+            done = true;
+        }
+        todo &= ~same;
+    }
+    if (!done) pos = atomicAdd(&counter[key], 1u);
+    return pos;
+}
+
 // ---------------------------------------------------------------- k_digits
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
                                                 uint32_t max_bits, uint32_t* keys, uint32_t* counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr s = fp_from_mont(fp_load(scalars + i));  // canonical little-endian integer (to_repr, arithmetic.rs:21)
+    const bool live = i < n;  // dead lanes still walk the windows: wave_agg_inc needs the whole wave
+    Fr s = live ? fp_from_mont(fp_load(scalars + i)) : fp_zero<FrParams>();  // canonical LE integer (to_repr, arithmetic.rs:21)
     // keep only the low max_bits bits (multiexp_bound contract)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -133,12 +176,10 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             carry = 0;
         }
         uint32_t out = KEY_INVALID;
-        if (mag != 0) {
-            uint32_t key = w * nb + (mag - 1);
-            atomicAdd(&counts[key], 1u);
-            out = key | neg;
-        }
-        keys[(size_t)w * n + i] = out;
+        uint32_t key = w * nb + (mag - 1);
+        if (mag != 0) out = key | neg;
+        wave_agg_inc(counts, key, mag != 0);
+        if (live) keys[(size_t)w * n + i] = out;
         w++;
     };
 #pragma unroll
@@ -157,121 +198,145 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
     }
 }
 
-// ---------------------------------------------------------------- k_scan (single workgroup)
-// starts[b] = sum_{b'<b} counts[b'];  segstarts[b] = sum_{b'<b} ceil(counts[b']/SEG);  cursor = starts.
-// Arrays have nbt + 1 entries (the last holds the totals).
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* counts, uint32_t nbt, uint32_t* starts,
-                                               uint32_t* cursor, uint32_t* segstarts) {
-    __shared__ uint32_t sh_a[1024], sh_b[1024];
-    __shared__ uint32_t base_a, base_b;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        base_a = 0;
-        base_b = 0;
+// ---------------------------------------------------------------- k_scan_* (3 launches)
+// starts[b] = sum_{b'<b} counts[b'] for b in [0, nbt]; cursor = starts (scatter write heads).
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total) {
+    // inclusive scan inside each wave64 with shuffles, then across the 4 waves through LDS
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= (uint32_t)off) x += y;
     }
+    if (lane == 63) sh[wave] = x;
     __syncthreads();
-    const uint32_t ITEMS = 4, CHUNK = 1024 * ITEMS;
-    for (uint32_t c0 = 0; c0 < nbt + 1; c0 += CHUNK) {
-        uint32_t va[ITEMS], vb[ITEMS], sa = 0, sb = 0;
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += sh[w];
+    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* counts, uint32_t nbt, uint32_t* starts,
+                                                    uint32_t* blocksums) {
+    __shared__ uint32_t sh[4];
+    const uint32_t ITEMS = SCAN_CHUNK / 256;
+    uint32_t base_idx = blockIdx.x * SCAN_CHUNK + threadIdx.x * ITEMS;
+    uint32_t v[SCAN_CHUNK / 256], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < ITEMS; k++) {
-            uint32_t idx = c0 + tid * ITEMS + k;
-            uint32_t cnt = (idx < nbt) ? counts[idx] : 0;
-            va[k] = sa;
-            vb[k] = sb;
-            sa += cnt;
-            sb += (cnt + SEG - 1) / SEG;
-        }
-        sh_a[tid] = sa;
-        sh_b[tid] = sb;
-        __syncthreads();
-        // Hillis-Steele inclusive scan over the 1024 thread totals
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t xa = 0, xb = 0;
-            if (tid >= off) {
-                xa = sh_a[tid - off];
-                xb = sh_b[tid - off];
-            }
-            __syncthreads();
-            sh_a[tid] += xa;
-            sh_b[tid] += xb;
-            __syncthreads();
-        }
-        uint32_t ea = base_a + sh_a[tid] - sa, eb = base_b + sh_b[tid] - sb;  // exclusive prefix of this thread
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        uint32_t idx = base_idx + k;
+        uint32_t c = (idx < nbt) ? counts[idx] : 0;
+        v[k] = sum;
+        sum += c;
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
 #pragma unroll
-        for (uint32_t k = 0; k < ITEMS; k++) {
-            uint32_t idx = c0 + tid * ITEMS + k;
-            if (idx <= nbt) {
-                starts[idx] = ea + va[k];
-                cursor[idx] = ea + va[k];
-                segstarts[idx] = eb + vb[k];
-            }
-        }
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        uint32_t idx = base_idx + k;
+        if (idx <= nbt) starts[idx] = ex + v[k];
+    }
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of the block sums in place (nblocks <= a few thousand)
+__global__ void __launch_bounds__(256) k_scan_blocks(uint32_t* blocksums, uint32_t nblocks) {
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nblocks; c0 += 256) {
+        uint32_t idx = c0 + threadIdx.x;
+        uint32_t v = idx < nblocks ? blocksums[idx] : 0;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan_256(v, sh, &total);
+        if (idx < nblocks) blocksums[idx] = carry + ex;
         __syncthreads();
-        if (tid == 1023) {
-            base_a += sh_a[1023];
-            base_b += sh_b[1023];
-        }
+        if (threadIdx.x == 0) carry += total;
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* starts, uint32_t* cursor, const uint32_t* blocksums,
+                                                  uint32_t nbt) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx > nbt) return;
+    uint32_t v = starts[idx] + blocksums[idx / SCAN_CHUNK];
+    starts[idx] = v;
+    cursor[idx] = v;
 }
 
 // ---------------------------------------------------------------- k_scatter
 __global__ void __launch_bounds__(256) k_scatter(const uint32_t* keys, size_t n, uint32_t* cursor, uint32_t* sorted) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     uint32_t w = blockIdx.y;
-    uint32_t key = keys[(size_t)w * n + i];
-    if (key == KEY_INVALID) return;
-    uint32_t pos = atomicAdd(&cursor[key & ~SIGN_BIT], 1u);
-    sorted[pos] = (uint32_t)i | (key & SIGN_BIT);
+    uint32_t key = (i < n) ? keys[(size_t)w * n + i] : KEY_INVALID;
+    bool valid = key != KEY_INVALID;
+    uint32_t pos = wave_agg_inc(cursor, key & ~SIGN_BIT, valid);
+    if (valid) sorted[pos] = (uint32_t)i | (key & SIGN_BIT);
 }
 
-// ---------------------------------------------------------------- k_acc_seg (hot loop)
-__global__ void __launch_bounds__(256) k_acc_seg(const Affine* bases, const uint32_t* sorted, const uint32_t* starts,
-                                                 const uint32_t* segstarts, uint32_t nbt, XYZZ* partials) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t total_items = segstarts[nbt];
-    if (t >= total_items) return;
-    // bucket = largest b with segstarts[b] <= t  (binary search; the table is L2-resident)
-    uint32_t lo = 0, hi = nbt;  // invariant: segstarts[lo] <= t < segstarts[hi]
+// ---------------------------------------------------------------- k_acc_slice (hot loop)
+__global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const uint32_t* sorted, const uint32_t* starts,
+                                                   uint32_t nbt, uint32_t log_s, XYZZ* partials) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // slice index
+    const uint32_t total = starts[nbt];                        // number of (non-zero digit) entries
+    uint32_t e = s << log_s;
+    if (e >= total) return;
+    uint32_t end = e + (1u << log_s);
+    if (end > total) end = total;
+    // bucket of the first entry: largest b with starts[b] <= e (ties -> the last one, which is non-empty)
+    uint32_t lo = 0, hi = nbt;  // invariant: starts[lo] <= e < starts[hi]
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
-        if (segstarts[mid] <= t)
+        if (starts[mid] <= e)
             lo = mid;
         else
             hi = mid;
     }
-    uint32_t b = lo, j = t - segstarts[b];
-    uint32_t e0 = starts[b] + j * SEG, e1 = starts[b + 1];
-    if (e1 > e0 + SEG) e1 = e0 + SEG;
+    uint32_t b = lo;
+    uint32_t bnext = starts[b + 1];  // first entry of the next non-empty bucket
     XYZZ acc = xyzz_identity();
-    for (uint32_t e = e0; e < e1; e++) {
+    for (; e < end; e++) {
+        if (e == bnext) {  // bucket boundary inside the slice (rare: once per ~n/2^(c-1) entries)
+            xyzz_store(partials + (b + s), acc);
+            acc = xyzz_identity();
+            do {
+                b++;
+                bnext = starts[b + 1];
+            } while (bnext == e);  // skip empty buckets
+        }
         uint32_t ref = sorted[e];
         Affine p = affine_load(bases + (ref & ~SIGN_BIT));
         acc = xyzz_madd(acc, p, (ref & SIGN_BIT) != 0);
     }
-    xyzz_store(partials + t, acc);
+    xyzz_store(partials + (b + s), acc);
 }
 
 // ---------------------------------------------------------------- k_finish / k_finish_heavy
-__global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint32_t* segstarts, uint32_t nbt,
-                                                XYZZ* buckets, uint32_t* heavy_list, uint32_t* heavy_count) {
+// bucket b's partials are slots b + first .. b + last, first/last = slices of its first/last entry
+__global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint32_t* starts, uint32_t nbt,
+                                                uint32_t log_s, XYZZ* buckets, uint32_t* heavy_list,
+                                                uint32_t* heavy_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbt) return;
-    uint32_t p0 = segstarts[b], p1 = segstarts[b + 1];
-    uint32_t np = p1 - p0;
-    if (np > FINISH_SERIAL) {
-        heavy_list[atomicAdd(heavy_count, 1u)] = b;
-        return;
-    }
+    uint32_t e0 = starts[b], e1 = starts[b + 1];
     XYZZ acc = xyzz_identity();
-    if (np >= 1) acc = xyzz_load(partials + p0);
-    for (uint32_t p = p0 + 1; p < p1; p++) acc = xyzz_add(acc, xyzz_load(partials + p));
+    if (e1 > e0) {
+        uint32_t first = e0 >> log_s, last = (e1 - 1) >> log_s;
+        if (last - first + 1 > FINISH_SERIAL) {
+            heavy_list[atomicAdd(heavy_count, 1u)] = b;
+            return;
+        }
+        acc = xyzz_load(partials + (b + first));
+        for (uint32_t sl = first + 1; sl <= last; sl++) acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
+    }
     xyzz_store(buckets + b, acc);
 }
 
-__global__ void __launch_bounds__(256) k_finish_heavy(const XYZZ* partials, const uint32_t* segstarts,
+__global__ void __launch_bounds__(256) k_finish_heavy(const XYZZ* partials, const uint32_t* starts, uint32_t log_s,
                                                       const uint32_t* heavy_list, const uint32_t* heavy_count,
                                                       XYZZ* buckets) {
     __shared__ XYZZ sh[256];
@@ -279,9 +344,9 @@ __global__ void __launch_bounds__(256) k_finish_heavy(const XYZZ* partials, cons
     uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
-        uint32_t p0 = segstarts[b], p1 = segstarts[b + 1];
+        uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
         XYZZ acc = xyzz_identity();
-        for (uint32_t p = p0 + tid; p < p1; p += 256) acc = xyzz_add(acc, xyzz_load(partials + p));
+        for (uint32_t sl = first + tid; sl <= last; sl += 256) acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
         sh[tid] = acc;
         __syncthreads();
         for (uint32_t off = 128; off >= 1; off >>= 1) {
@@ -386,7 +451,7 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
     uint32_t* counts = (uint32_t*)(scratch + s.off_counts);
     uint32_t* starts = (uint32_t*)(scratch + s.off_starts);
     uint32_t* cursor = (uint32_t*)(scratch + s.off_cursor);
-    uint32_t* segstarts = (uint32_t*)(scratch + s.off_segstarts);
+    uint32_t* blocksums = (uint32_t*)(scratch + s.off_blocksums);
     uint32_t* heavy = (uint32_t*)(scratch + s.off_heavy);  // [0] = count, [1..] = list
     XYZZ* partials = (XYZZ*)(scratch + s.off_partials);
     XYZZ* buckets = (XYZZ*)(scratch + s.off_buckets);
@@ -397,13 +462,17 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
     unsigned nblk = (unsigned)((s.n + 255) / 256);
     hipLaunchKernelGGL(k_digits, dim3(nblk), dim3(256), 0, stream, d_scalars, s.n, s.c, s.W, s.nb,
                        max_bits > 254 ? 254u : max_bits, keys, counts);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, counts, s.nbt, starts, cursor, segstarts);
+    hipLaunchKernelGGL(k_scan_local, dim3(s.scan_blocks), dim3(256), 0, stream, counts, s.nbt, starts, blocksums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, stream, blocksums, s.scan_blocks);
+    hipLaunchKernelGGL(k_scan_add, dim3((s.nbt + 1 + 255) / 256), dim3(256), 0, stream, starts, cursor, blocksums, s.nbt);
     hipLaunchKernelGGL(k_scatter, dim3(nblk, s.W), dim3(256), 0, stream, keys, s.n, cursor, sorted);
-    unsigned iblk = (unsigned)((s.max_items + 255) / 256);
-    hipLaunchKernelGGL(k_acc_seg, dim3(iblk), dim3(256), 0, stream, d_bases, sorted, starts, segstarts, s.nbt, partials);
-    hipLaunchKernelGGL(k_finish, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, segstarts, s.nbt, buckets,
-                       heavy + 1, heavy);
-    hipLaunchKernelGGL(k_finish_heavy, dim3(1024), dim3(256), 0, stream, partials, segstarts, heavy + 1, heavy, buckets);
+    unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
+    hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
+                       s.log_s, partials);
+    hipLaunchKernelGGL(k_finish, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
+                       buckets, heavy + 1, heavy);
+    hipLaunchKernelGGL(k_finish_heavy, dim3(1024), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1, heavy,
+                       buckets);
     hipLaunchKernelGGL(k_reduce, dim3(s.G, s.W), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
     H2_HIP(hipGetLastError());
 }

@@ -38,6 +38,12 @@ __global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, uint32_t mu
     fp_store(out + i, fp_pow_u32(base, i * mul));
 }
 
+// out[i] = in[i] * d
+__global__ void __launch_bounds__(256) k_scale_table(Fr* out, const Fr* in, Fr d, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) fp_store(out + i, fp_mul(fp_load(in + i), d));
+}
+
 // ---------------------------------------------------------------- the pass kernel
 struct PassArgs {
     const Fr* in;
@@ -45,9 +51,10 @@ struct PassArgs {
     const Fr* tw_bfly;  // R/2 entries: (w^(n/R))^e
     const Fr* tw_lo;    // min(n, 4096) entries: w^i
     const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
+    uint32_t hi_scaled;  // tw_hi already carries the uniform post-scale (1/n): never skip, no post multiply
     Fr pre3[3];         // has_pre3: x *= pre3[idx % 3] on the first-pass load (idx % 3 == 0 skipped)
     Fr post3[3];        // has_post3: y *= post3[idx % 3] on the final store
-    uint32_t has_pre3, has_post3;
+    uint32_t has_pre3, has_post3, post3_uniform;
     uint32_t log_n, B, s_log, t_log;
     uint32_t nprev;       // number of earlier passes
     uint32_t prevB[4];    // their bit widths
@@ -87,15 +94,31 @@ __device__ __forceinline__ Fr twiddle_pow(const PassArgs& a, uint32_t e) {
 
 extern __shared__ __attribute__((aligned(16))) uint4 h2_smem[];
 
+// LDS tiles keep the two 16-byte halves of an element in separate planes: a wave then reads 16 B at a
+// 16-B lane stride (conflict-free ds_read_b128) instead of 16 B at a 32-B stride (2-way conflicts).
+__device__ __forceinline__ Fr lds_get(const uint4* lo, const uint4* hi, uint32_t i) {
+    uint4 a = lo[i], b = hi[i];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const Fr& v) {
+    lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
 __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
-    Fr* tile = reinterpret_cast<Fr*>(h2_smem);
     const uint32_t B = a.B, R = 1u << B, log_c = a.log_c, C = 1u << log_c;
-    Fr* twb = tile + (R << log_c);  // R/2 butterfly twiddles
+    uint4* t_lo = h2_smem;                  // R*C low halves
+    uint4* t_hi = t_lo + (R << log_c);      // R*C high halves
+    uint4* w_lo = t_hi + (R << log_c);      // R/2 butterfly twiddles, low / high halves
+    uint4* w_hi = w_lo + (R >> 1) + 1;
     const uint32_t nthreads = blockDim.x;  // == max(R/2 * C, 1)
     const uint32_t tid = threadIdx.x;
     const uint32_t n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
 
-    for (uint32_t i = tid; i < (R >> 1); i += nthreads) twb[i] = fp_load(a.tw_bfly + i);
+    for (uint32_t i = tid; i < (R >> 1); i += nthreads) lds_put(w_lo, w_hi, i, fp_load(a.tw_bfly + i));
 
     const uint32_t tile_id = blockIdx.x;
     const uint32_t total = R << log_c;
@@ -133,9 +156,9 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
         if (a.nprev != 0) {
             // omega^(rho * S * K)
             uint32_t ex = (uint32_t)(((uint64_t)rho * K) << a.s_log) & n_mask;
-            if (ex != 0) x = fp_mul(x, twiddle_pow(a, ex));
+            if (ex != 0 || a.hi_scaled) x = fp_mul(x, twiddle_pow(a, ex));
         }
-        tile[(bitrev(rho, B) << log_c) + c] = x;
+        lds_put(t_lo, t_hi, (bitrev(rho, B) << log_c) + c, x);
     }
     __syncthreads();
 
@@ -143,16 +166,28 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
     const uint32_t nbf = total >> 1;
     for (uint32_t s = 0; s < B; s++) {
         const uint32_t h = 1u << s;
+        const uint32_t log_per = (B - 1 + log_c) - s;  // butterflies that share one twiddle index r: 2^log_per
+        const bool by_r = s != 0 && log_per >= 6 && (nthreads & 63) == 0;
         for (uint32_t t = tid; t < nbf; t += nthreads) {
-            uint32_t c = t & (C - 1), b = t >> log_c;
-            uint32_t r = b & (h - 1);
-            uint32_t i = ((b >> s) << (s + 1)) | r;
-            Fr* pu = tile + ((i << log_c) + c);
-            Fr* pv = tile + (((i + h) << log_c) + c);
-            Fr u = *pu, v = *pv;
-            if (s != 0) v = fp_mul(v, twb[r << (B - 1 - s)]);
-            *pu = fp_add(u, v);
-            *pv = fp_sub(u, v);
+            uint32_t c, r, i;
+            if (by_r) {
+                // early stages: order the butterflies by twiddle index so r is uniform across a wave and the
+                // r == 0 waves (twiddle 1) skip the multiplication: 1/2, 1/4, 1/8 ... of stages 1, 2, 3 ...
+                r = t >> log_per;
+                uint32_t j = t & ((1u << log_per) - 1);
+                c = j & (C - 1);
+                i = ((j >> log_c) << (s + 1)) | r;
+            } else {
+                c = t & (C - 1);
+                uint32_t b = t >> log_c;
+                r = b & (h - 1);
+                i = ((b >> s) << (s + 1)) | r;
+            }
+            const uint32_t iu = (i << log_c) + c, iv = ((i + h) << log_c) + c;
+            Fr u = lds_get(t_lo, t_hi, iu), v = lds_get(t_lo, t_hi, iv);
+            if (s != 0 && !(by_r && r == 0)) v = fp_mul(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
+            lds_put(t_lo, t_hi, iu, fp_add(u, v));
+            lds_put(t_lo, t_hi, iv, fp_sub(u, v));
         }
         __syncthreads();
     }
@@ -165,14 +200,15 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
             idx = base + (k << a.s_log) + c;
         else
             idx = ((tile_id << log_c) + c) + (k << a.t_log);
-        Fr y = tile[(k << log_c) + c];
-        if (a.is_last && a.has_post3) {
+        Fr y = lds_get(t_lo, t_hi, (k << log_c) + c);
+        if (a.is_last && a.has_post3 && !a.hi_scaled) {
             uint32_t m = idx % 3;
             y = fp_mul(y, m == 0 ? a.post3[0] : (m == 1 ? a.post3[1] : a.post3[2]));
         }
         fp_store(a.out + idx, y);
     }
 }
+
 
 // ---------------------------------------------------------------- plans
 static std::string plan_key(uint32_t log_n, const uint64_t omega[4]) {
@@ -194,9 +230,10 @@ Fr fr_from_u64x4(const uint64_t v[4]) {
 void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits) {
     bits.clear();
     if (log_n == 0) return;
-    uint32_t P = (log_n + 7) / 8;  // <= 8 bits per pass on average
-    uint32_t base = log_n / P, extra = log_n % P;
-    for (uint32_t p = 0; p < P; p++) bits.push_back(base + (p < extra ? 1 : 0));
+    // as many 8-bit passes as possible, the remainder first (it needs no inter-pass twiddle)
+    uint32_t rem = log_n % 8;
+    if (rem) bits.push_back(rem);
+    for (uint32_t p = 0; p < log_n / 8; p++) bits.push_back(8);
 }
 
 NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream) {
@@ -241,6 +278,7 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
 static void set_scale3(PassArgs& a, const Fr* pre3, const Fr* post3) {
     a.has_pre3 = pre3 != nullptr;
     a.has_post3 = post3 != nullptr;
+    a.post3_uniform = post3 && fp_eq(post3[0], post3[1]) && fp_eq(post3[0], post3[2]);
     for (int i = 0; i < 3; i++) {
         if (pre3) a.pre3[i] = pre3[i];
         if (post3) a.post3[i] = post3[i];
@@ -256,7 +294,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         a.in = src; a.out = dst; a.tw_bfly = pl->tables; a.tw_lo = pl->tw_lo; a.tw_hi = pl->tw_hi;
         set_scale3(a, pre3, post3); a.log_n = 0; a.B = 0; a.s_log = 0; a.t_log = 0; a.nprev = 0;
         a.is_last = 1; a.in_len = in_len; a.log_c = 0;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(64), 2 * sizeof(Fr), stream, a);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
         H2_HIP(hipGetLastError());
         return;
     }
@@ -289,20 +327,42 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         }
         a.is_last = last ? 1 : 0;
         a.in_len = (p == 0) ? in_len : (1u << L);
-        // columns per tile: 4 (128 B segments) when the geometry allows it
-        uint32_t log_c = 2;
-        if (!last) {
-            if (a.s_log < log_c) log_c = a.s_log;
-        } else {
-            if (consumed < log_c) log_c = consumed;  // number of DFTs = 2^consumed
+        if (last && p > 0 && a.post3_uniform && L > LO_BITS) {
+            // iNTT: fold the divisor into the high twiddle table used by the last pass's inter-pass twiddles
+            char key[80];
+            snprintf(key, sizeof key, "%08x%08x%08x%08x%08x%08x%08x%08x", post3[0].l[7], post3[0].l[6], post3[0].l[5],
+                     post3[0].l[4], post3[0].l[3], post3[0].l[2], post3[0].l[1], post3[0].l[0]);
+            Fr* scaled = nullptr;
+            {
+                std::lock_guard<std::mutex> g(pl->mu);
+                auto it = pl->scaled_hi.find(key);
+                if (it == pl->scaled_hi.end()) {
+                    uint32_t cnt = (1u << L) >> LO_BITS;
+                    H2_HIP(hipMalloc(&scaled, cnt * sizeof(Fr)));
+                    hipLaunchKernelGGL(k_scale_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, scaled, pl->tw_hi,
+                                       post3[0], cnt);
+                    pl->scaled_hi[key] = scaled;
+                } else {
+                    scaled = it->second;
+                }
+            }
+            a.tw_hi = scaled;
+            a.hi_scaled = 1;
         }
-        a.log_c = log_c;
-        uint32_t R = 1u << B, C = 1u << log_c;
-        uint32_t threads = (R >> 1) * C;
-        if (threads < 64) threads = 64;
-        uint32_t ntiles = (1u << L) / (R * C);
-        size_t lds = ((size_t)R * C + (R >> 1) + 1) * sizeof(Fr);
-        hipLaunchKernelGGL(k_ntt_pass, dim3(ntiles), dim3(threads), lds, stream, a);
+        {
+            // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
+            uint32_t log_c = (B < 8) ? (10 - B) : 2;
+            uint32_t avail = last ? consumed : a.s_log;  // last pass: number of DFTs = 2^consumed
+            if (avail < log_c) log_c = avail;
+            a.log_c = log_c;
+            uint32_t R = 1u << B, C = 1u << log_c;
+            uint32_t threads = (R >> 1) * C;
+            if (threads < 64) threads = 64;
+            if (threads > 512) threads = 512;
+            uint32_t ntiles = (1u << L) / (R * C);
+            size_t lds = ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
+            hipLaunchKernelGGL(k_ntt_pass, dim3(ntiles), dim3(threads), lds, stream, a);
+        }
         consumed += B;
     }
     H2_HIP(hipGetLastError());

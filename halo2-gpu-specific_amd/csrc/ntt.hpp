@@ -13,6 +13,8 @@ struct NttPlan {
     const Fr* tw_lo = nullptr;         // w^i,        i < min(n, 4096)
     const Fr* tw_hi = nullptr;         // w^(i<<12),  i < n >> 12
     std::vector<const Fr*> tw_bfly;    // per pass: (w^(n/R))^e, e < R/2
+    std::mutex mu;                     // guards scaled_hi
+    std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)
 };
 
 void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits);

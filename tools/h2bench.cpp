@@ -1,0 +1,221 @@
+// tools/h2bench.cpp -- C++ timing harness over the C ABI (no Python/torch start-up cost).
+// Build: make -C tools     Run on the GPU box: ./tools/h2bench [ntt LOGN REPS] [msm LOGN BITS REPS] [eval LOGN REPS]
+// Every leg checks a size-independent property (round trip / repeatability) so a timing is never
+// reported for a wrong result.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/halo2_hip.h"
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+#define H2(x)                                                     \
+    do {                                                          \
+        int rc_ = (x);                                            \
+        if (rc_ != 0) {                                           \
+            printf("h2 error %d: %s (%s)\n", rc_, h2_last_error(), #x); \
+            exit(1);                                              \
+        }                                                         \
+    } while (0)
+
+typedef unsigned __int128 u128;
+static const uint64_t RMOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const uint64_t RINV = 0xc2e1f593efffffffULL;
+static const uint64_t RR[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+static const uint64_t ROOT_CANON[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
+
+// minimal host Fr (only to derive omega / omega^-1 / n^-1 for the harness)
+static void fr_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t t[6] = {0};
+    for (int i = 0; i < 4; i++) {
+        u128 acc;
+        uint64_t c = 0;
+        for (int j = 0; j < 4; j++) { acc = (u128)a[j] * b[i] + t[j] + c; t[j] = (uint64_t)acc; c = (uint64_t)(acc >> 64); }
+        acc = (u128)t[4] + c; t[4] = (uint64_t)acc; t[5] = (uint64_t)(acc >> 64);
+        uint64_t m = t[0] * RINV;
+        acc = (u128)m * RMOD[0] + t[0]; c = (uint64_t)(acc >> 64);
+        for (int j = 1; j < 4; j++) { acc = (u128)m * RMOD[j] + t[j] + c; t[j - 1] = (uint64_t)acc; c = (uint64_t)(acc >> 64); }
+        acc = (u128)t[4] + c; t[3] = (uint64_t)acc; t[4] = t[5] + (uint64_t)(acc >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (t[i] > RMOD[i]) break; if (t[i] < RMOD[i]) { ge = false; break; } } }
+    if (ge) { u128 b = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - RMOD[i] - (uint64_t)b; t[i] = (uint64_t)d; b = (d >> 64) & 1; } }
+    memcpy(r, t, 32);
+}
+static void fr_pow(uint64_t r[4], const uint64_t a[4], const uint64_t e[4]) {
+    uint64_t one[4] = {1, 0, 0, 0}, acc[4];
+    fr_mul(acc, one, RR);  // Montgomery one
+    for (int i = 255; i >= 0; i--) {
+        fr_mul(acc, acc, acc);
+        if ((e[i / 64] >> (i % 64)) & 1) fr_mul(acc, acc, a);
+    }
+    memcpy(r, acc, 32);
+}
+static void fr_inv(uint64_t r[4], const uint64_t a[4]) {
+    uint64_t e[4] = {RMOD[0] - 2, RMOD[1], RMOD[2], RMOD[3]};
+    fr_pow(r, a, e);
+}
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void fill_random_fr(std::vector<uint64_t>& v, uint64_t seed) {
+    uint64_t s = seed;
+    for (size_t i = 0; i < v.size(); i++) {
+        s += 0x9e3779b97f4a7c15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        v[i] = z ^ (z >> 31);
+        if ((i & 3) == 3) v[i] &= 0x1fffffffffffffffULL;  // < r
+    }
+}
+
+static int bench_ntt(int log_n, int reps) {
+    size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> h(n * 4);
+    fill_random_fr(h, 1234);
+    uint64_t root[4], omega[4], omega_inv[4], nn[4] = {(uint64_t)n, 0, 0, 0}, n_m[4], n_inv[4];
+    fr_mul(root, ROOT_CANON, RR);
+    uint64_t e[4] = {(uint64_t)1 << (28 - log_n), 0, 0, 0};
+    fr_pow(omega, root, e);
+    fr_inv(omega_inv, omega);
+    fr_mul(n_m, nn, RR);
+    fr_inv(n_inv, n_m);
+    void *d_a, *d_t;
+    CK(hipMalloc(&d_a, n * 32));
+    CK(hipMalloc(&d_t, n * 32));
+    CK(hipMemcpy(d_a, h.data(), n * 32, hipMemcpyHostToDevice));
+    H2(h2_dev_ntt(d_a, d_t, omega, log_n, nullptr));
+    H2(h2_dev_intt(d_a, d_t, omega_inv, n_inv, log_n, nullptr));
+    H2(h2_synchronize());
+    float ms_f = 0, ms_i = 0;
+    H2(h2_timer_start(nullptr));
+    for (int r = 0; r < reps; r++) H2(h2_dev_ntt(d_a, d_t, omega, log_n, nullptr));
+    H2(h2_timer_stop(nullptr, &ms_f));
+    // reps forward transforms then reps inverse transforms compose to the identity only for reps == 1 per pair;
+    // undo by applying the inverse the same number of times (the NTT is a bijection, so this is exact)
+    H2(h2_timer_start(nullptr));
+    for (int r = 0; r < reps; r++) H2(h2_dev_intt(d_a, d_t, omega_inv, n_inv, log_n, nullptr));
+    H2(h2_timer_stop(nullptr, &ms_i));
+    std::vector<uint64_t> back(n * 4);
+    CK(hipMemcpy(back.data(), d_a, n * 32, hipMemcpyDeviceToHost));
+    bool ok = memcmp(back.data(), h.data(), n * 32) == 0;
+    double fr_ops = 3.0 * (n / 2) * log_n;
+    printf("ntt  log_n=%2d  fwd %8.3f ms  inv %8.3f ms  %.3e Fr-ops/s (fwd)  alg %.1f GB/s  roundtrip=%s\n", log_n,
+           ms_f / reps, ms_i / reps, fr_ops / (ms_f / reps * 1e-3), 64.0 * n * ((log_n + 11) / 12) / (ms_f / reps * 1e-3) / 1e9,
+           ok ? "ok" : "MISMATCH");
+    CK(hipFree(d_a));
+    CK(hipFree(d_t));
+    return ok ? 0 : 1;
+}
+
+static int bench_msm(int log_n, int bits, int reps, int mode) {
+    size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> h(n * 4);
+    fill_random_fr(h, 99);
+    if (mode == 1) {  // boolean column
+        for (size_t i = 0; i < n; i++) {
+            bool one = (h[4 * i] >> 7) & 1;
+            uint64_t v[4] = {one ? 1ull : 0ull, 0, 0, 0};
+            fr_mul(&h[4 * i], v, RR);
+        }
+    } else if (bits < 254) {  // canonical value < 2^bits, then to Montgomery
+        for (size_t i = 0; i < n; i++) {
+            uint64_t v[4] = {h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]};
+            for (int k = 0; k < 4; k++) {
+                int lo = 64 * k;
+                if (bits <= lo) v[k] = 0;
+                else if (bits < lo + 64) v[k] &= (((uint64_t)1 << (bits - lo)) - 1);
+            }
+            fr_mul(&h[4 * i], v, RR);
+        }
+    }
+    void *d_s, *d_b, *d_scr;
+    CK(hipMalloc(&d_s, n * 32));
+    CK(hipMalloc(&d_b, n * 64));
+    CK(hipMemcpy(d_s, h.data(), n * 32, hipMemcpyHostToDevice));
+    H2(h2_dev_random_points(0x48414c4f32ULL, n, d_b, nullptr));
+    size_t sb = h2_msm_scratch_bytes(n, bits);
+    CK(hipMalloc(&d_scr, sb));
+    uint64_t out0[12], out[12];
+    H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out0, nullptr));
+    H2(h2_synchronize());
+    double t0 = now();
+    for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, nullptr));
+    double t1 = now();
+    uint32_t c, W, nb;
+    h2_msm_shape(n, bits, &c, &W, &nb);
+    double adds = (double)n * W + 2.0 * nb * W + (double)W * c;
+    double ms = (t1 - t0) / reps * 1e3;
+    printf("msm  log_n=%2d bits=%3d mode=%d c=%u W=%u  %8.3f ms  %.3e G1-adds/s  %.3e pairs/s  scratch %.0f MiB\n", log_n, bits, mode,
+           c, W, ms, adds / (ms * 1e-3), n / (ms * 1e-3), sb / 1048576.0);
+    CK(hipFree(d_s));
+    CK(hipFree(d_b));
+    CK(hipFree(d_scr));
+    return 0;
+}
+
+static int bench_eval(int log_n, int reps) {
+    size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> h(n * 4);
+    fill_random_fr(h, 5);
+    void *d_l, *d_r, *d_o;
+    CK(hipMalloc(&d_l, n * 32));
+    CK(hipMalloc(&d_r, n * 32));
+    CK(hipMalloc(&d_o, n * 32));
+    CK(hipMemcpy(d_l, h.data(), n * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_r, h.data(), n * 32, hipMemcpyHostToDevice));
+    const char* names[] = {"mul_c", "sum_c", "sum", "mul", "sub", "lctheta", "lcbeta", "addgamma", "constant"};
+    int inputs[] = {1, 1, 2, 2, 2, 2, 2, 1, 0};
+    uint64_t c[4] = {h[0], h[1], h[2], h[3]};
+    for (int op = 0; op < 9; op++) {
+        H2(h2_dev_eval_op(op, d_o, d_l, d_r, 1, -1, n, c, nullptr));
+        float ms = 0;
+        H2(h2_timer_start(nullptr));
+        for (int r = 0; r < reps; r++) H2(h2_dev_eval_op(op, d_o, d_l, d_r, 1, -1, n, c, nullptr));
+        H2(h2_timer_stop(nullptr, &ms));
+        double bytes = 32.0 * (inputs[op] + 1) * n;
+        printf("eval %-9s log_n=%2d  %8.3f ms  %.1f GB/s algorithmic\n", names[op], log_n, ms / reps, bytes / (ms / reps * 1e-3) / 1e9);
+    }
+    CK(hipFree(d_l));
+    CK(hipFree(d_r));
+    CK(hipFree(d_o));
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (h2_device_count() < 1) {
+        printf("no device\n");
+        return 1;
+    }
+    int rc = 0;
+    if (argc < 2) {
+        rc |= bench_ntt(20, 20);
+        rc |= bench_ntt(24, 10);
+        rc |= bench_msm(20, 254, 5, 0);
+        rc |= bench_eval(24, 10);
+        return rc;
+    }
+    for (int i = 1; i < argc;) {
+        std::string cmd = argv[i];
+        if (cmd == "ntt" && i + 2 < argc) { rc |= bench_ntt(atoi(argv[i + 1]), atoi(argv[i + 2])); i += 3; }
+        else if (cmd == "msm" && i + 3 < argc) { rc |= bench_msm(atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), 0); i += 4; }
+        else if (cmd == "msmbool" && i + 2 < argc) { rc |= bench_msm(atoi(argv[i + 1]), 254, atoi(argv[i + 2]), 1); i += 3; }
+        else if (cmd == "eval" && i + 2 < argc) { rc |= bench_eval(atoi(argv[i + 1]), atoi(argv[i + 2])); i += 3; }
+        else { printf("bad args\n"); return 2; }
+    }
+    return rc;
+}
