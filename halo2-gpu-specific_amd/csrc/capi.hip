@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "evalh.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
@@ -375,6 +376,24 @@ int h2_dev_batch_unmont(void* d_a, size_t n, void* stream) {
     return guarded([&] {
         DeviceCtx* ctx = current_ctx();
         return batch_mont_launch((Fr*)d_a, n, false, pick_stream(ctx, stream));
+    });
+}
+
+// ------------------------------------------------------------------ evaluate_h
+int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
+    if (!desc || !values) return bad("h2_evaluate_h: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        return evalh_host(lease.ctx, desc, values);
+    });
+}
+
+int h2_dev_evaluate_h(const h2_evalh_desc* desc, void* d_values, void* stream) {
+    if (!desc || !d_values) return bad("h2_dev_evaluate_h: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);  // the interpreter work space is per device
+        return evalh_device(ctx, desc, (Fr*)d_values, pick_stream(ctx, stream), true);
     });
 }
 

@@ -55,6 +55,7 @@ struct DeviceCtx {
     std::mutex mu;                     // one in-flight host-API op per device
     DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
     DevBuf msm_scratch;
+    DevBuf evalh_scratch;
     std::map<std::string, NttPlan*> plans;
     hipDeviceProp_t prop;
 };

@@ -1,0 +1,469 @@
+// evalh.hip -- the quotient numerator h(X) on the extended coset: Evaluator::evaluate_h.
+//
+// Reference: CPU twin plonk/evaluation.rs:778-1226; cuda driver plonk/evaluation.rs:1229-1985, which
+// walks ProveExpression trees launching one elementwise kernel per AST node (evaluation_gpu.rs:594-803)
+// and re-derives extended cosets on demand through a 5-entry cache.  Here every coset stays resident
+// (288 GB of HBM) and the whole gate program runs in ONE pass over the extended domain:
+//   k_evalh_expr     per index: interpret the flattened `Calculation` program (evaluation.rs:95-266),
+//                    Horner-accumulate the gate value parts in y (:891-901), and emit the lookup /
+//                    shuffle compressed expressions (:903-997)
+//   k_evalh_perm     permutation argument terms (:1004-1085; cuda kernels eval_h_permutation_part1/2/
+//                    left_prepare/left_right/part3, :1341-1486) fused into one kernel
+//   k_evalh_lookup   logup terms (:1138-1182; cuda eval_h_logup / _z / _extra, :1655-1788)
+//   k_evalh_shuffle  shuffle terms (:1197-1219; cuda eval_h_shuffles, :1935-1952)
+// Intermediates of the interpreter live in a [calculation][thread] global array (coalesced, L2-resident);
+// the program itself is read with wave-uniform (scalar) loads, so there is no divergence.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "common.hpp"
+#include "evalh.hpp"
+#include "ntt.hpp"
+
+namespace h2 {
+
+struct EvalhProgram {  // everything the kernels need, device pointers
+    const Fr* constants;
+    const int32_t* rotations;
+    const h2_calculation* calcs;
+    const h2_value_source* value_parts;
+    const h2_calculation* lookup_calcs;
+    const uint32_t* lookup_sets;
+    const h2_calculation* shuffle_calcs;
+    const Fr* const* fixed;
+    const Fr* const* advice;
+    const Fr* const* instance;
+    uint32_t n_calcs, n_value_parts, n_lookups, n_shuffles;
+    uint32_t extended_k, rot_scale;
+    Fr y, beta, gamma, theta;
+};
+
+__device__ __forceinline__ size_t rot_idx(size_t idx, int32_t rot, uint32_t rot_scale, uint32_t extended_k) {
+    // (idx + rot * rot_scale) mod 2^extended_k  (get_rotation_idx, evaluation.rs:40-42)
+    long long v = (long long)idx + (long long)rot * (long long)rot_scale;
+    return (size_t)(v & (((long long)1 << extended_k) - 1));
+}
+
+struct Interp {
+    const EvalhProgram& p;
+    const Fr* inter;  // this thread's column of the intermediates array
+    size_t stride;    // distance between consecutive intermediates of one thread
+    size_t idx;
+
+    __device__ __forceinline__ Fr get(const h2_value_source& v) const {
+        switch (v.kind) {
+            case H2_VS_CONSTANT: return fp_load(p.constants + v.index);
+            case H2_VS_INTERMEDIATE: return fp_load(inter + (size_t)v.index * stride);
+            case H2_VS_FIXED: return fp_load(p.fixed[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
+            case H2_VS_ADVICE: return fp_load(p.advice[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
+            default: return fp_load(p.instance[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
+        }
+    }
+
+    __device__ __forceinline__ Fr eval(const h2_calculation& k) const {
+        Fr a = get(k.a);
+        switch (k.op) {
+            case H2_CALC_ADD: return fp_add(a, get(k.b));
+            case H2_CALC_SUB: return fp_sub(a, get(k.b));
+            case H2_CALC_MUL: return fp_mul(a, get(k.b));
+            case H2_CALC_NEGATE: return fp_neg(a);
+            case H2_CALC_LC_CHALLENGE: {
+                Fr x = (k.challenge == H2_CHALLENGE_BETA) ? p.beta : p.gamma;
+                if (k.power > 1) x = fp_pow_u32(x, k.power);
+                return fp_mul(fp_add(a, x), get(k.b));
+            }
+            case H2_CALC_LC_THETA: return fp_add(fp_mul(a, p.theta), get(k.b));
+            case H2_CALC_ADD_CHALLENGE: return fp_add(a, (k.challenge == H2_CHALLENGE_BETA) ? p.beta : p.gamma);
+            default: return a;  // Store
+        }
+    }
+};
+
+// lookup tables layout: [slot][idx], slots per lookup t: table, product_0, sum_0, product_1, sum_1, ...
+// (slot base of lookup t = sum_{t' < t} (1 + 2 * sets[t'])) -- the same order as lookup_calcs
+__global__ void __launch_bounds__(256) k_evalh_expr(EvalhProgram p, Fr* inter, Fr* values, Fr* lk_out, Fr* sh_out) {
+    const size_t size = (size_t)1 << p.extended_k;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr* my = inter + t;
+    for (size_t idx = t; idx < size; idx += nthreads) {
+        Interp in{p, my, nthreads, idx};
+        for (uint32_t i = 0; i < p.n_calcs; i++) fp_store(my + (size_t)i * nthreads, in.eval(p.calcs[i]));
+        Fr value = fp_zero<FrParams>();
+        for (uint32_t i = 0; i < p.n_value_parts; i++) value = fp_add(fp_mul(value, p.y), in.get(p.value_parts[i]));
+        fp_store(values + idx, value);
+        uint32_t slot = 0;
+        for (uint32_t lk = 0; lk < p.n_lookups; lk++) {
+            uint32_t cnt = 1 + 2 * p.lookup_sets[lk];
+            for (uint32_t j = 0; j < cnt; j++, slot++) fp_store(lk_out + (size_t)slot * size + idx, in.eval(p.lookup_calcs[slot]));
+        }
+        for (uint32_t i = 0; i < 2 * p.n_shuffles; i++) fp_store(sh_out + (size_t)i * size + idx, in.eval(p.shuffle_calcs[i]));
+    }
+}
+
+struct PermArgs {
+    Fr* values;
+    const Fr* const* perm_z;
+    const Fr* const* perm_cols;   // resolved column coset per permutation column
+    const Fr* const* perm_sigma;
+    const Fr *l0, *l_last, *l_active_row;
+    const Fr *tw_lo, *tw_hi;      // extended_omega^i tables (NTT plan)
+    uint32_t n_sets, n_columns, chunk_len, extended_k, rot_scale;
+    int32_t last_rotation;
+    Fr y, beta, gamma, delta, delta_start;  // delta_start = beta * ZETA
+};
+
+__global__ void __launch_bounds__(256) k_evalh_perm(PermArgs a) {
+    const size_t size = (size_t)1 << a.extended_k;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const Fr one = fp_one<FrParams>();
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+        const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
+        const size_t r_last = rot_idx(idx, a.last_rotation, a.rot_scale, a.extended_k);
+        Fr value = fp_load(a.values + idx);
+        const Fr l0 = fp_load(a.l0 + idx);
+        {   // l_0(X) * (1 - z_0(X))
+            Fr z0 = fp_load(a.perm_z[0] + idx);
+            value = fp_add(fp_mul(value, a.y), fp_mul(fp_sub(one, z0), l0));
+            // l_last(X) * (z_l(X)^2 - z_l(X))
+            Fr zl = fp_load(a.perm_z[a.n_sets - 1] + idx);
+            value = fp_add(fp_mul(value, a.y), fp_mul(fp_sub(fp_sqr(zl), zl), fp_load(a.l_last + idx)));
+        }
+        for (uint32_t s = 1; s < a.n_sets; s++) {  // l_0(X) * (z_i(X) - z_{i-1}(w^last X))
+            Fr d = fp_sub(fp_load(a.perm_z[s] + idx), fp_load(a.perm_z[s - 1] + r_last));
+            value = fp_add(fp_mul(value, a.y), fp_mul(d, l0));
+        }
+        // beta_term = extended_omega^idx
+        Fr beta_term;
+        if (a.extended_k <= 12) {
+            beta_term = fp_load(a.tw_lo + idx);
+        } else {
+            beta_term = fp_mul(fp_load(a.tw_lo + (idx & 4095)), fp_load(a.tw_hi + (idx >> 12)));
+        }
+        Fr current_delta = fp_mul(a.delta_start, beta_term);
+        const Fr lar = fp_load(a.l_active_row + idx);
+        for (uint32_t s = 0; s < a.n_sets; s++) {
+            uint32_t c0 = s * a.chunk_len, c1 = c0 + a.chunk_len;
+            if (c1 > a.n_columns) c1 = a.n_columns;
+            Fr left = fp_load(a.perm_z[s] + r_next), right = fp_load(a.perm_z[s] + idx);
+            for (uint32_t j = c0; j < c1; j++) {
+                Fr v = fp_load(a.perm_cols[j] + idx);
+                Fr sg = fp_load(a.perm_sigma[j] + idx);
+                left = fp_mul(left, fp_add(fp_add(v, fp_mul(a.beta, sg)), a.gamma));
+                right = fp_mul(right, fp_add(fp_add(v, current_delta), a.gamma));
+                current_delta = fp_mul(current_delta, a.delta);
+            }
+            value = fp_add(fp_mul(value, a.y), fp_mul(fp_sub(left, right), lar));
+        }
+        fp_store(a.values + idx, value);
+    }
+}
+
+struct LookupArgs {
+    Fr* values;
+    const Fr* const* zs;     // sets_len z cosets of this lookup
+    const Fr* m;
+    const Fr* table;         // lk_out slots of this lookup: table, product_0, sum_0, product_1, ...
+    const Fr *l0, *l_last, *l_active_row;
+    uint32_t sets_len, extended_k, rot_scale;
+    int32_t last_rotation;
+    Fr y;
+};
+
+__global__ void __launch_bounds__(256) k_evalh_lookup(LookupArgs a) {
+    const size_t size = (size_t)1 << a.extended_k;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+        const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
+        const size_t r_last = rot_idx(idx, a.last_rotation, a.rot_scale, a.extended_k);
+        Fr value = fp_load(a.values + idx);
+        const Fr l0 = fp_load(a.l0 + idx), lar = fp_load(a.l_active_row + idx);
+        const Fr z0 = fp_load(a.zs[0] + idx);
+        value = fp_add(fp_mul(value, a.y), fp_mul(z0, l0));
+        value = fp_add(fp_mul(value, a.y), fp_mul(fp_load(a.zs[a.sets_len - 1] + idx), fp_load(a.l_last + idx)));
+        {
+            Fr table = fp_load(a.table + idx);
+            Fr prod = fp_load(a.table + size + idx), sum = fp_load(a.table + 2 * size + idx);
+            Fr d = fp_sub(fp_load(a.zs[0] + r_next), z0);
+            Fr t = fp_mul(fp_add(fp_mul(d, table), fp_load(a.m + idx)), prod);
+            t = fp_sub(t, fp_mul(table, sum));
+            value = fp_add(fp_mul(value, a.y), fp_mul(t, lar));
+        }
+        for (uint32_t i = 1; i < a.sets_len; i++) {
+            Fr d = fp_sub(fp_load(a.zs[i] + idx), fp_load(a.zs[i - 1] + r_last));
+            value = fp_add(fp_mul(value, a.y), fp_mul(d, l0));
+        }
+        for (uint32_t i = 1; i < a.sets_len; i++) {
+            Fr d = fp_sub(fp_load(a.zs[i] + r_next), fp_load(a.zs[i] + idx));
+            Fr t = fp_sub(fp_mul(d, fp_load(a.table + (size_t)(1 + 2 * i) * size + idx)),
+                          fp_load(a.table + (size_t)(2 + 2 * i) * size + idx));
+            value = fp_add(fp_mul(value, a.y), fp_mul(t, lar));
+        }
+        fp_store(a.values + idx, value);
+    }
+}
+
+struct ShuffleArgs {
+    Fr* values;
+    const Fr* z;
+    const Fr *input, *shuffle;
+    const Fr *l0, *l_last, *l_active_row;
+    uint32_t extended_k, rot_scale;
+    Fr y;
+};
+
+__global__ void __launch_bounds__(256) k_evalh_shuffle(ShuffleArgs a) {
+    const size_t size = (size_t)1 << a.extended_k;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const Fr one = fp_one<FrParams>();
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+        const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
+        Fr value = fp_load(a.values + idx);
+        const Fr z = fp_load(a.z + idx);
+        value = fp_add(fp_mul(value, a.y), fp_mul(fp_sub(one, z), fp_load(a.l0 + idx)));
+        value = fp_add(fp_mul(value, a.y), fp_mul(fp_sub(fp_sqr(z), z), fp_load(a.l_last + idx)));
+        Fr t = fp_sub(fp_mul(fp_load(a.z + r_next), fp_load(a.shuffle + idx)), fp_mul(z, fp_load(a.input + idx)));
+        value = fp_add(fp_mul(value, a.y), fp_mul(t, fp_load(a.l_active_row + idx)));
+        fp_store(a.values + idx, value);
+    }
+}
+
+// ---------------------------------------------------------------- host driver
+namespace {
+struct Arena {  // bump allocator over one host staging block mirrored to one device block
+    std::vector<char> host;
+    char* dev = nullptr;
+    size_t off = 0;
+    template <class T>
+    const T* put(const T* src, size_t count) {
+        off = (off + 15) & ~(size_t)15;
+        size_t bytes = count * sizeof(T);
+        if (host.size() < off + bytes + 16) host.resize(off + bytes + 16);
+        if (bytes) memcpy(host.data() + off, src, bytes);
+        const T* d = reinterpret_cast<const T*>(dev + off);
+        off += bytes;
+        return d;
+    }
+};
+}  // namespace
+
+int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream_t stream, bool have_lock) {
+    if (!d || !d_values) {
+        set_last_error("h2_evaluate_h: null argument");
+        return H2_ERR_INVALID;
+    }
+    if (d->extended_k < d->k || d->extended_k > 28) {
+        set_last_error("h2_evaluate_h: bad k / extended_k");
+        return H2_ERR_INVALID;
+    }
+    if (d->n_perm_sets && d->chunk_len == 0) {
+        set_last_error("h2_evaluate_h: chunk_len must be non-zero when permutation sets are present");
+        return H2_ERR_INVALID;
+    }
+    const size_t size = (size_t)1 << d->extended_k;
+    const uint32_t rot_scale = 1u << (d->extended_k - d->k);
+
+    // ---- stage the program and pointer tables (a few KB) into one device block
+    size_t n_lookup_calcs = 0, n_lookup_z = 0;
+    for (uint32_t t = 0; t < d->n_lookups; t++) {
+        n_lookup_calcs += 1 + 2 * (size_t)d->lookup_sets[t];
+        n_lookup_z += d->lookup_sets[t];
+    }
+    size_t need = 4096 + d->n_constants * 32 + d->n_rotations * 4 + (d->n_calculations + n_lookup_calcs + 2 * d->n_shuffles) * sizeof(h2_calculation) +
+                  d->n_value_parts * sizeof(h2_value_source) + d->n_lookups * 4 +
+                  ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + n_lookup_z) * 8 + 64 * 16;
+    // ---- work space: interpreter intermediates + lookup / shuffle compressed expressions
+    const unsigned blocks = 256 * 8, threads = 256;
+    const size_t nthreads = (size_t)blocks * threads;
+    size_t inter_bytes = (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
+    size_t lk_bytes = (n_lookup_calcs ? n_lookup_calcs : 1) * size * sizeof(Fr);
+    size_t sh_bytes = (d->n_shuffles ? 2 * (size_t)d->n_shuffles : 1) * size * sizeof(Fr);
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t total = align(need) + align(inter_bytes) + align(lk_bytes) + align(sh_bytes);
+    char* block = (char*)ctx->evalh_scratch.get(total);
+    Arena ar;
+    ar.dev = block;
+    Fr* d_inter = (Fr*)(block + align(need));
+    Fr* d_lk = (Fr*)((char*)d_inter + align(inter_bytes));
+    Fr* d_sh = (Fr*)((char*)d_lk + align(lk_bytes));
+
+    EvalhProgram p{};
+    p.constants = (const Fr*)ar.put(d->constants, (size_t)d->n_constants * 4);
+    p.rotations = ar.put(d->rotations, d->n_rotations);
+    p.calcs = ar.put(d->calculations, d->n_calculations);
+    p.value_parts = ar.put(d->value_parts, d->n_value_parts);
+    p.lookup_calcs = ar.put(d->lookup_calcs, n_lookup_calcs);
+    p.lookup_sets = ar.put(d->lookup_sets, d->n_lookups);
+    p.shuffle_calcs = ar.put(d->shuffle_calcs, 2 * (size_t)d->n_shuffles);
+    p.fixed = (const Fr* const*)ar.put(d->fixed, d->n_fixed);
+    p.advice = (const Fr* const*)ar.put(d->advice, d->n_advice);
+    p.instance = (const Fr* const*)ar.put(d->instance, d->n_instance);
+    const Fr* const* d_perm_z = (const Fr* const*)ar.put(d->perm_z, d->n_perm_sets);
+    const Fr* const* d_perm_sigma = (const Fr* const*)ar.put(d->perm_sigma, d->n_perm_columns);
+    std::vector<const uint64_t*> cols(d->n_perm_columns);
+    for (uint32_t j = 0; j < d->n_perm_columns; j++) {  // evaluation.rs:1060-1064
+        uint32_t ty = d->perm_col_type[j], ix = d->perm_col_index[j];
+        const uint64_t* const* tab = ty == H2_ANY_ADVICE ? d->advice : (ty == H2_ANY_FIXED ? d->fixed : d->instance);
+        uint32_t lim = ty == H2_ANY_ADVICE ? d->n_advice : (ty == H2_ANY_FIXED ? d->n_fixed : d->n_instance);
+        if (ix >= lim) {
+            set_last_error("h2_evaluate_h: permutation column index out of range");
+            return H2_ERR_INVALID;
+        }
+        cols[j] = tab[ix];
+    }
+    const Fr* const* d_perm_cols = (const Fr* const*)ar.put(cols.data(), cols.size());
+    const Fr* const* d_lookup_z = (const Fr* const*)ar.put(d->lookup_z, n_lookup_z);
+    if (ar.off > need) {
+        set_last_error("h2_evaluate_h: internal staging overflow");
+        return H2_ERR_INVALID;
+    }
+    H2_HIP(hipMemcpyAsync(block, ar.host.data(), ar.off, hipMemcpyHostToDevice, stream));
+    H2_HIP(hipStreamSynchronize(stream));  // the staging vector dies with this frame
+
+    p.n_calcs = d->n_calculations;
+    p.n_value_parts = d->n_value_parts;
+    p.n_lookups = d->n_lookups;
+    p.n_shuffles = d->n_shuffles;
+    p.extended_k = d->extended_k;
+    p.rot_scale = rot_scale;
+    p.y = fr_from_u64x4(d->y);
+    p.beta = fr_from_u64x4(d->beta);
+    p.gamma = fr_from_u64x4(d->gamma);
+    p.theta = fr_from_u64x4(d->theta);
+
+    hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
+
+    const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
+    unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 256 * 16);
+    if (d->n_perm_sets) {
+        NttPlan* pl;
+        if (have_lock) {
+            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+        } else {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+        }
+        PermArgs a{};
+        a.values = d_values;
+        a.perm_z = d_perm_z;
+        a.perm_cols = d_perm_cols;
+        a.perm_sigma = d_perm_sigma;
+        a.l0 = (const Fr*)d->l0;
+        a.l_last = (const Fr*)d->l_last;
+        a.l_active_row = (const Fr*)d->l_active_row;
+        a.tw_lo = pl->tw_lo;
+        a.tw_hi = pl->tw_hi;
+        a.n_sets = d->n_perm_sets;
+        a.n_columns = d->n_perm_columns;
+        a.chunk_len = d->chunk_len;
+        a.extended_k = d->extended_k;
+        a.rot_scale = rot_scale;
+        a.last_rotation = last_rotation;
+        a.y = p.y;
+        a.beta = p.beta;
+        a.gamma = p.gamma;
+        a.delta = fr_from_u64x4(d->delta);
+        a.delta_start = fp_mul(p.beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
+        hipLaunchKernelGGL(k_evalh_perm, dim3(eblocks), dim3(256), 0, stream, a);
+    }
+    size_t zoff = 0, slot = 0;
+    for (uint32_t lk = 0; lk < d->n_lookups; lk++) {
+        LookupArgs a{};
+        a.values = d_values;
+        a.zs = d_lookup_z + zoff;
+        a.m = (const Fr*)d->lookup_m[lk];
+        a.table = d_lk + slot * size;
+        a.l0 = (const Fr*)d->l0;
+        a.l_last = (const Fr*)d->l_last;
+        a.l_active_row = (const Fr*)d->l_active_row;
+        a.sets_len = d->lookup_sets[lk];
+        a.extended_k = d->extended_k;
+        a.rot_scale = rot_scale;
+        a.last_rotation = last_rotation;
+        a.y = p.y;
+        hipLaunchKernelGGL(k_evalh_lookup, dim3(eblocks), dim3(256), 0, stream, a);
+        zoff += d->lookup_sets[lk];
+        slot += 1 + 2 * (size_t)d->lookup_sets[lk];
+    }
+    for (uint32_t sh = 0; sh < d->n_shuffles; sh++) {
+        ShuffleArgs a{};
+        a.values = d_values;
+        a.z = (const Fr*)d->shuffle_z[sh];
+        a.input = d_sh + (size_t)(2 * sh) * size;
+        a.shuffle = d_sh + (size_t)(2 * sh + 1) * size;
+        a.l0 = (const Fr*)d->l0;
+        a.l_last = (const Fr*)d->l_last;
+        a.l_active_row = (const Fr*)d->l_active_row;
+        a.extended_k = d->extended_k;
+        a.rot_scale = rot_scale;
+        a.y = p.y;
+        hipLaunchKernelGGL(k_evalh_shuffle, dim3(eblocks), dim3(256), 0, stream, a);
+    }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+// Host-buffer variant: upload every coset the descriptor references (each distinct pointer once),
+// run, read the values back.
+int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
+    if (!d || !values) {
+        set_last_error("h2_evaluate_h: null argument");
+        return H2_ERR_INVALID;
+    }
+    const size_t size = (size_t)1 << d->extended_k, bytes = size * sizeof(Fr);
+    std::map<const uint64_t*, const uint64_t*> up;  // host -> device
+    std::vector<void*> owned;
+    auto cleanup = [&] {
+        for (void* q : owned) hipFree(q);
+    };
+    try {
+        auto dev_of = [&](const uint64_t* h) -> const uint64_t* {
+            if (!h) return nullptr;
+            auto it = up.find(h);
+            if (it != up.end()) return it->second;
+            void* q = nullptr;
+            H2_HIP(hipMalloc(&q, bytes));
+            owned.push_back(q);
+            H2_HIP(hipMemcpyAsync(q, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+            up[h] = (const uint64_t*)q;
+            return (const uint64_t*)q;
+        };
+        h2_evalh_desc dd = *d;
+        size_t n_lookup_z = 0;
+        for (uint32_t t = 0; t < d->n_lookups; t++) n_lookup_z += d->lookup_sets[t];
+        auto map_table = [&](const uint64_t* const* tab, size_t n, std::vector<const uint64_t*>& out) {
+            out.resize(n);
+            for (size_t i = 0; i < n; i++) out[i] = dev_of(tab[i]);
+            return out.data();
+        };
+        std::vector<const uint64_t*> t_fixed, t_adv, t_inst, t_pz, t_ps, t_lz, t_lm, t_sz;
+        dd.fixed = map_table(d->fixed, d->n_fixed, t_fixed);
+        dd.advice = map_table(d->advice, d->n_advice, t_adv);
+        dd.instance = map_table(d->instance, d->n_instance, t_inst);
+        dd.perm_z = map_table(d->perm_z, d->n_perm_sets, t_pz);
+        dd.perm_sigma = map_table(d->perm_sigma, d->n_perm_columns, t_ps);
+        dd.lookup_z = map_table(d->lookup_z, n_lookup_z, t_lz);
+        dd.lookup_m = map_table(d->lookup_m, d->n_lookups, t_lm);
+        dd.shuffle_z = map_table(d->shuffle_z, d->n_shuffles, t_sz);
+        dd.l0 = dev_of(d->l0);
+        dd.l_last = dev_of(d->l_last);
+        dd.l_active_row = dev_of(d->l_active_row);
+        void* d_values = nullptr;
+        H2_HIP(hipMalloc(&d_values, bytes));
+        owned.push_back(d_values);
+        int rc = evalh_device(ctx, &dd, (Fr*)d_values, ctx->stream, true);
+        if (rc == H2_OK) {
+            H2_HIP(hipMemcpyAsync(values, d_values, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            H2_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        cleanup();
+        return rc;
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+}
+
+}  // namespace h2

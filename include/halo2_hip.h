@@ -105,6 +105,76 @@ int h2_eval_op(int op, uint64_t *res, const uint64_t *l, const uint64_t *r, int3
 /* EvaluationDomain::divide_by_vanishing_poly: poly/domain.rs:354-373: a[i] *= t_evals[i % t_len] */
 int h2_divide_by_vanishing_poly(uint64_t *a, size_t size, const uint64_t *t_evaluations, size_t t_len);
 
+
+/* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
+ * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
+ * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:
+ * ValueSource :44-57, Calculation :95-112, value_parts, lookup_results, shuffle_results.  All column
+ * pointers are extended cosets (2^extended_k Fr).  One circuit instance (the cuda path asserts it,
+ * plonk/evaluation.rs:1259). */
+enum { H2_VS_CONSTANT = 0, H2_VS_INTERMEDIATE = 1, H2_VS_FIXED = 2, H2_VS_ADVICE = 3, H2_VS_INSTANCE = 4 };
+enum {
+    H2_CALC_ADD = 0, H2_CALC_SUB = 1, H2_CALC_MUL = 2, H2_CALC_NEGATE = 3,
+    H2_CALC_LC_CHALLENGE = 4, /* (a + challenge^power) * b */
+    H2_CALC_LC_THETA = 5,     /* a * theta + b */
+    H2_CALC_ADD_CHALLENGE = 6,/* a + challenge */
+    H2_CALC_STORE = 7
+};
+enum { H2_CHALLENGE_BETA = 0, H2_CHALLENGE_GAMMA = 1 };
+enum { H2_ANY_ADVICE = 0, H2_ANY_FIXED = 1, H2_ANY_INSTANCE = 2 };
+
+typedef struct {
+    uint32_t kind;  /* H2_VS_* */
+    uint32_t index; /* constant / intermediate / column index */
+    uint32_t rot;   /* index into `rotations` (columns only) */
+} h2_value_source;
+
+typedef struct {
+    uint32_t op; /* H2_CALC_* */
+    h2_value_source a, b;
+    uint32_t challenge; /* H2_CHALLENGE_* (LC_CHALLENGE, ADD_CHALLENGE) */
+    uint32_t power;     /* LC_CHALLENGE exponent p (p <= 1 means the challenge itself) */
+} h2_calculation;
+
+typedef struct {
+    uint32_t k, extended_k;
+    uint32_t blinding_factors; /* cs.blinding_factors(): last_rotation = -(blinding_factors + 1) */
+    uint32_t chunk_len;        /* cs.degree() - 2: permutation columns per product set */
+    /* the straight-line program */
+    const uint64_t *constants;          uint32_t n_constants;    /* Fr each */
+    const int32_t *rotations;           uint32_t n_rotations;
+    const h2_calculation *calculations; uint32_t n_calculations;
+    const h2_value_source *value_parts; uint32_t n_value_parts;
+    /* lookup_results[t] = (table, products[sets], sums[sets]); flattened per lookup as
+     * table, product_0, sum_0, product_1, sum_1, ...  (lookup_sets[t] = number of sets >= 1) */
+    uint32_t n_lookups; const uint32_t *lookup_sets; const h2_calculation *lookup_calcs;
+    /* shuffle_results[i] = (input, shuffle), flattened */
+    uint32_t n_shuffles; const h2_calculation *shuffle_calcs;
+    /* columns */
+    const uint64_t *const *fixed;    uint32_t n_fixed;
+    const uint64_t *const *advice;   uint32_t n_advice;
+    const uint64_t *const *instance; uint32_t n_instance;
+    const uint64_t *l0, *l_last, *l_active_row;
+    /* permutation argument: sets[i].permutation_product_coset, p.columns, pk.permutation.cosets */
+    uint32_t n_perm_sets;    const uint64_t *const *perm_z;
+    uint32_t n_perm_columns; const uint32_t *perm_col_type; const uint32_t *perm_col_index;
+    const uint64_t *const *perm_sigma;
+    /* logup lookups: z cosets of every set of every lookup (in order), m coset per lookup */
+    const uint64_t *const *lookup_z; const uint64_t *const *lookup_m;
+    /* shuffles: product coset per shuffle */
+    const uint64_t *const *shuffle_z;
+    /* challenges and field constants */
+    uint64_t y[4], beta[4], gamma[4], theta[4];
+    uint64_t delta[4], zeta[4], extended_omega[4]; /* FieldExt::DELTA, ::ZETA, domain.get_extended_omega() */
+} h2_evalh_desc;
+
+/* Host buffers everywhere (descriptor and every pointer in it); values: 2^extended_k Fr out. */
+int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);
+/* Column / table pointers inside `desc` are DEVICE pointers (the descriptor itself and its program
+ * arrays -- constants, rotations, calculations, ... and the pointer tables -- stay in host memory).
+ * d_values: 2^extended_k Fr on the device.  Work space is taken from the library's arena. */
+int h2_dev_evaluate_h(const h2_evalh_desc *desc, void *d_values, void *stream);
+
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for
  * log_n <= 8).  Results land in d_a (in place from the caller's view). */

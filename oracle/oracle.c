@@ -844,3 +844,277 @@ EXPORT void oracle_eval_op(int op, u256 *res, const u256 *l, const u256 *r, int6
 }
 
 EXPORT int oracle_version(void) { return 1; }
+
+/* ------------------------------------------------------------------ */
+/* Evaluator::evaluate_h (CPU) -- plonk/evaluation.rs:778-1226         */
+/* ------------------------------------------------------------------ */
+#include "../include/halo2_hip.h" /* the flattened Evaluator descriptor (plain C types only) */
+
+/* evaluation.rs:40-42 */
+static inline size_t get_rotation_idx(size_t idx, int32_t rot, int32_t rot_scale, int64_t isize) {
+    int64_t v = ((int64_t)idx + (int64_t)rot * rot_scale) % isize;
+    if (v < 0) v += isize;
+    return (size_t)v;
+}
+
+typedef struct {
+    const h2_evalh_desc *d;
+    const size_t *rotations; /* resolved per index */
+    const u256 *intermediates;
+} evalh_ctx;
+
+/* ValueSource::get, evaluation.rs:61-85 */
+static inline u256 vs_get(const evalh_ctx *c, const h2_value_source *v) {
+    const h2_evalh_desc *d = c->d;
+    switch (v->kind) {
+        case H2_VS_CONSTANT: return ((const u256 *)d->constants)[v->index];
+        case H2_VS_INTERMEDIATE: return c->intermediates[v->index];
+        case H2_VS_FIXED: return ((const u256 *)d->fixed[v->index])[c->rotations[v->rot]];
+        case H2_VS_ADVICE: return ((const u256 *)d->advice[v->index])[c->rotations[v->rot]];
+        default: return ((const u256 *)d->instance[v->index])[c->rotations[v->rot]];
+    }
+}
+
+/* Calculation::evaluate, evaluation.rs:114-266 */
+static inline u256 calc_eval(const evalh_ctx *c, const h2_calculation *k, const u256 *beta, const u256 *gamma,
+                             const u256 *theta) {
+    u256 a = vs_get(c, &k->a), b, r, x;
+    switch (k->op) {
+        case H2_CALC_ADD: b = vs_get(c, &k->b); fr_add(&r, &a, &b); return r;
+        case H2_CALC_SUB: b = vs_get(c, &k->b); fr_sub(&r, &a, &b); return r;
+        case H2_CALC_MUL: b = vs_get(c, &k->b); fr_mul(&r, &a, &b); return r;
+        case H2_CALC_NEGATE: fr_neg(&r, &a); return r;
+        case H2_CALC_LC_CHALLENGE:
+            b = vs_get(c, &k->b);
+            x = (k->challenge == H2_CHALLENGE_BETA) ? *beta : *gamma;
+            if (k->power > 1) fr_pow_u64(&x, &x, k->power); /* :207-208 */
+            fr_add(&r, &a, &x);
+            fr_mul(&r, &r, &b);
+            return r;
+        case H2_CALC_LC_THETA: b = vs_get(c, &k->b); fr_mul(&r, &a, theta); fr_add(&r, &r, &b); return r;
+        case H2_CALC_ADD_CHALLENGE:
+            x = (k->challenge == H2_CHALLENGE_BETA) ? *beta : *gamma;
+            fr_add(&r, &a, &x);
+            return r;
+        default: return a; /* Store */
+    }
+}
+
+static const u256 *perm_column(const h2_evalh_desc *d, uint32_t j) { /* evaluation.rs:1060-1064 */
+    switch (d->perm_col_type[j]) {
+        case H2_ANY_ADVICE: return (const u256 *)d->advice[d->perm_col_index[j]];
+        case H2_ANY_FIXED: return (const u256 *)d->fixed[d->perm_col_index[j]];
+        default: return (const u256 *)d->instance[d->perm_col_index[j]];
+    }
+}
+
+EXPORT void oracle_evaluate_h(const h2_evalh_desc *d, u256 *values) {
+    const size_t size = (size_t)1 << d->extended_k;
+    const int32_t rot_scale = 1 << (d->extended_k - d->k); /* :794 */
+    const int64_t isize = (int64_t)size;
+    const u256 *y = (const u256 *)d->y, *beta = (const u256 *)d->beta, *gamma = (const u256 *)d->gamma,
+               *theta = (const u256 *)d->theta;
+    const u256 *l0 = (const u256 *)d->l0, *l_last = (const u256 *)d->l_last,
+               *l_active_row = (const u256 *)d->l_active_row;
+    const u256 one = fr_ONE;
+
+    size_t total_sets = 0, extra_sets = 0;
+    for (uint32_t t = 0; t < d->n_lookups; t++) {
+        total_sets += d->lookup_sets[t];
+        extra_sets += d->lookup_sets[t] - 1;
+    }
+    /* :812-824 intermediate tables */
+    u256 *lk_table = (u256 *)calloc(size * (d->n_lookups ? d->n_lookups : 1), sizeof(u256));
+    u256 *lk_prod = (u256 *)calloc(size * (d->n_lookups ? d->n_lookups : 1), sizeof(u256));
+    u256 *lk_sum = (u256 *)calloc(size * (d->n_lookups ? d->n_lookups : 1), sizeof(u256));
+    u256 *lk_prod_set = (u256 *)calloc(size * (extra_sets ? extra_sets : 1), sizeof(u256));
+    u256 *lk_sum_set = (u256 *)calloc(size * (extra_sets ? extra_sets : 1), sizeof(u256));
+    u256 *sh_input = (u256 *)calloc(size * (d->n_shuffles ? d->n_shuffles : 1), sizeof(u256));
+    u256 *sh_table = (u256 *)calloc(size * (d->n_shuffles ? d->n_shuffles : 1), sizeof(u256));
+    memset(values, 0, size * sizeof(u256)); /* :807 domain.empty_extended() */
+
+    /* :846-1001 "expressions" */
+#pragma omp parallel
+    {
+        size_t *rotations = (size_t *)malloc((d->n_rotations ? d->n_rotations : 1) * sizeof(size_t));
+        u256 *intermediates = (u256 *)calloc(d->n_calculations ? d->n_calculations : 1, sizeof(u256));
+        evalh_ctx c = {d, rotations, intermediates};
+#pragma omp for schedule(static)
+        for (size_t idx = 0; idx < size; idx++) {
+            for (uint32_t r = 0; r < d->n_rotations; r++) rotations[r] = get_rotation_idx(idx, d->rotations[r], rot_scale, isize);
+            for (uint32_t i = 0; i < d->n_calculations; i++)
+                intermediates[i] = calc_eval(&c, &d->calculations[i], beta, gamma, theta);
+            u256 value = values[idx];
+            for (uint32_t i = 0; i < d->n_value_parts; i++) { /* :891-901 */
+                u256 p = vs_get(&c, &d->value_parts[i]);
+                fr_mul(&value, &value, y);
+                fr_add(&value, &value, &p);
+            }
+            values[idx] = value;
+            size_t off = 0, extra = 0; /* :903-973 */
+            for (uint32_t t = 0; t < d->n_lookups; t++) {
+                const h2_calculation *lc = d->lookup_calcs + off;
+                lk_table[t * size + idx] = calc_eval(&c, &lc[0], beta, gamma, theta);
+                lk_prod[t * size + idx] = calc_eval(&c, &lc[1], beta, gamma, theta);
+                lk_sum[t * size + idx] = calc_eval(&c, &lc[2], beta, gamma, theta);
+                for (uint32_t s = 1; s < d->lookup_sets[t]; s++) {
+                    lk_prod_set[extra * size + idx] = calc_eval(&c, &lc[1 + 2 * s], beta, gamma, theta);
+                    lk_sum_set[extra * size + idx] = calc_eval(&c, &lc[2 + 2 * s], beta, gamma, theta);
+                    extra++;
+                }
+                off += 1 + 2 * (size_t)d->lookup_sets[t];
+            }
+            for (uint32_t i = 0; i < d->n_shuffles; i++) { /* :976-997 */
+                sh_input[i * size + idx] = calc_eval(&c, &d->shuffle_calcs[2 * i], beta, gamma, theta);
+                sh_table[i * size + idx] = calc_eval(&c, &d->shuffle_calcs[2 * i + 1], beta, gamma, theta);
+            }
+        }
+        free(rotations);
+        free(intermediates);
+    }
+
+    const int32_t last_rotation = -((int32_t)d->blinding_factors + 1); /* :1010 */
+
+    /* :1004-1085 permutations */
+    if (d->n_perm_sets != 0) {
+        u256 delta_start; /* :1012 beta * ZETA */
+        fr_mul(&delta_start, beta, (const u256 *)d->zeta);
+        const u256 *first_set = (const u256 *)d->perm_z[0], *last_set = (const u256 *)d->perm_z[d->n_perm_sets - 1];
+#pragma omp parallel for schedule(static)
+        for (size_t idx = 0; idx < size; idx++) {
+            u256 beta_term, value = values[idx], t, u;
+            fr_pow_u64(&beta_term, (const u256 *)d->extended_omega, (uint64_t)idx); /* :1019, :1081 */
+            size_t r_next = get_rotation_idx(idx, 1, rot_scale, isize);
+            size_t r_last = get_rotation_idx(idx, last_rotation, rot_scale, isize);
+            /* :1026-1027 l_0(X) * (1 - z_0(X)) */
+            fr_sub(&t, &one, &first_set[idx]);
+            fr_mul(&t, &t, &l0[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            /* :1030-1034 l_last(X) * (z_l(X)^2 - z_l(X)) */
+            fr_mul(&t, &last_set[idx], &last_set[idx]);
+            fr_sub(&t, &t, &last_set[idx]);
+            fr_mul(&t, &t, &l_last[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            /* :1037-1045 */
+            for (uint32_t s = 1; s < d->n_perm_sets; s++) {
+                fr_sub(&t, &((const u256 *)d->perm_z[s])[idx], &((const u256 *)d->perm_z[s - 1])[r_last]);
+                fr_mul(&t, &t, &l0[idx]);
+                fr_mul(&value, &value, y);
+                fr_add(&value, &value, &t);
+            }
+            /* :1051-1080 */
+            u256 current_delta;
+            fr_mul(&current_delta, &delta_start, &beta_term);
+            for (uint32_t s = 0; s < d->n_perm_sets; s++) {
+                uint32_t c0 = s * d->chunk_len, c1 = c0 + d->chunk_len;
+                if (c1 > d->n_perm_columns) c1 = d->n_perm_columns;
+                const u256 *z = (const u256 *)d->perm_z[s];
+                u256 left = z[r_next], right = z[idx];
+                for (uint32_t j = c0; j < c1; j++) {
+                    const u256 *col = perm_column(d, j), *sigma = (const u256 *)d->perm_sigma[j];
+                    fr_mul(&t, beta, &sigma[idx]);
+                    fr_add(&t, &t, &col[idx]);
+                    fr_add(&t, &t, gamma);
+                    fr_mul(&left, &left, &t);
+                }
+                for (uint32_t j = c0; j < c1; j++) {
+                    const u256 *col = perm_column(d, j);
+                    fr_add(&u, &col[idx], &current_delta);
+                    fr_add(&u, &u, gamma);
+                    fr_mul(&right, &right, &u);
+                    fr_mul(&current_delta, &current_delta, (const u256 *)d->delta);
+                }
+                fr_sub(&t, &left, &right);
+                fr_mul(&t, &t, &l_active_row[idx]);
+                fr_mul(&value, &value, y);
+                fr_add(&value, &value, &t);
+            }
+            values[idx] = value;
+        }
+    }
+
+    /* :1088-1184 lookups (z / m cosets are inputs here; the reference extends them in place :1128-1136) */
+    size_t zoff = 0, ext_off = 0;
+    for (uint32_t lk = 0; lk < d->n_lookups; lk++) {
+        const uint32_t sets_len = d->lookup_sets[lk];
+        const u256 *table = lk_table + (size_t)lk * size, *input_product = lk_prod + (size_t)lk * size,
+                   *input_product_sum = lk_sum + (size_t)lk * size;
+        const u256 *const *zs = (const u256 *const *)(d->lookup_z + zoff);
+        const u256 *m = (const u256 *)d->lookup_m[lk];
+        const size_t my_ext = ext_off;
+#pragma omp parallel for schedule(static)
+        for (size_t idx = 0; idx < size; idx++) {
+            u256 value = values[idx], t, u;
+            size_t r_next = get_rotation_idx(idx, 1, rot_scale, isize);
+            size_t r_last = get_rotation_idx(idx, last_rotation, rot_scale, isize);
+            fr_mul(&t, &zs[0][idx], &l0[idx]); /* :1147 */
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            fr_mul(&t, &zs[sets_len - 1][idx], &l_last[idx]); /* :1150 */
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            fr_sub(&t, &zs[0][r_next], &zs[0][idx]); /* :1157-1162 */
+            fr_mul(&t, &t, &table[idx]);
+            fr_add(&t, &t, &m[idx]);
+            fr_mul(&t, &t, &input_product[idx]);
+            fr_mul(&u, &table[idx], &input_product_sum[idx]);
+            fr_sub(&t, &t, &u);
+            fr_mul(&t, &t, &l_active_row[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            for (uint32_t i = 1; i < sets_len; i++) { /* :1165-1168 */
+                fr_sub(&t, &zs[i][idx], &zs[i - 1][r_last]);
+                fr_mul(&t, &t, &l0[idx]);
+                fr_mul(&value, &value, y);
+                fr_add(&value, &value, &t);
+            }
+            for (uint32_t i = 1; i < sets_len; i++) { /* :1176-1182 */
+                fr_sub(&t, &zs[i][r_next], &zs[i][idx]);
+                fr_mul(&t, &t, &lk_prod_set[(my_ext + i - 1) * size + idx]);
+                fr_sub(&t, &t, &lk_sum_set[(my_ext + i - 1) * size + idx]);
+                fr_mul(&t, &t, &l_active_row[idx]);
+                fr_mul(&value, &value, y);
+                fr_add(&value, &value, &t);
+            }
+            values[idx] = value;
+        }
+        zoff += sets_len;
+        ext_off += sets_len - 1;
+    }
+
+    /* :1188-1220 shuffles */
+    for (uint32_t sh = 0; sh < d->n_shuffles; sh++) {
+        const u256 *input_coset = sh_input + (size_t)sh * size, *shuffle_coset = sh_table + (size_t)sh * size;
+        const u256 *z = (const u256 *)d->shuffle_z[sh];
+#pragma omp parallel for schedule(static)
+        for (size_t idx = 0; idx < size; idx++) {
+            u256 value = values[idx], t, u;
+            size_t r_next = get_rotation_idx(idx, 1, rot_scale, isize);
+            fr_sub(&t, &one, &z[idx]); /* :1205 */
+            fr_mul(&t, &t, &l0[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            fr_mul(&t, &z[idx], &z[idx]); /* :1207-1209 */
+            fr_sub(&t, &t, &z[idx]);
+            fr_mul(&t, &t, &l_last[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            fr_mul(&t, &z[r_next], &shuffle_coset[idx]); /* :1215-1218 */
+            fr_mul(&u, &z[idx], &input_coset[idx]);
+            fr_sub(&t, &t, &u);
+            fr_mul(&t, &t, &l_active_row[idx]);
+            fr_mul(&value, &value, y);
+            fr_add(&value, &value, &t);
+            values[idx] = value;
+        }
+    }
+    free(lk_table);
+    free(lk_prod);
+    free(lk_sum);
+    free(lk_prod_set);
+    free(lk_sum_set);
+    free(sh_input);
+    free(sh_table);
+}

@@ -1,0 +1,29 @@
+"""GPU parity of evaluate_h (h2_evaluate_h through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from evalh_cases import oracle_evaluate_h, random_case
+from halo2_gpu_specific_amd import evaluation as ev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,k,ek", [(1, 2, 3), (2, 5, 7), (3, 8, 10), (4, 10, 12), (5, 12, 14), (6, 13, 13)])
+def test_evaluate_h_vs_oracle(oracle, seed, k, ek):
+    kw = random_case(seed, k, ek, oracle, n_calcs=40)
+    b = ev.Builder().build(**kw)
+    assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
+
+
+def test_evaluate_h_shapes(oracle):
+    for kwargs in (dict(with_perm=False), dict(lookup_sets=()), dict(n_shuffles=0), dict(lookup_sets=(2,), n_shuffles=1),
+                   dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=3)):
+        kw = random_case(11, 6, 8, oracle, **kwargs)
+        b = ev.Builder().build(**kw)
+        assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b)), kwargs
+
+
+def test_evaluate_h_k16(oracle):
+    kw = random_case(21, 16, 18, oracle, n_calcs=60)
+    b = ev.Builder().build(**kw)
+    assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
