@@ -133,6 +133,16 @@ def main():
     avg_launch_ms = ev_ms.value / launches
     achieved_gbs = (alg_bytes_per_transform / passes) / (avg_launch_ms * 1e-3) / 1e9
 
+    # HBM bytes per k_ntt_pass launch from the PMC passes committed under profiles/ (separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); null when the file is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_v2_hbm_traffic.json")) as f:
+            if log_n == 24:
+                traffic = json.load(f)["kernels"]["h2::k_ntt_pass"]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     out = {
         "metric": "NTT Fr-ops/s @ k=24 (forward+inverse 2^24 BN254 Fr NTT; MSM G1-adds/s under 'msm')",
         "value": value,
@@ -158,12 +168,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes_per_transform / passes,
             "avg_launch_ms": avg_launch_ms,
             "launches_per_transform": passes,
-            "note": "VALU-bound in practice: 14n 254-bit Montgomery multiplications per transform on the "
-            "half-rate v_mad_u64_u32 pipe (tools/ubench.hip); see DESIGN.md",
+            "note": "VALU-bound in practice: ~15n 254-bit Montgomery multiplications per transform against a measured "
+            "chip ceiling of 1.31e11 multiplications/s (tools/mulbench.hip, profiles/r1_mulbench.txt); see DESIGN.md",
         },
     }
 
