@@ -40,15 +40,16 @@ static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 256;    // threads per k_reduce workgroup
 static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce thread
-static constexpr uint32_t SCAN_CHUNK = 4096;  // histogram entries per k_scan_local workgroup (256 threads x 16)
+static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
 
 struct MsmShape {
     uint32_t c, W, nb, nbt, G;  // window bits, windows, buckets/window, total buckets, reduce groups/window
     uint32_t log_s;             // slice length S = 2^log_s entries
-    uint32_t scan_blocks;
+    uint32_t lo_bits, hi_bits;  // bucket id = hi (partition inside the window) : lo (bin inside the partition)
+    uint32_t np;                // partitions = W << hi_bits
     size_t n, entries, max_items;
     // scratch offsets (bytes)
-    size_t off_keys, off_sorted, off_counts, off_starts, off_cursor, off_blocksums, off_heavy, off_partials,
+    size_t off_keys, off_sorted, off_tmp, off_pcount, off_pbase, off_pcursor, off_starts, off_heavy, off_partials,
         off_buckets, off_winpart, total;
 };
 
@@ -88,7 +89,13 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
         int v = atoi(env);
         if (v >= 1 && v <= 10) s.log_s = (uint32_t)v;
     }
-    s.scan_blocks = (s.nbt + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    // two-level counting sort: the low bits of a bucket id are resolved inside LDS (k_bucket_sort), the
+    // high bits select one of 2^hi_bits partitions per window (k_partition); W << hi_bits <= 16384 so
+    // the per-workgroup partition histogram of k_digits fits in 64 KiB of LDS
+    s.lo_bits = (s.c - 1 < 8) ? (s.c - 1) : 8;
+    while (((size_t)s.W << (s.c - 1 - s.lo_bits)) > 16384) s.lo_bits++;
+    s.hi_bits = s.c - 1 - s.lo_bits;
+    s.np = s.W << s.hi_bits;
     s.max_items = (s.entries >> s.log_s) + s.nbt + 2;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -98,10 +105,11 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     };
     s.off_keys = take(s.entries * 4);
     s.off_sorted = take(s.entries * 4);
-    s.off_counts = take(((size_t)s.nbt + 2) * 4);
+    s.off_tmp = take(s.entries * 8);
+    s.off_pcount = take(((size_t)s.np + 2) * 4);
+    s.off_pbase = take(((size_t)s.np + 2) * 4);
+    s.off_pcursor = take(((size_t)s.np + 2) * 4);
     s.off_starts = take(((size_t)s.nbt + 2) * 4);
-    s.off_cursor = take(((size_t)s.nbt + 2) * 4);
-    s.off_blocksums = take(((size_t)s.scan_blocks + 2) * 4);
     s.off_heavy = take(((size_t)s.nbt + 2) * 4);
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
@@ -118,88 +126,75 @@ void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows
     if (buckets_per_window) *buckets_per_window = s.nb;
 }
 
-// ---------------------------------------------------------------- wave-aggregated atomics
-// atomicAdd(&counter[key], 1) for every `valid` lane, returning the lane's slot.  Lanes of a wave that
-// share a key are served by ONE atomic (up to 4 distinct hot keys per call are aggregated, the rest fall
-// back to per-lane atomics): a column of equal / boolean scalars would otherwise serialise hundreds of
-// thousands of atomics on a single address.
-__device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* counter, uint32_t key, bool valid) {
-    const uint32_t lane = __lane_id();
-    uint64_t todo = __ballot(valid);
-    uint32_t pos = 0;
-    bool done = !valid;
-#pragma unroll 1
-    for (int it = 0; it < 4 && todo != 0; it++) {
-        int leader = __ffsll((unsigned long long)todo) - 1;
-        uint32_t lkey = __shfl(key, leader, 64);
-        uint64_t same = __ballot(!done && key == lkey);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&counter[lkey], (uint32_t)__popcll(same));
-        base = __shfl(base, leader, 64);
-        if (!done && key == lkey) {
-            pos = base + (uint32_t)__popcll(same & (((uint64_t)1 << lane) - 1));
-            done = true;
-        }
-        todo &= ~same;
-    }
-    if (!done) pos = atomicAdd(&counter[key], 1u);
-    return pos;
-}
-
 // ---------------------------------------------------------------- k_digits
+// One thread per scalar (grid-stride): Montgomery -> canonical, signed c-bit digits, keys[w][i] =
+// bucket | sign (KEY_INVALID for a zero digit), and the histogram of (window, bucket >> lo_bits)
+// partitions, privatised in LDS and flushed once per workgroup.
+extern __shared__ __attribute__((aligned(16))) uint32_t h2_msm_smem[];
+
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
-                                                uint32_t max_bits, uint32_t* keys, uint32_t* counts) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;  // dead lanes still walk the windows: wave_agg_inc needs the whole wave
-    Fr s = live ? fp_from_mont(fp_load(scalars + i)) : fp_zero<FrParams>();  // canonical LE integer (to_repr, arithmetic.rs:21)
-    // keep only the low max_bits bits (multiexp_bound contract)
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        int lo_bit = 32 * k;
-        if ((int)max_bits <= lo_bit)
-            s.l[k] = 0;
-        else if ((int)max_bits < lo_bit + 32)
-            s.l[k] &= (1u << (max_bits - lo_bit)) - 1;
-    }
+                                                uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
+                                                uint32_t* keys, uint32_t* pcount) {
+    uint32_t* hist = h2_msm_smem;
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-    uint64_t buf = 0;
-    int nbits = 0;
-    uint32_t w = 0, carry = 0;
-    auto emit = [&](uint32_t raw) {
-        raw += carry;
-        uint32_t neg = 0, mag = raw;
-        if (raw > half) {  // digit = raw - 2^c  (negative)
-            mag = (1u << c) - raw;
-            neg = SIGN_BIT;
-            carry = 1;
-        } else {
-            carry = 0;
-        }
-        uint32_t out = KEY_INVALID;
-        uint32_t key = w * nb + (mag - 1);
-        if (mag != 0) out = key | neg;
-        wave_agg_inc(counts, key, mag != 0);
-        if (live) keys[(size_t)w * n + i] = out;
-        w++;
-    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr s = fp_from_mont(fp_load(scalars + i));  // canonical little-endian integer (to_repr, arithmetic.rs:21)
+        // keep only the low max_bits bits (multiexp_bound contract)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        buf |= (uint64_t)s.l[k] << nbits;
-        nbits += 32;
-        while (nbits >= (int)c && w < W) {
+        for (int k = 0; k < 8; k++) {
+            int lo_bit = 32 * k;
+            if ((int)max_bits <= lo_bit)
+                s.l[k] = 0;
+            else if ((int)max_bits < lo_bit + 32)
+                s.l[k] &= (1u << (max_bits - lo_bit)) - 1;
+        }
+        uint64_t buf = 0;
+        int nbits = 0;
+        uint32_t w = 0, carry = 0;
+        auto emit = [&](uint32_t raw) {
+            raw += carry;
+            uint32_t neg = 0, mag = raw;
+            if (raw > half) {  // digit = raw - 2^c  (negative)
+                mag = (1u << c) - raw;
+                neg = SIGN_BIT;
+                carry = 1;
+            } else {
+                carry = 0;
+            }
+            uint32_t out = KEY_INVALID;
+            if (mag != 0) {
+                uint32_t bucket = mag - 1;
+                out = bucket | neg;
+                atomicAdd(&hist[(w << hi_bits) + (bucket >> lo_bits)], 1u);
+            }
+            keys[(size_t)w * n + i] = out;
+            w++;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            buf |= (uint64_t)s.l[k] << nbits;
+            nbits += 32;
+            while (nbits >= (int)c && w < W) {
+                emit((uint32_t)buf & mask);
+                buf >>= c;
+                nbits -= c;
+            }
+        }
+        while (w < W) {
             emit((uint32_t)buf & mask);
             buf >>= c;
-            nbits -= c;
         }
     }
-    while (w < W) {
-        emit((uint32_t)buf & mask);
-        buf >>= c;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+        uint32_t v = hist[k];
+        if (v) atomicAdd(&pcount[k], v);
     }
 }
 
-// ---------------------------------------------------------------- k_scan_* (3 launches)
-// starts[b] = sum_{b'<b} counts[b'] for b in [0, nbt]; cursor = starts (scatter write heads).
+// ---------------------------------------------------------------- k_scan_parts (single workgroup)
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh, uint32_t* total) {
     // inclusive scan inside each wave64 with shuffles, then across the 4 waves through LDS
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,64 +213,103 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + x - v;
 }
 
-__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* counts, uint32_t nbt, uint32_t* starts,
-                                                    uint32_t* blocksums) {
-    __shared__ uint32_t sh[4];
-    const uint32_t ITEMS = SCAN_CHUNK / 256;
-    uint32_t base_idx = blockIdx.x * SCAN_CHUNK + threadIdx.x * ITEMS;
-    uint32_t v[SCAN_CHUNK / 256], sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < ITEMS; k++) {
-        uint32_t idx = base_idx + k;
-        uint32_t c = (idx < nbt) ? counts[idx] : 0;
-        v[k] = sum;
-        sum += c;
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
-#pragma unroll
-    for (uint32_t k = 0; k < ITEMS; k++) {
-        uint32_t idx = base_idx + k;
-        if (idx <= nbt) starts[idx] = ex + v[k];
-    }
-    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
-}
-
-// single workgroup: exclusive scan of the block sums in place (nblocks <= a few thousand)
-__global__ void __launch_bounds__(256) k_scan_blocks(uint32_t* blocksums, uint32_t nblocks) {
+// pbase[p] = sum_{p' < p} pcount[p'] (p <= np), pcursor = pbase, starts[nbt] = total entries
+__global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint32_t np, uint32_t* pbase,
+                                                    uint32_t* pcursor, uint32_t* starts, uint32_t nbt) {
     __shared__ uint32_t sh[4];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t c0 = 0; c0 < nblocks; c0 += 256) {
+    for (uint32_t c0 = 0; c0 < np + 1; c0 += 256) {
         uint32_t idx = c0 + threadIdx.x;
-        uint32_t v = idx < nblocks ? blocksums[idx] : 0;
+        uint32_t v = idx < np ? pcount[idx] : 0;
         uint32_t total;
         uint32_t ex = block_exclusive_scan_256(v, sh, &total);
-        if (idx < nblocks) blocksums[idx] = carry + ex;
+        if (idx <= np) {
+            pbase[idx] = carry + ex;
+            pcursor[idx] = carry + ex;
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry += total;
         __syncthreads();
     }
+    if (threadIdx.x == 0) starts[nbt] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_scan_add(uint32_t* starts, uint32_t* cursor, const uint32_t* blocksums,
-                                                  uint32_t nbt) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx > nbt) return;
-    uint32_t v = starts[idx] + blocksums[idx / SCAN_CHUNK];
-    starts[idx] = v;
-    cursor[idx] = v;
+// ---------------------------------------------------------------- k_partition (sort pass A)
+// Workgroup = PART_T consecutive keys of one window.  Local ranks come from LDS atomics; each
+// non-empty partition costs ONE global atomic per workgroup (space reservation), and the entries of a
+// partition land in a contiguous run, so the 8-byte stores of a workgroup merge into full lines.
+__global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t hi_bits,
+                                                   uint32_t* pcursor, uint2* tmp) {
+    uint32_t* cnt = h2_msm_smem;               // 2^hi_bits local counters, then the reserved bases
+    const uint32_t nparts = 1u << hi_bits, w = blockIdx.y;
+    for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const uint32_t ITEMS = PART_T / 256;
+    uint32_t key[PART_T / 256], rank[PART_T / 256];
+    const size_t i0 = (size_t)blockIdx.x * PART_T;
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        size_t i = i0 + k * 256 + threadIdx.x;
+        key[k] = (i < n) ? keys[(size_t)w * n + i] : KEY_INVALID;
+        rank[k] = 0;
+        if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&cnt[(key[k] & ~SIGN_BIT) >> lo_bits], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) {
+        uint32_t v = cnt[k];
+        cnt[k] = v ? atomicAdd(&pcursor[(w << hi_bits) + k], v) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        if (key[k] == KEY_INVALID) continue;
+        uint32_t bucket = key[k] & ~SIGN_BIT;
+        uint32_t i = (uint32_t)(i0 + k * 256 + threadIdx.x);
+        tmp[cnt[bucket >> lo_bits] + rank[k]] = make_uint2(i | (key[k] & SIGN_BIT), bucket & ((1u << lo_bits) - 1));
+    }
 }
 
-// ---------------------------------------------------------------- k_scatter
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* keys, size_t n, uint32_t* cursor, uint32_t* sorted) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t w = blockIdx.y;
-    uint32_t key = (i < n) ? keys[(size_t)w * n + i] : KEY_INVALID;
-    bool valid = key != KEY_INVALID;
-    uint32_t pos = wave_agg_inc(cursor, key & ~SIGN_BIT, valid);
-    if (valid) sorted[pos] = (uint32_t)i | (key & SIGN_BIT);
+// ---------------------------------------------------------------- k_bucket_sort (sort pass B)
+// One workgroup per partition: histogram of the low bucket bits in LDS, exclusive scan -> the start
+// offset of every bucket of the partition (written to `starts`), then the entries are placed.
+__global__ void __launch_bounds__(256) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
+                                                     uint32_t hi_bits, uint32_t nb, uint32_t* starts, uint32_t* sorted) {
+    uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
+    __shared__ uint32_t sh[4];
+    const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
+    const uint32_t e0 = pbase[p], e1 = pbase[p + 1];
+    for (uint32_t k = threadIdx.x; k < nbins; k += 256) bins[k] = 0;
+    __syncthreads();
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) atomicAdd(&bins[tmp[e].y], 1u);
+    __syncthreads();
+    // exclusive scan of nbins (<= 512) counters: 256 threads x (nbins / 256) consecutive bins
+    const uint32_t per = (nbins + 255) / 256;
+    uint32_t local[2] = {0, 0}, sum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t b = threadIdx.x * per + k;
+        uint32_t v = b < nbins ? bins[b] : 0;
+        local[k] = sum;
+        sum += v;
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
+    // bucket index of bin b of partition p: window w = p >> hi_bits, bucket = ((p & (2^hi_bits - 1)) << lo_bits) | b
+    const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t b = threadIdx.x * per + k;
+        if (b < nbins) {
+            uint32_t st = e0 + ex + local[k];
+            bins[b] = st;
+            starts[(size_t)w * nb + ((hi << lo_bits) | b)] = st;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        uint2 v = tmp[e];
+        sorted[atomicAdd(&bins[v.y], 1u)] = v.x;
+    }
 }
 
 // ---------------------------------------------------------------- k_acc_slice (hot loop)
@@ -448,24 +482,27 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
                        hipStream_t stream) {
     uint32_t* keys = (uint32_t*)(scratch + s.off_keys);
     uint32_t* sorted = (uint32_t*)(scratch + s.off_sorted);
-    uint32_t* counts = (uint32_t*)(scratch + s.off_counts);
+    uint2* tmp = (uint2*)(scratch + s.off_tmp);
+    uint32_t* pcount = (uint32_t*)(scratch + s.off_pcount);
+    uint32_t* pbase = (uint32_t*)(scratch + s.off_pbase);
+    uint32_t* pcursor = (uint32_t*)(scratch + s.off_pcursor);
     uint32_t* starts = (uint32_t*)(scratch + s.off_starts);
-    uint32_t* cursor = (uint32_t*)(scratch + s.off_cursor);
-    uint32_t* blocksums = (uint32_t*)(scratch + s.off_blocksums);
     uint32_t* heavy = (uint32_t*)(scratch + s.off_heavy);  // [0] = count, [1..] = list
     XYZZ* partials = (XYZZ*)(scratch + s.off_partials);
     XYZZ* buckets = (XYZZ*)(scratch + s.off_buckets);
     XYZZ* winpart = (XYZZ*)(scratch + s.off_winpart);
 
-    H2_HIP(hipMemsetAsync(counts, 0, ((size_t)s.nbt + 2) * 4, stream));
+    H2_HIP(hipMemsetAsync(pcount, 0, ((size_t)s.np + 2) * 4, stream));
     H2_HIP(hipMemsetAsync(heavy, 0, 4, stream));
     unsigned nblk = (unsigned)((s.n + 255) / 256);
-    hipLaunchKernelGGL(k_digits, dim3(nblk), dim3(256), 0, stream, d_scalars, s.n, s.c, s.W, s.nb,
-                       max_bits > 254 ? 254u : max_bits, keys, counts);
-    hipLaunchKernelGGL(k_scan_local, dim3(s.scan_blocks), dim3(256), 0, stream, counts, s.nbt, starts, blocksums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, stream, blocksums, s.scan_blocks);
-    hipLaunchKernelGGL(k_scan_add, dim3((s.nbt + 1 + 255) / 256), dim3(256), 0, stream, starts, cursor, blocksums, s.nbt);
-    hipLaunchKernelGGL(k_scatter, dim3(nblk, s.W), dim3(256), 0, stream, keys, s.n, cursor, sorted);
+    unsigned dblk = nblk < 1024 ? nblk : 1024;  // grid-stride: one LDS histogram flush per workgroup
+    hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
+                       max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount);
+    hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.W), dim3(256),
+                       (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp);
+    hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(256), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
+                       s.hi_bits, s.nb, starts, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
                        s.log_s, partials);
