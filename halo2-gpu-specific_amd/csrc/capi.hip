@@ -342,6 +342,17 @@ int h2_dev_msm(const void* d_scalars, const void* d_bases, size_t n, uint32_t ma
     });
 }
 
+int h2_dev_msm_batch(const void* const* d_scalars, size_t count, const void* d_bases, size_t n, uint32_t max_bits,
+                     void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, void* stream) {
+    if (count && (!d_scalars || !out_xyz || (n && !d_bases))) return bad("h2_dev_msm_batch: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);  // uses the context's two internal streams and pinned staging
+        return msm_device_batch(ctx, (const Fr* const*)d_scalars, count, (const uint64_t*)d_bases, n, max_bits, d_scratch,
+                                scratch_bytes, out_xyz, pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
     if (!d_out && n) return bad("h2_dev_random_points: null argument");
     return guarded([&] {

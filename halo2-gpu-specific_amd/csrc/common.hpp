@@ -46,6 +46,13 @@ struct DevBuf {
     void release();
 };
 
+// Grow-only pinned host buffer (async device-to-host staging).
+struct PinnedBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    void* get(size_t bytes);
+};
+
 struct NttPlan;  // ntt.hip
 
 struct DeviceCtx {
@@ -56,6 +63,7 @@ struct DeviceCtx {
     DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
     DevBuf msm_scratch;
     DevBuf evalh_scratch;
+    PinnedBuf pinned;
     std::map<std::string, NttPlan*> plans;
     hipDeviceProp_t prop;
 };

@@ -26,6 +26,15 @@ void* DevBuf::get(size_t bytes) {
     cap = want;
     return ptr;
 }
+void* PinnedBuf::get(size_t bytes) {
+    if (bytes <= cap) return ptr;
+    if (ptr) H2_HIP(hipHostFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    H2_HIP(hipHostMalloc(&ptr, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return ptr;
+}
 void DevBuf::release() {
     if (ptr) hipFree(ptr);
     ptr = nullptr;

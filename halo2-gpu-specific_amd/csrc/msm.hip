@@ -551,6 +551,52 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     return H2_OK;
 }
 
+// Batch of MSMs over ONE set of bases (the prover commits every advice / fixed / z column against the
+// same g_lagrange: plonk/prover.rs:293-299, :477-487, keygen.rs:288-291).  Consecutive MSMs alternate
+// between two streams with their own scratch halves, so the latency-bound tail of one MSM (k_finish,
+// k_reduce: about one wave per SIMD) overlaps the ALU-bound hot loop of the next, and the host-side
+// window combine of MSM i runs while the GPU works on i+1, i+2.
+int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, const uint64_t* d_bases, size_t n,
+                     uint32_t max_bits, void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream) {
+    if (count == 0) return H2_OK;
+    if (n == 0 || max_bits == 0) {
+        for (size_t i = 0; i < count; i++) msm_identity(out_xyz + 12 * i);
+        return H2_OK;
+    }
+    if (n > 0x7fffffffu) {
+        set_last_error("h2 msm: n must be < 2^31");
+        return H2_ERR_INVALID;
+    }
+    MsmShape s = msm_shape(n, max_bits);
+    const size_t per = align_up(s.total, 256);
+    if (!d_scratch || scratch_bytes < 2 * per) {
+        set_last_error("h2 msm batch: scratch too small (need 2 x h2_msm_scratch_bytes, 256-byte aligned)");
+        return H2_ERR_INVALID;
+    }
+    const size_t wp = (size_t)s.W * s.G;
+    // pinned staging for the per-MSM window partials (async read-back)
+    XYZZ* h_win = (XYZZ*)ctx->pinned.get(count * wp * sizeof(XYZZ));
+    hipStream_t st[2] = {ctx->stream, ctx->copy_stream};
+    H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete
+    std::vector<hipEvent_t> done(count);
+    for (size_t i = 0; i < count; i++) {
+        char* scratch = (char*)d_scratch + (i & 1) * per;
+        hipStream_t q = st[i & 1];
+        msm_launch(s, d_scalars[i], (const Affine*)d_bases, max_bits, scratch, q);
+        H2_HIP(hipMemcpyAsync(h_win + i * wp, scratch + s.off_winpart, wp * sizeof(XYZZ), hipMemcpyDeviceToHost, q));
+        H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        H2_HIP(hipEventRecord(done[i], q));
+    }
+    std::vector<XYZZ> winpart(wp);
+    for (size_t i = 0; i < count; i++) {
+        H2_HIP(hipEventSynchronize(done[i]));
+        H2_HIP(hipEventDestroy(done[i]));
+        memcpy(winpart.data(), h_win + i * wp, wp * sizeof(XYZZ));
+        msm_host_tail(s, winpart, out_xyz + 12 * i);
+    }
+    return H2_OK;
+}
+
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
                               uint64_t out_xyz[12]) {
     Affine* d_bases = (Affine*)ctx->buf_c.get(n * sizeof(Affine));

@@ -195,6 +195,13 @@ size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits);
 int h2_msm_shape(size_t n, uint32_t max_bits, uint32_t *c, uint32_t *windows, uint32_t *buckets_per_window);
 int h2_dev_msm(const void *d_scalars, const void *d_bases, size_t n, uint32_t max_bits, void *d_scratch,
                size_t scratch_bytes, uint64_t out_xyz[12], void *stream);
+/* `count` MSMs over the SAME bases (one per column: plonk/prover.rs:293-299 commits every advice column
+ * against g_lagrange; :477-487, :540-549 the z polynomials).  d_scalars: host array of `count` device
+ * pointers.  scratch_bytes >= 2 * round_up(h2_msm_scratch_bytes(n, max_bits), 256): consecutive MSMs
+ * alternate between two internal streams so one MSM's latency-bound bucket reduction overlaps the next
+ * one's accumulation.  out_xyz: count x 12 u64 in HOST memory.  Synchronous. */
+int h2_dev_msm_batch(const void *const *d_scalars, size_t count, const void *d_bases, size_t n, uint32_t max_bits,
+                     void *d_scratch, size_t scratch_bytes, uint64_t *out_xyz, void *stream);
 int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,
                    const uint64_t c[4], void *stream);
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);

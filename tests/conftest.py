@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # torch bundles its own HIP runtime: when it is used in the same process as libhalo2_hip.so it has to
+    # initialise first, so that both bind to one runtime instance (the loader reuses the loaded SONAME)
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001 - torch is optional plumbing for the tests
+        pass
 
 
 @pytest.fixture(scope="session")

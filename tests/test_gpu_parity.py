@@ -282,3 +282,30 @@ def test_commit_lagrange_and_ifft(oracle):
     c_coeff = ar.best_multiexp(vals, g)
     assert _affine(oracle, c_lagrange) == _affine(oracle, c_coeff)
     assert _affine(oracle, c_lagrange) == _affine(oracle, oracle.best_multiexp(a, gl))
+
+
+def test_msm_batch_shared_bases(oracle):
+    """h2_dev_msm_batch: several columns committed against the same bases (plonk/prover.rs:293-299),
+    pipelined on two streams; each result must equal the oracle's MSM of that column."""
+    import ctypes
+
+    import torch
+
+    L = h2.lib()
+    n, count = 1 << 12, 5
+    pts = oracle.random_g1(901, n)
+    cols = [oracle.random_fr(910 + i, n) for i in range(count)]
+    cols[2][: n // 2] = 0  # a half-empty column
+    dev = torch.device("cuda", 0)
+    d_pts = torch.from_numpy(pts.view(np.int64)).to(dev)
+    d_cols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    per = (L.h2_msm_scratch_bytes(n, 254) + 255) // 256 * 256
+    scratch = torch.empty(2 * per, dtype=torch.uint8, device=dev)
+    ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_cols])
+    out = np.zeros((count, 12), dtype=np.uint64)
+    rc = L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 254, scratch.data_ptr(), 2 * per, out.ctypes.data, None)
+    assert rc == 0, L.h2_last_error()
+    for i in range(count):
+        assert _affine(oracle, out[i]) == _affine(oracle, oracle.best_multiexp(cols[i], pts)), i
+    # too-small scratch is refused, not overrun
+    assert L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 254, scratch.data_ptr(), per, out.ctypes.data, None) == 1

@@ -156,12 +156,26 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
     double t0 = now();
     for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, nullptr));
     double t1 = now();
+    // batch of 8 MSMs over the same bases (pipelined on two internal streams)
+    const int BATCH = 8;
+    void* d_scr2;
+    size_t sb2 = 2 * ((sb + 255) / 256 * 256);
+    CK(hipMalloc(&d_scr2, sb2));
+    const void* ptrs[BATCH];
+    for (int b = 0; b < BATCH; b++) ptrs[b] = d_s;
+    uint64_t outs[BATCH * 12];
+    H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, nullptr));
+    double b0 = now();
+    for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, nullptr));
+    double b1 = now();
+    double bms = (b1 - b0) / reps / BATCH * 1e3;
+    CK(hipFree(d_scr2));
     uint32_t c, W, nb;
     h2_msm_shape(n, bits, &c, &W, &nb);
     double adds = (double)n * W + 2.0 * nb * W + (double)W * c;
     double ms = (t1 - t0) / reps * 1e3;
-    printf("msm  log_n=%2d bits=%3d mode=%d c=%u W=%u  %8.3f ms  %.3e G1-adds/s  %.3e pairs/s  scratch %.0f MiB\n", log_n, bits, mode,
-           c, W, ms, adds / (ms * 1e-3), n / (ms * 1e-3), sb / 1048576.0);
+    printf("msm  log_n=%2d bits=%3d mode=%d c=%u W=%u  %8.3f ms  %.3e G1-adds/s  %.3e pairs/s  scratch %.0f MiB | batch of %d: %7.3f ms/MSM %.3e G1-adds/s\n", log_n, bits, mode,
+           c, W, ms, adds / (ms * 1e-3), n / (ms * 1e-3), sb / 1048576.0, BATCH, bms, adds / (bms * 1e-3));
     CK(hipFree(d_s));
     CK(hipFree(d_b));
     CK(hipFree(d_scr));
