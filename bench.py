@@ -76,7 +76,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("H2_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

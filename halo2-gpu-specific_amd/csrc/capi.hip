@@ -232,6 +232,15 @@ int h2_msm(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t ma
     });
 }
 
+int h2_bases_register(const uint64_t* bases, size_t n) {
+    if (!bases || n == 0) return bad("h2_bases_register: null / empty range");
+    return bases_register(bases, n);
+}
+int h2_bases_unregister(const uint64_t* bases) {
+    if (!bases) return bad("h2_bases_unregister: null");
+    return bases_unregister(bases);
+}
+
 int h2_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) {
     if (!out_xyz || (count && !points_xyz)) return bad("h2_g1_sum: null argument");
     g1_sum_host(points_xyz, count, out_xyz);

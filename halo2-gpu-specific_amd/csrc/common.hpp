@@ -64,6 +64,7 @@ struct DeviceCtx {
     DevBuf msm_scratch;
     DevBuf evalh_scratch;
     PinnedBuf pinned;
+    std::map<const void*, void*> resident;  // registered host base ranges -> device copies (msm.hip)
     std::map<std::string, NttPlan*> plans;
     hipDeviceProp_t prop;
 };

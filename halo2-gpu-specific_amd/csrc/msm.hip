@@ -27,6 +27,8 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 
 #include "common.hpp"
@@ -597,10 +599,67 @@ int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, c
     return H2_OK;
 }
 
+// ---- resident SRS: host ranges the caller promised not to modify (h2_bases_register).  The reference
+// re-uploads the bases on every MSM (arithmetic.rs:354-360); at 2^20 that is 64 MiB of PCIe per call,
+// about as long as the MSM itself.
+namespace {
+std::mutex g_reg_mu;
+std::map<const uint64_t*, size_t> g_registered;  // host base pointer -> number of points
+}  // namespace
+
+int bases_register(const uint64_t* bases, size_t n) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_registered[bases] = n;
+    return H2_OK;
+}
+
+int bases_unregister(const uint64_t* bases) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_registered.erase(bases);
+    // device copies are dropped lazily by the owning context (resident_drop) on its next MSM
+    return H2_OK;
+}
+
+// device copy of a registered range that contains [bases, bases + n) -- or nullptr
+static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size_t n) {
+    const uint64_t* key = nullptr;
+    size_t len = 0;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        // drop device copies whose registration is gone
+        for (auto it = ctx->resident.begin(); it != ctx->resident.end();) {
+            if (!g_registered.count((const uint64_t*)it->first)) {
+                hipFree(it->second);
+                it = ctx->resident.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        auto it = g_registered.upper_bound(bases);
+        if (it == g_registered.begin()) return nullptr;
+        --it;
+        if (bases + 8 * n > it->first + 8 * it->second) return nullptr;
+        key = it->first;
+        len = it->second;
+    }
+    auto rit = ctx->resident.find((const void*)key);
+    if (rit == ctx->resident.end()) {
+        void* d = nullptr;
+        H2_HIP(hipMalloc(&d, len * sizeof(Affine)));
+        H2_HIP(hipMemcpyAsync(d, key, len * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+        rit = ctx->resident.emplace((const void*)key, d).first;
+    }
+    return (const Affine*)rit->second + (bases - key) / 8;
+}
+
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
                               uint64_t out_xyz[12]) {
-    Affine* d_bases = (Affine*)ctx->buf_c.get(n * sizeof(Affine));
-    H2_HIP(hipMemcpyAsync(d_bases, bases, n * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+    const Affine* d_bases = resident_lookup(ctx, bases, n);
+    if (!d_bases) {
+        Affine* up = (Affine*)ctx->buf_c.get(n * sizeof(Affine));
+        H2_HIP(hipMemcpyAsync(up, bases, n * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+        d_bases = up;
+    }
     size_t sb = msm_scratch_bytes(n, max_bits);
     void* scratch = ctx->msm_scratch.get(sb);
     return msm_device(ctx, d_scalars, (const uint64_t*)d_bases, n, max_bits, scratch, sb, out_xyz, ctx->stream);

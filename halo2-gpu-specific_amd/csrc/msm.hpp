@@ -13,6 +13,8 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
                void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
 int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, const uint64_t* d_bases, size_t n,
                      uint32_t max_bits, void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
+int bases_register(const uint64_t* bases, size_t n);
+int bases_unregister(const uint64_t* bases);
 int msm_host(DeviceCtx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
              uint64_t out_xyz[12]);
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n,

@@ -71,6 +71,12 @@ int h2_msm(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t ma
 /* gpu_multiexp_bound: arithmetic.rs:413-440 -- contiguous ceil(n/N_GPU) chunks, one pooled
  * device each, partial points summed on the host. */
 int h2_msm_multi(const uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
+/* Resident SRS (an improvement the reference lacks: it re-uploads the bases on every call,
+ * arithmetic.rs:354-360).  After h2_bases_register(g, n) every host-buffer MSM whose `bases` range lies
+ * inside [g, g + n) uses a device copy uploaded once per device (Params::g / g_lagrange never change,
+ * poly/commitment.rs:23-29).  The caller must not modify a registered range before unregistering it. */
+int h2_bases_register(const uint64_t *bases, size_t n);
+int h2_bases_unregister(const uint64_t *bases);
 /* Host-side fold of `count` partial results (12 x u64 Jacobian each): the
  * `.reduce(|acc, x| acc + x)` of arithmetic.rs:433-435; also used after an all-gather of per-rank
  * partial points when one MSM is split across processes (one process per GPU). */

@@ -309,3 +309,25 @@ def test_msm_batch_shared_bases(oracle):
         assert _affine(oracle, out[i]) == _affine(oracle, oracle.best_multiexp(cols[i], pts)), i
     # too-small scratch is refused, not overrun
     assert L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 254, scratch.data_ptr(), per, out.ctypes.data, None) == 1
+
+
+def test_resident_bases(oracle):
+    """h2_bases_register: MSMs over sub-ranges of a registered SRS reuse one device copy"""
+    L = h2.lib()
+    n = 1 << 16
+    pts = oracle.random_g1(77, n)
+    s = oracle.random_fr(78, n)
+    want_full = _affine(oracle, oracle.best_multiexp(s, pts))
+    want_half = _affine(oracle, oracle.best_multiexp(s[: n // 2], pts[n // 4 : n // 4 + n // 2]))
+    assert L.h2_bases_register(pts.ctypes.data, n) == 0
+    try:
+        for _ in range(2):
+            assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(s, pts, 254)) == want_full
+            sub = pts[n // 4 : n // 4 + n // 2]  # a view into the registered range (commit with size < n)
+            assert sub.ctypes.data == pts.ctypes.data + 64 * (n // 4)
+            out = np.zeros(12, dtype=np.uint64)
+            assert L.h2_msm(s.ctypes.data, sub.ctypes.data, n // 2, 254, out.ctypes.data) == 0
+            assert _affine(oracle, out) == want_half
+    finally:
+        assert L.h2_bases_unregister(pts.ctypes.data) == 0
+    assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(s, pts, 254)) == want_full  # back to per-call upload
