@@ -38,6 +38,16 @@ __global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, uint32_t mu
     fp_store(out + i, fp_pow_u32(base, i * mul));
 }
 
+// out[(rho << kbits) | K] = base^((rho * K << s_log) mod n)   -- the complete inter-pass twiddle set of a pass
+__global__ void __launch_bounds__(256) k_direct_table(Fr* out, Fr base, uint32_t kbits, uint32_t s_log, uint32_t log_n,
+                                                      uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t rho = i >> kbits, K = i & ((1u << kbits) - 1);
+    uint32_t e = (uint32_t)(((uint64_t)rho * K) << s_log) & ((1u << log_n) - 1);
+    fp_store(out + i, fp_pow_u32(base, e));
+}
+
 // out[i] = in[i] * d
 __global__ void __launch_bounds__(256) k_scale_table(Fr* out, const Fr* in, Fr d, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,6 +61,7 @@ struct PassArgs {
     const Fr* tw_bfly;  // R/2 entries: (w^(n/R))^e
     const Fr* tw_lo;    // min(n, 4096) entries: w^i
     const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
+    const Fr* tw_direct;  // non-null: inter-pass twiddle = tw_direct[(rho << consumed) | K] (no generation multiply)
     uint32_t hi_scaled;  // tw_hi already carries the uniform post-scale (1/n): never skip, no post multiply
     Fr pre3[3];         // has_pre3: x *= pre3[idx % 3] on the first-pass load (idx % 3 == 0 skipped)
     Fr post3[3];        // has_post3: y *= post3[idx % 3] on the final store
@@ -156,7 +167,11 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
         if (a.nprev != 0) {
             // omega^(rho * S * K)
             uint32_t ex = (uint32_t)(((uint64_t)rho * K) << a.s_log) & n_mask;
-            if (ex != 0 || a.hi_scaled) x = fp_mul(x, twiddle_pow(a, ex));
+            if (a.tw_direct != nullptr) {
+                if (ex != 0) x = fp_mul(x, fp_load(a.tw_direct + ((rho << a.t_log) | K)));
+            } else if (ex != 0 || a.hi_scaled) {
+                x = fp_mul(x, twiddle_pow(a, ex));
+            }
         }
         lds_put(t_lo, t_hi, (bitrev(rho, B) << log_c) + c, x);
     }
@@ -268,6 +283,24 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
             hipLaunchKernelGGL(k_pow_table, dim3((half + 255) / 256), dim3(256), 0, stream, pl->tables + bf_off[p], w,
                                n >> pl->bits[p], half);
     }
+    // passes whose whole inter-pass twiddle set has <= 2^16 entries get it tabulated (2 MiB, L2-resident):
+    // the pass then spends one multiplication per element on twiddles instead of two
+    {
+        uint32_t consumed = 0;
+        for (size_t p = 0; p < pl->bits.size(); p++) {
+            const uint32_t B = pl->bits[p];
+            const bool last = p + 1 == pl->bits.size();
+            Fr* tab = nullptr;
+            if (p > 0 && !last && B + consumed <= 16) {
+                uint32_t cnt = 1u << (B + consumed);
+                H2_HIP(hipMalloc(&tab, (size_t)cnt * sizeof(Fr)));
+                hipLaunchKernelGGL(k_direct_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, tab, w, consumed,
+                                   log_n - consumed - B, log_n, cnt);
+            }
+            pl->tw_direct.push_back(tab);
+            consumed += B;
+        }
+    }
     H2_HIP(hipGetLastError());
     ctx->plans[key] = pl;
     return pl;
@@ -313,6 +346,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         a.tw_bfly = pl->tw_bfly[p];
         a.tw_lo = pl->tw_lo;
         a.tw_hi = pl->tw_hi;
+        a.tw_direct = pl->tw_direct[p];
         set_scale3(a, (p == 0) ? pre3 : nullptr, last ? post3 : nullptr);
         a.log_n = L;
         a.B = B;
