@@ -109,8 +109,58 @@ H2_DEV Fp<P> fp_reduce_once(const Fp<P>& a) {
     return r;
 }
 
+// ---- carry-chain primitives (device): explicit SGPR-pair carries so two independent chains can be
+// interleaved -- on gfx950 a VALU-written carry cannot feed the very next VALU instruction, so a lone
+// chain is padded with s_nop by hipcc while two alternating chains issue back to back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
+#define H2_ASM_CHAINS 1
+H2_DEV uint32_t add_co(uint32_t a, uint32_t b, uint64_t& c) {
+    uint32_t r;
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+H2_DEV uint32_t addc_co(uint32_t a, uint32_t b, uint64_t& c) {
+    uint32_t r;
+    asm("v_addc_co_u32 %0, %1, %2, %3, %1" : "=v"(r), "+s"(c) : "v"(a), "v"(b));
+    return r;
+}
+H2_DEV uint32_t sub_co(uint32_t a, uint32_t b, uint64_t& c) {
+    uint32_t r;
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+H2_DEV uint32_t subb_co(uint32_t a, uint32_t b, uint64_t& c) {
+    uint32_t r;
+    asm("v_subb_co_u32 %0, %1, %2, %3, %1" : "=v"(r), "+s"(c) : "v"(a), "v"(b));
+    return r;
+}
+// mask ? x : y   (mask = per-lane carry/borrow bits)
+H2_DEV uint32_t sel_co(uint32_t y, uint32_t x, uint64_t mask) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(y), "v"(x), "s"(mask));
+    return r;
+}
+#endif
+
 template <class P>
 H2_DEV Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
+#ifdef H2_ASM_CHAINS
+    // s = a + b (chain A) and t = s - p (chain B, one limb behind); the final borrow of B picks s or t
+    Fp<P> s, t, r;
+    uint64_t ca, cb;
+    s.l[0] = add_co(a.l[0], b.l[0], ca);
+    s.l[1] = addc_co(a.l[1], b.l[1], ca);
+    t.l[0] = sub_co(s.l[0], P::MOD[0], cb);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        s.l[i] = addc_co(a.l[i], b.l[i], ca);
+        t.l[i - 1] = subb_co(s.l[i - 1], P::MOD[i - 1], cb);
+    }
+    t.l[7] = subb_co(s.l[7], P::MOD[7], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(t.l[i], s.l[i], cb);  // borrow: s < p, keep s
+    return r;
+#else
     Fp<P> s;
     uint64_t c = 0;
 #pragma unroll
@@ -120,10 +170,28 @@ H2_DEV Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
         c >>= 32;
     }
     return fp_reduce_once(s);  // p < 2^254: a + b < 2^255, no carry out of limb 7
+#endif
 }
 
 template <class P>
 H2_DEV Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
+#ifdef H2_ASM_CHAINS
+    // d = a - b (chain A) and u = d + p (chain B, one limb behind); the final borrow of A picks u or d
+    Fp<P> d, u, r;
+    uint64_t ca, cb;
+    d.l[0] = sub_co(a.l[0], b.l[0], ca);
+    d.l[1] = subb_co(a.l[1], b.l[1], ca);
+    u.l[0] = add_co(d.l[0], P::MOD[0], cb);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        d.l[i] = subb_co(a.l[i], b.l[i], ca);
+        u.l[i - 1] = addc_co(d.l[i - 1], P::MOD[i - 1], cb);
+    }
+    u.l[7] = addc_co(d.l[7], P::MOD[7], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(d.l[i], u.l[i], ca);  // borrow: a < b, take d + p
+    return r;
+#else
     Fp<P> d;
     uint64_t borrow = 0;
 #pragma unroll
@@ -142,6 +210,7 @@ H2_DEV Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
         c >>= 32;
     }
     return r;
+#endif
 }
 
 template <class P>
