@@ -92,23 +92,6 @@ H2_DEV bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
     return o == 0;
 }
 
-// r = a - p if a >= p else a   (a < 2p)
-template <class P>
-H2_DEV Fp<P> fp_reduce_once(const Fp<P>& a) {
-    Fp<P> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] - P::MOD[i] - borrow;
-        d.l[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    Fp<P> r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
-    return r;
-}
-
 // ---- carry-chain primitives (device): explicit SGPR-pair carries so two independent chains can be
 // interleaved -- on gfx950 a VALU-written carry cannot feed the very next VALU instruction, so a lone
 // chain is padded with s_nop by hipcc while two alternating chains issue back to back.
@@ -141,6 +124,34 @@ H2_DEV uint32_t sel_co(uint32_t y, uint32_t x, uint64_t mask) {
     return r;
 }
 #endif
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class P>
+H2_DEV Fp<P> fp_reduce_once(const Fp<P>& a) {
+#ifdef H2_ASM_CHAINS
+    Fp<P> t, r;
+    uint64_t cb;
+    t.l[0] = sub_co(a.l[0], P::MOD[0], cb);
+#pragma unroll
+    for (int i = 1; i < 8; i++) t.l[i] = subb_co(a.l[i], P::MOD[i], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(t.l[i], a.l[i], cb);  // borrow: a < p, keep a
+    return r;
+#else
+    Fp<P> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - P::MOD[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+    return r;
+#endif
+}
 
 template <class P>
 H2_DEV Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
