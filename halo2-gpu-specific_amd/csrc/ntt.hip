@@ -21,6 +21,8 @@
 //   * zero padding  (eval_fft_prepare, evaluation_gpu.rs:890-900; domain.rs:280)
 //   * zeta-power coset pre-scale (distribute_powers_zeta, domain.rs:382-398)
 //   * 1/n and zeta^-1 post-scale (domain.rs:404-409, :341)
+#include <cstdlib>
+
 #include "common.hpp"
 #include "ntt.hpp"
 
@@ -385,7 +387,9 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         }
         {
             // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
+            static const int env_logc = getenv("H2_NTT_LOGC") ? atoi(getenv("H2_NTT_LOGC")) : -1;
             uint32_t log_c = (B < 8) ? (10 - B) : 2;
+            if (env_logc >= 0 && B == 8) log_c = (uint32_t)env_logc;
             uint32_t avail = last ? consumed : a.s_log;  // last pass: number of DFTs = 2^consumed
             if (avail < log_c) log_c = avail;
             a.log_c = log_c;
