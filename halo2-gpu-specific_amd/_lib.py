@@ -59,6 +59,11 @@ SYMBOLS = {
     "h2_dev_batch_mont": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_batch_unmont": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_random_points": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
+    "h2_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_dev_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
+    "h2_batch_invert": (ctypes.c_int, [_vp, _sz]),
+    "h2_dev_batch_invert": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "h2_dev_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_dev_evaluate_h": (ctypes.c_int, [_vp, _vp, _vp]),
     "h2_timer_start": (ctypes.c_int, [_vp]),

@@ -140,3 +140,18 @@ def eval_op(op, l=None, r=None, l_rot=0, r_rot=0, c=None, size=None, res=None):
     cc = _fr(c) if c is not None else None
     check(lib().h2_eval_op(op, _p(res), _p(l), _p(r), l_rot, r_rot, size, _p(cc)), "h2_eval_op")
     return res
+
+
+def eval_polynomial(poly, point):
+    """arithmetic.rs:714-735"""
+    poly = _fr(poly).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().h2_eval_polynomial(_p(poly), len(poly), _p(_fr(point)), _p(out)), "h2_eval_polynomial")
+    return out
+
+
+def batch_invert(a):
+    """arithmetic.rs:840-844 (in place)"""
+    a = _fr(a)
+    check(lib().h2_batch_invert(_p(a), len(a)), "h2_batch_invert")
+    return a

@@ -399,6 +399,63 @@ int h2_dev_batch_unmont(void* d_a, size_t n, void* stream) {
     });
 }
 
+// ------------------------------------------------------------------ adjacent numerics (a24)
+int h2_dev_eval_polynomial(const void* d_poly, size_t n, const uint64_t point[4], uint64_t out[4], void* stream) {
+    if (!point || !out || (n && !d_poly)) return bad("h2_dev_eval_polynomial: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        Fr* tmp = (Fr*)ctx->buf_d.get(eval_polynomial_tmp_elems(n) * sizeof(Fr));
+        return eval_polynomial_launch((const Fr*)d_poly, n, point, tmp, out, pick_stream(ctx, stream));
+    });
+}
+
+int h2_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]) {
+    if (!point || !out || (n && !poly)) return bad("h2_eval_polynomial: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Fr* d = (Fr*)ctx->buf_a.get((n ? n : 1) * sizeof(Fr));
+        Fr* tmp = (Fr*)ctx->buf_d.get(eval_polynomial_tmp_elems(n) * sizeof(Fr));
+        if (n) H2_HIP(hipMemcpyAsync(d, poly, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        return eval_polynomial_launch(d, n, point, tmp, out, ctx->stream);
+    });
+}
+
+int h2_dev_batch_invert(void* d_a, void* d_tmp, size_t n, void* stream) {
+    if (n && (!d_a || !d_tmp)) return bad("h2_dev_batch_invert: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return batch_invert_launch((Fr*)d_a, (Fr*)d_tmp, n, pick_stream(ctx, stream));
+    });
+}
+
+int h2_batch_invert(uint64_t* a, size_t n) {
+    if (n && !a) return bad("h2_batch_invert: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Fr* d = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        Fr* t = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
+        H2_HIP(hipMemcpyAsync(d, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = batch_invert_launch(d, t, n, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_lincomb(void* d_res, const void* const* d_polys, const uint64_t* coeffs, size_t count, size_t size,
+                   void* stream) {
+    if (!d_res || (count && (!d_polys || !coeffs))) return bad("h2_dev_lincomb: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return lincomb_launch((Fr*)d_res, (const Fr* const*)d_polys, coeffs, count, size, pick_stream(ctx, stream));
+    });
+}
+
 // ------------------------------------------------------------------ evaluate_h
 int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h: null argument");

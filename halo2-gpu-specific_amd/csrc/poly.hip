@@ -7,6 +7,9 @@
 //   batch_mont / batch_unmont  (arithmetic.rs:235-241,280-286)
 // and the CPU loops Polynomial +,-,*scalar (poly.rs:191-257) and
 // divide_by_vanishing_poly (poly/domain.rs:354-373).
+#include <algorithm>
+#include <cstring>
+
 #include "common.hpp"
 #include "poly.hpp"
 
@@ -130,6 +133,195 @@ int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream) {
         hipLaunchKernelGGL(k_batch_mont<true>, dim3(grid_for(n)), dim3(256), 0, stream, a, n);
     else
         hipLaunchKernelGGL(k_batch_mont<false>, dim3(grid_for(n)), dim3(256), 0, stream, a, n);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+
+// ---------------------------------------------------------------- eval_polynomial (Horner) on device
+// arithmetic.rs:707-735 evaluates p(x) by per-thread Horner over contiguous chunks + powers of x.  Here a
+// workgroup folds 4096 coefficients: lane t runs Horner in x^256 over a[t], a[t+256], ... (coalesced loads),
+// then an 8-level LDS tree combines the 256 lanes with x, x^2, x^4, ...  The per-workgroup values form a
+// 4096-times shorter polynomial in x^4096, folded again by the same kernel until one element is left.
+struct EvalPolyArgs {
+    const Fr* in;
+    Fr* out;
+    size_t n;
+    Fr x256;     // x^256
+    Fr xpow[8];  // x^(2^l), l = 0..7
+};
+
+__global__ void __launch_bounds__(256) k_eval_poly(EvalPolyArgs a) {
+    __shared__ uint4 sh_lo[256], sh_hi[256];
+    const uint32_t t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 4096;
+    Fr acc = fp_zero<FrParams>();
+#pragma unroll 1
+    for (int j = 15; j >= 0; j--) {
+        size_t i = base + (size_t)j * 256 + t;
+        Fr c = (i < a.n) ? fp_load(a.in + i) : fp_zero<FrParams>();
+        acc = fp_add(fp_mul(acc, a.x256), c);
+    }
+    // tree: after level l, lane t (multiple of 2^(l+1)) holds sum_{u < 2^(l+1)} v[t+u] x^u
+    for (int l = 0; l < 8; l++) {
+        sh_lo[t] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+        sh_hi[t] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+        __syncthreads();
+        const uint32_t step = 1u << l;
+        if ((t & (2 * step - 1)) == 0) {
+            uint4 lo = sh_lo[t + step], hi = sh_hi[t + step];
+            Fr o;
+            o.l[0] = lo.x; o.l[1] = lo.y; o.l[2] = lo.z; o.l[3] = lo.w;
+            o.l[4] = hi.x; o.l[5] = hi.y; o.l[6] = hi.z; o.l[7] = hi.w;
+            acc = fp_add(acc, fp_mul(o, a.xpow[l]));
+        }
+        __syncthreads();
+    }
+    if (t == 0) fp_store(a.out + blockIdx.x, acc);
+}
+
+// result (host) = sum_i poly[i] * x^i.  d_tmp: ceil(n / 4096) + ceil(n / 4096^2) + 2 elements of scratch.
+int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],
+                           hipStream_t stream) {
+    Fr x = fr_host(point);
+    if (n == 0) {
+        memset(out, 0, 32);
+        return H2_OK;
+    }
+    const Fr* in = d_poly;
+    Fr* dst = d_tmp;
+    size_t cnt = n;
+    for (;;) {
+        EvalPolyArgs a;
+        a.in = in;
+        a.out = dst;
+        a.n = cnt;
+        Fr p = x;
+        for (int l = 0; l < 8; l++) {
+            a.xpow[l] = p;
+            p = fp_sqr(p);
+        }
+        a.x256 = p;  // x^256
+        size_t blocks = (cnt + 4095) / 4096;
+        hipLaunchKernelGGL(k_eval_poly, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (blocks == 1) break;
+        // next level: polynomial in x^4096 over the block values
+        for (int l = 0; l < 4; l++) p = fp_sqr(p);  // x^256 -> x^4096
+        x = p;
+        in = dst;
+        dst = dst + blocks;
+        cnt = blocks;
+    }
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipMemcpyAsync(out, dst, 32, hipMemcpyDeviceToHost, stream));
+    H2_HIP(hipStreamSynchronize(stream));
+    return H2_OK;
+}
+
+size_t eval_polynomial_tmp_elems(size_t n) {
+    size_t total = 2, c = n;
+    while (c > 1) {
+        c = (c + 4095) / 4096;
+        total += c;
+        if (c == 1) break;
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------- batch_invert on device
+// arithmetic.rs:840-844 (`parallelize` + ff::BatchInvert per chunk).  Montgomery's trick per lane over a
+// strided set of <= 64 elements (coalesced across lanes); zeros stay zero.  3 multiplications per element
+// plus one field inversion (a^(r-2), ~390 multiplications) per lane.
+__device__ __forceinline__ Fr fr_inv_device(const Fr& a) {
+    // exponent r - 2, little-endian u32 limbs
+    const uint32_t E[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    Fr acc = fp_one<FrParams>();
+#pragma unroll 1
+    for (int bit = 253; bit >= 0; bit--) {
+        acc = fp_sqr(acc);
+        if ((E[bit >> 5] >> (bit & 31)) & 1) acc = fp_mul(acc, a);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_batch_invert(Fr* a, Fr* prefix, size_t n, size_t nthreads) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nthreads) return;
+    Fr acc = fp_one<FrParams>();
+    size_t last = t;
+    for (size_t i = t; i < n; i += nthreads) {
+        Fr v = fp_load(a + i);
+        fp_store(prefix + i, acc);
+        if (!fp_is_zero(v)) acc = fp_mul(acc, v);
+        last = i;
+    }
+    Fr inv = fr_inv_device(acc);
+    for (size_t i = last;; i -= nthreads) {
+        Fr v = fp_load(a + i);
+        if (!fp_is_zero(v)) {
+            fp_store(a + i, fp_mul(inv, fp_load(prefix + i)));
+            inv = fp_mul(inv, v);
+        }
+        if (i < nthreads) break;
+    }
+}
+
+int batch_invert_launch(Fr* d_a, Fr* d_tmp, size_t n, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    size_t nthreads = (n + 63) / 64;
+    if (nthreads < 256) nthreads = n < 256 ? n : 256;
+    hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, d_a, d_tmp, n,
+                       nthreads);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+// ---------------------------------------------------------------- linear combination of polynomials
+// res[i] = sum_j c_j * p_j[i]: the GWC / SHPLONK batching `poly_batch = poly_batch * v + p` (gwc/prover.rs:39-151,
+// shplonk/prover.rs:110-209) with the powers of v supplied by the caller; one pass over every input instead of one
+// eval_mul_c + eval_sum launch per polynomial.
+static constexpr int LINCOMB_MAX = 8;
+struct LincombArgs {
+    const Fr* p[LINCOMB_MAX];
+    Fr c[LINCOMB_MAX];
+    Fr* res;
+    size_t size;
+    int count, accumulate;
+};
+
+__global__ void __launch_bounds__(256) k_lincomb(LincombArgs a) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.size; i += stride) {
+        Fr acc = a.accumulate ? fp_load(a.res + i) : fp_zero<FrParams>();
+#pragma unroll
+        for (int j = 0; j < LINCOMB_MAX; j++)
+            if (j < a.count) acc = fp_add(acc, fp_mul(fp_load(a.p[j] + i), a.c[j]));
+        fp_store(a.res + i, acc);
+    }
+}
+
+int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size_t count, size_t size, hipStream_t stream) {
+    if (size == 0) return H2_OK;
+    if (count == 0) {
+        H2_HIP(hipMemsetAsync(res, 0, size * sizeof(Fr), stream));
+        return H2_OK;
+    }
+    for (size_t j0 = 0; j0 < count; j0 += LINCOMB_MAX) {
+        LincombArgs a{};
+        a.count = (int)std::min<size_t>(LINCOMB_MAX, count - j0);
+        for (int j = 0; j < a.count; j++) {
+            a.p[j] = polys[j0 + j];
+            a.c[j] = fr_host(coeffs + 4 * (j0 + j));
+            if (a.p[j] == res && (j0 + j) != 0) {
+                set_last_error("h2_dev_lincomb: the result may only alias the first input");
+                return H2_ERR_INVALID;
+            }
+        }
+        a.res = res;
+        a.size = size;
+        a.accumulate = j0 != 0;
+        hipLaunchKernelGGL(k_lincomb, dim3(grid_for(size)), dim3(256), 0, stream, a);
+    }
     H2_HIP(hipGetLastError());
     return H2_OK;
 }

@@ -7,4 +7,9 @@ int eval_op_launch(int op, Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int
                    const uint64_t c[4], hipStream_t stream);
 int divide_by_vanishing_launch(Fr* a, size_t size, const Fr* t, size_t t_len, hipStream_t stream);
 int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream);
+int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],
+                           hipStream_t stream);
+size_t eval_polynomial_tmp_elems(size_t n);
+int batch_invert_launch(Fr* d_a, Fr* d_tmp, size_t n, hipStream_t stream);
+int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size_t count, size_t size, hipStream_t stream);
 }  // namespace h2

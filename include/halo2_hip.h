@@ -112,6 +112,22 @@ int h2_eval_op(int op, uint64_t *res, const uint64_t *l, const uint64_t *r, int3
 int h2_divide_by_vanishing_poly(uint64_t *a, size_t size, const uint64_t *t_evaluations, size_t t_len);
 
 
+/* ---- adjacent numerics the prover runs between the transforms ------------ */
+/* eval_polynomial: arithmetic.rs:714-735 (Horner; prover.rs:731-737 evaluates every committed polynomial
+ * at x).  out = sum_i poly[i] * point^i.  Synchronous (the result is host memory). */
+int h2_eval_polynomial(const uint64_t *poly, size_t n, const uint64_t point[4], uint64_t out[4]);
+int h2_dev_eval_polynomial(const void *d_poly, size_t n, const uint64_t point[4], uint64_t out[4], void *stream);
+/* batch_invert: arithmetic.rs:840-844 -- every non-zero element replaced by its inverse, zeros kept
+ * (ff::BatchInvert).  d_tmp: n Fr of scratch. */
+int h2_batch_invert(uint64_t *a, size_t n);
+int h2_dev_batch_invert(void *d_a, void *d_tmp, size_t n, void *stream);
+/* res[i] = sum_j coeffs[j] * polys[j][i] -- the GWC / SHPLONK batching loops (poly/multiopen/gwc/prover.rs:39-151:
+ * `poly_batch = poly_batch * v + poly`, cuda branch eval_mul_c + eval_sum per polynomial; shplonk/prover.rs:110-209)
+ * with the challenge powers supplied by the caller.  d_polys: HOST array of `count` device pointers; coeffs:
+ * count x 4 u64 on the host.  d_res may alias d_polys[0] only. */
+int h2_dev_lincomb(void *d_res, const void *const *d_polys, const uint64_t *coeffs, size_t count, size_t size,
+                   void *stream);
+
 /* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
  * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
  * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:
