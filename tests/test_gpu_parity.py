@@ -331,3 +331,35 @@ def test_resident_bases(oracle):
     finally:
         assert L.h2_bases_unregister(pts.ctypes.data) == 0
     assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(s, pts, 254)) == want_full  # back to per-call upload
+
+
+def test_concurrent_callers(oracle):
+    """Threading contract (SURVEY.md 8(b)): every entry point is called concurrently from rayon workers;
+    the blocking device pool serialises them (arithmetic.rs:314-331).  8 threads mix NTTs and MSMs."""
+    import threading
+
+    log_n = 12
+    n = 1 << log_n
+    w = fr_mont(omega_for(log_n))
+    xs = [oracle.random_fr(700 + i, n) for i in range(8)]
+    pts = oracle.random_g1(800, n)
+    want_ntt = [oracle.best_fft(x, w, log_n) for x in xs]
+    want_msm = [_affine(oracle, oracle.best_multiexp(x, pts)) for x in xs]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                if i % 2 == 0:
+                    assert np.array_equal(ar.best_fft(xs[i].copy(), w, log_n), want_ntt[i])
+                else:
+                    assert _affine(oracle, ar.best_multiexp(xs[i], pts)) == want_msm[i]
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
