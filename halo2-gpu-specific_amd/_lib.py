@@ -63,6 +63,10 @@ SYMBOLS = {
     "h2_dev_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
     "h2_batch_invert": (ctypes.c_int, [_vp, _sz]),
     "h2_dev_batch_invert": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "h2_kate_division": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_dev_kate_division": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
+    "h2_prefix_product": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_dev_prefix_product": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
     "h2_dev_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_dev_evaluate_h": (ctypes.c_int, [_vp, _vp, _vp]),

@@ -155,3 +155,20 @@ def batch_invert(a):
     a = _fr(a)
     check(lib().h2_batch_invert(_p(a), len(a)), "h2_batch_invert")
     return a
+
+
+def kate_division(a, b):
+    """arithmetic.rs:754-773: a(X) / (X - b), no remainder"""
+    a = _fr(a).reshape(-1, 4)
+    q = np.zeros((max(len(a) - 1, 0), 4), dtype=np.uint64)
+    check(lib().h2_kate_division(_p(a), len(a), _p(_fr(b)), _p(q)), "h2_kate_division")
+    return q
+
+
+def prefix_product(f, init, n=None):
+    """z[0] = init, z[i] = z[i-1] * f[i-1] (permutation/prover.rs:151-160)"""
+    f = _fr(f).reshape(-1, 4)
+    n = len(f) + 1 if n is None else n
+    z = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().h2_prefix_product(_p(f), n, _p(_fr(init)), _p(z)), "h2_prefix_product")
+    return z

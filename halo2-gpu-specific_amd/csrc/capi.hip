@@ -9,6 +9,7 @@
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
+#include "scan.hpp"
 
 using namespace h2;
 
@@ -442,6 +443,63 @@ int h2_batch_invert(uint64_t* a, size_t n) {
         int rc = batch_invert_launch(d, t, n, ctx->stream);
         if (rc != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(a, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_kate_division(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
+    if (!b || (n >= 2 && (!d_a || !d_q))) return bad("h2_dev_kate_division: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        return kate_division_launch((const Fr*)d_a, n, b, (Fr*)d_q, tmp, pick_stream(ctx, stream));
+    });
+}
+
+int h2_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* q) {
+    if (!b || (n >= 2 && (!a || !q))) return bad("h2_kate_division: null argument");
+    return guarded([&] {
+        if (n < 2) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Fr* d_a = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        Fr* d_q = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        H2_HIP(hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = kate_division_launch(d_a, n, b, d_q, tmp, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(q, d_q, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_prefix_product(const void* d_f, size_t n, const uint64_t init[4], void* d_z, void* stream) {
+    if (!init || (n && !d_z) || (n > 1 && !d_f)) return bad("h2_dev_prefix_product: null argument");
+    if (d_f == d_z && n > 1) return bad("h2_dev_prefix_product: in-place is not supported");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        return prefix_product_launch((const Fr*)d_f, n, init, (Fr*)d_z, tmp, pick_stream(ctx, stream));
+    });
+}
+
+int h2_prefix_product(const uint64_t* f, size_t n, const uint64_t init[4], uint64_t* z) {
+    if (!init || (n && !z) || (n > 1 && !f)) return bad("h2_prefix_product: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Fr* d_f = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        Fr* d_z = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        if (n > 1) H2_HIP(hipMemcpyAsync(d_f, f, (n - 1) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = prefix_product_launch(d_f, n, init, d_z, tmp, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(z, d_z, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });

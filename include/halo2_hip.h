@@ -121,6 +121,15 @@ int h2_dev_eval_polynomial(const void *d_poly, size_t n, const uint64_t point[4]
  * (ff::BatchInvert).  d_tmp: n Fr of scratch. */
 int h2_batch_invert(uint64_t *a, size_t n);
 int h2_dev_batch_invert(void *d_a, void *d_tmp, size_t n, void *stream);
+/* kate_division: arithmetic.rs:754-773 -- q(X) = a(X) / (X - b) without remainder; a: n coefficients,
+ * q: n - 1 (multiopen: gwc/prover.rs:154-160, shplonk/prover.rs).  A blocked affine prefix scan. */
+int h2_kate_division(const uint64_t *a, size_t n, const uint64_t b[4], uint64_t *q);
+int h2_dev_kate_division(const void *d_a, size_t n, const uint64_t b[4], void *d_q, void *stream);
+/* Grand-product column: z[0] = init, z[i] = z[i-1] * f[i-1] for i < n (f has n - 1 used entries) -- the
+ * serial loops of permutation/prover.rs:151-160 (`z.push(last_z); for row in 1..n { tmp *= modified_values[row-1] }`),
+ * shuffle/prover.rs and the logup grand sums' multiplicative twin.  f and z must not alias. */
+int h2_prefix_product(const uint64_t *f, size_t n, const uint64_t init[4], uint64_t *z);
+int h2_dev_prefix_product(const void *d_f, size_t n, const uint64_t init[4], void *d_z, void *stream);
 /* res[i] = sum_j coeffs[j] * polys[j][i] -- the GWC / SHPLONK batching loops (poly/multiopen/gwc/prover.rs:39-151:
  * `poly_batch = poly_batch * v + poly`, cuda branch eval_mul_c + eval_sum per polynomial; shplonk/prover.rs:110-209)
  * with the challenge powers supplied by the caller.  d_polys: HOST array of `count` device pointers; coeffs:

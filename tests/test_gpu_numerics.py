@@ -84,3 +84,30 @@ def test_lincomb(oracle):
     # aliasing a later input is refused
     ptrs3 = (ctypes.c_void_p * 2)(d_polys[1].data_ptr(), d_polys[0].data_ptr())
     assert L.h2_dev_lincomb(d_polys[0].data_ptr(), ptrs3, two.ctypes.data, 2, size, None) == 1
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 1024, 1025, 1026, 4097, 100003, (1 << 20) + 2, (1 << 22) + 1])
+def test_kate_division(oracle, n):
+    a = oracle.random_fr(5000 + (n % 983), n)
+    b = oracle.random_fr(5100, 1)[0]
+    want = np.zeros((n - 1, 4), dtype=np.uint64)
+    oracle.lib.oracle_kate_division(_ptr(a), n, _ptr(b), _ptr(want))
+    got = ar.kate_division(a, b)
+    assert np.array_equal(got, want)
+    if n <= 1026:  # the recurrence itself, in big integers: q[i] = a[i+1] + b*q[i+1]
+        av, bv, q, nxt = from_mont(a), from_mont(b)[0], [0] * (n - 1), 0
+        for i in range(n - 2, -1, -1):
+            nxt = (av[i + 1] + bv * nxt) % R_MOD
+            q[i] = nxt
+        assert from_mont(got) == q
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1024, 1025, 1026, 5000, (1 << 20) + 7])
+def test_prefix_product(oracle, n):
+    f = oracle.random_fr(6000 + (n % 971), max(n - 1, 1))[: n - 1]
+    init = oracle.random_fr(6100, 1)[0]
+    got = ar.prefix_product(f, init, n)
+    z = [from_mont(init)[0]]
+    for v in from_mont(f) if n > 1 else []:
+        z.append(z[-1] * v % R_MOD)
+    assert from_mont(got) == z
