@@ -514,6 +514,28 @@ int h2_dev_lincomb(void* d_res, const void* const* d_polys, const uint64_t* coef
     });
 }
 
+int h2_dev_permutation_sigma(void* d_out, const void* d_map_col, const void* d_map_row, size_t n,
+                             const uint64_t delta[4], const uint64_t omega[4], void* stream) {
+    if (n && (!d_out || !d_map_col || !d_map_row || !delta || !omega)) return bad("h2_dev_permutation_sigma: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return perm_sigma_launch((Fr*)d_out, (const uint32_t*)d_map_col, (const uint32_t*)d_map_row, n, delta, omega,
+                                 pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_permutation_terms(void* d_num, void* d_den, const void* d_value, const void* d_sigma, size_t n,
+                             const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
+                             const uint64_t omega[4], int first, void* stream) {
+    if (n && (!d_num || !d_den || !d_value || !d_sigma || !beta || !gamma || !delta_pow || !omega))
+        return bad("h2_dev_permutation_terms: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return perm_terms_launch((Fr*)d_num, (Fr*)d_den, (const Fr*)d_value, (const Fr*)d_sigma, n, beta, gamma,
+                                 delta_pow, omega, first, pick_stream(ctx, stream));
+    });
+}
+
 // ------------------------------------------------------------------ evaluate_h
 int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h: null argument");

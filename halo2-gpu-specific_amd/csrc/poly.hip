@@ -326,4 +326,85 @@ int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size
     return H2_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Permutation argument, the elementwise parts around the grand-product scan:
+//   keygen   permutation/keygen.rs:197-238   sigma_col[j] = DELTA^{c} * omega^{r} for mapping[col][j] = (c, r)
+//   prover   permutation/prover.rs:89-128    per column of a set:
+//              den[i] *= beta * sigma[i] + gamma + value[i]
+//              num[i] *= DELTA^{col} * omega^{i} * beta + gamma + value[i]
+// omega^i: every lane raises omega to its first index once and then steps by omega^256 over PT_ITEMS strided
+// (coalesced) elements.
+static constexpr int PT_ITEMS = 8;
+
+__global__ void __launch_bounds__(256) k_perm_sigma(Fr* out, const uint32_t* map_col, const uint32_t* map_row, size_t n,
+                                                    Fr delta, Fr omega) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = fp_mul(fp_pow_u32(delta, map_col[i]), fp_pow_u32(omega, map_row[i]));
+    fp_store(out + i, v);
+}
+
+struct PermTermsArgs {
+    Fr *num, *den;
+    const Fr *value, *sigma;
+    size_t n;
+    Fr beta, gamma;
+    Fr delta_beta;  // DELTA^{col} * beta
+    Fr omega, omega_step;  // omega, omega^256
+    int first;      // 1: overwrite num / den, 0: multiply into them
+};
+
+__global__ void __launch_bounds__(256) k_perm_terms(PermTermsArgs a) {
+    const size_t base = (size_t)blockIdx.x * (256 * PT_ITEMS) + threadIdx.x;
+    if (base >= a.n) return;
+    Fr w = fp_mul(fp_pow_u32(a.omega, (uint32_t)base), a.delta_beta);
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+        size_t i = base + (size_t)k * 256;
+        if (i >= a.n) break;
+        Fr v = fp_add(fp_load(a.value + i), a.gamma);
+        Fr nu = fp_add(w, v);
+        Fr de = fp_add(fp_mul(a.beta, fp_load(a.sigma + i)), v);
+        if (!a.first) {
+            nu = fp_mul(nu, fp_load(a.num + i));
+            de = fp_mul(de, fp_load(a.den + i));
+        }
+        fp_store(a.num + i, nu);
+        fp_store(a.den + i, de);
+        w = fp_mul(w, a.omega_step);
+    }
+}
+
+int perm_sigma_launch(Fr* out, const uint32_t* map_col, const uint32_t* map_row, size_t n, const uint64_t delta[4],
+                      const uint64_t omega[4], hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_perm_sigma, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, map_col, map_row, n,
+                       fr_host(delta), fr_host(omega));
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+int perm_terms_launch(Fr* num, Fr* den, const Fr* value, const Fr* sigma, size_t n, const uint64_t beta[4],
+                      const uint64_t gamma[4], const uint64_t delta_pow[4], const uint64_t omega[4], int first,
+                      hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    PermTermsArgs a{};
+    a.num = num;
+    a.den = den;
+    a.value = value;
+    a.sigma = sigma;
+    a.n = n;
+    a.beta = fr_host(beta);
+    a.gamma = fr_host(gamma);
+    a.delta_beta = fp_mul(fr_host(delta_pow), a.beta);
+    a.omega = fr_host(omega);
+    a.omega_step = fp_pow_u32(a.omega, 256);
+    a.first = first;
+    const size_t per = 256 * PT_ITEMS;
+    hipLaunchKernelGGL(k_perm_terms, dim3((unsigned)((n + per - 1) / per)), dim3(256), 0, stream, a);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+
 }  // namespace h2

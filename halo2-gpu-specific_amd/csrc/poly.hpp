@@ -12,4 +12,9 @@ int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], 
 size_t eval_polynomial_tmp_elems(size_t n);
 int batch_invert_launch(Fr* d_a, Fr* d_tmp, size_t n, hipStream_t stream);
 int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size_t count, size_t size, hipStream_t stream);
+int perm_sigma_launch(Fr* out, const uint32_t* map_col, const uint32_t* map_row, size_t n, const uint64_t delta[4],
+                      const uint64_t omega[4], hipStream_t stream);
+int perm_terms_launch(Fr* num, Fr* den, const Fr* value, const Fr* sigma, size_t n, const uint64_t beta[4],
+                      const uint64_t gamma[4], const uint64_t delta_pow[4], const uint64_t omega[4], int first,
+                      hipStream_t stream);
 }  // namespace h2

@@ -1,0 +1,604 @@
+"""keygen + create_proof on the device-resident C ABI: the caller of the hot path.
+
+Every polynomial lives in HBM from upload to the last opening; the host sees only what the protocol hashes
+(commitments, evaluations) plus the handful of low coefficients SHPLONK adjusts.  Orchestration follows
+
+  plonk/keygen.rs:330-440              keygen_pk: fixed polys, l0 / l_last / l_active_row, permutation pk
+  plonk/permutation/keygen.rs:112-261  cycle -> mapping -> sigma polynomials
+  plonk/prover.rs:206-850              create_proof_ext (advice, challenges, permutation products, vanishing
+                                       argument, evaluations, multiopen)
+  plonk/permutation/prover.rs:47-330   commit / evaluate / open
+  plonk/vanishing/prover.rs:40-160     random poly, h pieces, h(x)
+  poly/multiopen/shplonk.rs:58-135, shplonk/prover.rs:89-225
+
+All arithmetic on vectors runs in libhalo2_hip.so (`h2_dev_*`); torch only owns the device buffers and the
+stream.  There is no CPU path in this file: without the library or a GPU it raises.
+"""
+import ctypes
+import hashlib
+
+import numpy as np
+
+from . import evaluation as ev
+from ._lib import check, lib
+from .circuit import compile_gates
+from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, jacobian_to_affine,
+                         point_to_bytes)
+
+ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
+ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+S = 28
+_vp = ctypes.c_void_p
+_FR = ctypes.c_uint64 * 4
+
+
+def _fr(v):
+    """canonical integer -> Montgomery limbs for the C ABI"""
+    return _FR(*fr_to_mont_limbs(v % R_MOD))
+
+
+def _inv(v):
+    return pow(v, -1, R_MOD)
+
+
+class Domain:
+    """EvaluationDomain::new (poly/domain.rs:44-149) -- the scalars only"""
+
+    def __init__(self, k, degree):
+        self.k, self.n = k, 1 << k
+        self.quotient_poly_degree = degree - 1
+        ek = k
+        while (1 << ek) < self.n * self.quotient_poly_degree:
+            ek += 1
+        self.extended_k, self.extended_n = ek, 1 << ek
+        self.extended_omega = pow(ROOT_OF_UNITY, 1 << (S - ek), R_MOD)
+        self.omega = pow(self.extended_omega, 1 << (ek - k), R_MOD)
+        self.omega_inv, self.extended_omega_inv = _inv(self.omega), _inv(self.extended_omega)
+        self.ifft_divisor, self.extended_ifft_divisor = _inv(self.n), _inv(self.extended_n)
+        self.g_coset, self.g_coset_inv = ZETA, ZETA * ZETA % R_MOD
+        # t_evaluations: 1 / (ZETA^n * extended_omega^(n*i) - 1), i < 2^(extended_k - k)  (:91-131)
+        t_len = 1 << (ek - k)
+        zn, wn = pow(ZETA, self.n, R_MOD), pow(self.extended_omega, self.n, R_MOD)
+        self.t_evaluations = [_inv((zn * pow(wn, i, R_MOD) - 1) % R_MOD) for i in range(t_len)]
+
+    def rotate_omega(self, x, rot):
+        return x * pow(self.omega if rot >= 0 else self.omega_inv, abs(rot), R_MOD) % R_MOD
+
+
+class Device:
+    """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
+
+    def __init__(self, device=0):
+        import torch  # plumbing only: device memory and the stream
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("create_proof needs a HIP device: there is no CPU path")
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.L = lib()
+        self.tstream = torch.cuda.Stream(device=self.dev)
+        self.stream = _vp(self.tstream.cuda_stream)
+        self._scratch = None
+
+    # -- memory -----------------------------------------------------------------------------------------
+    def empty(self, n):
+        with self.torch.cuda.stream(self.tstream):
+            return self.torch.empty((n, 4), dtype=self.torch.int64, device=self.dev)
+
+    def zeros(self, n):
+        with self.torch.cuda.stream(self.tstream):
+            return self.torch.zeros((n, 4), dtype=self.torch.int64, device=self.dev)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        with self.torch.cuda.stream(self.tstream):
+            t = self.torch.from_numpy(a.view(np.int64)).to(self.dev, non_blocking=False)
+        return t
+
+    def download(self, t):
+        with self.torch.cuda.stream(self.tstream):
+            return t.cpu().numpy().view(np.uint64)
+
+    def clone(self, t):
+        with self.torch.cuda.stream(self.tstream):
+            return t.clone()
+
+    def set_rows(self, t, start, values):
+        """t[start : start + len(values)] <- canonical integers (stored Montgomery)"""
+        a = np.array([fr_to_mont_limbs(v) for v in values], dtype=np.uint64)
+        with self.torch.cuda.stream(self.tstream):
+            t[start:start + len(values)] = self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+
+    def get_rows(self, t, start, count):
+        with self.torch.cuda.stream(self.tstream):
+            a = t[start:start + count].cpu().numpy().view(np.uint64)
+        return [fr_from_mont_limbs(r) for r in a]
+
+    def sync(self):
+        self.tstream.synchronize()
+
+    def scratch(self, nbytes):
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = None
+            with self.torch.cuda.stream(self.tstream):
+                self._scratch = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.dev)
+        return self._scratch
+
+    # -- transforms -------------------------------------------------------------------------------------
+    def intt(self, t, dom):
+        """lagrange_to_coeff in place (poly/domain.rs:233-266)"""
+        tmp = self.empty(dom.n)
+        check(self.L.h2_dev_intt(t.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                 self.stream), "h2_dev_intt")
+        return t
+
+    def coeff_to_extended(self, t, dom, out=None):
+        out = out if out is not None else self.empty(dom.extended_n)
+        tmp = self.empty(dom.extended_n)
+        check(self.L.h2_dev_coeff_to_extended(t.data_ptr(), out.data_ptr(), tmp.data_ptr(), dom.k, dom.extended_k,
+                                              _fr(dom.g_coset), _fr(dom.g_coset_inv), _fr(dom.extended_omega),
+                                              self.stream), "h2_dev_coeff_to_extended")
+        return out
+
+    def extended_to_coeff(self, t, dom):
+        tmp = self.empty(dom.extended_n)
+        check(self.L.h2_dev_extended_to_coeff(t.data_ptr(), tmp.data_ptr(), dom.extended_k, _fr(dom.g_coset),
+                                              _fr(dom.g_coset_inv), _fr(dom.extended_omega_inv),
+                                              _fr(dom.extended_ifft_divisor), self.stream), "h2_dev_extended_to_coeff")
+        return t
+
+    # -- commitments ------------------------------------------------------------------------------------
+    def msm(self, scalars, bases, n, max_bits=254):
+        """[Params::commit / commit_lagrange(_with_bound)] over device-resident bases -> affine point"""
+        return self.msm_batch([scalars], bases, n, max_bits)[0]
+
+    def msm_batch(self, columns, bases, n, max_bits=254):
+        count = len(columns)
+        if count == 0:
+            return []
+        per = (self.L.h2_msm_scratch_bytes(n, max_bits) + 255) // 256 * 256
+        scratch = self.scratch(2 * per)
+        out = np.zeros((count, 12), dtype=np.uint64)
+        if count == 1:
+            check(self.L.h2_dev_msm(columns[0].data_ptr(), bases.data_ptr(), n, max_bits, scratch.data_ptr(), per,
+                                    out.ctypes.data, self.stream), "h2_dev_msm")
+        else:
+            ptrs = (_vp * count)(*[c.data_ptr() for c in columns])
+            check(self.L.h2_dev_msm_batch(ptrs, count, bases.data_ptr(), n, max_bits, scratch.data_ptr(), 2 * per,
+                                          out.ctypes.data, self.stream), "h2_dev_msm_batch")
+        return [jacobian_to_affine(r) for r in out]
+
+    # -- elementwise / scans ----------------------------------------------------------------------------
+    def eval_op(self, op, res, l=None, r=None, c=None, size=None):
+        size = size if size is not None else res.shape[0]
+        check(self.L.h2_dev_eval_op(op, res.data_ptr(), l.data_ptr() if l is not None else None,
+                                    r.data_ptr() if r is not None else None, 0, 0, size,
+                                    _fr(c) if c is not None else None, self.stream), "h2_dev_eval_op")
+        return res
+
+    def eval_polynomial(self, t, n, x):
+        out = _FR()
+        check(self.L.h2_dev_eval_polynomial(t.data_ptr(), n, _fr(x), out, self.stream), "h2_dev_eval_polynomial")
+        return fr_from_mont_limbs(out)
+
+    def lincomb(self, res, polys, coeffs, size):
+        ptrs = (_vp * len(polys))(*[p.data_ptr() for p in polys])
+        cf = np.array([fr_to_mont_limbs(c % R_MOD) for c in coeffs], dtype=np.uint64)
+        check(self.L.h2_dev_lincomb(res.data_ptr(), ptrs, cf.ctypes.data, len(polys), size, self.stream),
+              "h2_dev_lincomb")
+        return res
+
+    def kate_division(self, a, n, b, out):
+        """out[0 : n-1] = a / (X - b); out[n-1] = 0  (arithmetic.rs:754-773, resized as shplonk/prover.rs:112)"""
+        check(self.L.h2_dev_kate_division(a.data_ptr(), n, _fr(b), out.data_ptr(), self.stream), "h2_dev_kate_division")
+        with self.torch.cuda.stream(self.tstream):
+            out[n - 1:n] = 0
+        return out
+
+    def sub_low(self, t, low):
+        """t[i] -= low[i] for the first few coefficients"""
+        if not low:
+            return
+        cur = self.get_rows(t, 0, len(low))
+        self.set_rows(t, 0, [(c - l) % R_MOD for c, l in zip(cur, low)])
+
+
+class Params:
+    """poly/commitment.rs:23-29: k, n, g, g_lagrange -- both tables resident on the device"""
+
+    def __init__(self, device, k, g, g_lagrange):
+        self.k, self.n = k, 1 << k
+        self.g = g if not isinstance(g, np.ndarray) else device.upload(g)
+        self.g_lagrange = g_lagrange if not isinstance(g_lagrange, np.ndarray) else device.upload(g_lagrange)
+        assert self.g.shape[0] == self.n and self.g_lagrange.shape[0] == self.n
+
+    @staticmethod
+    def synthetic(device, k, seed=0x48414C4F32):
+        """Timing-only parameters: two tables of valid curve points with no common trapdoor, so proofs made
+        with them exercise exactly the same work but cannot verify."""
+        n = 1 << k
+        tabs = []
+        for i in range(2):
+            with device.torch.cuda.stream(device.tstream):
+                t = device.torch.empty((n, 8), dtype=device.torch.int64, device=device.dev)
+            check(device.L.h2_dev_random_points(seed + i, n, t.data_ptr(), device.stream), "h2_dev_random_points")
+            tabs.append(t)
+        device.sync()
+        return Params(device, k, tabs[0], tabs[1])
+
+
+def max_scalar_bits(col):
+    """find_max_scalar_bits (plonk/prover.rs:237-254) on a canonical (n, 4) u64 column"""
+    for limb in (3, 2, 1, 0):
+        m = int(col[:, limb].max())
+        if m:
+            return 64 * limb + m.bit_length()
+    return 0
+
+
+def permutation_mapping(ncols, n, copies):
+    """`copies`: (m, 4) integers (left column position, left row, right column position, right row).
+    Returns (map_col, map_row) u32 arrays of shape (ncols, n): every cycle sorted by (column, row), each cell
+    pointing at its successor (plonk/permutation/keygen.rs:112-143)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    ids = np.arange(ncols * n, dtype=np.int64)
+    nxt = ids.copy()
+    copies = np.asarray(copies, dtype=np.int64).reshape(-1, 4)
+    if len(copies):
+        l = copies[:, 0] * n + copies[:, 1]
+        r = copies[:, 2] * n + copies[:, 3]
+        nodes, inv = np.unique(np.concatenate([l, r]), return_inverse=True)
+        m = len(nodes)
+        graph = coo_matrix((np.ones(len(l), dtype=np.int8), (inv[:len(l)], inv[len(l):])), shape=(m, m))
+        _, labels = connected_components(graph, directed=False)
+        order = np.lexsort((nodes, labels))          # by cycle, then by (column, row)
+        sl, sn = labels[order], nodes[order]
+        succ = np.roll(sn, -1)
+        ends = np.flatnonzero(sl != np.roll(sl, -1)) if m > 1 else np.array([0])
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        succ[ends] = sn[starts]
+        nxt[sn] = succ
+    return (nxt // n).astype(np.uint32).reshape(ncols, n), (nxt % n).astype(np.uint32).reshape(ncols, n)
+
+
+def vk_digest(cs, k, fixed_commitments, perm_commitments):
+    """VerifyingKey::hash_into (plonk.rs:91-109) with our own canonical text in place of the Debug string"""
+    s = "halo2-hip-vk circuit=%s k=%d advice=%d fixed=%d degree=%d fixed_commitments=%s permutation_commitments=%s" % (
+        cs.name, k, cs.num_advice, cs.num_fixed, cs.degree(),
+        ",".join(point_to_bytes(p).hex() for p in fixed_commitments),
+        ",".join(point_to_bytes(p).hex() for p in perm_commitments))
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    h.update(len(s).to_bytes(8, "little"))
+    h.update(s.encode())
+    return int.from_bytes(h.digest(), "little") % R_MOD
+
+
+class ProvingKey:
+    pass
+
+
+def keygen(device, params, cs, fixed, copies):
+    """keygen_vk + keygen_pk.  fixed: list of canonical (n, 4) u64 columns; copies: see permutation_mapping."""
+    D, L = device, device.L
+    dom = Domain(params.k, cs.degree())
+    n, bf = dom.n, cs.blinding_factors()
+    assert n >= cs.minimum_rows()
+    pk = ProvingKey()
+    pk.cs, pk.domain = cs, dom
+    # fixed columns: values, coefficient form, extended cosets
+    pk.fixed_values = []
+    for col in fixed:
+        t = D.upload(col)
+        check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+        pk.fixed_values.append(t)
+    pk.fixed_commitments = D.msm_batch(pk.fixed_values, params.g_lagrange, n, 254)
+    pk.fixed_polys = [D.intt(D.clone(t), dom) for t in pk.fixed_values]
+    pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys]
+    # permutation: sigma columns (Lagrange), polys, cosets
+    ncols = len(cs.perm_columns)
+    map_col, map_row = permutation_mapping(ncols, n, copies)
+    pk.sigma_values = []
+    for i in range(ncols):
+        out = D.empty(n)
+        with D.torch.cuda.stream(D.tstream):
+            mc = D.torch.from_numpy(map_col[i].view(np.int32)).to(D.dev)
+            mr = D.torch.from_numpy(map_row[i].view(np.int32)).to(D.dev)
+        check(L.h2_dev_permutation_sigma(out.data_ptr(), mc.data_ptr(), mr.data_ptr(), n, _fr(DELTA), _fr(dom.omega),
+                                         D.stream), "h2_dev_permutation_sigma")
+        D.sync()
+        pk.sigma_values.append(out)
+    pk.perm_commitments = D.msm_batch(pk.sigma_values, params.g_lagrange, n, 254)
+    pk.sigma_polys = [D.intt(D.clone(t), dom) for t in pk.sigma_values]
+    pk.sigma_cosets = [D.coeff_to_extended(t, dom) for t in pk.sigma_polys]
+    # l0, l_last, l_active_row = 1 - (l_last + l_blind) on the extended coset (keygen.rs:395-425)
+    def lagrange_coset(rows):
+        t = D.zeros(n)
+        D.set_rows(t, rows[0], [1] * len(rows))
+        return D.coeff_to_extended(D.intt(t, dom), dom)
+
+    pk.l0 = lagrange_coset([0])
+    pk.l_last = lagrange_coset([n - bf - 1])
+    l_blind = lagrange_coset(list(range(n - bf, n)))
+    tmp = D.eval_op(2, D.empty(dom.extended_n), pk.l_last, l_blind)            # H2_OP_SUM
+    one = D.eval_op(8, D.empty(dom.extended_n), c=1)                           # H2_OP_CONSTANT
+    pk.l_active_row = D.eval_op(4, one, one, tmp)                              # H2_OP_SUB
+    pk.t_evaluations = D.upload(np.array([fr_to_mont_limbs(v) for v in dom.t_evaluations], dtype=np.uint64))
+    # the gate program
+    g, parts = compile_gates(cs)
+    pk.graph, pk.value_parts = g, parts
+    pk.transcript_repr = vk_digest(cs, params.k, pk.fixed_commitments, pk.perm_commitments)
+    D.sync()
+    return pk
+
+
+def _column(kind, idx, advice, fixed):
+    return {"advice": advice, "fixed": fixed}[kind][idx]
+
+
+def _intermediate_sets(queries):
+    """construct_intermediate_sets (poly/multiopen/shplonk.rs:58-135) on (key, rotation, point, eval) tuples:
+    BTreeMap / BTreeSet iteration orders become sorted()."""
+    rot_point = {}
+    for _, rot, point, _ in queries:
+        assert rot_point.setdefault(rot, point) == point
+    super_point_set = [rot_point[r] for r in sorted(rot_point)]
+    order, rotsets = [], {}
+    for key, rot, _, _ in queries:
+        if key not in rotsets:
+            rotsets[key] = set()
+            order.append(key)
+        rotsets[key].add(rot)
+    groups = {}
+    for key in order:
+        groups.setdefault(tuple(sorted(rotsets[key])), []).append(key)
+    evals = {(key, rot): e for key, rot, _, e in queries}
+    sets = [{"points": [rot_point[r] for r in rots],
+             "commitments": [(key, [evals[(key, r)] for r in rots]) for key in groups[rots]]}
+            for rots in sorted(groups)]
+    return sets, super_point_set
+
+
+def _lagrange_interpolate(points, evals):
+    """arithmetic.rs:849-903 on host integers (at most a handful of points)"""
+    n = len(points)
+    out = [0] * n
+    for j in range(n):
+        num, den = [1], 1
+        for m in range(n):
+            if m != j:
+                num = [((num[i - 1] if i else 0) - points[m] * (num[i] if i < len(num) else 0)) % R_MOD
+                       for i in range(len(num) + 1)]
+                den = den * (points[j] - points[m]) % R_MOD
+        c = evals[j] * _inv(den) % R_MOD
+        for i in range(n):
+            out[i] = (out[i] + c * num[i]) % R_MOD
+    return out
+
+
+def _horner(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R_MOD
+    return acc
+
+
+def _vanishing(roots, z):
+    acc = 1
+    for r in roots:
+        acc = acc * (z - r) % R_MOD
+    return acc
+
+
+def create_proof(device, params, pk, advice, rng, timings=None):
+    """plonk/prover.rs:206-850 (SHPLONK multiopen).  advice: list of canonical (n, 4) u64 columns (rows past the
+    usable range are overwritten with blinding values); rng: a rng.ProverRng.  Returns the proof bytes."""
+    import time
+
+    D, L = device, device.L
+    cs, dom = pk.cs, pk.domain
+    n, bf, ek = dom.n, cs.blinding_factors(), dom.extended_k
+    en = dom.extended_n
+    last_rot = -(bf + 1)
+    marks = [("start", time.perf_counter())]
+
+    def mark(name):
+        if timings is not None:
+            D.sync()
+            marks.append((name, time.perf_counter()))
+
+    transcript = Blake2bWrite()
+    transcript.common_scalar(pk.transcript_repr)
+
+    # ---- advice columns: blinding rows, bounded commitments (prover.rs:255-312) ----------------------------
+    unusable_rows_start = n - (bf + 1)
+    max_bits = 0
+    advice_dev = []
+    for col in advice:
+        col = np.array(col, dtype=np.uint64, copy=True).reshape(n, 4)
+        col[unusable_rows_start:] = 0
+        for r in range(unusable_rows_start, n):
+            col[r, 0] = rng.u16()
+        max_bits = max(max_bits, max_scalar_bits(col))
+        t = D.upload(col)
+        check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+        advice_dev.append(t)
+    for P in D.msm_batch(advice_dev, params.g_lagrange, n, max(max_bits, 1)):
+        transcript.write_point(P)
+    mark("advice commit")
+    theta = transcript.squeeze_challenge_scalar()
+    beta = transcript.squeeze_challenge_scalar()
+    gamma = transcript.squeeze_challenge_scalar()
+
+    # ---- permutation grand products (permutation/prover.rs:47-165) -----------------------------------
+    chunk = cs.degree() - 2
+    cols = cs.perm_columns
+    z_dev, last_z = [], 1
+    num, den, tmp = D.empty(n), D.empty(n), D.empty(n)
+    for si in range(0, len(cols), chunk):
+        for ci in range(si, min(si + chunk, len(cols))):
+            values = _column(*cols[ci], advice_dev, pk.fixed_values)
+            check(L.h2_dev_permutation_terms(num.data_ptr(), den.data_ptr(), values.data_ptr(),
+                                             pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
+                                             _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
+                                             D.stream), "h2_dev_permutation_terms")
+        check(L.h2_dev_batch_invert(den.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
+        D.eval_op(3, num, num, den)                                                   # H2_OP_MUL
+        z = D.empty(n)
+        check(L.h2_dev_prefix_product(num.data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+        D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+        last_z = D.get_rows(z, n - (bf + 1), 1)[0]
+        z_dev.append(z)
+    del num, den, tmp
+    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every set
+    for P in D.msm_batch(z_dev, params.g_lagrange, n, 254):
+        transcript.write_point(P)
+    z_polys = [D.intt(z, dom) for z in z_dev]
+    mark("permutation")
+
+    # ---- vanishing argument: random polynomial (vanishing/prover.rs:40-67) ------------------------------
+    random_poly = D.upload(rng.random_poly_limbs(n))
+    transcript.write_point(D.msm(random_poly, params.g, n))
+    y = transcript.squeeze_challenge_scalar()
+    mark("vanishing commit")
+
+    # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
+    advice_polys = [D.intt(t, dom) for t in advice_dev]          # in place: the Lagrange values are not needed again
+    advice_cosets = [D.coeff_to_extended(t, dom) for t in advice_polys]
+    z_cosets = [D.coeff_to_extended(t, dom) for t in z_polys]
+    mark("cosets")
+    g = pk.graph
+    b = ev.Builder().build(
+        k=dom.k, extended_k=ek, blinding_factors=bf, chunk_len=chunk,
+        constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
+        calculations=g.calculations, value_parts=pk.value_parts,
+        fixed=[t.data_ptr() for t in pk.fixed_cosets], advice=[t.data_ptr() for t in advice_cosets],
+        l0=pk.l0.data_ptr(), l_last=pk.l_last.data_ptr(), l_active_row=pk.l_active_row.data_ptr(),
+        perm_z=[t.data_ptr() for t in z_cosets],
+        perm_columns=[({"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}[kd], i) for kd, i in cols],
+        perm_sigma=[t.data_ptr() for t in pk.sigma_cosets],
+        y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
+        delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.extended_omega))
+    h = D.empty(en)
+    check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), h.data_ptr(), D.stream), "h2_dev_evaluate_h")
+    del advice_cosets, z_cosets
+    mark("evaluate_h")
+
+    # ---- vanishing construct: divide, back to coefficients, commit the pieces (vanishing/prover.rs:69-112) -
+    check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
+                                            D.stream), "h2_dev_divide_by_vanishing_poly")
+    D.extended_to_coeff(h, dom)
+    pieces = [h[i * n:(i + 1) * n] for i in range(dom.quotient_poly_degree)]
+    for P in D.msm_batch(pieces, params.g, n, 254):
+        transcript.write_point(P)
+    x = transcript.squeeze_challenge_scalar()
+    xn = pow(x, n, R_MOD)
+    mark("vanishing construct")
+
+    # ---- evaluations (prover.rs:700-790) ------------------------------------------------------------------
+    evals = {}
+
+    def evaluate(key, poly, rot):
+        pt = dom.rotate_omega(x, rot)
+        if (key, rot) not in evals:
+            evals[(key, rot)] = (pt, D.eval_polynomial(poly, n, pt))
+        return evals[(key, rot)][1]
+
+    for c, rot in cs.advice_queries:
+        transcript.write_scalar(evaluate(("advice", c), advice_polys[c], rot))
+    for c, rot in cs.fixed_queries:
+        transcript.write_scalar(evaluate(("fixed", c), pk.fixed_polys[c], rot))
+    # h(X) = sum_i x^(n i) piece_i (vanishing/prover.rs:120-124)
+    h_poly = D.lincomb(D.empty(n), pieces, [pow(xn, i, R_MOD) for i in range(len(pieces))], n)
+    transcript.write_scalar(evaluate(("random",), random_poly, 0))
+    for i, p in enumerate(pk.sigma_polys):
+        transcript.write_scalar(evaluate(("sigma", i), p, 0))
+    for i, p in enumerate(z_polys):
+        transcript.write_scalar(evaluate(("z", i), p, 0))
+        transcript.write_scalar(evaluate(("z", i), p, 1))
+        if i + 1 < len(z_polys):
+            transcript.write_scalar(evaluate(("z", i), p, last_rot))
+    mark("evaluations")
+
+    # ---- multiopen query list in the reference's order (prover.rs:792-840) -----------------------------------
+    polys, queries = {}, []
+
+    def query(key, poly, rot):
+        polys[key] = poly
+        queries.append((key, rot, dom.rotate_omega(x, rot), evaluate(key, poly, rot)))
+
+    for c, rot in cs.advice_queries:
+        query(("advice", c), advice_polys[c], rot)
+    for i, p in enumerate(z_polys):
+        query(("z", i), p, 0)
+        query(("z", i), p, 1)
+    for i in reversed(range(len(z_polys) - 1)):
+        query(("z", i), z_polys[i], last_rot)
+    for c, rot in cs.fixed_queries:
+        query(("fixed", c), pk.fixed_polys[c], rot)
+    for i, p in enumerate(pk.sigma_polys):
+        query(("sigma", i), p, 0)
+    query(("h",), h_poly, 0)
+    query(("random",), random_poly, 0)
+    _shplonk(D, params, transcript, queries, polys, n)
+    mark("multiopen")
+    if timings is not None:
+        for (_, t0), (name, t1) in zip(marks, marks[1:]):
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+    return transcript.finalize()
+
+
+def _shplonk(D, params, transcript, queries, polys, n):
+    """poly/multiopen/shplonk/prover.rs:89-225.  Every fold `acc * c + p` of the reference is a linear combination
+    with powers of the challenge; the device computes each one in a single pass (h2_dev_lincomb) and the host
+    adjusts the <= 3 low coefficients the low-degree equivalents r_i(X) touch."""
+    y = transcript.squeeze_challenge_scalar()
+    sets, super_points = _intermediate_sets(queries)
+    for rs in sets:
+        rs["low"] = [_lagrange_interpolate(rs["points"], e) for _, e in rs["commitments"]]
+    v = transcript.squeeze_challenge_scalar()
+    # quotient contribution of every rotation set: (sum_i y^(m-1-i) (p_i - r_i)) / prod (X - point)
+    quotients = []
+    ping, pong = D.empty(n), D.empty(n)
+    for rs in sets:
+        m = len(rs["commitments"])
+        ypow = [pow(y, m - 1 - i, R_MOD) for i in range(m)]
+        n_x = D.lincomb(D.empty(n), [polys[key] for key, _ in rs["commitments"]], ypow, n)
+        width = len(rs["points"])
+        low = [sum(ypow[i] * rs["low"][i][j] for i in range(m)) % R_MOD for j in range(width)]
+        D.sub_low(n_x, low)
+        cur = n_x
+        for pt in rs["points"]:
+            nxt = ping if cur is not ping else pong
+            D.kate_division(cur, n, pt, nxt)
+            cur = nxt
+        quotients.append(D.clone(cur))
+    R = len(sets)
+    vpow = [pow(v, R - 1 - r, R_MOD) for r in range(R)]
+    h_x = D.lincomb(D.empty(n), quotients, vpow, n)
+    del quotients
+    transcript.write_point(D.msm(h_x, params.g, n))
+    u = transcript.squeeze_challenge_scalar()
+    zt_eval = _vanishing(super_points, u)
+    # linearisation: l(X) = sum_r v^(R-1-r) z_r sum_i y^(m-1-i) (p_i - r_i(u)) - zt(u) h(X), then / (X - u) / z_0
+    z_diffs = [_vanishing([p for p in super_points if p not in rs["points"]], u) for rs in sets]
+    scale = _inv(z_diffs[0])
+    lin_polys, lin_coeffs, const = [], [], 0
+    for r, rs in enumerate(sets):
+        m = len(rs["commitments"])
+        for i, (key, _) in enumerate(rs["commitments"]):
+            c = vpow[r] * z_diffs[r] % R_MOD * pow(y, m - 1 - i, R_MOD) % R_MOD * scale % R_MOD
+            lin_polys.append(polys[key])
+            lin_coeffs.append(c)
+            const = (const + c * _horner(rs["low"][i], u)) % R_MOD
+    lin_polys.append(h_x)
+    lin_coeffs.append((-zt_eval * scale) % R_MOD)
+    l_x = D.lincomb(ping, lin_polys, lin_coeffs, n)
+    D.sub_low(l_x, [const])
+    if D.eval_polynomial(l_x, n, u) != 0:
+        raise AssertionError("shplonk: l(u) != 0")   # the reference's must_be_zero (prover.rs:204-207)
+    D.kate_division(l_x, n, u, pong)
+    transcript.write_point(D.msm(pong, params.g, n))

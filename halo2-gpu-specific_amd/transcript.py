@@ -1,0 +1,84 @@
+"""Blake2b transcript and the byte encodings of the proof stream -- transcript.rs:15-300
+(`Blake2bWrite` / `Blake2bRead` with `Challenge255`).  Host logic on Python integers; points arrive from the
+device as Jacobian Montgomery limbs and are normalised here (the reference's `to_affine` / `batch_normalize`).
+
+Conventions that cannot be checked against pairing_bn256@30b052f without a Rust toolchain ("parity unpinned",
+DESIGN.md): the compressed point is x little-endian with bit 7 of byte 31 carrying the parity of y and the
+identity encoded as 32 zero bytes; challenges are `from_bytes_wide` = the 512-bit little-endian digest mod r.
+"""
+import hashlib
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+_MONT_INV_R = pow(1 << 256, -1, R_MOD)
+_MONT_INV_Q = pow(1 << 256, -1, Q_MOD)
+_M64 = (1 << 64) - 1
+
+BLAKE2B_PREFIX_CHALLENGE = b"\x00"
+BLAKE2B_PREFIX_POINT = b"\x01"
+BLAKE2B_PREFIX_SCALAR = b"\x02"
+
+
+def limbs_to_int(l):
+    return int(l[0]) | int(l[1]) << 64 | int(l[2]) << 128 | int(l[3]) << 192
+
+
+def fr_from_mont_limbs(l):
+    return limbs_to_int(l) * _MONT_INV_R % R_MOD
+
+
+def fr_to_mont_limbs(v):
+    m = (v << 256) % R_MOD
+    return [(m >> (64 * i)) & _M64 for i in range(4)]
+
+
+def jacobian_to_affine(xyz):
+    """12 u64 (x, y, z Montgomery Fq limbs, Jacobian) -> (x, y) canonical integers, or None for the identity"""
+    x, y, z = (limbs_to_int(xyz[4 * i:4 * i + 4]) * _MONT_INV_Q % Q_MOD for i in range(3))
+    if z == 0:
+        return None
+    zi = pow(z, -1, Q_MOD)
+    zi2 = zi * zi % Q_MOD
+    return (x * zi2 % Q_MOD, y * zi2 % Q_MOD * zi % Q_MOD)
+
+
+def point_to_bytes(P):
+    if P is None:
+        return bytes(32)
+    b = bytearray(P[0].to_bytes(32, "little"))
+    b[31] |= (P[1] & 1) << 7
+    return bytes(b)
+
+
+class Blake2bWrite:
+    """transcript.rs:152-226"""
+
+    def __init__(self):
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.writer = bytearray()
+
+    def squeeze_challenge_scalar(self):
+        self.state.update(BLAKE2B_PREFIX_CHALLENGE)
+        return int.from_bytes(self.state.copy().digest(), "little") % R_MOD
+
+    def common_point(self, P):
+        if P is None:
+            raise ValueError("cannot write points at infinity to the transcript")
+        self.state.update(BLAKE2B_PREFIX_POINT)
+        self.state.update(P[0].to_bytes(32, "little"))
+        self.state.update(P[1].to_bytes(32, "little"))
+
+    def common_scalar(self, v):
+        self.state.update(BLAKE2B_PREFIX_SCALAR)
+        self.state.update(v.to_bytes(32, "little"))
+
+    def write_point(self, P):
+        self.common_point(P)
+        self.writer += point_to_bytes(P)
+
+    def write_scalar(self, v):
+        self.common_scalar(v)
+        self.writer += v.to_bytes(32, "little")
+
+    def finalize(self):
+        return bytes(self.writer)

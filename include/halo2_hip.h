@@ -137,6 +137,19 @@ int h2_dev_prefix_product(const void *d_f, size_t n, const uint64_t init[4], voi
 int h2_dev_lincomb(void *d_res, const void *const *d_polys, const uint64_t *coeffs, size_t count, size_t size,
                    void *stream);
 
+/* Permutation argument, the elementwise work on either side of the grand-product scan.
+ * keygen (plonk/permutation/keygen.rs:197-238): out[j] = DELTA^{map_col[j]} * omega^{map_row[j]} -- one sigma column
+ * in Lagrange form from the cycle mapping (u32 device arrays of n entries). */
+int h2_dev_permutation_sigma(void *d_out, const void *d_map_col, const void *d_map_row, size_t n,
+                             const uint64_t delta[4], const uint64_t omega[4], void *stream);
+/* prover (plonk/permutation/prover.rs:89-128), one call per column of a set:
+ *   den[i] (*)= beta * sigma[i] + gamma + value[i];   num[i] (*)= delta_pow * omega^i * beta + gamma + value[i]
+ * first != 0 overwrites num / den, otherwise multiplies into them.  delta_pow = DELTA^{column position}.
+ * The caller follows with h2_dev_batch_invert(den), an elementwise product and h2_dev_prefix_product. */
+int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, const void *d_sigma, size_t n,
+                             const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
+                             const uint64_t omega[4], int first, void *stream);
+
 /* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
  * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
  * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:

@@ -1,0 +1,117 @@
+"""Proof-level parity on the GPU: keygen + create_proof on the device-resident C ABI
+(halo2-gpu-specific_amd/prover.py) against the independent big-integer prover / verifier of ref_plonk.py on the
+same SRS trapdoor, witness and seeded blinding stream.  Small k: proof bytes identical.  Larger k: the proof is
+accepted by the reference verifier (the pairing check done with the setup trapdoor)."""
+import os
+
+import numpy as np
+import pytest
+
+import ref_plonk as rp
+from h2util import fr_mont, ints_to_arr
+from test_plonk_host import S_TRAPDOOR, rot_gate_cs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    from halo2_gpu_specific_amd import prover
+
+    return prover.Device()
+
+
+def srs(oracle, device, k):
+    """Params::unsafe_setup with the fixed trapdoor (oracle restatement, pinned by tests/golden/setup_kat.json)"""
+    from halo2_gpu_specific_amd import prover
+
+    n = 1 << k
+    g = np.zeros((n, 8), dtype=np.uint64)
+    gl = np.zeros((n, 8), dtype=np.uint64)
+    s = fr_mont(S_TRAPDOOR)
+    oracle.lib.oracle_unsafe_setup(k, s.ctypes.data, g.ctypes.data, gl.ctypes.data)
+    return prover.Params(device, k, g, gl)
+
+
+def cols_to_arr(cols):
+    return [ints_to_arr(c) for c in cols]
+
+
+CASES = [("mini", 4), ("mini", 6), ("mini", 9), ("rot", 5), ("rot", 8)]
+
+
+@pytest.mark.parametrize("which,k", CASES)
+def test_proof_bytes_match_reference_prover(oracle, device, which, k):
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    ref_cs = rp.MiniPlonk if which == "mini" else rp.RotGate
+    cs = circuits.mini_plonk() if which == "mini" else rot_gate_cs()
+    adv, fixed, copies = ref_cs.synthesize(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    rpk = rp.keygen(ref_cs, k, S_TRAPDOOR, fixed, copies)
+    # keygen: commitments to the fixed and sigma columns, the sigma columns themselves, the vk digest
+    assert pk.fixed_commitments == rpk.fixed_commitments
+    assert pk.perm_commitments == rpk.perm_commitments
+    for got, want in zip(pk.sigma_values, rpk.sigma_values):
+        assert device.get_rows(got, 0, 1 << k) == want
+    assert pk.transcript_repr == rpk.transcript_repr
+    for seed in (1, 2):
+        proof = prover.create_proof(device, params, pk, cols_to_arr(adv), ProverRng(seed))
+        want = rp.create_proof(rpk, adv, ProverRng(seed))
+        assert len(proof) == len(want)
+        first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
+        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+    assert rp.verify_proof(rpk, proof)
+
+
+def test_bad_witness_is_rejected(oracle, device):
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 5
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    params = srs(oracle, device, k)
+    cs = circuits.mini_plonk()
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    vk = rp.Keys()
+    vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
+    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+    assert rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)))
+    adv[2][0, 0] += 1
+    assert not rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)))
+
+
+@pytest.mark.parametrize("k", [int(os.environ.get("H2_TEST_PLONK_K", "16"))])
+def test_large_proof_is_accepted_by_reference_verifier(oracle, device, k):
+    """mini-PLONK at a size where the scans, the multi-pass NTTs and the two-level MSM sort all take their
+    multi-workgroup paths; checked by the verifier (evaluations + SHPLONK equation with the trapdoor)"""
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    params = srs(oracle, device, k)
+    cs = circuits.mini_plonk()
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    # the fixed-column commitments against the trapdoor: [p(s)]G with p(s) from the oracle's Horner
+    dom = rp.Domain(k, 3)
+    for col, com in zip(fixed, pk.fixed_commitments):
+        lag = [int(v) for v in col[:, 0]]
+        # p(s) = sum_i v_i L_i(s) with L_i(s) = (s^n - 1) w^i / (n (s - w^i)); the columns are 0/1 valued
+        sn1 = (pow(S_TRAPDOOR, dom.n, rp.R) - 1) * dom.n_inv % rp.R
+        acc, w = 0, 1
+        for v in lag:
+            if v:
+                acc = (acc + w * rp.inv((S_TRAPDOOR - w) % rp.R)) % rp.R
+            w = w * dom.omega % rp.R
+        assert com == rp.g1_mul(rp.G1, acc * sn1 % rp.R)
+        break  # one column is enough (2^k modular inversions in Python)
+    vk = rp.Keys()
+    vk.cs, vk.dom, vk.s = rp.MiniPlonk, dom, S_TRAPDOOR
+    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+    timings = {}
+    proof = prover.create_proof(device, params, pk, adv, ProverRng(22), timings=timings)
+    assert len(proof) == 32 * (3 + 3 + 1 + 2 + 3 + 4 + 1 + 3 + 8 + 2)
+    assert rp.verify_proof(vk, proof)
+    print("create_proof k=%d:" % k, {n: round(t * 1e3, 2) for n, t in timings.items()})

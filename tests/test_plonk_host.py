@@ -1,0 +1,195 @@
+"""CPU tests of the proof-level test infrastructure and of the product's host logic around the device path:
+the big-integer reference prover is accepted by the (trapdoor) verifier, rejects tampering and a bad witness,
+and the product's host-side pieces (transcript, permutation mapping, gate flattening, domain scalars, rng)
+agree with the independent restatements in ref_plonk.py."""
+import random
+
+import numpy as np
+import pytest
+
+import ref_plonk as rp
+from halo2_gpu_specific_amd import circuit as hc
+from halo2_gpu_specific_amd import circuits, evaluation as ev, prover, transcript
+from halo2_gpu_specific_amd.rng import ProverRng
+
+S_TRAPDOOR = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
+
+
+def rot_gate_cs():
+    """the product-side description of ref_plonk.RotGate"""
+    cs = hc.ConstraintSystem("rot-gate")
+    a, b, c = cs.advice_column(), cs.advice_column(), cs.advice_column()
+    s0, s1 = cs.fixed_column(), cs.fixed_column()
+    for col in (a, b, c):
+        cs.enable_equality(col)
+    q0, q1 = cs.query_fixed(s0), cs.query_fixed(s1)
+    cs.enable_equality(s1)
+    cs.set_minimum_degree(4)
+    cs.create_gate("sum", [q0 * (cs.query_advice(a) + cs.query_advice(b) - cs.query_advice(c))])
+    cs.create_gate("step", [q1 * (cs.query_advice(a, 1) - cs.query_advice(c)) * (cs.query_advice(b, -1) + q0)])
+    return cs
+
+
+@pytest.mark.parametrize("cs,k", [(rp.MiniPlonk, 4), (rp.MiniPlonk, 5), (rp.RotGate, 5)])
+def test_reference_prover_is_accepted(cs, k):
+    adv, fixed, copies = cs.synthesize(k)
+    pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
+    proof = rp.create_proof(pk, adv, ProverRng(11))
+    assert rp.verify_proof(pk, proof)
+    assert proof == rp.create_proof(pk, adv, ProverRng(11)), "same seed, same proof"
+    assert proof != rp.create_proof(pk, adv, ProverRng(12))
+    # any flipped scalar / point byte must be rejected (a decoding assert counts as a rejection)
+    for pos in (5, 32 * 3 + 1, len(proof) - 40, len(proof) - 3):
+        bad = bytearray(proof)
+        bad[pos] ^= 4
+        try:
+            assert not rp.verify_proof(pk, bytes(bad))
+        except AssertionError:
+            pass
+
+
+def test_reference_verifier_rejects_bad_witness():
+    adv, fixed, copies = rp.MiniPlonk.synthesize(4)
+    pk = rp.keygen(rp.MiniPlonk, 4, S_TRAPDOOR, fixed, copies)
+    bad = [c[:] for c in adv]
+    bad[2][0] += 1                      # a * a != c on row 0
+    assert not rp.verify_proof(pk, rp.create_proof(pk, bad, ProverRng(3)))
+    bad = [c[:] for c in adv]
+    bad[0][1], bad[2][1] = 6, 31        # row 1 still satisfies a + b = c, but a0 = a1 is broken
+    assert not rp.verify_proof(pk, rp.create_proof(pk, bad, ProverRng(3)))
+
+
+def test_transcript_matches_reference_restatement():
+    rnd = random.Random(1)
+    a, b = transcript.Blake2bWrite(), rp.Transcript()
+    for step in range(40):
+        kind = rnd.randrange(3)
+        if kind == 0:
+            assert a.squeeze_challenge_scalar() == b.squeeze()
+        elif kind == 1:
+            v = rnd.randrange(rp.R)
+            a.write_scalar(v)
+            b.write_scalar(v)
+        else:
+            P = rp.g1_mul(rp.G1, rnd.randrange(1, rp.R))
+            a.write_point(P)
+            b.write_point(P)
+    assert a.finalize() == bytes(b.out)
+    with pytest.raises(ValueError):
+        a.write_point(None)
+    # the compressed encoding round-trips through the reference decoder
+    P = rp.g1_mul(rp.G1, 0xABCDEF)
+    assert rp.point_from_bytes(transcript.point_to_bytes(P)) == P
+    assert rp.point_from_bytes(transcript.point_to_bytes(rp.g1_neg(P))) == rp.g1_neg(P)
+
+
+def test_jacobian_normalisation():
+    P = rp.g1_mul(rp.G1, 777)
+    z = 0x1234567890ABCDEF
+    xyz = [P[0] * z * z % rp.Q, P[1] * z ** 3 % rp.Q, z]
+    limbs = []
+    for v in xyz:
+        m = (v << 256) % rp.Q
+        limbs += [(m >> (64 * i)) & (2 ** 64 - 1) for i in range(4)]
+    assert transcript.jacobian_to_affine(limbs) == P
+    assert transcript.jacobian_to_affine([0] * 4 + limbs[4:8] + [0] * 4) is None
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_permutation_mapping_matches_reference(seed):
+    rnd = random.Random(seed)
+    ncols, n = 4, 32
+    copies = []
+    for _ in range(rnd.randrange(1, 60)):
+        copies.append(((rnd.randrange(ncols), rnd.randrange(n)), (rnd.randrange(ncols), rnd.randrange(n))))
+    want = rp.permutation_mapping(ncols, n, copies)
+    mc, mr = prover.permutation_mapping(ncols, n, [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    got = [[(int(mc[c][j]), int(mr[c][j])) for j in range(n)] for c in range(ncols)]
+    assert got == want
+    mc, mr = prover.permutation_mapping(2, 8, np.zeros((0, 4)))
+    assert (mc == np.repeat(np.arange(2), 8).reshape(2, 8)).all() and (mr == np.tile(np.arange(8), (2, 1))).all()
+
+
+def _run_program(g, parts, adv, fix):
+    inter = []
+
+    def get(v):
+        if v.kind == ev.VS_CONSTANT:
+            return g.constants[v.index]
+        if v.kind == ev.VS_INTERMEDIATE:
+            return inter[v.index]
+        return (fix if v.kind == ev.VS_FIXED else adv)(v.index, g.rotations[v.rot])
+
+    for c in g.calculations:
+        a = get(c.a)
+        inter.append({ev.CALC_ADD: lambda: a + get(c.b), ev.CALC_SUB: lambda: a - get(c.b), ev.CALC_MUL: lambda: a * get(c.b),
+                      ev.CALC_NEGATE: lambda: -a, ev.CALC_STORE: lambda: a}[c.op]() % rp.R)
+    return [get(p) for p in parts]
+
+
+@pytest.mark.parametrize("make,ref", [(circuits.mini_plonk, rp.MiniPlonk), (rot_gate_cs, rp.RotGate)])
+def test_constraint_system_and_gate_program(make, ref):
+    cs = make()
+    assert cs.advice_queries == ref.advice_queries and cs.fixed_queries == ref.fixed_queries
+    assert cs.perm_columns == ref.perm_columns
+    assert cs.degree() == ref.degree and cs.blinding_factors() == ref.blinding_factors
+    assert (cs.num_advice, cs.num_fixed) == (ref.num_advice, ref.num_fixed)
+    g, parts = hc.compile_gates(cs)
+    rnd = random.Random(5)
+    for _ in range(10):
+        vals = {}
+        adv = lambda c, r: vals.setdefault(("a", c, r), rnd.randrange(rp.R))  # noqa: E731
+        fix = lambda c, r: vals.setdefault(("f", c, r), rnd.randrange(rp.R))  # noqa: E731
+        assert _run_program(g, parts, adv, fix) == ref.gates(adv, fix)
+
+
+def test_mini_plonk_witness_matches_reference():
+    for k in (4, 6):
+        adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+        radv, rfixed, rcopies = rp.MiniPlonk.synthesize(k)
+        assert [[int(v) for v in c[:, 0]] for c in adv] == radv and all(not c[:, 1:].any() for c in adv)
+        assert [[int(v) for v in c[:, 0]] for c in fixed] == rfixed
+        assert sorted(map(tuple, copies.tolist())) == sorted((l[0], l[1], r[0], r[1]) for l, r in rcopies)
+
+
+@pytest.mark.parametrize("k,degree", [(4, 3), (7, 4), (9, 6), (22, 3)])
+def test_domain_scalars(k, degree):
+    d = prover.Domain(k, degree)
+    assert pow(d.omega, 1 << k, rp.R) == 1 and pow(d.omega, 1 << (k - 1), rp.R) != 1
+    assert pow(d.extended_omega, 1 << d.extended_k, rp.R) == 1
+    assert (1 << d.extended_k) >= (degree - 1) << k > (1 << (d.extended_k - 1))
+    if k <= 9:
+        r = rp.Domain(k, degree)
+        assert (d.omega, d.extended_omega, d.extended_k) == (r.omega, r.extended_omega, r.extended_k)
+        zn = pow(prover.ZETA, 1 << k, rp.R)
+        for i, t in enumerate(d.t_evaluations):
+            assert t * (zn * pow(d.extended_omega, i << k, rp.R) - 1) % rp.R == 1
+    assert d.rotate_omega(5, -3) * pow(d.omega, 3, rp.R) % rp.R == 5
+
+
+def test_rng_is_a_fixed_stream():
+    a, b = ProverRng(9), ProverRng(9)
+    assert [a.next_u64() for _ in range(4)] == [b.next_u64() for _ in range(4)]
+    assert a.fr() == b.fr() < rp.R and a.u16() == b.u16() < 65536
+    limbs = a.random_poly_limbs(16)
+    ints = b.random_poly(16)
+    assert [transcript.fr_from_mont_limbs(r) for r in limbs] == ints
+    assert ProverRng(10).next_u64() != ProverRng(9).next_u64()
+
+
+def test_max_scalar_bits():
+    col = np.zeros((8, 4), dtype=np.uint64)
+    assert prover.max_scalar_bits(col) == 0
+    col[3, 0] = 30
+    assert prover.max_scalar_bits(col) == 5
+    col[5, 2] = 1
+    assert prover.max_scalar_bits(col) == 129
+
+
+def test_prover_refuses_to_run_without_a_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        prover.Device()
