@@ -18,14 +18,15 @@ def mini_plonk():
     return cs
 
 
-def mini_plonk_synthesize(k, a=5):
+def mini_plonk_synthesize(k, a=5, alloc=None):
     """`synthesize` (:224-254): 2^(k-4) times { raw_multiply(a, a, a^2); raw_add(a, a^2, a + a^2); copy a0 = a1;
     copy b1 = c0 }, one region per row.  Returns (advice[3], fixed[4], copies) with canonical (n, 4) u64 columns and
-    copies as (m, 4) = (left column position, left row, right column position, right row)."""
+    copies as (m, 4) = (left column position, left row, right column position, right row).  `alloc(count, n)`
+    supplies the advice columns (e.g. prover.Device.pinned_columns, so that the witness is DMA-able)."""
     n = 1 << k
     pairs = 1 << (k - 4)
     assert a * a + a < (1 << 64)
-    adv = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    adv = alloc(3, n) if alloc else [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
     fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(4)]
     r0 = np.arange(pairs) * 2
     r1 = r0 + 1

@@ -371,6 +371,14 @@ int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
     });
 }
 
+int h2_dev_random_fr(uint64_t seed, size_t n, void* d_out, void* stream) {
+    if (!d_out && n) return bad("h2_dev_random_fr: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return random_fr_launch(seed, n, (uint64_t*)d_out, pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_eval_op(int op, void* d_res, const void* d_l, const void* d_r, int32_t l_rot, int32_t r_rot, size_t size,
                    const uint64_t c[4], void* stream) {
     return guarded([&] {

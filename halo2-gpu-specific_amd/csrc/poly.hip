@@ -407,4 +407,31 @@ int perm_terms_launch(Fr* num, Fr* den, const Fr* value, const Fr* sigma, size_t
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The vanishing argument's blinding polynomial (vanishing/prover.rs:47-61: a parallel fill from thread_rng).
+// Counter-based so that the host restatement can reproduce it: limb j of element i = mix64(seed + 4 i + j),
+// top limb cut to 61 bits (< 2^253 < r: a valid Montgomery residue used as is).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_random_fr(uint64_t seed, size_t n, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one u64 limb per lane: coalesced stores
+    if (i >= 4 * n) return;
+    uint64_t v = mix64(seed + i);
+    if ((i & 3) == 3) v &= (1ull << 61) - 1;
+    out[i] = v;
+}
+
+int random_fr_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_random_fr, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, stream, seed, n, d_out);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+
 }  // namespace h2

@@ -81,6 +81,7 @@ class Device:
         self.tstream = torch.cuda.Stream(device=self.dev)
         self.stream = _vp(self.tstream.cuda_stream)
         self._scratch = None
+        self._pinned = {}
 
     # -- memory -----------------------------------------------------------------------------------------
     def empty(self, n):
@@ -94,8 +95,10 @@ class Device:
     def upload(self, a):
         a = np.ascontiguousarray(a)
         with self.torch.cuda.stream(self.tstream):
-            t = self.torch.from_numpy(a.view(np.int64)).to(self.dev, non_blocking=False)
-        return t
+            src = self._pinned.get(a.ctypes.data)
+            if src is not None and src.numel() == a.size:
+                return src.to(self.dev, non_blocking=True)
+            return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
 
     def download(self, t):
         with self.torch.cuda.stream(self.tstream):
@@ -110,6 +113,37 @@ class Device:
         a = np.array([fr_to_mont_limbs(v) for v in values], dtype=np.uint64)
         with self.torch.cuda.stream(self.tstream):
             t[start:start + len(values)] = self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+
+    def set_rows_raw(self, t, start, small):
+        """t[start : start + len(small)] <- small non-negative integers < 2^63, limb 0 only (no Montgomery form)"""
+        a = np.zeros((len(small), 4), dtype=np.int64)
+        a[:, 0] = small
+        with self.torch.cuda.stream(self.tstream):
+            t[start:start + len(small)] = self.torch.from_numpy(a).to(self.dev)
+
+    def max_scalar_bits(self, t):
+        """find_max_scalar_bits (plonk/prover.rs:237-254) of a canonical column resident on the device"""
+        torch = self.torch
+        sign = -(1 << 63)
+        with torch.cuda.stream(self.tstream):
+            # unsigned maxima of the four limbs: flip the sign bit so that the signed max orders them as unsigned
+            m = ((t ^ sign).amax(dim=0) ^ sign).cpu().tolist()
+        for limb in (3, 2, 1, 0):
+            v = m[limb] & ((1 << 64) - 1)
+            if v:
+                return 64 * limb + v.bit_length()
+        return 0
+
+    def pinned_columns(self, count, n):
+        """`count` zeroed (n, 4) u64 numpy columns in page-locked host memory: a witness synthesised into them
+        reaches the device by DMA instead of through the driver's staging copies"""
+        out = []
+        for _ in range(count):
+            t = self.torch.zeros((n, 4), dtype=self.torch.int64).pin_memory()
+            a = t.numpy().view(np.uint64)
+            self._pinned[a.ctypes.data] = t
+            out.append(a)
+        return out
 
     def get_rows(self, t, start, count):
         with self.torch.cuda.stream(self.tstream):
@@ -154,20 +188,23 @@ class Device:
         """[Params::commit / commit_lagrange(_with_bound)] over device-resident bases -> affine point"""
         return self.msm_batch([scalars], bases, n, max_bits)[0]
 
-    def msm_batch(self, columns, bases, n, max_bits=254):
+    def msm_batch(self, columns, bases, n, max_bits=254, also=None):
+        """one MSM per column over the same bases, pipelined inside the library; `also` = (scalars, other bases) is
+        one more MSM over a different table, overlapped with the tail of the batch where possible"""
         count = len(columns)
-        if count == 0:
-            return []
         per = (self.L.h2_msm_scratch_bytes(n, max_bits) + 255) // 256 * 256
         scratch = self.scratch(2 * per)
-        out = np.zeros((count, 12), dtype=np.uint64)
+        out = np.zeros((count + (1 if also else 0), 12), dtype=np.uint64)
         if count == 1:
             check(self.L.h2_dev_msm(columns[0].data_ptr(), bases.data_ptr(), n, max_bits, scratch.data_ptr(), per,
                                     out.ctypes.data, self.stream), "h2_dev_msm")
-        else:
+        elif count > 1:
             ptrs = (_vp * count)(*[c.data_ptr() for c in columns])
             check(self.L.h2_dev_msm_batch(ptrs, count, bases.data_ptr(), n, max_bits, scratch.data_ptr(), 2 * per,
                                           out.ctypes.data, self.stream), "h2_dev_msm_batch")
+        if also:
+            check(self.L.h2_dev_msm(also[0].data_ptr(), also[1].data_ptr(), n, max_bits, scratch.data_ptr(), per,
+                                    out[count:].ctypes.data, self.stream), "h2_dev_msm")
         return [jacobian_to_affine(r) for r in out]
 
     # -- elementwise / scans ----------------------------------------------------------------------------
@@ -418,12 +455,9 @@ def create_proof(device, params, pk, advice, rng, timings=None):
     max_bits = 0
     advice_dev = []
     for col in advice:
-        col = np.array(col, dtype=np.uint64, copy=True).reshape(n, 4)
-        col[unusable_rows_start:] = 0
-        for r in range(unusable_rows_start, n):
-            col[r, 0] = rng.u16()
-        max_bits = max(max_bits, max_scalar_bits(col))
-        t = D.upload(col)
+        t = D.upload(col)                                        # canonical; DMA when the column is pinned memory
+        D.set_rows_raw(t, unusable_rows_start, [rng.u16() for _ in range(unusable_rows_start, n)])
+        max_bits = max(max_bits, D.max_scalar_bits(t))
         check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
         advice_dev.append(t)
     for P in D.msm_batch(advice_dev, params.g_lagrange, n, max(max_bits, 1)):
@@ -453,17 +487,19 @@ def create_proof(device, params, pk, advice, rng, timings=None):
         last_z = D.get_rows(z, n - (bf + 1), 1)[0]
         z_dev.append(z)
     del num, den, tmp
-    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every set
-    for P in D.msm_batch(z_dev, params.g_lagrange, n, 254):
+    # vanishing argument: the random polynomial (vanishing/prover.rs:40-67), generated on the device
+    random_poly = D.empty(n)
+    check(L.h2_dev_random_fr(rng.random_poly_seed(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
+    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every set; the random polynomial's commitment does
+    # not depend on anything hashed in between, so its MSM rides in the same pipelined batch (hashing order kept)
+    z_commitments = D.msm_batch(z_dev, params.g_lagrange, n, 254, also=(random_poly, params.g))
+    random_commitment = z_commitments.pop()
+    for P in z_commitments:
         transcript.write_point(P)
     z_polys = [D.intt(z, dom) for z in z_dev]
     mark("permutation")
-
-    # ---- vanishing argument: random polynomial (vanishing/prover.rs:40-67) ------------------------------
-    random_poly = D.upload(rng.random_poly_limbs(n))
-    transcript.write_point(D.msm(random_poly, params.g, n))
+    transcript.write_point(random_commitment)
     y = transcript.squeeze_challenge_scalar()
-    mark("vanishing commit")
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
     advice_polys = [D.intt(t, dom) for t in advice_dev]          # in place: the Lagrange values are not needed again

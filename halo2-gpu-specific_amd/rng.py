@@ -48,16 +48,26 @@ class ProverRng:
             v |= self.next_u64() << (64 * i)
         return v % R_MOD
 
-    def random_poly_limbs(self, n):
-        """The vanishing argument's blinding polynomial (vanishing/prover.rs:47-61 fills it from thread_rng, one
-        element at a time): n x 4 u64 limbs < 2^253 < r from a PCG64 stream keyed by this stream, used directly
-        as the in-memory (Montgomery) representation."""
-        g = np.random.Generator(np.random.PCG64(self.next_u64()))
-        a = g.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    def random_poly_seed(self):
+        """one draw keys the counter-based generator of the vanishing argument's blinding polynomial"""
+        return self.next_u64()
+
+    @staticmethod
+    def random_poly_limbs(seed, n):
+        """Host twin of h2_dev_random_fr (csrc/poly.hip k_random_fr): n x 4 u64 limbs, limb j of element i =
+        mix64(seed + 4 i + j) with splitmix64's output function, the top limb cut to 61 bits.  The 253-bit value
+        is the in-memory (Montgomery) representation."""
+        with np.errstate(over="ignore"):
+            z = np.uint64(seed) + np.arange(4 * n, dtype=np.uint64)
+            z += np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(31)
+        a = z.reshape(n, 4)
         a[:, 3] &= np.uint64((1 << 61) - 1)
         return a
 
     def random_poly(self, n):
-        """the same polynomial as canonical integers"""
-        a = self.random_poly_limbs(n)
+        """the blinding polynomial as canonical integers (consumes one draw)"""
+        a = self.random_poly_limbs(self.random_poly_seed(), n)
         return [(int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192) * _R_INV % R_MOD for r in a]

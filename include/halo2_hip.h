@@ -150,6 +150,12 @@ int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, cons
                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                              const uint64_t omega[4], int first, void *stream);
 
+/* The vanishing argument's blinding polynomial (plonk/vanishing/prover.rs:47-61, a parallel fill from thread_rng):
+ * n Fr from a counter-based generator -- u64 limb j of element i = mix64(seed + 4 i + j) (splitmix64's output
+ * function), the top limb cut to 61 bits; the 253-bit value is used directly as the Montgomery representation.
+ * halo2-gpu-specific_amd/rng.py holds the host twin the reference prover of the tests draws from. */
+int h2_dev_random_fr(uint64_t seed, size_t n, void *d_out, void *stream);
+
 /* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
  * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
  * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:

@@ -171,9 +171,21 @@ def test_rng_is_a_fixed_stream():
     a, b = ProverRng(9), ProverRng(9)
     assert [a.next_u64() for _ in range(4)] == [b.next_u64() for _ in range(4)]
     assert a.fr() == b.fr() < rp.R and a.u16() == b.u16() < 65536
-    limbs = a.random_poly_limbs(16)
+    limbs = ProverRng.random_poly_limbs(a.random_poly_seed(), 16)
     ints = b.random_poly(16)
-    assert [transcript.fr_from_mont_limbs(r) for r in limbs] == ints
+    assert [transcript.fr_from_mont_limbs(r) for r in limbs] == ints and (limbs[:, 3] < (1 << 61)).all()
+    # the counter-based generator, element by element (the device kernel k_random_fr is its twin)
+    def mix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+    seed = 2**64 - 5  # wraps
+    got = ProverRng.random_poly_limbs(seed, 3)
+    for i in range(3):
+        for j in range(4):
+            want = mix64((seed + 4 * i + j) & (2**64 - 1)) & ((1 << 61) - 1 if j == 3 else 2**64 - 1)
+            assert int(got[i, j]) == want
     assert ProverRng(10).next_u64() != ProverRng(9).next_u64()
 
 

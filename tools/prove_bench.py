@@ -1,0 +1,41 @@
+"""create_proof wall-clock on one GPU for the mini-PLONK circuit (BASELINE config 4: k = 22), per phase.
+usage: python tools/prove_bench.py [k] [reps]      (synthetic SRS: timing only, the proof cannot verify)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402  (first, so that the library binds to torch's HIP runtime)
+
+torch.cuda.init()
+
+from halo2_gpu_specific_amd import circuits, prover  # noqa: E402
+from halo2_gpu_specific_amd.rng import ProverRng  # noqa: E402
+
+
+def main():
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    D = prover.Device()
+    t0 = time.perf_counter()
+    params = prover.Params.synthetic(D, k)
+    t1 = time.perf_counter()
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k, alloc=D.pinned_columns)
+    t2 = time.perf_counter()
+    pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
+    t3 = time.perf_counter()
+    print("k=%d  srs %.3fs  synthesize %.3fs  keygen %.3fs" % (k, t1 - t0, t2 - t1, t3 - t2))
+    for rep in range(reps):
+        timings = {}
+        ta = time.perf_counter()
+        proof = prover.create_proof(D, params, pk, adv, ProverRng(rep), timings=timings if rep else None)
+        D.sync()
+        tb = time.perf_counter()
+        print("rep %d: create_proof %.1f ms  (%d bytes)  %s" % (rep, (tb - ta) * 1e3, len(proof),
+                                                                 {n: round(t * 1e3, 1) for n, t in timings.items()}))
+    print("peak device memory: %.2f GiB" % (torch.cuda.max_memory_allocated() / 2**30))
+
+
+if __name__ == "__main__":
+    main()
