@@ -14,7 +14,7 @@
 //                 additions per lane whatever the bucket sizes are; a partial sum is emitted at
 //                 every bucket boundary inside the slice                              [hot loop]
 //   k_finish      per bucket: fold its slice partials (serial when few, else queued)
-//   k_finish_heavy one workgroup per heavy bucket: strided fold + LDS tree
+//   k_finish_heavy HEAVY_SPLIT workgroups per heavy bucket (strided fold + LDS tree), k_finish_heavy2 folds their results
 //   k_reduce      per window: sum_b (b+1) * B_b by chunked running sums + small scalar mul + LDS tree
 //   host          adds the <= W*G partial window sums and runs the W*c doublings (Horner)
 // Slicing the *sorted list* evenly (instead of giving each bucket to a thread) keeps every lane of
@@ -38,6 +38,8 @@
 namespace h2 {
 
 static constexpr uint32_t FINISH_SERIAL = 8; // partials a single thread folds in k_finish
+static constexpr uint32_t SORT_T = 1024;      // threads of a k_bucket_sort workgroup (one partition each)
+static constexpr uint32_t HEAVY_SPLIT = 64;   // workgroups sharing one heavy bucket in k_finish_heavy
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 256;    // threads per k_reduce workgroup
@@ -276,41 +278,99 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
 // ---------------------------------------------------------------- k_bucket_sort (sort pass B)
 // One workgroup per partition: histogram of the low bucket bits in LDS, exclusive scan -> the start
 // offset of every bucket of the partition (written to `starts`), then the entries are placed.
-__global__ void __launch_bounds__(256) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
-                                                     uint32_t hi_bits, uint32_t nb, uint32_t* starts, uint32_t* sorted) {
+// A partition far above the average size means a skewed column (a witness column that is mostly one value:
+// every such scalar lands in one bucket): its entries would serialise on one LDS counter, so the counter updates
+// are aggregated per wave -- lanes holding the key of the first active lane are served by one atomic, twice,
+// and only what is left falls back to per-lane atomics.
+__device__ __forceinline__ uint32_t lds_count_aggregated(uint32_t* bins, uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t active = __ballot(valid);
+    uint32_t result = 0;
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        if (active == 0) break;
+        const int leader = __ffsll((unsigned long long)active) - 1;
+        const uint32_t k = __shfl(key, leader, 64);
+        const uint64_t same = __ballot(valid && key == k) & active;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&bins[k], (uint32_t)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if ((same >> lane) & 1) result = base + (uint32_t)__popcll(same & ((1ull << lane) - 1));
+        active &= ~same;
+    }
+    if ((active >> lane) & 1) result = atomicAdd(&bins[key], 1u);
+    return result;
+}
+
+__global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
+                                                        uint32_t hi_bits, uint32_t nb, uint32_t skew_threshold,
+                                                        uint32_t* starts, uint32_t* sorted) {
     uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
     __shared__ uint32_t sh[4];
     const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
     const uint32_t e0 = pbase[p], e1 = pbase[p + 1];
-    for (uint32_t k = threadIdx.x; k < nbins; k += 256) bins[k] = 0;
+    const bool skewed = (e1 - e0) > skew_threshold;  // uniform over the workgroup
+    for (uint32_t k = threadIdx.x; k < nbins; k += SORT_T) bins[k] = 0;
     __syncthreads();
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) atomicAdd(&bins[tmp[e].y], 1u);
-    __syncthreads();
-    // exclusive scan of nbins (<= 512) counters: 256 threads x (nbins / 256) consecutive bins
-    const uint32_t per = (nbins + 255) / 256;
-    uint32_t local[2] = {0, 0}, sum = 0;
-    for (uint32_t k = 0; k < per; k++) {
-        uint32_t b = threadIdx.x * per + k;
-        uint32_t v = b < nbins ? bins[b] : 0;
-        local[k] = sum;
-        sum += v;
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
-    // bucket index of bin b of partition p: window w = p >> hi_bits, bucket = ((p & (2^hi_bits - 1)) << lo_bits) | b
-    const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
-    for (uint32_t k = 0; k < per; k++) {
-        uint32_t b = threadIdx.x * per + k;
-        if (b < nbins) {
-            uint32_t st = e0 + ex + local[k];
-            bins[b] = st;
-            starts[(size_t)w * nb + ((hi << lo_bits) | b)] = st;
+    if (!skewed) {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_T) atomicAdd(&bins[tmp[e].y], 1u);
+    } else {
+        for (uint32_t e = e0 + threadIdx.x; e < e1 + (SORT_T - 1); e += 4 * SORT_T) {  // whole waves stay in the loop
+            uint32_t key[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) key[j] = (e + j * SORT_T < e1) ? tmp[e + j * SORT_T].y : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_count_aggregated(bins, key[j], e + j * SORT_T < e1);
         }
     }
     __syncthreads();
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        uint2 v = tmp[e];
-        sorted[atomicAdd(&bins[v.y], 1u)] = v.x;
+    // exclusive scan of nbins (<= 512) counters by the first 256 threads: (nbins / 256) consecutive bins each
+    const uint32_t per = (nbins + 255) / 256;
+    uint32_t local[2] = {0, 0}, sum = 0;
+    if (threadIdx.x < 256) {
+        for (uint32_t k = 0; k < per; k++) {
+            uint32_t b = threadIdx.x * per + k;
+            uint32_t v = b < nbins ? bins[b] : 0;
+            local[k] = sum;
+            sum += v;
+        }
+    }
+    __syncthreads();
+    // bucket index of bin b of partition p: window w = p >> hi_bits, bucket = ((p & (2^hi_bits - 1)) << lo_bits) | b
+    const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
+    if (threadIdx.x < 256) {  // the first four waves, whole: the scan's barriers are matched below
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
+        for (uint32_t k = 0; k < per; k++) {
+            uint32_t b = threadIdx.x * per + k;
+            if (b < nbins) {
+                uint32_t st = e0 + ex + local[k];
+                bins[b] = st;
+                starts[(size_t)w * nb + ((hi << lo_bits) | b)] = st;
+            }
+        }
+    } else {
+        __syncthreads();  // block_exclusive_scan_256 holds two barriers
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!skewed) {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_T) {
+            uint2 v = tmp[e];
+            sorted[atomicAdd(&bins[v.y], 1u)] = v.x;
+        }
+    } else {
+        for (uint32_t e = e0 + threadIdx.x; e < e1 + (SORT_T - 1); e += 4 * SORT_T) {
+            uint2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (e + j * SORT_T < e1) ? tmp[e + j * SORT_T] : make_uint2(0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool valid = e + j * SORT_T < e1;
+                uint32_t slot = lds_count_aggregated(bins, v[j].y, valid);
+                if (valid) sorted[slot] = v[j].x;
+            }
+        }
     }
 }
 
@@ -372,20 +432,44 @@ __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint
     xyzz_store(buckets + b, acc);
 }
 
-__global__ void __launch_bounds__(256) k_finish_heavy(const XYZZ* partials, const uint32_t* starts, uint32_t log_s,
-                                                      const uint32_t* heavy_list, const uint32_t* heavy_count,
-                                                      XYZZ* buckets) {
+// Heavy bucket h, part y (of HEAVY_SPLIT): folds the partial slots first + y, first + y + HEAVY_SPLIT, ... and
+// leaves the result in slot first + y -- a slot of its own set, written after its last read, so the parts of one
+// bucket never race.  k_finish_heavy2 then folds the (at most HEAVY_SPLIT) leading slots.
+__global__ void __launch_bounds__(256) k_finish_heavy(XYZZ* partials, const uint32_t* starts, uint32_t log_s,
+                                                      const uint32_t* heavy_list, const uint32_t* heavy_count) {
     __shared__ XYZZ sh[256];
+    const uint32_t tid = threadIdx.x, part = blockIdx.y;
+    uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        uint32_t b = heavy_list[h];
+        uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
+        if (first + part > last) continue;  // uniform over the workgroup
+        XYZZ acc = xyzz_identity();
+        for (uint32_t sl = first + part + tid * HEAVY_SPLIT; sl <= last; sl += 256 * HEAVY_SPLIT)
+            acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t off = 128; off >= 1; off >>= 1) {
+            if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
+            __syncthreads();
+        }
+        if (tid == 0) xyzz_store(partials + (b + first + part), sh[0]);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(HEAVY_SPLIT) k_finish_heavy2(const XYZZ* partials, const uint32_t* starts,
+                                                                uint32_t log_s, const uint32_t* heavy_list,
+                                                                const uint32_t* heavy_count, XYZZ* buckets) {
+    __shared__ XYZZ sh[HEAVY_SPLIT];
     const uint32_t tid = threadIdx.x;
     uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
-        XYZZ acc = xyzz_identity();
-        for (uint32_t sl = first + tid; sl <= last; sl += 256) acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
-        sh[tid] = acc;
+        sh[tid] = (first + tid <= last) ? xyzz_load(partials + (b + first + tid)) : xyzz_identity();
         __syncthreads();
-        for (uint32_t off = 128; off >= 1; off >>= 1) {
+        for (uint32_t off = HEAVY_SPLIT / 2; off >= 1; off >>= 1) {
             if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
             __syncthreads();
         }
@@ -503,15 +587,19 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.W), dim3(256),
                        (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp);
-    hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(256), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
-                       s.hi_bits, s.nb, starts, sorted);
+    // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
+    uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
+    hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
+                       s.hi_bits, s.nb, skew_threshold, starts, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
                        s.log_s, partials);
     hipLaunchKernelGGL(k_finish, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
                        buckets, heavy + 1, heavy);
-    hipLaunchKernelGGL(k_finish_heavy, dim3(1024), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1, heavy,
-                       buckets);
+    hipLaunchKernelGGL(k_finish_heavy, dim3(64, HEAVY_SPLIT), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1,
+                       heavy);
+    hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
+                       heavy, buckets);
     hipLaunchKernelGGL(k_reduce, dim3(s.G, s.W), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
     H2_HIP(hipGetLastError());
 }
