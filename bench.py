@@ -261,17 +261,17 @@ def main():
         params = prover.Params.synthetic(D, pk_k)  # timing-only SRS: same work, proofs do not verify
         adv, fixed, copies = circuits.mini_plonk_synthesize(pk_k, alloc=D.pinned_columns)
         pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
-        proof = prover.create_proof(D, params, pk, adv, ProverRng(1))  # warm-up (arena growth, plan caches)
-        assert proof == prover.create_proof(D, params, pk, adv, ProverRng(1)), "create_proof is not deterministic"
+        proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))  # warm-up (arena growth, plan caches)
+        assert proof == prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1)), "create_proof is not deterministic"
         phases = {}
         barrier()
         p0 = time.perf_counter()
         for i in range(args.prove_steps):
-            prover.create_proof(D, params, pk, adv, ProverRng(2 + i))
+            prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(2 + i))
         D.sync()
         barrier()
         pelapsed = time.perf_counter() - p0
-        prover.create_proof(D, params, pk, adv, ProverRng(1), timings=phases)  # per-phase split (adds syncs: untimed)
+        prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=phases)  # per-phase split (adds syncs: untimed)
         if dist is not None:
             t = torch.tensor([pelapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -431,8 +431,18 @@ def _vanishing(roots, z):
 
 
 def create_proof(device, params, pk, advice, rng, timings=None):
-    """plonk/prover.rs:206-850 (SHPLONK multiopen).  advice: list of canonical (n, 4) u64 columns (rows past the
-    usable range are overwritten with blinding values); rng: a rng.ProverRng.  Returns the proof bytes."""
+    """plonk/prover.rs:877-893: the GWC multiopen, as the reference's `create_proof`"""
+    return create_proof_ext(device, params, pk, advice, rng, True, timings)
+
+
+def create_proof_with_shplonk(device, params, pk, advice, rng, timings=None):
+    """plonk/prover.rs:856-871"""
+    return create_proof_ext(device, params, pk, advice, rng, False, timings)
+
+
+def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
+    """plonk/prover.rs:206-850.  advice: list of canonical (n, 4) u64 columns (rows past the usable range are
+    overwritten with blinding values); rng: a rng.ProverRng.  Returns the proof bytes."""
     import time
 
     D, L = device, device.L
@@ -579,12 +589,32 @@ def create_proof(device, params, pk, advice, rng, timings=None):
         query(("sigma", i), p, 0)
     query(("h",), h_poly, 0)
     query(("random",), random_poly, 0)
-    _shplonk(D, params, transcript, queries, polys, n)
+    (_gwc if use_gwc else _shplonk)(D, params, transcript, queries, polys, n)
     mark("multiopen")
     if timings is not None:
         for (_, t0), (name, t1) in zip(marks, marks[1:]):
             timings[name] = timings.get(name, 0.0) + (t1 - t0)
     return transcript.finalize()
+
+
+def _gwc(D, params, transcript, queries, polys, n):
+    """poly/multiopen/gwc/prover.rs:20-175: per opening point, batch = sum_i v^(m-1-i) p_i, witness =
+    (batch - batch(z)) / (X - z).  The reference's cuda branch (:57-151) uploads every p_i again for its eval_mul_c /
+    eval_sum pair; here they never left the device and one lincomb forms the batch."""
+    v = transcript.squeeze_challenge_scalar()
+    groups = {}
+    for qu in queries:
+        groups.setdefault(qu[1], []).append(qu)          # BTreeMap<Rotation, Vec<Q>> (gwc.rs:40-49)
+    witnesses = []
+    for rot in sorted(groups):
+        group = groups[rot]
+        z, m = group[0][2], len(group)
+        vpow = [pow(v, m - 1 - i, R_MOD) for i in range(m)]
+        batch = D.lincomb(D.empty(n), [polys[key] for key, _, _, _ in group], vpow, n)
+        D.sub_low(batch, [sum(c * e for c, (_, _, _, e) in zip(vpow, group)) % R_MOD])   # = batch(z)
+        witnesses.append(D.kate_division(batch, n, z, D.empty(n)))
+    for P in D.msm_batch(witnesses, params.g, n, 254):
+        transcript.write_point(P)
 
 
 def _shplonk(D, params, transcript, queries, polys, n):

@@ -425,8 +425,8 @@ def fold(polys, ch, n):
     return acc
 
 
-def create_proof(pk, advice_in, rng):
-    """plonk/prover.rs:206-850 with SHPLONK; one circuit instance, no instance columns, no lookups/shuffles"""
+def create_proof(pk, advice_in, rng, use_gwc=False):
+    """plonk/prover.rs:206-850 (create_proof_ext); one circuit instance, no instance columns, no lookups/shuffles"""
     cs, dom = pk.cs, pk.dom
     n, bf = dom.n, cs.blinding_factors
     t = Transcript()
@@ -552,8 +552,26 @@ def create_proof(pk, advice_in, rng):
         q(("sigma", i), p, 0)
     q(("h",), h_poly, 0)
     q(("random",), random_poly, 0)
-    shplonk_prove(pk, t, queries, polys, n)
+    (gwc_prove if use_gwc else shplonk_prove)(pk, t, queries, polys, n)
     return bytes(t.out)
+
+
+def gwc_sets(queries):
+    """poly/multiopen/gwc.rs:36-60: queries grouped by rotation, groups in rotation order"""
+    groups = {}
+    for qu in queries:
+        groups.setdefault(qu[1], []).append(qu)
+    return [groups[r] for r in sorted(groups)]
+
+
+def gwc_prove(pk, t, queries, polys, n):
+    """poly/multiopen/gwc/prover.rs:20-175"""
+    v = t.squeeze()
+    for group in gwc_sets(queries):
+        z = group[0][2]
+        batch = fold([polys[key] for key, _, _, _ in group], v, n)
+        batch[0] = (batch[0] - eval_poly(batch, z)) % R
+        t.write_point(commit(pk, kate_division(batch, z)))
 
 
 def shplonk_prove(pk, t, queries, polys, n):
@@ -592,7 +610,7 @@ def shplonk_prove(pk, t, queries, polys, n):
 
 
 # ---- verifier (plonk/verifier.rs) with the trapdoor standing in for the pairing ---------------------------
-def verify_proof(pk, proof):
+def verify_proof(pk, proof, use_gwc=False):
     """True iff the proof is accepted.  e(L, [s]G2) == e(Rgt, G2) is checked as [s]L == Rgt (s is known in the
     unsafe test setup), everything else follows plonk/verifier.rs:128-507."""
     cs, dom = pk.cs, pk.dom
@@ -668,6 +686,8 @@ def verify_proof(pk, proof):
         q(("sigma", i), pk.perm_commitments[i], 0, ev)
     q(("h",), h_commitment, 0, expected_h)
     q(("random",), random_commitment, 0, random_eval)
+    if use_gwc:
+        return gwc_verify(pk, t, proof, queries, commitments)
     # shplonk/verifier.rs:23-103
     rsets, super_points = intermediate_sets(queries)
     sy = t.squeeze()
@@ -698,3 +718,26 @@ def verify_proof(pk, proof):
     right = g1_add(right, g1_mul(h1, -z_0))
     right = g1_add(right, g1_mul(h2, u))
     return g1_mul(h2, pk.s) == right
+
+
+def gwc_verify(pk, t, proof, queries, commitments):
+    """poly/multiopen/gwc/verifier.rs:16-95"""
+    v = t.squeeze()
+    u = t.squeeze()
+    commitment_multi, eval_multi, witness, witness_with_aux = None, 0, None, None
+    for group in gwc_sets(queries):
+        z = group[0][2]
+        wi = t.read_point()
+        witness_with_aux = g1_add(g1_mul(witness_with_aux, u), g1_mul(wi, z))
+        witness = g1_add(g1_mul(witness, u), wi)
+        commitment_multi = g1_mul(commitment_multi, u)
+        eval_multi = eval_multi * u % R
+        cb, eb = None, 0
+        for key, _, _, ev in group:
+            cb = g1_add(g1_mul(cb, v), commitments[key])
+            eb = (eb * v + ev) % R
+        commitment_multi = g1_add(commitment_multi, cb)
+        eval_multi = (eval_multi + eb) % R
+    assert t.pos == len(proof), "trailing bytes in the proof"
+    right = g1_add(g1_add(witness_with_aux, commitment_multi), g1_mul(G1, -eval_multi))
+    return g1_mul(witness, pk.s) == right

@@ -57,13 +57,13 @@ def test_proof_bytes_match_reference_prover(oracle, device, which, k):
     for got, want in zip(pk.sigma_values, rpk.sigma_values):
         assert device.get_rows(got, 0, 1 << k) == want
     assert pk.transcript_repr == rpk.transcript_repr
-    for seed in (1, 2):
-        proof = prover.create_proof(device, params, pk, cols_to_arr(adv), ProverRng(seed))
-        want = rp.create_proof(rpk, adv, ProverRng(seed))
+    for seed, use_gwc in ((1, False), (2, False), (3, True)):
+        proof = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(seed), use_gwc)
+        want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc)
         assert len(proof) == len(want)
         first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
         assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
-    assert rp.verify_proof(rpk, proof)
+        assert rp.verify_proof(rpk, proof, use_gwc=use_gwc)
 
 
 def test_bad_witness_is_rejected(oracle, device):
@@ -78,9 +78,11 @@ def test_bad_witness_is_rejected(oracle, device):
     vk = rp.Keys()
     vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
     vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
-    assert rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)))
+    assert rp.verify_proof(vk, prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(5)))
+    assert rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)), use_gwc=True)
     adv[2][0, 0] += 1
-    assert not rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)))
+    assert not rp.verify_proof(vk, prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(5)))
+    assert not rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(5)), use_gwc=True)
 
 
 @pytest.mark.parametrize("k", [int(os.environ.get("H2_TEST_PLONK_K", "16"))])
@@ -111,7 +113,9 @@ def test_large_proof_is_accepted_by_reference_verifier(oracle, device, k):
     vk.cs, vk.dom, vk.s = rp.MiniPlonk, dom, S_TRAPDOOR
     vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
     timings = {}
-    proof = prover.create_proof(device, params, pk, adv, ProverRng(22), timings=timings)
+    proof = prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(22), timings=timings)
     assert len(proof) == 32 * (3 + 3 + 1 + 2 + 3 + 4 + 1 + 3 + 8 + 2)
     assert rp.verify_proof(vk, proof)
+    gwc = prover.create_proof(device, params, pk, adv, ProverRng(23))
+    assert len(gwc) == len(proof) + 32 and rp.verify_proof(vk, gwc, use_gwc=True)
     print("create_proof k=%d:" % k, {n: round(t * 1e3, 2) for n, t in timings.items()})

@@ -38,6 +38,8 @@ def test_reference_prover_is_accepted(cs, k):
     assert rp.verify_proof(pk, proof)
     assert proof == rp.create_proof(pk, adv, ProverRng(11)), "same seed, same proof"
     assert proof != rp.create_proof(pk, adv, ProverRng(12))
+    gwc = rp.create_proof(pk, adv, ProverRng(11), use_gwc=True)
+    assert rp.verify_proof(pk, gwc, use_gwc=True) and gwc[:len(proof) - 64] == proof[:-64] and gwc != proof
     # any flipped scalar / point byte must be rejected (a decoding assert counts as a rejection)
     for pos in (5, 32 * 3 + 1, len(proof) - 40, len(proof) - 3):
         bad = bytearray(proof)
