@@ -51,3 +51,21 @@ def allgather_fold(partial_xyz, group=None, device=None):
     dist.all_gather(gathered, mine, group=group)
     pts = np.stack([t.cpu().numpy().view(np.uint64) for t in gathered])
     return g1_sum(pts)
+
+
+def allgather_fold_many(partials_xyz, group=None, device=None):
+    """`partials_xyz`: (count, 12) -- this rank's partial point of each of `count` range-split MSMs.  One
+    all-gather of world x count x 96 B, then `count` local folds in rank order (so every rank derives the same
+    Jacobian representation, hence the same transcript).  Returns (count, 12)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    mine_np = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 12)
+    mine = torch.from_numpy(mine_np.view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    pts = np.stack([t.cpu().numpy().view(np.uint64) for t in gathered])      # (world, count, 12)
+    return np.stack([g1_sum(pts[:, j, :]) for j in range(mine_np.shape[0])])

@@ -69,7 +69,9 @@ class Domain:
 class Device:
     """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, group=None, force_collective=False):
+        """`group`: a torch.distributed process group (None = the default group when one is initialised) over which
+        every MSM of a proof is range-split; all ranks must then run the same proof on the same inputs."""
         import torch  # plumbing only: device memory and the stream
 
         if not torch.cuda.is_available():
@@ -82,6 +84,11 @@ class Device:
         self.stream = _vp(self.tstream.cuda_stream)
         self._scratch = None
         self._pinned = {}
+        self.group, self.group_size, self.group_rank, self.force_collective = group, 1, 0, force_collective
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            self.group_size, self.group_rank = dist.get_world_size(group), dist.get_rank(group)
 
     # -- memory -----------------------------------------------------------------------------------------
     def empty(self, n):
@@ -190,22 +197,37 @@ class Device:
 
     def msm_batch(self, columns, bases, n, max_bits=254, also=None):
         """one MSM per column over the same bases, pipelined inside the library; `also` = (scalars, other bases) is
-        one more MSM over a different table, overlapped with the tail of the batch where possible"""
-        count = len(columns)
-        per = (self.L.h2_msm_scratch_bytes(n, max_bits) + 255) // 256 * 256
+        one more MSM over a different table.  With a process group (one process per GPU, every rank holding the same
+        polynomials) each MSM is split into contiguous ranges over the ranks -- gpu_multiexp_bound's split
+        (arithmetic.rs:413-440) -- and the partial points are all-gathered and folded (parallel.py)."""
+        lo, hi = 0, n
+        collective = self.group_size > 1 or self.force_collective
+        if collective:
+            from .parallel import allgather_fold_many, msm_split_range
+
+            lo, hi = msm_split_range(n, self.group_size, self.group_rank)
+        out = self.msm_partial(columns, bases, lo, hi, max_bits, also)
+        if collective:
+            out = allgather_fold_many(out, group=self.group, device=self.dev)
+        return [jacobian_to_affine(r) for r in out]
+
+    def msm_partial(self, columns, bases, lo, hi, max_bits=254, also=None):
+        """the MSMs restricted to the index range [lo, hi): raw Jacobian results, (count (+1), 12) u64"""
+        count, m = len(columns), hi - lo
+        per = (self.L.h2_msm_scratch_bytes(m, max_bits) + 255) // 256 * 256
         scratch = self.scratch(2 * per)
         out = np.zeros((count + (1 if also else 0), 12), dtype=np.uint64)
         if count == 1:
-            check(self.L.h2_dev_msm(columns[0].data_ptr(), bases.data_ptr(), n, max_bits, scratch.data_ptr(), per,
-                                    out.ctypes.data, self.stream), "h2_dev_msm")
+            check(self.L.h2_dev_msm(columns[0].data_ptr() + 32 * lo, bases.data_ptr() + 64 * lo, m, max_bits,
+                                    scratch.data_ptr(), per, out.ctypes.data, self.stream), "h2_dev_msm")
         elif count > 1:
-            ptrs = (_vp * count)(*[c.data_ptr() for c in columns])
-            check(self.L.h2_dev_msm_batch(ptrs, count, bases.data_ptr(), n, max_bits, scratch.data_ptr(), 2 * per,
-                                          out.ctypes.data, self.stream), "h2_dev_msm_batch")
+            ptrs = (_vp * count)(*[c.data_ptr() + 32 * lo for c in columns])
+            check(self.L.h2_dev_msm_batch(ptrs, count, bases.data_ptr() + 64 * lo, m, max_bits, scratch.data_ptr(),
+                                          2 * per, out.ctypes.data, self.stream), "h2_dev_msm_batch")
         if also:
-            check(self.L.h2_dev_msm(also[0].data_ptr(), also[1].data_ptr(), n, max_bits, scratch.data_ptr(), per,
-                                    out[count:].ctypes.data, self.stream), "h2_dev_msm")
-        return [jacobian_to_affine(r) for r in out]
+            check(self.L.h2_dev_msm(also[0].data_ptr() + 32 * lo, also[1].data_ptr() + 64 * lo, m, max_bits,
+                                    scratch.data_ptr(), per, out[count:].ctypes.data, self.stream), "h2_dev_msm")
+        return out
 
     # -- elementwise / scans ----------------------------------------------------------------------------
     def eval_op(self, op, res, l=None, r=None, c=None, size=None):

@@ -25,6 +25,17 @@ partial = oracle.best_multiexp(s[lo:hi], p[lo:hi], threads=1)
 full = parallel.allgather_fold(partial)
 want = arr_to_points(oracle.to_affine(oracle.best_multiexp(s, p, threads=2)))[0]
 assert arr_to_points(oracle.to_affine(full))[0] == want, "rank %%d: folded MSM differs" %% rank
+# the prover's shape: several range-split MSMs folded by one all-gather (parallel.allgather_fold_many)
+cols3 = [oracle.random_fr(20 + j, n) for j in range(3)]
+partials = np.stack([oracle.best_multiexp(c[lo:hi], p[lo:hi], threads=1) for c in cols3])
+folded = parallel.allgather_fold_many(partials)
+for j, c in enumerate(cols3):
+    want_j = arr_to_points(oracle.to_affine(oracle.best_multiexp(c, p, threads=2)))[0]
+    assert arr_to_points(oracle.to_affine(folded[j]))[0] == want_j, "rank %%d: column %%d differs" %% (rank, j)
+# every rank must end with the same representation (the transcript hashes the normalised point, but the fold
+# order is fixed anyway)
+chk = torch.from_numpy(folded.view(np.int64).copy()); ref = chk.clone(); dist.broadcast(ref, 0)
+assert torch.equal(chk, ref)
 cols = parallel.shard_columns(7, world, rank)
 t = torch.zeros(7, dtype=torch.int64); t[cols] = 1
 dist.all_reduce(t)
