@@ -610,7 +610,20 @@ def shplonk_prove(pk, t, queries, polys, n):
 
 
 # ---- verifier (plonk/verifier.rs) with the trapdoor standing in for the pairing ---------------------------
-def verify_proof(pk, proof, use_gwc=False):
+def opening_check(pk, left, right, pairing):
+    """the decision of the `PairMSM` (poly/multiopen.rs:29-55, plonk/verifier.rs:496-507):
+    e(left, [s]G2) * e(-right, G2) == 1.  pairing=False: the same statement through the setup trapdoor,
+    [s]left == right; pairing=True: the real BN254 pairing on ParamsVerifier's s_g2 (bn254_pairing.py)."""
+    if not pairing:
+        return g1_mul(left, pk.s) == right
+    import bn254_pairing as bp
+
+    if getattr(pk, "s_g2", None) is None:
+        pk.s_g2 = bp.g2_mul(bp.G2, pk.s)       # Params::unsafe_setup's additional_data (poly/commitment.rs:113-116)
+    return bp.pairing_check([(left, pk.s_g2), (g1_neg(right), bp.G2)])
+
+
+def verify_proof(pk, proof, use_gwc=False, pairing=False):
     """True iff the proof is accepted.  e(L, [s]G2) == e(Rgt, G2) is checked as [s]L == Rgt (s is known in the
     unsafe test setup), everything else follows plonk/verifier.rs:128-507."""
     cs, dom = pk.cs, pk.dom
@@ -687,7 +700,7 @@ def verify_proof(pk, proof, use_gwc=False):
     q(("h",), h_commitment, 0, expected_h)
     q(("random",), random_commitment, 0, random_eval)
     if use_gwc:
-        return gwc_verify(pk, t, proof, queries, commitments)
+        return gwc_verify(pk, t, proof, queries, commitments, pairing)
     # shplonk/verifier.rs:23-103
     rsets, super_points = intermediate_sets(queries)
     sy = t.squeeze()
@@ -717,10 +730,10 @@ def verify_proof(pk, proof, use_gwc=False):
     right = g1_add(outer, g1_mul(G1, -r_outer))
     right = g1_add(right, g1_mul(h1, -z_0))
     right = g1_add(right, g1_mul(h2, u))
-    return g1_mul(h2, pk.s) == right
+    return opening_check(pk, h2, right, pairing)
 
 
-def gwc_verify(pk, t, proof, queries, commitments):
+def gwc_verify(pk, t, proof, queries, commitments, pairing=False):
     """poly/multiopen/gwc/verifier.rs:16-95"""
     v = t.squeeze()
     u = t.squeeze()
@@ -740,4 +753,4 @@ def gwc_verify(pk, t, proof, queries, commitments):
         eval_multi = (eval_multi + eb) % R
     assert t.pos == len(proof), "trailing bytes in the proof"
     right = g1_add(g1_add(witness_with_aux, commitment_multi), g1_mul(G1, -eval_multi))
-    return g1_mul(witness, pk.s) == right
+    return opening_check(pk, witness, right, pairing)

@@ -118,6 +118,8 @@ def test_large_proof_is_accepted_by_reference_verifier(oracle, device, k):
     assert rp.verify_proof(vk, proof)
     gwc = prover.create_proof(device, params, pk, adv, ProverRng(23))
     assert len(gwc) == len(proof) + 32 and rp.verify_proof(vk, gwc, use_gwc=True)
+    # and through the real pairing e(L, [s]G2) = e(R, G2) (N3) rather than the trapdoor
+    assert rp.verify_proof(vk, proof, pairing=True) and rp.verify_proof(vk, gwc, use_gwc=True, pairing=True)
     print("create_proof k=%d:" % k, {n: round(t * 1e3, 2) for n, t in timings.items()})
 
 

@@ -50,6 +50,37 @@ def test_reference_prover_is_accepted(cs, k):
             pass
 
 
+def test_pairing_self_checks():
+    import bn254_pairing as bp
+
+    assert bp.g2_on_curve(bp.G2) and bp.g2_mul(bp.G2, bp.R) is None and bp.g2_mul(bp.G2, 2) is not None
+    x = [3] + [5] * 11
+    assert bp.f12_mul(x, bp.f12_inv(x)) == bp.ONE12
+    e = bp.pairing(bp.G2, rp.G1)
+    assert e != bp.ONE12 and bp.f12_pow(e, bp.R) == bp.ONE12                      # non-degenerate, order r
+    a, b = 0x1234567, 0x7654321
+    assert bp.pairing(bp.g2_mul(bp.G2, b), rp.g1_mul(rp.G1, a)) == bp.f12_pow(e, a * b % bp.R)   # bilinear
+    assert bp.pairing(bp.G2, None) == bp.ONE12
+
+
+def test_reference_verifier_with_the_real_pairing():
+    """N3: the acceptance decision through e(L, [s]G2) = e(R, G2) instead of the trapdoor, both multiopen schemes"""
+    adv, fixed, copies = rp.MiniPlonk.synthesize(4)
+    pk = rp.keygen(rp.MiniPlonk, 4, S_TRAPDOOR, fixed, copies)
+    for use_gwc in (False, True):
+        proof = rp.create_proof(pk, adv, ProverRng(21), use_gwc=use_gwc)
+        assert rp.verify_proof(pk, proof, use_gwc=use_gwc, pairing=True)
+        bad = bytearray(proof)
+        bad[-1] ^= 0x40 if use_gwc else 0x01
+        try:
+            assert not rp.verify_proof(pk, bytes(bad), use_gwc=use_gwc, pairing=True)
+        except AssertionError:
+            pass
+    wrong = [c[:] for c in adv]
+    wrong[2][0] += 1
+    assert not rp.verify_proof(pk, rp.create_proof(pk, wrong, ProverRng(21)), pairing=True)
+
+
 def test_reference_verifier_rejects_bad_witness():
     adv, fixed, copies = rp.MiniPlonk.synthesize(4)
     pk = rp.keygen(rp.MiniPlonk, 4, S_TRAPDOOR, fixed, copies)
