@@ -308,6 +308,68 @@ class RotGate(MiniPlonk):
         return adv, fixed, copies
 
 
+class LookupShuffle:
+    """instance column + two logup lookups (one with two input sets, one of them holding two inputs, and a
+    duplicated table row) + one shuffle group of two units + an advice/instance copy constraint.
+    advice: a b c d e g h g2 h2 p p2 w;  fixed: q t0 t1 u qi;  instance: one column."""
+    num_advice, num_fixed, num_instance = 12, 5, 1
+    instance_queries = [(0, 0)]
+    advice_queries = [(11, 0)] + [(c, 0) for c in range(11)]      # enable_equality(w) first, then a..p2
+    fixed_queries = [(0, 0), (4, 0), (1, 0), (2, 0), (3, 0)]       # q, qi (gates), then t0, t1, u (lookups)
+    perm_columns = [("advice", 11), ("instance", 0)]
+    degree = 6
+    blinding_factors = 5
+    name = "lookup-shuffle"
+
+    @staticmethod
+    def gates(adv, fix, inst):
+        q, qi = fix(0, 0), fix(4, 0)
+        a, b, w = adv(0, 0), adv(1, 0), adv(11, 0)
+        return [q * (a * a + 1 - b) % R, qi * (w - inst(0, 0)) % R]
+
+    lookups = [
+        {"table": lambda adv, fix, inst: [fix(1, 0), fix(2, 0)],
+         "input_sets": [[lambda adv, fix, inst: [fix(0, 0) * adv(0, 0) % R, fix(0, 0) * adv(1, 0) % R],
+                         lambda adv, fix, inst: [adv(2, 0), adv(3, 0)]],
+                        [lambda adv, fix, inst: [fix(0, 0) * adv(2, 0) % R, fix(0, 0) * adv(3, 0) % R]]]},
+        {"table": lambda adv, fix, inst: [fix(3, 0)],
+         "input_sets": [[lambda adv, fix, inst: [adv(4, 0)]]]},
+    ]
+    shuffles = [[(lambda adv, fix, inst: [adv(5, 0), adv(6, 0)], lambda adv, fix, inst: [adv(7, 0), adv(8, 0)]),
+                 (lambda adv, fix, inst: [adv(9, 0)], lambda adv, fix, inst: [adv(10, 0)])]]
+
+    @staticmethod
+    def synthesize(k):
+        n = 1 << k
+        usable = n - 6
+        adv = [[0] * n for _ in range(12)]
+        fixed = [[0] * n for _ in range(5)]
+        t0, t1, u = fixed[1], fixed[2], fixed[3]
+        for i in range(1, usable):
+            t0[i], t1[i] = i, i * i + 1
+        t0[usable - 1], t1[usable - 1] = t0[3], t1[3]          # a duplicated table row
+        for i in range(usable):
+            u[i] = 7 * i + 3
+        for i in range(usable):
+            if 1 <= i <= usable // 3:
+                fixed[0][i] = 1
+                r = 1 + (3 * i) % (usable - 2)
+                adv[0][i], adv[1][i] = t0[r], t1[r]
+            r = (5 * i + 2) % (usable - 1)
+            adv[2][i], adv[3][i] = t0[r], t1[r]
+            adv[4][i] = u[(i * i) % usable]
+            adv[5][i], adv[6][i] = i + 1, 1000 - i
+            adv[9][i] = i * i + 5
+        for i in range(usable):
+            adv[7][i], adv[8][i] = adv[5][usable - 1 - i], adv[6][usable - 1 - i]
+            adv[10][i] = adv[9][(i + 3) % usable]
+        adv[11][0] = 42
+        fixed[4][0] = 1
+        copies = [((0, 0), (1, 0))]
+        instances = [[42, 7]]
+        return adv, fixed, copies, instances
+
+
 def permutation_mapping(ncols, n, copies):
     """cycles -> mapping: each cycle sorted by (column, row), every cell maps to its successor
     (permutation/keygen.rs:112-143); the merge order does not matter"""
@@ -425,37 +487,154 @@ def fold(polys, ch, n):
     return acc
 
 
-def create_proof(pk, advice_in, rng, use_gwc=False):
-    """plonk/prover.rs:206-850 (create_proof_ext); one circuit instance, no instance columns, no lookups/shuffles"""
+def _cs_get(cs, name, default):
+    return getattr(cs, name, default)
+
+
+def _gates(cs, adv, fix, inst):
+    try:
+        return list(cs.gates(adv, fix, inst))
+    except TypeError:
+        return list(cs.gates(adv, fix))
+
+
+def _compress(values, theta):
+    """evaluate_with_theta / the verifier's compress_expressions: fold(0, acc * theta + v)"""
+    acc = 0
+    for v in values:
+        acc = (acc * theta + v) % R
+    return acc
+
+
+def _argument_expressions(cs, adv, fix, inst, theta, beta, gamma, l0, ll, la, point_beta, perm, lookups, shuffles, sig,
+                          perm_vals):
+    """everything after the gates in the order of plonk/evaluation.rs:1017-1219 == plonk/verifier.rs:300-383.
+    perm: list of (z, z_next, z_prev_last); lookups: list of (m, [(z, z_next, z_prev_last)]); shuffles: list of
+    (z, z_next); sig[i], perm_vals[i]: sigma_i / the permuted column's value at the point."""
+    chunk = cs.degree - 2
+    cols = cs.perm_columns
+    exprs = []
+    if perm:
+        exprs.append(l0 * (1 - perm[0][0]) % R)
+        exprs.append(ll * (perm[-1][0] * perm[-1][0] - perm[-1][0]) % R)
+        for i in range(1, len(perm)):
+            exprs.append(l0 * (perm[i][0] - perm[i][2]) % R)
+        for i in range(len(perm)):
+            left, right = perm[i][1], perm[i][0]
+            cur = point_beta * pow(DELTA, i * chunk, R) % R
+            for ci in range(i * chunk, min((i + 1) * chunk, len(cols))):
+                left = left * (perm_vals[ci] + beta * sig[ci] + gamma) % R
+                right = right * (perm_vals[ci] + cur + gamma) % R
+                cur = cur * DELTA % R
+            exprs.append(la * (left - right) % R)
+    for lk, (m, zsets) in zip(_cs_get(cs, "lookups", []), lookups):
+        tau = (_compress(lk["table"](adv, fix, inst), theta) + beta) % R
+        phis = [[(_compress(e(adv, fix, inst), theta) + beta) % R for e in st] for st in lk["input_sets"]]
+
+        def prod_sum(phi):
+            prod = 1
+            for v in phi:
+                prod = prod * v % R
+            sm = 0
+            for i in range(len(phi)):
+                term = 1
+                for j, v in enumerate(phi):
+                    if j != i:
+                        term = term * v % R
+                sm = (sm + term) % R
+            return prod, sm
+
+        exprs.append(l0 * zsets[0][0] % R)
+        exprs.append(ll * zsets[-1][0] % R)
+        prod, sm = prod_sum(phis[0])
+        exprs.append(la * (((zsets[0][1] - zsets[0][0]) * tau + m) * prod - tau * sm) % R)
+        for i in range(1, len(zsets)):
+            exprs.append(l0 * (zsets[i][0] - zsets[i][2]) % R)
+        for i in range(1, len(zsets)):
+            prod, sm = prod_sum(phis[i])
+            exprs.append(la * ((zsets[i][1] - zsets[i][0]) * prod - sm) % R)
+    for group, (z, z_next) in zip(_cs_get(cs, "shuffles", []), shuffles):
+        a = b = 1
+        for i, (inp, shf) in enumerate(group):
+            ch = pow(beta, i + 1, R)
+            a = a * (_compress(inp(adv, fix, inst), theta) + ch) % R
+            b = b * (_compress(shf(adv, fix, inst), theta) + ch) % R
+        exprs.append(l0 * (1 - z) % R)
+        exprs.append(ll * (z * z - z) % R)
+        exprs.append(la * (z_next * b - z * a) % R)
+    return exprs
+
+
+def create_proof(pk, advice_in, rng, use_gwc=False, instances=()):
+    """plonk/prover.rs:206-850 (create_proof_ext); one circuit instance"""
     cs, dom = pk.cs, pk.dom
     n, bf = dom.n, cs.blinding_factors
+    usable = n - (bf + 1)
     t = Transcript()
     t.common_scalar(pk.transcript_repr)
+    # instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written
+    assert len(instances) == _cs_get(cs, "num_instance", 0)
+    instance = []
+    for vals in instances:
+        assert len(vals) <= usable, "InstanceTooLarge"
+        instance.append(list(vals) + [0] * (n - len(vals)))
+    instance_polys = [dom.lagrange_to_coeff(col) for col in instance]
+    for p in instance_polys:
+        t.common_point(commit(pk, p))
     # advice: blinding rows (prover.rs:281-289), commitments
     advice = [col[:] for col in advice_in]
     for col in advice:
-        for r in range(n - (bf + 1), n):
+        for r in range(usable, n):
             col[r] = rng.u16()
     advice_polys = [dom.lagrange_to_coeff(col) for col in advice]
     for p in advice_polys:
         t.write_point(commit(pk, p))
-    theta = t.squeeze()  # noqa: F841 - drawn even without lookups (prover.rs:318)
+    theta = t.squeeze()
+
+    def row_access(i):
+        return (lambda c, r: advice[c][(i + r) % n], lambda c, r: pk.fixed_values[c][(i + r) % n],
+                lambda c, r: instance[c][(i + r) % n])
+
+    # lookups: compressed inputs / table and the multiplicities (logup/prover.rs:63-240)
+    lk_state = []
+    for lk in _cs_get(cs, "lookups", []):
+        table = [_compress(lk["table"](*row_access(i)), theta) for i in range(n)]
+        inputs = [[[_compress(e(*row_access(i)), theta) for i in range(n)] for e in st] for st in lk["input_sets"]]
+        first = {}
+        for i in range(usable):
+            first.setdefault(table[i], i)          # a duplicated table value is credited to its first row
+        m = [0] * n
+        for st in inputs:
+            for col in st:
+                for i in range(usable):
+                    m[first[col[i]]] += 1          # KeyError = "logup binary_search_by_key should hit"
+        for i in range(usable, n):
+            m[i] = rng.u16()
+        m_poly = dom.lagrange_to_coeff(m)
+        t.write_point(commit(pk, m_poly))
+        lk_state.append({"table": table, "inputs": inputs, "m": m, "m_poly": m_poly})
+    # shuffles: compressed expressions (shuffle/prover.rs:40-80)
+    sh_state = []
+    for group in _cs_get(cs, "shuffles", []):
+        sh_state.append([([_compress(inp(*row_access(i)), theta) for i in range(n)],
+                          [_compress(shf(*row_access(i)), theta) for i in range(n)]) for inp, shf in group])
     beta = t.squeeze()
     gamma = t.squeeze()
     # permutation grand products (permutation/prover.rs:47-165)
     chunk = cs.degree - 2
     cols = cs.perm_columns
+    colvals = {"advice": advice, "fixed": pk.fixed_values, "instance": instance}
     zs, last_z = [], 1
     for si in range(0, len(cols), chunk):
         mv = [1] * n
         for ci in range(si, min(si + chunk, len(cols))):
-            vals = column_values(*cols[ci], advice, pk.fixed_values)
+            vals = colvals[cols[ci][0]][cols[ci][1]]
             for i in range(n):
                 mv[i] = mv[i] * (beta * pk.sigma_values[ci][i] + gamma + vals[i]) % R
         mv = [inv(v) for v in mv]
         dw = pow(DELTA, si, R)
         for ci in range(si, min(si + chunk, len(cols))):
-            vals = column_values(*cols[ci], advice, pk.fixed_values)
+            vals = colvals[cols[ci][0]][cols[ci][1]]
             for i in range(n):
                 mv[i] = mv[i] * (dw * beta + gamma + vals[i]) % R
                 dw = dw * dom.omega % R
@@ -465,45 +644,86 @@ def create_proof(pk, advice_in, rng, use_gwc=False):
             z.append(z[i] * mv[i] % R)
         for i in range(n - bf, n):
             z[i] = rng.fr()
-        last_z = z[n - (bf + 1)]
+        last_z = z[usable]
         zs.append(z)
     z_polys = [dom.lagrange_to_coeff(z) for z in zs]
+    # lookup grand sums (logup/prover.rs:243-415, blinding prover.rs:446-465)
+    for st in lk_state:
+        st["z_polys"] = []
+        last = 0
+        for si, cols_in in enumerate(st["inputs"]):
+            g = [0] * n
+            for col in cols_in:
+                for i in range(n):
+                    g[i] = (g[i] + inv((beta + col[i]) % R)) % R
+            if si == 0:
+                for i in range(n):
+                    g[i] = (g[i] - inv((beta + st["table"][i]) % R) * st["m"][i]) % R
+            z = [last]
+            for i in range(usable):
+                z.append((z[i] + g[i]) % R)
+            last = z[usable]
+            z += [rng.fr() for _ in range(bf)]
+            assert len(z) == n
+            st["z_polys"].append(dom.lagrange_to_coeff(z))
+        assert last == 0, "the lookup does not hold"
+    # shuffle products (shuffle/prover.rs:82-150, blinding prover.rs:512-530)
+    sh_polys = []
+    for group in sh_state:
+        prod = [1] * n
+        for i, (_, shf) in enumerate(group):
+            ch = pow(beta, i + 1, R)
+            for r in range(n):
+                prod[r] = prod[r] * (ch + shf[r]) % R
+        prod = [inv(v) for v in prod]
+        for i, (inp, _) in enumerate(group):
+            ch = pow(beta, i + 1, R)
+            for r in range(n):
+                prod[r] = prod[r] * (ch + inp[r]) % R
+        z = [1]
+        for i in range(usable):
+            z.append(z[i] * prod[i] % R)
+        assert z[usable] == 1, "the shuffle does not hold"
+        z += [rng.fr() for _ in range(bf)]
+        sh_polys.append(dom.lagrange_to_coeff(z))
     for p in z_polys:
+        t.write_point(commit(pk, p))
+    for st in lk_state:
+        for p in st["z_polys"]:
+            t.write_point(commit(pk, p))
+    for p in sh_polys:
         t.write_point(commit(pk, p))
     # vanishing argument: random polynomial (vanishing/prover.rs:40-67)
     random_poly = rng.random_poly(n)
     t.write_point(commit(pk, random_poly))
     y = t.squeeze()
     # h(X) on the extended coset
-    adv_c = [dom.coeff_to_extended(p) for p in advice_polys]
-    fix_c = [dom.coeff_to_extended(p) for p in pk.fixed_polys]
-    sig_c = [dom.coeff_to_extended(p) for p in pk.sigma_polys]
-    z_c = [dom.coeff_to_extended(p) for p in z_polys]
+    ext = dom.coeff_to_extended
+    adv_c = [ext(p) for p in advice_polys]
+    fix_c = [ext(p) for p in pk.fixed_polys]
+    ins_c = [ext(p) for p in instance_polys]
+    sig_c = [ext(p) for p in pk.sigma_polys]
+    z_c = [ext(p) for p in z_polys]
+    lk_c = [(ext(st["m_poly"]), [ext(p) for p in st["z_polys"]]) for st in lk_state]
+    sh_c = [ext(p) for p in sh_polys]
     en = dom.extended_n
     scale = en // n
     last_rot = -(bf + 1)
+    colc = {"advice": adv_c, "fixed": fix_c, "instance": ins_c}
     h = [0] * en
     point = ZETA
     for j in range(en):
         adv = lambda c, r: adv_c[c][(j + r * scale) % en]  # noqa: E731
         fix = lambda c, r: fix_c[c][(j + r * scale) % en]  # noqa: E731
-        exprs = list(cs.gates(adv, fix))
-        l0, ll, la = pk.l0[j], pk.l_last[j], pk.l_active_row[j]
-        exprs.append(l0 * (1 - z_c[0][j]) % R)
-        exprs.append(ll * (z_c[-1][j] * z_c[-1][j] - z_c[-1][j]) % R)
-        for i in range(1, len(z_c)):
-            exprs.append(l0 * (z_c[i][j] - z_c[i - 1][(j + last_rot * scale) % en]) % R)
-        for i in range(len(z_c)):
-            left = z_c[i][(j + scale) % en]
-            right = z_c[i][j]
-            cur = beta * point % R * pow(DELTA, i * chunk, R) % R
-            for ci in range(i * chunk, min((i + 1) * chunk, len(cols))):
-                kind, idx = cols[ci]
-                v = (adv_c if kind == "advice" else fix_c)[idx][j]
-                left = left * (v + beta * sig_c[ci][j] + gamma) % R
-                right = right * (v + cur + gamma) % R
-                cur = cur * DELTA % R
-            exprs.append(la * (left - right) % R)
+        ins = lambda c, r: ins_c[c][(j + r * scale) % en]  # noqa: E731
+        jn, jl = (j + scale) % en, (j + last_rot * scale) % en
+        exprs = _gates(cs, adv, fix, ins)
+        exprs += _argument_expressions(
+            cs, adv, fix, ins, theta, beta, gamma, pk.l0[j], pk.l_last[j], pk.l_active_row[j], beta * point % R,
+            [(z_c[i][j], z_c[i][jn], z_c[i - 1][jl] if i else None) for i in range(len(z_c))],
+            [(mc[j], [(zc[i][j], zc[i][jn], zc[i - 1][jl] if i else None) for i in range(len(zc))]) for mc, zc in lk_c],
+            [(zc[j], zc[jn]) for zc in sh_c],
+            [c[j] for c in sig_c], [colc[kd][ix][j] for kd, ix in cs.perm_columns])
         acc = 0
         for e in exprs:
             acc = (acc * y + e) % R
@@ -516,6 +736,8 @@ def create_proof(pk, advice_in, rng, use_gwc=False):
     x = t.squeeze()
     xn = pow(x, n, R)
     # evaluations (prover.rs:700-790)
+    for c, rot in _cs_get(cs, "instance_queries", []):
+        t.write_scalar(eval_poly(instance_polys[c], dom.rotate_omega(x, rot)))
     for c, rot in cs.advice_queries:
         t.write_scalar(eval_poly(advice_polys[c], dom.rotate_omega(x, rot)))
     for c, rot in cs.fixed_queries:
@@ -525,11 +747,21 @@ def create_proof(pk, advice_in, rng, use_gwc=False):
     for p in pk.sigma_polys:
         t.write_scalar(eval_poly(p, x))
     x_next, x_last = dom.rotate_omega(x, 1), dom.rotate_omega(x, last_rot)
-    for i, p in enumerate(z_polys):
+
+    def write_set_evals(polys_):
+        for i, p in enumerate(polys_):
+            t.write_scalar(eval_poly(p, x))
+            t.write_scalar(eval_poly(p, x_next))
+            if i + 1 < len(polys_):
+                t.write_scalar(eval_poly(p, x_last))
+
+    write_set_evals(z_polys)
+    for st in lk_state:
+        t.write_scalar(eval_poly(st["m_poly"], x))
+        write_set_evals(st["z_polys"])
+    for p in sh_polys:
         t.write_scalar(eval_poly(p, x))
         t.write_scalar(eval_poly(p, x_next))
-        if i + 1 < len(z_polys):
-            t.write_scalar(eval_poly(p, x_last))
     # multiopen query list (prover.rs:792-840)
     polys = {}
     queries = []
@@ -539,13 +771,24 @@ def create_proof(pk, advice_in, rng, use_gwc=False):
         pt = dom.rotate_omega(x, rot)
         queries.append((key, rot, pt, eval_poly(poly, pt)))
 
+    def open_sets(name, polys_):
+        for i, p in enumerate(polys_):
+            q((name, i), p, 0)
+            q((name, i), p, 1)
+        for i in reversed(range(len(polys_) - 1)):
+            q((name, i), polys_[i], last_rot)
+
+    for c, rot in _cs_get(cs, "instance_queries", []):
+        q(("instance", c), instance_polys[c], rot)
     for c, rot in cs.advice_queries:
         q(("advice", c), advice_polys[c], rot)
-    for i, p in enumerate(z_polys):
-        q(("z", i), p, 0)
-        q(("z", i), p, 1)
-    for i in reversed(range(len(z_polys) - 1)):
-        q(("z", i), z_polys[i], last_rot)
+    open_sets("z", z_polys)
+    for li, st in enumerate(lk_state):
+        q(("lookup_m", li), st["m_poly"], 0)
+        open_sets("lookup_z%d" % li, st["z_polys"])
+    for i, p in enumerate(sh_polys):
+        q(("shuffle_z", i), p, 0)
+        q(("shuffle_z", i), p, 1)
     for c, rot in cs.fixed_queries:
         q(("fixed", c), pk.fixed_polys[c], rot)
     for i, p in enumerate(pk.sigma_polys):
@@ -623,55 +866,72 @@ def opening_check(pk, left, right, pairing):
     return bp.pairing_check([(left, pk.s_g2), (g1_neg(right), bp.G2)])
 
 
-def verify_proof(pk, proof, use_gwc=False, pairing=False):
-    """True iff the proof is accepted.  e(L, [s]G2) == e(Rgt, G2) is checked as [s]L == Rgt (s is known in the
-    unsafe test setup), everything else follows plonk/verifier.rs:128-507."""
+def verify_proof(pk, proof, use_gwc=False, pairing=False, instances=()):
+    """True iff the proof is accepted (plonk/verifier.rs:128-507)."""
     cs, dom = pk.cs, pk.dom
     n, bf = dom.n, cs.blinding_factors
     t = Transcript(proof)
     t.common_scalar(pk.transcript_repr)
+    assert len(instances) == _cs_get(cs, "num_instance", 0)
+    instance_commitments = []
+    for vals in instances:
+        assert len(vals) <= n - (bf + 1)
+        instance_commitments.append(commit(pk, dom.lagrange_to_coeff(list(vals) + [0] * (n - len(vals)))))
+        t.common_point(instance_commitments[-1])
     advice_commitments = [t.read_point() for _ in range(cs.num_advice)]
-    t.squeeze()  # theta
+    theta = t.squeeze()
+    lookups_cs, shuffles_cs = _cs_get(cs, "lookups", []), _cs_get(cs, "shuffles", [])
+    m_commitments = [t.read_point() for _ in lookups_cs]
     beta = t.squeeze()
     gamma = t.squeeze()
     chunk = cs.degree - 2
     nsets = (len(cs.perm_columns) + chunk - 1) // chunk
     z_commitments = [t.read_point() for _ in range(nsets)]
+    lk_z_commitments = [[t.read_point() for _ in lk["input_sets"]] for lk in lookups_cs]
+    sh_commitments = [t.read_point() for _ in shuffles_cs]
     random_commitment = t.read_point()
     y = t.squeeze()
     h_commitments = [t.read_point() for _ in range(dom.quotient_poly_degree)]
     x = t.squeeze()
+    instance_queries = _cs_get(cs, "instance_queries", [])
+    instance_evals = [t.read_scalar() for _ in instance_queries]
     advice_evals = [t.read_scalar() for _ in cs.advice_queries]
     fixed_evals = [t.read_scalar() for _ in cs.fixed_queries]
     random_eval = t.read_scalar()
     sigma_evals = [t.read_scalar() for _ in cs.perm_columns]
-    z_evals = []
-    for i in range(nsets):
-        e = {"cur": t.read_scalar(), "next": t.read_scalar()}
-        if i + 1 < nsets:
-            e["last"] = t.read_scalar()
-        z_evals.append(e)
+
+    def read_set_evals(count):
+        out = []
+        for i in range(count):
+            e = {"cur": t.read_scalar(), "next": t.read_scalar()}
+            if i + 1 < count:
+                e["last"] = t.read_scalar()
+            out.append(e)
+        return out
+
+    z_evals = read_set_evals(nsets)
+    lk_evals = []
+    for lk in lookups_cs:
+        m_eval = t.read_scalar()
+        lk_evals.append((m_eval, read_set_evals(len(lk["input_sets"]))))
+    sh_evals = [(t.read_scalar(), t.read_scalar()) for _ in shuffles_cs]
     xn = pow(x, n, R)
     last_rot = -(bf + 1)
     l_evals = dom.l_i_range(x, xn, range(last_rot, 1))
     l_last, l_blind, l_0 = l_evals[0], sum(l_evals[1:1 + bf]) % R, l_evals[1 + bf]
     adv = lambda c, r: advice_evals[cs.advice_queries.index((c, r))]  # noqa: E731
     fix = lambda c, r: fixed_evals[cs.fixed_queries.index((c, r))]  # noqa: E731
-    exprs = list(cs.gates(adv, fix))
-    exprs.append(l_0 * (1 - z_evals[0]["cur"]) % R)
-    exprs.append((z_evals[-1]["cur"] ** 2 - z_evals[-1]["cur"]) * l_last % R)
-    for i in range(1, nsets):
-        exprs.append((z_evals[i]["cur"] - z_evals[i - 1]["last"]) * l_0 % R)
-    for i in range(nsets):
-        left, right = z_evals[i]["next"], z_evals[i]["cur"]
-        cur = beta * x % R * pow(DELTA, i * chunk, R) % R
-        for ci in range(i * chunk, min((i + 1) * chunk, len(cs.perm_columns))):
-            kind, idx = cs.perm_columns[ci]
-            ev = adv(idx, 0) if kind == "advice" else fix(idx, 0)
-            left = left * (ev + beta * sigma_evals[ci] + gamma) % R
-            right = right * (ev + cur + gamma) % R
-            cur = cur * DELTA % R
-        exprs.append((left - right) * (1 - (l_last + l_blind)) % R)
+    ins = lambda c, r: instance_evals[instance_queries.index((c, r))]  # noqa: E731
+    getters = {"advice": adv, "fixed": fix, "instance": ins}
+
+    def triples(evs):
+        return [(evs[i]["cur"], evs[i]["next"], evs[i - 1]["last"] if i else None) for i in range(len(evs))]
+
+    exprs = _gates(cs, adv, fix, ins)
+    exprs += _argument_expressions(
+        cs, adv, fix, ins, theta, beta, gamma, l_0, l_last, (1 - (l_last + l_blind)) % R, beta * x % R,
+        triples(z_evals), [(m_eval, triples(evs)) for m_eval, evs in lk_evals], sh_evals,
+        sigma_evals, [getters[kd](ix, 0) for kd, ix in cs.perm_columns])
     expected_h = 0
     for e in exprs:
         expected_h = (expected_h * y + e) % R
@@ -686,13 +946,24 @@ def verify_proof(pk, proof, use_gwc=False, pairing=False):
         commitments[key] = com
         queries.append((key, rot, dom.rotate_omega(x, rot), ev))
 
+    def open_sets(name, coms, evs):
+        for i in range(len(coms)):
+            q((name, i), coms[i], 0, evs[i]["cur"])
+            q((name, i), coms[i], 1, evs[i]["next"])
+        for i in reversed(range(len(coms) - 1)):
+            q((name, i), coms[i], last_rot, evs[i]["last"])
+
+    for (c, rot), ev in zip(instance_queries, instance_evals):
+        q(("instance", c), instance_commitments[c], rot, ev)
     for (c, rot), ev in zip(cs.advice_queries, advice_evals):
         q(("advice", c), advice_commitments[c], rot, ev)
-    for i in range(nsets):
-        q(("z", i), z_commitments[i], 0, z_evals[i]["cur"])
-        q(("z", i), z_commitments[i], 1, z_evals[i]["next"])
-    for i in reversed(range(nsets - 1)):
-        q(("z", i), z_commitments[i], last_rot, z_evals[i]["last"])
+    open_sets("z", z_commitments, z_evals)
+    for li, (m_eval, evs) in enumerate(lk_evals):
+        q(("lookup_m", li), m_commitments[li], 0, m_eval)
+        open_sets("lookup_z%d" % li, lk_z_commitments[li], evs)
+    for i, (cur, nxt) in enumerate(sh_evals):
+        q(("shuffle_z", i), sh_commitments[i], 0, cur)
+        q(("shuffle_z", i), sh_commitments[i], 1, nxt)
     for (c, rot), ev in zip(cs.fixed_queries, fixed_evals):
         q(("fixed", c), pk.fixed_commitments[c], rot, ev)
     for i, ev in enumerate(sigma_evals):
