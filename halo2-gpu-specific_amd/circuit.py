@@ -108,6 +108,8 @@ class ConstraintSystem:
         self.num_advice_queries = []
         self.gates = []              # (name, [Expression])
         self.perm_columns = []       # ("advice" | "fixed" | "instance", index)
+        self.lookups = []            # (name, [table Expression], [[[input Expression]]]): logup::Argument (plonk/logup.rs:11-16)
+        self.shuffles = []           # groups of (name, [input Expression], [shuffle Expression]): shuffle::Argument (plonk/shuffle.rs:8-22)
         self.minimum_degree = None
 
     # -- columns ------------------------------------------------------------------------------------------
@@ -167,13 +169,44 @@ class ConstraintSystem:
     def set_minimum_degree(self, d):
         self.minimum_degree = d
 
+    def lookup_any(self, name, table_expressions, input_expressions_sets):
+        """One logup argument with its input sets given explicitly (what `chunk_lookups` produces from the traced
+        `lookup_any` calls, plonk/logup.rs:73-153): set 0 shares its polynomial with the table term."""
+        for st in input_expressions_sets:
+            for inputs in st:
+                assert len(inputs) == len(table_expressions)
+        self.lookups.append((name, list(table_expressions), [[list(i) for i in st] for st in input_expressions_sets]))
+
+    def shuffle_group(self, units):
+        """units: [(name, [input Expression], [shuffle Expression])] sharing one product polynomial"""
+        for _, inp, shf in units:
+            assert len(inp) == len(shf)
+        self.shuffles.append([(nm, list(i), list(sh)) for nm, i, sh in units])
+
     # -- derived quantities -------------------------------------------------------------------------------
     def degree(self):
         d = 3  # permutation::Argument::required_degree (plonk/permutation.rs:42-69)
         for _, polys in self.gates:
             for p in polys:
                 d = max(d, p.degree())
-        return max(d, self.minimum_degree or 1)
+        for _, table, sets in self.lookups:      # logup::Argument::required_degree (plonk/logup.rs:31-50)
+            tdeg = max([1] + [e.degree() for e in table])
+            ideg = max([1] + [e.degree() for st in sets for inputs in st for e in inputs])
+            d = max(d, 4, 2 + ideg + tdeg)
+        for group in self.shuffles:              # shuffle::ArgumentUnit::required_degree (plonk/shuffle.rs:43-54)
+            for _, inp, shf in group:
+                d = max(d, 2 + max([1] + [e.degree() for e in inp + shf]))
+        d = max(d, self.minimum_degree or 1)
+        # what the chunking of the reference guarantees (logup.rs:88-150, shuffle.rs:57-80): every argument polynomial fits
+        for _, table, sets in self.lookups:
+            tdeg = max([1] + [e.degree() for e in table])
+            for si, st in enumerate(sets):
+                total = 2 + (tdeg if si == 0 else 0) + sum(max([1] + [e.degree() for e in inputs]) for inputs in st)
+                assert total <= d, "lookup input set %d needs degree %d > %d" % (si, total, d)
+        for group in self.shuffles:
+            total = 2 + sum(max([1] + [e.degree() for e in inp + shf]) for _, inp, shf in group)
+            assert total <= d, "shuffle group needs degree %d > %d" % (total, d)
+        return d
 
     def blinding_factors(self):
         factors = max(self.num_advice_queries) if self.num_advice_queries else 1
@@ -202,12 +235,16 @@ class GraphEvaluator:
             self.rotations.append(r)
         return self.rotations.index(r)
 
-    def _calc(self, op, a, b=None):
-        key = (op, (a.kind, a.index, a.rot), (b.kind, b.index, b.rot) if b is not None else None)
+    def _calc(self, op, a, b=None, challenge=0, power=0):
+        key = (op, (a.kind, a.index, a.rot), (b.kind, b.index, b.rot) if b is not None else None, challenge, power)
         if key not in self._seen:
-            self.calculations.append(ev.calc(op, a, b))
+            self.calculations.append(ev.calc(op, a, b, challenge, power))
             self._seen[key] = len(self.calculations) - 1
         return ev.vs(ev.VS_INTERMEDIATE, self._seen[key])
+
+    def add_calculation(self, c):
+        """an already-built `Calculation` becomes an intermediate"""
+        return self._calc(c.op, c.a, c.b, c.challenge, c.power)
 
     def add_expression(self, e):
         if isinstance(e, Constant):
@@ -229,8 +266,76 @@ class GraphEvaluator:
 
 def compile_gates(cs):
     """Evaluator::new (plonk/evaluation.rs:298-330): every polynomial of every gate becomes one value part"""
+    g, parts, _, _ = compile_evaluator(cs)
+    return g, parts
+
+
+def _evaluate_lc(g, expressions):
+    """theta-compression of an expression list (evaluation.rs:343-353)"""
+    parts = [g.add_expression(e) for e in expressions]
+    lc = parts[0]
+    for part in parts[1:]:
+        lc = g._calc(ev.CALC_LC_THETA, lc, part)
+    return lc
+
+
+def compile_evaluator(cs):
+    """Evaluator::new (plonk/evaluation.rs:307-575): gates -> value parts; per lookup (table + beta, per input set the
+    product of the phi_i = f_i + beta and the sum of the all-but-one products); per shuffle group the two running
+    products with the challenges beta^(i+1).  The per-argument results are `Calculation`s evaluated after the shared
+    program, exactly the `lookup_results` / `shuffle_results` the device interpreter expects."""
     g = GraphEvaluator()
     parts = [g.add_expression(p) for _, polys in cs.gates for p in polys]
+    one = g.add_constant(1)
+    lookups = []
+    for _, table, sets in cs.lookups:
+        table_calc = ev.calc(ev.CALC_ADD_CHALLENGE, _evaluate_lc(g, table), None, ev.CHALLENGE_BETA)
+        phis = [[g._calc(ev.CALC_ADD_CHALLENGE, _evaluate_lc(g, inputs), None, ev.CHALLENGE_BETA) for inputs in st]
+                for st in sets]
+        prods, sums = [], []
+        for phi in phis:
+            prod = phi[0]
+            for p_ in phi[1:]:
+                prod = g._calc(ev.CALC_MUL, prod, p_)
+            prods.append(ev.calc(ev.CALC_STORE, prod))
+        for phi in phis:
+            if len(phi) > 1:
+                terms = []
+                for i in range(len(phi)):
+                    rest = [v for j, v in enumerate(phi) if j != i]
+                    acc = rest[0]
+                    for v in rest[1:]:
+                        acc = g._calc(ev.CALC_MUL, acc, v)
+                    terms.append(acc)
+                total = terms[0]
+                for v in terms[1:]:
+                    total = g._calc(ev.CALC_ADD, total, v)
+                sums.append(ev.calc(ev.CALC_STORE, total))
+            else:
+                sums.append(ev.calc(ev.CALC_STORE, one))
+        lookups.append((table_calc, prods, sums))
+    shuffles = []
+    for group in cs.shuffles:
+        ins = [_evaluate_lc(g, inp) for _, inp, _ in group]
+        shs = [_evaluate_lc(g, shf) for _, _, shf in group]
+
+        def running(vals):
+            c = ev.calc(ev.CALC_ADD_CHALLENGE, vals[0], None, ev.CHALLENGE_BETA)
+            for i, part in enumerate(vals[1:], start=1):
+                c = ev.calc(ev.CALC_LC_CHALLENGE, part, g.add_calculation(c), ev.CHALLENGE_BETA, i + 1)
+            return c
+
+        shuffles.append((running(ins), running(shs)))
+    if not g.rotations:
+        g.add_rotation(0)
+    return g, parts, lookups, shuffles
+
+
+def compile_compress(expressions):
+    """evaluate_with_theta (plonk/evaluation.rs:2330-2398) as a program: the value parts, Horner-folded by the
+    interpreter with y := theta on the n-point Lagrange domain (extended_k := k)"""
+    g = GraphEvaluator()
+    parts = [g.add_expression(e) for e in expressions]
     if not g.rotations:
         g.add_rotation(0)
     return g, parts

@@ -9,6 +9,7 @@
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
+#include "logup.hpp"
 #include "scan.hpp"
 
 using namespace h2;
@@ -541,6 +542,29 @@ int h2_dev_permutation_terms(void* d_num, void* d_den, const void* d_value, cons
         DeviceCtx* ctx = current_ctx();
         return perm_terms_launch((Fr*)d_num, (Fr*)d_den, (const Fr*)d_value, (const Fr*)d_sigma, n, beta, gamma,
                                  delta_pow, omega, first, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_prefix_sum(const void* d_f, size_t n, const uint64_t init[4], void* d_z, void* stream) {
+    if (!init || (n && !d_z) || (n > 1 && !d_f)) return bad("h2_dev_prefix_sum: null argument");
+    if (d_f == d_z && n > 1) return bad("h2_dev_prefix_sum: in-place is not supported");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        return prefix_sum_launch((const Fr*)d_f, n, init, (Fr*)d_z, tmp, pick_stream(ctx, stream));
+    });
+}
+
+size_t h2_logup_scratch_bytes(size_t n) { return logup_scratch_bytes(n); }
+
+int h2_dev_logup_multiplicity(const void* d_table, const void* const* d_inputs, size_t n_inputs, size_t usable_rows,
+                              size_t n, void* d_m, void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (!d_table || !d_m || !d_scratch || (n_inputs && !d_inputs)) return bad("h2_dev_logup_multiplicity: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return logup_multiplicity_launch((const Fr*)d_table, (const Fr* const*)d_inputs, n_inputs, usable_rows, n, (Fr*)d_m,
+                                         d_scratch, scratch_bytes, pick_stream(ctx, stream));
     });
 }
 

@@ -1,0 +1,136 @@
+// logup.hip -- the multiplicity column m(X) of a logup lookup (plonk/logup/prover.rs:104-180).
+// The reference sorts the compressed table on the CPU, binary-searches every compressed input value (with a
+// per-thread BTreeMap cache) and merges per-thread count maps.  Here the first `usable` table rows are inserted
+// into an open-addressing hash table of row indices keyed by the 256-bit value (a duplicated table value keeps
+// its LOWEST row: atomicMin), every input value probes the table and bumps a 32-bit counter of the row it hits
+// (wave-aggregated: padding rows make most lanes hit the same row), and the counters become field elements.
+// An input value that is not in the table is an error (the reference panics: "logup binary_search_by_key should hit").
+#include "common.hpp"
+#include "logup.hpp"
+
+namespace h2 {
+
+static constexpr uint32_t SLOT_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t key_hash(const Fr& k) {
+    uint32_t h = 0x9e3779b9u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        h ^= k.l[i];
+        h *= 0x85ebca6bu;
+        h ^= h >> 13;
+    }
+    h *= 0xc2b2ae35u;
+    return h ^ (h >> 16);
+}
+
+__global__ void __launch_bounds__(256) k_logup_build(const Fr* table, uint32_t usable, uint32_t mask, uint32_t* slots) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= usable) return;
+    Fr key = fp_load(table + i);
+    uint32_t h = key_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = atomicCAS(&slots[h], SLOT_EMPTY, i);
+        if (cur == SLOT_EMPTY) return;                      // claimed an empty slot
+        if (fp_eq(fp_load(table + cur), key)) {             // same value already present: keep the lowest row
+            atomicMin(&slots[h], i);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// One lane per (input column, row).  count[row hit] += 1, aggregated over the lanes of a wave that hit the row of
+// the first active lane (two rounds), the rest individually.
+__global__ void __launch_bounds__(256) k_logup_count(const Fr* table, const Fr* input, uint32_t usable, uint32_t mask,
+                                                     const uint32_t* slots, uint32_t* count, uint32_t* miss) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = i < usable;
+    uint32_t hit = SLOT_EMPTY;
+    if (valid) {
+        Fr key = fp_load(input + i);
+        uint32_t h = key_hash(key) & mask;
+        for (;;) {
+            uint32_t cur = slots[h];
+            if (cur == SLOT_EMPTY) break;
+            if (fp_eq(fp_load(table + cur), key)) {
+                hit = cur;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        if (hit == SLOT_EMPTY) {
+            atomicAdd(miss, 1u);
+            valid = false;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t active = __ballot(valid);
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        if (active == 0) break;
+        const int leader = __ffsll((unsigned long long)active) - 1;
+        const uint32_t k = __shfl(hit, leader, 64);
+        const uint64_t same = __ballot(valid && hit == k) & active;
+        if ((int)lane == leader) atomicAdd(&count[k], (uint32_t)__popcll(same));
+        active &= ~same;
+    }
+    if ((active >> lane) & 1) atomicAdd(&count[hit], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_logup_emit(const uint32_t* count, uint32_t usable, size_t n, Fr* m) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = fp_zero<FrParams>();
+    if (i < usable) {
+        v.l[0] = count[i];
+        v = fp_to_mont(v);
+    }
+    fp_store(m + i, v);
+}
+
+static uint32_t table_capacity(size_t usable) {
+    uint32_t cap = 64;
+    while ((size_t)cap < 2 * usable) cap <<= 1;
+    return cap;
+}
+
+size_t logup_scratch_bytes(size_t n) { return ((size_t)table_capacity(n) + n + 64) * sizeof(uint32_t); }
+
+int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size_t n_inputs, size_t usable, size_t n,
+                              Fr* d_m, void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+    if (usable > n || n >= 0x7fffffffu) {
+        set_last_error("h2_dev_logup_multiplicity: bad sizes");
+        return H2_ERR_INVALID;
+    }
+    if (scratch_bytes < logup_scratch_bytes(n)) {
+        set_last_error("h2_dev_logup_multiplicity: scratch too small (h2_logup_scratch_bytes)");
+        return H2_ERR_INVALID;
+    }
+    const uint32_t cap = table_capacity(usable), mask = cap - 1;
+    uint32_t* slots = (uint32_t*)d_scratch;
+    uint32_t* count = slots + cap;
+    uint32_t* miss = count + n;
+    H2_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, stream));
+    H2_HIP(hipMemsetAsync(count, 0, (n + 1) * 4, stream));
+    const unsigned blocks = (unsigned)((usable + 255) / 256);
+    if (usable) {
+        hipLaunchKernelGGL(k_logup_build, dim3(blocks), dim3(256), 0, stream, d_table, (uint32_t)usable, mask, slots);
+        for (size_t j = 0; j < n_inputs; j++)
+            hipLaunchKernelGGL(k_logup_count, dim3(blocks), dim3(256), 0, stream, d_table, d_inputs[j], (uint32_t)usable,
+                               mask, slots, count, miss);
+    }
+    hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, (uint32_t)usable, n,
+                       d_m);
+    H2_HIP(hipGetLastError());
+    uint32_t h_miss = 0;
+    H2_HIP(hipMemcpyAsync(&h_miss, miss, 4, hipMemcpyDeviceToHost, stream));
+    H2_HIP(hipStreamSynchronize(stream));
+    if (h_miss) {
+        set_last_error("logup: " + std::to_string(h_miss) + " input value(s) are missing from the table");
+        return H2_ERR_INVALID;
+    }
+    return H2_OK;
+}
+
+}  // namespace h2

@@ -26,8 +26,8 @@ struct ScanArgs {
     // index maps: logical element j reads in[in_rev ? in_top - j : j], writes out[out_rev ? out_top - j : j + out_shift]
     size_t in_top, out_top;
     int in_rev, out_rev, out_shift;
-    int affine;     // 0: r_j = r_{j-1} * a_j ; 1: r_j = a_j + b * r_{j-1}
-    int has_init;   // multiplicative scan: a_0 is multiplied by `init` on load
+    int affine;     // 0: r_j = r_{j-1} * a_j ; 1: r_j = a_j + b * r_{j-1} ; 2: r_j = r_{j-1} + a_j
+    int has_init;   // modes 0 / 2: a_0 is multiplied by / added to `init` on load
     Fr init;
     Fr bp[SC_ITEMS + 1];  // affine: b^1 .. b^4 in bp[1..4]
     Fr bstep[8];          // affine: b^(4 * 2^d), d = 0..7
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_scan_local(ScanArgs a) {
         Fr v = neutral;
         if (j < a.n) {
             v = fp_load(a.in + (a.in_rev ? a.in_top - j : j));
-            if (a.has_init && j == 0) v = fp_mul(v, a.init);
+            if (a.has_init && j == 0) v = a.affine == 2 ? fp_add(v, a.init) : fp_mul(v, a.init);
         }
         lds_st(s_lo, s_hi, (uint32_t)(k * 256 + t), v);
     }
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_scan_local(ScanArgs a) {
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; k++) {
         Fr v = lds_ld(s_lo, s_hi, t * SC_ITEMS + k);
-        run = a.affine ? fp_add(v, fp_mul(a.bp[1], run)) : fp_mul(run, v);
+        run = a.affine == 1 ? fp_add(v, fp_mul(a.bp[1], run)) : a.affine == 2 ? fp_add(run, v) : fp_mul(run, v);
         loc[k] = run;
     }
     __syncthreads();
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_scan_local(ScanArgs a) {
         const uint32_t off = 1u << d;
         if (t >= off) {
             Fr o = lds_ld(s_lo, s_hi, t - off);
-            agg = a.affine ? fp_add(agg, fp_mul(a.bstep[d], o)) : fp_mul(agg, o);
+            agg = a.affine == 1 ? fp_add(agg, fp_mul(a.bstep[d], o)) : a.affine == 2 ? fp_add(agg, o) : fp_mul(agg, o);
         }
         __syncthreads();
     }
@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(256) k_scan_local(ScanArgs a) {
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; k++) {
         Fr v = loc[k];
-        if (has_carry) v = a.affine ? fp_add(v, fp_mul(a.bp[k + 1], carry)) : fp_mul(v, carry);
+        if (has_carry)
+            v = a.affine == 1 ? fp_add(v, fp_mul(a.bp[k + 1], carry)) : a.affine == 2 ? fp_add(v, carry) : fp_mul(v, carry);
         lds_st(s_lo, s_hi, t * SC_ITEMS + k, v);
     }
     __syncthreads();
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) k_scan_fix(FixArgs a) {
         if (j >= a.n) continue;
         Fr* dst = a.out + (a.out_rev ? a.out_top - j : j + a.out_shift);
         Fr v = fp_load(dst);
-        v = a.affine ? fp_add(v, fp_mul(fp_load(a.bpow + p), carry)) : fp_mul(v, carry);
+        v = a.affine == 1 ? fp_add(v, fp_mul(fp_load(a.bpow + p), carry)) : a.affine == 2 ? fp_add(v, carry) : fp_mul(v, carry);
         fp_store(dst, v);
     }
 }
@@ -162,7 +163,7 @@ static void scan_run(ScanArgs a, const Fr& b, Fr* tmp, hipStream_t stream) {
     if (n == 0) return;
     const size_t blocks = (n + SC_BLOCK - 1) / SC_BLOCK;
     Fr* bpow = nullptr;
-    if (a.affine) {
+    if (a.affine == 1) {
         Fr p = b;
         for (int k = 1; k <= SC_ITEMS; k++) {
             a.bp[k] = p;
@@ -197,7 +198,7 @@ static void scan_run(ScanArgs a, const Fr& b, Fr* tmp, hipStream_t stream) {
             up.in = tmp;
             up.out = tmp;
             up.n = blocks;
-            up.affine = 0;
+            up.affine = a.affine;
             scan_run(up, b, tmp + blocks, stream);
         }
     }
@@ -245,6 +246,27 @@ int prefix_product_launch(const Fr* d_f, size_t n, const uint64_t init[4], Fr* d
         s.n = n - 1;
         s.out_shift = 1;
         s.affine = 0;
+        s.has_init = 1;
+        s.init = i0;
+        scan_run(s, i0, d_tmp, stream);
+    }
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipStreamSynchronize(stream));  // `i0` is a stack temporary of this frame
+    return H2_OK;
+}
+
+// z[0] = init; z[i] = z[i-1] + f[i-1], i < n   (the logup grand sums: logup/prover.rs:353-367)
+int prefix_sum_launch(const Fr* d_f, size_t n, const uint64_t init[4], Fr* d_z, Fr* d_tmp, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    Fr i0 = fr_from(init);
+    H2_HIP(hipMemcpyAsync(d_z, &i0, sizeof(Fr), hipMemcpyHostToDevice, stream));
+    if (n > 1) {
+        ScanArgs s{};
+        s.in = d_f;
+        s.out = d_z;
+        s.n = n - 1;
+        s.out_shift = 1;
+        s.affine = 2;
         s.has_init = 1;
         s.init = i0;
         scan_run(s, i0, d_tmp, stream);

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import evaluation as ev
 from ._lib import check, lib
-from .circuit import compile_gates
+from .circuit import compile_compress, compile_evaluator
 from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, jacobian_to_affine,
                          point_to_bytes)
 
@@ -200,6 +200,8 @@ class Device:
         one more MSM over a different table.  With a process group (one process per GPU, every rank holding the same
         polynomials) each MSM is split into contiguous ranges over the ranks -- gpu_multiexp_bound's split
         (arithmetic.rs:413-440) -- and the partial points are all-gathered and folded (parallel.py)."""
+        if not columns and not also:
+            return []
         lo, hi = 0, n
         collective = self.group_size > 1 or self.force_collective
         if collective:
@@ -386,9 +388,13 @@ def keygen(device, params, cs, fixed, copies):
     one = D.eval_op(8, D.empty(dom.extended_n), c=1)                           # H2_OP_CONSTANT
     pk.l_active_row = D.eval_op(4, one, one, tmp)                              # H2_OP_SUB
     pk.t_evaluations = D.upload(np.array([fr_to_mont_limbs(v) for v in dom.t_evaluations], dtype=np.uint64))
-    # the gate program
-    g, parts = compile_gates(cs)
-    pk.graph, pk.value_parts = g, parts
+    # Evaluator::new: the gate program with the lookup / shuffle result calculations, and the compression programs
+    # (evaluate_with_theta) of every lookup / shuffle expression list
+    pk.graph, pk.value_parts, pk.lookup_calcs, pk.shuffle_calcs = compile_evaluator(cs)
+    pk.lookup_programs = [(compile_compress(table), [[compile_compress(inputs) for inputs in st] for st in sets])
+                          for _, table, sets in cs.lookups]
+    pk.shuffle_programs = [[(compile_compress(inp), compile_compress(shf)) for _, inp, shf in group]
+                           for group in cs.shuffles]
     pk.transcript_repr = vk_digest(cs, params.k, pk.fixed_commitments, pk.perm_commitments)
     D.sync()
     return pk
@@ -452,19 +458,41 @@ def _vanishing(roots, z):
     return acc
 
 
-def create_proof(device, params, pk, advice, rng, timings=None):
+def create_proof(device, params, pk, advice, rng, timings=None, instances=()):
     """plonk/prover.rs:877-893: the GWC multiopen, as the reference's `create_proof`"""
-    return create_proof_ext(device, params, pk, advice, rng, True, timings)
+    return create_proof_ext(device, params, pk, advice, rng, True, timings, instances)
 
 
-def create_proof_with_shplonk(device, params, pk, advice, rng, timings=None):
+def create_proof_with_shplonk(device, params, pk, advice, rng, timings=None, instances=()):
     """plonk/prover.rs:856-871"""
-    return create_proof_ext(device, params, pk, advice, rng, False, timings)
+    return create_proof_ext(device, params, pk, advice, rng, False, timings, instances)
 
 
-def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
+_ANY = {"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}
+
+
+def _compress(D, dom, program, theta, fixed, advice, instance):
+    """evaluate_with_theta (plonk/evaluation.rs:2330-2398): the theta-compression of an expression list over the
+    n-point Lagrange domain = the evaluator program with y := theta and extended_k := k"""
+    g, parts = program
+    zero = fr_to_mont_limbs(0)
+    b = ev.Builder().build(
+        k=dom.k, extended_k=dom.k, blinding_factors=0, chunk_len=1,
+        constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
+        calculations=g.calculations, value_parts=parts,
+        fixed=[t.data_ptr() for t in fixed], advice=[t.data_ptr() for t in advice],
+        instance=[t.data_ptr() for t in instance],
+        y=fr_to_mont_limbs(theta), beta=zero, gamma=zero, theta=fr_to_mont_limbs(theta),
+        delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.omega))
+    out = D.empty(dom.n)
+    check(D.L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h (compress)")
+    return out
+
+
+def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=()):
     """plonk/prover.rs:206-850.  advice: list of canonical (n, 4) u64 columns (rows past the usable range are
-    overwritten with blinding values); rng: a rng.ProverRng.  Returns the proof bytes."""
+    overwritten with blinding values); instances: one list of canonical integers per instance column;
+    rng: a rng.ProverRng.  Returns the proof bytes."""
     import time
 
     D, L = device, device.L
@@ -472,6 +500,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
     n, bf, ek = dom.n, cs.blinding_factors(), dom.extended_k
     en = dom.extended_n
     last_rot = -(bf + 1)
+    usable = n - (bf + 1)
     marks = [("start", time.perf_counter())]
 
     def mark(name):
@@ -482,13 +511,26 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
     transcript = Blake2bWrite()
     transcript.common_scalar(pk.transcript_repr)
 
+    # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------
+    if len(instances) != cs.num_instance:
+        raise ValueError("InvalidInstances")
+    instance_dev = []
+    for vals in instances:
+        if len(vals) > usable:
+            raise ValueError("InstanceTooLarge")
+        t = D.zeros(n)
+        D.set_rows(t, 0, list(vals))
+        instance_dev.append(t)
+    for P in D.msm_batch(instance_dev, params.g_lagrange, n, 254):
+        transcript.common_point(P)
+    instance_polys = [D.intt(D.clone(t), dom) for t in instance_dev]
+
     # ---- advice columns: blinding rows, bounded commitments (prover.rs:255-312) ----------------------------
-    unusable_rows_start = n - (bf + 1)
     max_bits = 0
     advice_dev = []
     for col in advice:
         t = D.upload(col)                                        # canonical; DMA when the column is pinned memory
-        D.set_rows_raw(t, unusable_rows_start, [rng.u16() for _ in range(unusable_rows_start, n)])
+        D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
         max_bits = max(max_bits, D.max_scalar_bits(t))
         check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
         advice_dev.append(t)
@@ -496,17 +538,41 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
         transcript.write_point(P)
     mark("advice commit")
     theta = transcript.squeeze_challenge_scalar()
+
+    # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
+    def compress(program):
+        return _compress(D, dom, program, theta, pk.fixed_values, advice_dev, instance_dev)
+
+    lookups = []
+    for table_prog, set_progs in pk.lookup_programs:
+        st = {"table": compress(table_prog), "inputs": [[compress(pr) for pr in progs] for progs in set_progs]}
+        flat = [c for cols_ in st["inputs"] for c in cols_]
+        m = D.empty(n)
+        nbytes = L.h2_logup_scratch_bytes(n)
+        ptrs = (_vp * len(flat))(*[c.data_ptr() for c in flat])
+        check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
+                                          D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
+        D.set_rows(m, usable, [rng.u16() for _ in range(usable, n)])
+        st["m"], st["m_bits"] = m, max(16, (usable * len(flat)).bit_length())
+        lookups.append(st)
+    if lookups:
+        for P in D.msm_batch([st["m"] for st in lookups], params.g_lagrange, n, max(st["m_bits"] for st in lookups)):
+            transcript.write_point(P)
+    # ---- shuffles: compressed expressions (shuffle/prover.rs:40-80) ----------------------------------------------
+    shuffles = [[(compress(ip), compress(sp)) for ip, sp in group] for group in pk.shuffle_programs]
+    mark("lookups compress")
     beta = transcript.squeeze_challenge_scalar()
     gamma = transcript.squeeze_challenge_scalar()
 
     # ---- permutation grand products (permutation/prover.rs:47-165) -----------------------------------
     chunk = cs.degree() - 2
     cols = cs.perm_columns
+    colvals = {"advice": advice_dev, "fixed": pk.fixed_values, "instance": instance_dev}
     z_dev, last_z = [], 1
     num, den, tmp = D.empty(n), D.empty(n), D.empty(n)
     for si in range(0, len(cols), chunk):
         for ci in range(si, min(si + chunk, len(cols))):
-            values = _column(*cols[ci], advice_dev, pk.fixed_values)
+            values = colvals[cols[ci][0]][cols[ci][1]]
             check(L.h2_dev_permutation_terms(num.data_ptr(), den.data_ptr(), values.data_ptr(),
                                              pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
                                              _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
@@ -516,43 +582,97 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
         z = D.empty(n)
         check(L.h2_dev_prefix_product(num.data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
         D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
-        last_z = D.get_rows(z, n - (bf + 1), 1)[0]
+        last_z = D.get_rows(z, usable, 1)[0]
         z_dev.append(z)
+    # ---- lookup grand sums (logup/prover.rs:243-415; blinding prover.rs:446-465) -------------------------------
+    for st in lookups:
+        st["z"] = []
+        last = 0
+        for si, cols_in in enumerate(st["inputs"]):
+            for j, col in enumerate(cols_in):                       # sum_i 1 / (beta + f_i)
+                dst = num if j == 0 else den
+                D.eval_op(1, dst, col, c=beta)                      # H2_OP_SUM_C
+                check(L.h2_dev_batch_invert(dst.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
+                if j:
+                    D.eval_op(2, num, num, den)                     # H2_OP_SUM
+            if si == 0:                                             # - m / (beta + t)
+                D.eval_op(1, den, st["table"], c=beta)
+                check(L.h2_dev_batch_invert(den.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
+                D.eval_op(3, den, den, st["m"])
+                D.eval_op(4, num, num, den)                         # H2_OP_SUB
+            z = D.empty(n)
+            check(L.h2_dev_prefix_sum(num.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
+            last = D.get_rows(z, usable, 1)[0]
+            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+            st["z"].append(z)
+        if last != 0:
+            raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
+    # ---- shuffle products (shuffle/prover.rs:82-150; blinding prover.rs:512-530) -------------------------------
+    shuffle_z = []
+    for group in shuffles:
+        for i, (_, shf) in enumerate(group):                        # prod_i (beta^(i+1) + shuffle_i), inverted
+            if i == 0:
+                D.eval_op(1, num, shf, c=beta)
+            else:
+                D.eval_op(6, num, shf, num, c=pow(beta, i + 1, R_MOD))      # H2_OP_LCBETA: (l + c) * r
+        check(L.h2_dev_batch_invert(num.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
+        for i, (inp, _) in enumerate(group):
+            D.eval_op(6, num, inp, num, c=pow(beta, i + 1, R_MOD))
+        z = D.empty(n)
+        check(L.h2_dev_prefix_product(num.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+        if D.get_rows(z, usable, 1)[0] != 1:
+            raise ValueError("shuffle product does not return to one")
+        D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+        shuffle_z.append(z)
     del num, den, tmp
     # vanishing argument: the random polynomial (vanishing/prover.rs:40-67), generated on the device
     random_poly = D.empty(n)
     check(L.h2_dev_random_fr(rng.random_poly_seed(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
-    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every set; the random polynomial's commitment does
+    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z; the random polynomial's commitment does
     # not depend on anything hashed in between, so its MSM rides in the same pipelined batch (hashing order kept)
-    z_commitments = D.msm_batch(z_dev, params.g_lagrange, n, 254, also=(random_poly, params.g))
+    all_z = z_dev + [z for st in lookups for z in st["z"]] + shuffle_z
+    z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254, also=(random_poly, params.g))
     random_commitment = z_commitments.pop()
     for P in z_commitments:
         transcript.write_point(P)
     z_polys = [D.intt(z, dom) for z in z_dev]
+    for st in lookups:
+        st["z_polys"] = [D.intt(z, dom) for z in st["z"]]
+        st["m_poly"] = D.intt(st["m"], dom)
+        del st["table"], st["inputs"]
+    shuffle_polys = [D.intt(z, dom) for z in shuffle_z]
+    del shuffles
     mark("permutation")
     transcript.write_point(random_commitment)
     y = transcript.squeeze_challenge_scalar()
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
     advice_polys = [D.intt(t, dom) for t in advice_dev]          # in place: the Lagrange values are not needed again
-    advice_cosets = [D.coeff_to_extended(t, dom) for t in advice_polys]
-    z_cosets = [D.coeff_to_extended(t, dom) for t in z_polys]
+    ext = lambda t: D.coeff_to_extended(t, dom)  # noqa: E731
+    advice_cosets = [ext(t) for t in advice_polys]
+    instance_cosets = [ext(t) for t in instance_polys]
+    z_cosets = [ext(t) for t in z_polys]
+    lookup_z_cosets = [ext(t) for st in lookups for t in st["z_polys"]]
+    lookup_m_cosets = [ext(st["m_poly"]) for st in lookups]
+    shuffle_cosets = [ext(t) for t in shuffle_polys]
     mark("cosets")
     g = pk.graph
     b = ev.Builder().build(
         k=dom.k, extended_k=ek, blinding_factors=bf, chunk_len=chunk,
         constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
-        calculations=g.calculations, value_parts=pk.value_parts,
+        calculations=g.calculations, value_parts=pk.value_parts, lookups=pk.lookup_calcs, shuffles=pk.shuffle_calcs,
         fixed=[t.data_ptr() for t in pk.fixed_cosets], advice=[t.data_ptr() for t in advice_cosets],
+        instance=[t.data_ptr() for t in instance_cosets],
         l0=pk.l0.data_ptr(), l_last=pk.l_last.data_ptr(), l_active_row=pk.l_active_row.data_ptr(),
-        perm_z=[t.data_ptr() for t in z_cosets],
-        perm_columns=[({"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}[kd], i) for kd, i in cols],
+        perm_z=[t.data_ptr() for t in z_cosets], perm_columns=[(_ANY[kd], i) for kd, i in cols],
         perm_sigma=[t.data_ptr() for t in pk.sigma_cosets],
+        lookup_z=[t.data_ptr() for t in lookup_z_cosets], lookup_m=[t.data_ptr() for t in lookup_m_cosets],
+        shuffle_z=[t.data_ptr() for t in shuffle_cosets],
         y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
         delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.extended_omega))
     h = D.empty(en)
     check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), h.data_ptr(), D.stream), "h2_dev_evaluate_h")
-    del advice_cosets, z_cosets
+    del advice_cosets, instance_cosets, z_cosets, lookup_z_cosets, lookup_m_cosets, shuffle_cosets
     mark("evaluate_h")
 
     # ---- vanishing construct: divide, back to coefficients, commit the pieces (vanishing/prover.rs:69-112) -
@@ -575,6 +695,15 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
             evals[(key, rot)] = (pt, D.eval_polynomial(poly, n, pt))
         return evals[(key, rot)][1]
 
+    def write_set_evals(name, polys_):
+        for i, p in enumerate(polys_):
+            transcript.write_scalar(evaluate((name, i), p, 0))
+            transcript.write_scalar(evaluate((name, i), p, 1))
+            if i + 1 < len(polys_):
+                transcript.write_scalar(evaluate((name, i), p, last_rot))
+
+    for c, rot in cs.instance_queries:
+        transcript.write_scalar(evaluate(("instance", c), instance_polys[c], rot))
     for c, rot in cs.advice_queries:
         transcript.write_scalar(evaluate(("advice", c), advice_polys[c], rot))
     for c, rot in cs.fixed_queries:
@@ -584,11 +713,13 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
     transcript.write_scalar(evaluate(("random",), random_poly, 0))
     for i, p in enumerate(pk.sigma_polys):
         transcript.write_scalar(evaluate(("sigma", i), p, 0))
-    for i, p in enumerate(z_polys):
-        transcript.write_scalar(evaluate(("z", i), p, 0))
-        transcript.write_scalar(evaluate(("z", i), p, 1))
-        if i + 1 < len(z_polys):
-            transcript.write_scalar(evaluate(("z", i), p, last_rot))
+    write_set_evals("z", z_polys)
+    for li, st in enumerate(lookups):                                  # logup/prover.rs:419-446
+        transcript.write_scalar(evaluate(("lookup_m", li), st["m_poly"], 0))
+        write_set_evals("lookup_z%d" % li, st["z_polys"])
+    for i, p in enumerate(shuffle_polys):                              # shuffle/prover.rs:196-212
+        transcript.write_scalar(evaluate(("shuffle_z", i), p, 0))
+        transcript.write_scalar(evaluate(("shuffle_z", i), p, 1))
     mark("evaluations")
 
     # ---- multiopen query list in the reference's order (prover.rs:792-840) -----------------------------------
@@ -598,13 +729,24 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None):
         polys[key] = poly
         queries.append((key, rot, dom.rotate_omega(x, rot), evaluate(key, poly, rot)))
 
+    def open_sets(name, polys_):
+        for i, p in enumerate(polys_):
+            query((name, i), p, 0)
+            query((name, i), p, 1)
+        for i in reversed(range(len(polys_) - 1)):
+            query((name, i), polys_[i], last_rot)
+
+    for c, rot in cs.instance_queries:
+        query(("instance", c), instance_polys[c], rot)
     for c, rot in cs.advice_queries:
         query(("advice", c), advice_polys[c], rot)
-    for i, p in enumerate(z_polys):
-        query(("z", i), p, 0)
-        query(("z", i), p, 1)
-    for i in reversed(range(len(z_polys) - 1)):
-        query(("z", i), z_polys[i], last_rot)
+    open_sets("z", z_polys)
+    for li, st in enumerate(lookups):
+        query(("lookup_m", li), st["m_poly"], 0)
+        open_sets("lookup_z%d" % li, st["z_polys"])
+    for i, p in enumerate(shuffle_polys):
+        query(("shuffle_z", i), p, 0)
+        query(("shuffle_z", i), p, 1)
     for c, rot in cs.fixed_queries:
         query(("fixed", c), pk.fixed_polys[c], rot)
     for i, p in enumerate(pk.sigma_polys):

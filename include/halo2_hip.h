@@ -156,6 +156,18 @@ int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, cons
  * halo2-gpu-specific_amd/rng.py holds the host twin the reference prover of the tests draws from. */
 int h2_dev_random_fr(uint64_t seed, size_t n, void *d_out, void *stream);
 
+/* Grand-sum column: z[0] = init, z[i] = z[i-1] + f[i-1] for i < n -- the `scan` of plonk/logup/prover.rs:353-367. */
+int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d_z, void *stream);
+/* The multiplicity column of a logup lookup (plonk/logup/prover.rs:104-180): for every row r < usable_rows of each
+ * compressed input column, the table row holding that value is credited once; m[row] = credit as a field element
+ * (Montgomery), m[row >= usable_rows] = 0 (the caller writes the blinding values there, :217-221).  A duplicated table
+ * value collects its credits on its lowest row (the reference's binary search lands on an implementation-defined
+ * duplicate; the argument is indifferent).  d_inputs: HOST array of n_inputs device pointers.  Returns H2_ERR_INVALID
+ * when an input value is absent from the table (the reference panics).  Synchronous. */
+size_t h2_logup_scratch_bytes(size_t n);
+int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
+                              size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
+
 /* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
  * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
  * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:

@@ -9,7 +9,7 @@ import pytest
 
 import ref_plonk as rp
 from h2util import fr_mont, ints_to_arr
-from test_plonk_host import S_TRAPDOOR, rot_gate_cs
+from test_plonk_host import S_TRAPDOOR, lookup_shuffle_cs, rot_gate_cs
 
 pytestmark = pytest.mark.gpu
 
@@ -186,3 +186,35 @@ dist.destroy_process_group()
     assert res.returncode == 0, res.stdout + res.stderr
     line = [l for l in res.stdout.splitlines() if l.startswith("PROOF ")][0]
     assert bytes.fromhex(line.split()[1]) == want
+
+
+@pytest.mark.parametrize("k", [5, 8])
+def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
+    """instance column + logup lookups (two input sets, a duplicated table row) + a shuffle group, end to end:
+    multiplicities from the device hash table, grand sums / products from the scans, the lookup and shuffle terms of
+    the fused evaluate_h -- bytes equal to the reference prover's, SHPLONK and GWC"""
+    from halo2_gpu_specific_amd import prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    adv, fixed, copies, inst = rp.LookupShuffle.synthesize(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, lookup_shuffle_cs(), cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    rpk = rp.keygen(rp.LookupShuffle, k, S_TRAPDOOR, fixed, copies)
+    assert pk.transcript_repr == rpk.transcript_repr
+    for seed, use_gwc in ((1, False), (2, True)):
+        proof = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(seed), use_gwc, instances=inst)
+        want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=inst)
+        assert len(proof) == len(want)
+        first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
+        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+        assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=inst)
+    # a value missing from the table: the reference panics, the library reports it
+    bad = [c[:] for c in adv]
+    bad[4][2] = 5
+    from halo2_gpu_specific_amd._lib import H2Error
+    with pytest.raises(H2Error, match="missing from the table"):
+        prover.create_proof_with_shplonk(device, params, pk, cols_to_arr(bad), ProverRng(1), instances=inst)
+    bad = [c[:] for c in adv]
+    bad[10][1] += 1
+    with pytest.raises(ValueError, match="shuffle"):
+        prover.create_proof_with_shplonk(device, params, pk, cols_to_arr(bad), ProverRng(1), instances=inst)

@@ -30,6 +30,103 @@ def rot_gate_cs():
     return cs
 
 
+def lookup_shuffle_cs():
+    """the product-side description of ref_plonk.LookupShuffle"""
+    cs = hc.ConstraintSystem("lookup-shuffle")
+    adv = [cs.advice_column() for _ in range(12)]
+    fx = [cs.fixed_column() for _ in range(5)]
+    inst = cs.instance_column()
+    cs.enable_equality(adv[11])
+    cs.enable_equality(inst)
+    q, qi = cs.query_fixed(fx[0]), cs.query_fixed(fx[4])
+    a, b, c, d, e, g, h, g2, h2, p, p2 = (cs.query_advice(adv[i]) for i in range(11))
+    w, pub = cs.query_advice(adv[11]), cs.query_instance(inst)
+    t0, t1, u = cs.query_fixed(fx[1]), cs.query_fixed(fx[2]), cs.query_fixed(fx[3])
+    cs.create_gate("square", [q * (a * a + 1 - b)])
+    cs.create_gate("public", [qi * (w - pub)])
+    cs.lookup_any("pairs", [t0, t1], [[[q * a, q * b], [c, d]], [[q * c, q * d]]])
+    cs.lookup_any("single", [u], [[[e]]])
+    cs.shuffle_group([("gh", [g, h], [g2, h2]), ("p", [p], [p2])])
+    cs.set_minimum_degree(6)
+    return cs
+
+
+def test_reference_prover_with_lookups_shuffles_instances():
+    cs, k = rp.LookupShuffle, 5
+    adv, fixed, copies, inst = cs.synthesize(k)
+    pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
+    for use_gwc in (False, True):
+        proof = rp.create_proof(pk, adv, ProverRng(4), use_gwc=use_gwc, instances=inst)
+        assert rp.verify_proof(pk, proof, use_gwc=use_gwc, instances=inst)
+        assert not rp.verify_proof(pk, proof, use_gwc=use_gwc, instances=[[43, 7]])
+    assert rp.verify_proof(pk, proof, use_gwc=True, instances=inst, pairing=True)
+    bad = [c[:] for c in adv]
+    bad[4][2] = 5                                   # e[2] is not in the table u
+    with pytest.raises(KeyError):
+        rp.create_proof(pk, bad, ProverRng(4), instances=inst)
+    bad = [c[:] for c in adv]
+    bad[10][1] += 1                                 # p2 is no longer a permutation of p
+    with pytest.raises(AssertionError, match="shuffle"):
+        rp.create_proof(pk, bad, ProverRng(4), instances=inst)
+    bad = [c[:] for c in adv]
+    bad[11][0] = 41                                 # w[0] != the public input
+    assert not rp.verify_proof(pk, rp.create_proof(pk, bad, ProverRng(4), instances=inst), instances=inst)
+
+
+def test_lookup_shuffle_constraint_system_mirrors_reference():
+    cs, ref = lookup_shuffle_cs(), rp.LookupShuffle
+    assert cs.advice_queries == ref.advice_queries and cs.fixed_queries == ref.fixed_queries
+    assert cs.instance_queries == ref.instance_queries and cs.perm_columns == ref.perm_columns
+    assert cs.degree() == ref.degree and cs.blinding_factors() == ref.blinding_factors
+    g, parts, lookups, shuffles = hc.compile_evaluator(cs)
+    assert [len(p) for _, p, _ in lookups] == [2, 1] and len(shuffles) == 1
+    # run the program + the argument calculations on random values against the reference's closed formulas
+    rnd = random.Random(8)
+    theta, beta = rnd.randrange(rp.R), rnd.randrange(rp.R)
+    vals = {}
+    adv = lambda c, r: vals.setdefault(("a", c, r), rnd.randrange(rp.R))  # noqa: E731
+    fix = lambda c, r: vals.setdefault(("f", c, r), rnd.randrange(rp.R))  # noqa: E731
+    ins = lambda c, r: vals.setdefault(("i", c, r), rnd.randrange(rp.R))  # noqa: E731
+    inter = []
+
+    def get(v):
+        if v.kind == ev.VS_CONSTANT:
+            return g.constants[v.index]
+        if v.kind == ev.VS_INTERMEDIATE:
+            return inter[v.index]
+        return {ev.VS_FIXED: fix, ev.VS_ADVICE: adv, ev.VS_INSTANCE: ins}[v.kind](v.index, g.rotations[v.rot])
+
+    def run(c):
+        a = get(c.a)
+        if c.op == ev.CALC_ADD: return (a + get(c.b)) % rp.R
+        if c.op == ev.CALC_SUB: return (a - get(c.b)) % rp.R
+        if c.op == ev.CALC_MUL: return a * get(c.b) % rp.R
+        if c.op == ev.CALC_NEGATE: return -a % rp.R
+        if c.op == ev.CALC_LC_THETA: return (a * theta + get(c.b)) % rp.R
+        if c.op == ev.CALC_ADD_CHALLENGE: return (a + beta) % rp.R
+        if c.op == ev.CALC_LC_CHALLENGE: return (a + pow(beta, c.power, rp.R)) * get(c.b) % rp.R
+        return a
+
+    for c in g.calculations:
+        inter.append(run(c))
+    assert [get(p) for p in parts] == ref.gates(adv, fix, ins)
+    for (table, prods, sums), lk in zip(lookups, ref.lookups):
+        assert run(table) == (rp._compress(lk["table"](adv, fix, ins), theta) + beta) % rp.R
+        for pc, sc, st in zip(prods, sums, lk["input_sets"]):
+            phi = [(rp._compress(e(adv, fix, ins), theta) + beta) % rp.R for e in st]
+            prod = 1
+            for v in phi:
+                prod = prod * v % rp.R
+            assert run(pc) == prod
+            assert run(sc) == sum(prod * rp.inv(v) for v in phi) % rp.R
+    (ia, sb), group = shuffles[0], ref.shuffles[0]
+    want_a = want_b = 1
+    for i, (inp, shf) in enumerate(group):
+        want_a = want_a * (rp._compress(inp(adv, fix, ins), theta) + pow(beta, i + 1, rp.R)) % rp.R
+        want_b = want_b * (rp._compress(shf(adv, fix, ins), theta) + pow(beta, i + 1, rp.R)) % rp.R
+    assert (run(ia), run(sb)) == (want_a, want_b)
+
+
 @pytest.mark.parametrize("cs,k", [(rp.MiniPlonk, 4), (rp.MiniPlonk, 5), (rp.RotGate, 5)])
 def test_reference_prover_is_accepted(cs, k):
     adv, fixed, copies = cs.synthesize(k)
