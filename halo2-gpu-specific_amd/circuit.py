@@ -7,8 +7,10 @@ h2_dev_evaluate_h interprets.
   Expression         plonk/circuit.rs:609-1060
   GraphEvaluator     plonk/evaluation.rs:298-560  (add_expression / add_calculation / add_constant / add_rotation)
 
-Lookups and shuffles are not wired into the host prover here (the device interpreter supports them, see
-evaluation.py); circuits are custom gates + copy constraints.
+  logup / shuffle    plonk/logup.rs:11-50, plonk/shuffle.rs:8-54 -- arguments are registered with their input sets /
+                     groups given explicitly (the result of the reference's chunking passes)
+
+Circuits are custom gates + copy constraints + logup lookups + shuffle groups over advice / fixed / instance columns.
 """
 from . import evaluation as ev
 

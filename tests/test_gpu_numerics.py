@@ -111,3 +111,125 @@ def test_prefix_product(oracle, n):
     for v in from_mont(f) if n > 1 else []:
         z.append(z[-1] * v % R_MOD)
     assert from_mont(got) == z
+
+
+# ---- the permutation / logup building blocks of the device prover (csrc/poly.hip, scan.hip, logup.hip) ---------
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1024, 1025, 5000, 300001])
+def test_prefix_sum(oracle, n):
+    """z[0] = init, z[i] = z[i-1] + f[i-1] (logup/prover.rs:353-367) against Python integers"""
+    L = h2.lib()
+    f = oracle.random_fr(4100 + n % 13, n)
+    init = 0x1234567 if n % 2 else 0
+    d_f, d_z = _dev(f), _dev(np.zeros((n, 4), dtype=np.uint64))
+    assert L.h2_dev_prefix_sum(d_f.data_ptr(), n, fr_mont(init).ctypes.data, d_z.data_ptr(), None) == 0
+    got = from_mont(_host(d_z))
+    fv = from_mont(f)
+    acc, want = init, []
+    for i in range(n):
+        want.append(acc)
+        acc = (acc + fv[i]) % R_MOD
+    assert got == want
+
+
+@pytest.mark.parametrize("usable,n", [(10, 16), (250, 256), (4090, 4096), (100000, 1 << 17)])
+def test_logup_multiplicity(oracle, usable, n):
+    """m[row] = how often the table row's value occurs among the first `usable` rows of the inputs, duplicates
+    credited to the lowest row; rows past `usable` are ignored and left zero; a missing value is an error"""
+    import random
+
+    L = h2.lib()
+    rnd = random.Random(usable)
+    table = oracle.random_fr(77, n)
+    for _ in range(max(1, usable // 8)):                       # duplicated table values
+        table[rnd.randrange(usable)] = table[rnd.randrange(usable)]
+    table[usable:] = table[0]                                  # rows past usable must not be credited
+    inputs = []
+    for j in range(3):
+        idx = np.array([rnd.randrange(usable) if rnd.random() < 0.7 else 3 for _ in range(n)])   # row 3 is hot
+        inputs.append(table[idx].copy())
+    d_table, d_in = _dev(table), [_dev(a) for a in inputs]
+    d_m = _dev(np.zeros((n, 4), dtype=np.uint64))
+    nbytes = L.h2_logup_scratch_bytes(n)
+    import torch
+
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in d_in])
+    rc = L.h2_dev_logup_multiplicity(d_table.data_ptr(), ptrs, 3, usable, n, d_m.data_ptr(), scratch.data_ptr(), nbytes, None)
+    assert rc == 0, L.h2_last_error()
+    first = {}
+    keys = [tuple(int(x) for x in r) for r in table]
+    for i in range(usable):
+        first.setdefault(keys[i], i)
+    want = [0] * n
+    for a in inputs:
+        for i in range(usable):
+            want[first[tuple(int(x) for x in a[i])]] += 1
+    assert from_mont(_host(d_m)) == want
+    # one absent value
+    inputs[1][usable // 2] = fr_mont(0xDEADBEEF)
+    d_bad = _dev(inputs[1])
+    ptrs = (ctypes.c_void_p * 1)(d_bad.data_ptr())
+    rc = L.h2_dev_logup_multiplicity(d_table.data_ptr(), ptrs, 1, usable, n, d_m.data_ptr(), scratch.data_ptr(), nbytes, None)
+    assert rc == 1 and b"missing from the table" in L.h2_last_error()
+    assert L.h2_dev_logup_multiplicity(d_table.data_ptr(), ptrs, 1, usable, n, d_m.data_ptr(), scratch.data_ptr(), 16, None) == 1
+
+
+@pytest.mark.parametrize("n", [8, 256, 2048, 2049, 70000])
+def test_permutation_sigma_and_terms(oracle, n):
+    """sigma[j] = DELTA^c * omega^r; num / den products of permutation/prover.rs:89-128, against Python integers"""
+    import random
+
+    import torch
+
+    L = h2.lib()
+    rnd = random.Random(n)
+    DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
+    omega = from_mont(oracle.random_fr(9, 1))[0]
+    mc = np.array([rnd.randrange(5) for _ in range(n)], dtype=np.uint32)
+    mr = np.array([rnd.randrange(n) for _ in range(n)], dtype=np.uint32)
+    d_mc, d_mr = torch.from_numpy(mc.view(np.int32)).cuda(), torch.from_numpy(mr.view(np.int32)).cuda()
+    d_sig = _dev(np.zeros((n, 4), dtype=np.uint64))
+    assert L.h2_dev_permutation_sigma(d_sig.data_ptr(), d_mc.data_ptr(), d_mr.data_ptr(), n, fr_mont(DELTA).ctypes.data,
+                                      fr_mont(omega).ctypes.data, None) == 0
+    assert L.h2_synchronize() == 0          # stream NULL = the library's own (non-blocking) stream
+    sigma = from_mont(_host(d_sig))
+    if n <= 2049:
+        assert sigma == [pow(DELTA, int(c), R_MOD) * pow(omega, int(r), R_MOD) % R_MOD for c, r in zip(mc, mr)]
+    beta, gamma = rnd.randrange(R_MOD), rnd.randrange(R_MOD)
+    vals = [oracle.random_fr(20 + j, n) for j in range(2)]
+    d_num, d_den = _dev(np.zeros((n, 4), dtype=np.uint64)), _dev(np.zeros((n, 4), dtype=np.uint64))
+    want_num, want_den = [1] * n, [1] * n
+    for j in range(2):
+        dp = pow(DELTA, j + 3, R_MOD)
+        d_v = _dev(vals[j])
+        assert L.h2_dev_permutation_terms(d_num.data_ptr(), d_den.data_ptr(), d_v.data_ptr(), d_sig.data_ptr(), n,
+                                          fr_mont(beta).ctypes.data, fr_mont(gamma).ctypes.data, fr_mont(dp).ctypes.data,
+                                          fr_mont(omega).ctypes.data, 1 if j == 0 else 0, None) == 0
+        v = from_mont(vals[j])
+        w = 1
+        for i in range(n):
+            want_num[i] = want_num[i] * (dp * w % R_MOD * beta + gamma + v[i]) % R_MOD
+            want_den[i] = want_den[i] * (beta * sigma[i] + gamma + v[i]) % R_MOD
+            w = w * omega % R_MOD
+    assert L.h2_synchronize() == 0
+    assert from_mont(_host(d_num)) == want_num and from_mont(_host(d_den)) == want_den
+
+
+def test_random_fr_matches_host_twin():
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    L = h2.lib()
+    for seed, n in ((5, 1), (2**64 - 3, 1000), (0x48414C4F32, 1 << 18)):
+        d = _dev(np.zeros((n, 4), dtype=np.uint64))
+        assert L.h2_dev_random_fr(seed, n, d.data_ptr(), None) == 0 and L.h2_synchronize() == 0
+        assert np.array_equal(_host(d), ProverRng.random_poly_limbs(seed, n))
