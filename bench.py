@@ -29,6 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+MUL_CEILING = 1.31e11  # 254-bit Montgomery multiplications/s, whole chip (tools/mulbench.hip, profiles/r1_mulbench.txt)
 
 
 def fr_limbs(v):
@@ -246,6 +247,13 @@ def main():
             "buckets_per_window": nb.value,
             "g1_adds_per_msm": adds,
             "g1_adds_formula": "n*W + 2*2^(c-1)*W + W*c (bucket accumulate + running-sum reduce + window doublings)",
+            "alu_roofline": {
+                "bound": "integer multiplier (not HBM: 96 B per pair)",
+                "peak_adds_per_s": world * MUL_CEILING / 10.0,
+                "frac": (world * args.msm_steps * BATCH * adds / belapsed) / (world * MUL_CEILING / 10.0),
+                "note": "peak = measured chip ceiling of 1.31e11 254-bit Montgomery multiplications/s (profiles/r1_mulbench.txt) "
+                "/ 10 multiplications per mixed XYZZ addition; field additions, sorting and the bucket reduction are not credited",
+            },
             "steps": args.msm_steps,
         }
         del scratch2

@@ -47,6 +47,9 @@ class Constant(Expression):
     def degree(self):
         return 0
 
+    def identifier(self):
+        return "0x%064x" % self.v
+
 
 class Query(Expression):
     kind = None
@@ -57,17 +60,21 @@ class Query(Expression):
     def degree(self):
         return 1
 
+    def identifier(self):
+        """Expression::identifier (plonk/circuit.rs:805-837): keys the lookup tracer by table"""
+        return "%s[%d][%d]" % (self.name, self.column, self.rotation)
+
 
 class Fixed(Query):
-    kind = ev.VS_FIXED
+    kind, name = ev.VS_FIXED, "fixed"
 
 
 class Advice(Query):
-    kind = ev.VS_ADVICE
+    kind, name = ev.VS_ADVICE, "advice"
 
 
 class Instance(Query):
-    kind = ev.VS_INSTANCE
+    kind, name = ev.VS_INSTANCE, "instance"
 
 
 class Negated(Expression):
@@ -77,6 +84,9 @@ class Negated(Expression):
     def degree(self):
         return self.e.degree()
 
+    def identifier(self):
+        return "(-%s)" % self.e.identifier()
+
 
 class Sum(Expression):
     def __init__(self, a, b):
@@ -84,6 +94,9 @@ class Sum(Expression):
 
     def degree(self):
         return max(self.a.degree(), self.b.degree())
+
+    def identifier(self):
+        return "(%s+%s)" % (self.a.identifier(), self.b.identifier())
 
 
 class Product(Expression):
@@ -93,6 +106,9 @@ class Product(Expression):
     def degree(self):
         return self.a.degree() + self.b.degree()
 
+    def identifier(self):
+        return "(%s*%s)" % (self.a.identifier(), self.b.identifier())
+
 
 class Scaled(Expression):
     def __init__(self, e, c):
@@ -100,6 +116,9 @@ class Scaled(Expression):
 
     def degree(self):
         return self.e.degree()
+
+    def identifier(self):
+        return "%s*0x%064x" % (self.e.identifier(), self.c)
 
 
 class ConstraintSystem:
@@ -113,6 +132,8 @@ class ConstraintSystem:
         self.lookups = []            # (name, [table Expression], [[[input Expression]]]): logup::Argument (plonk/logup.rs:11-16)
         self.shuffles = []           # groups of (name, [input Expression], [shuffle Expression]): shuffle::Argument (plonk/shuffle.rs:8-22)
         self.minimum_degree = None
+        self.lookup_tracer = {}      # table identifier -> (name, [table Expression], [(name, [input Expression])])
+        self.shuffle_tracer = []     # (name, [input Expression], [shuffle Expression])
 
     # -- columns ------------------------------------------------------------------------------------------
     def advice_column(self):
@@ -179,6 +200,69 @@ class ConstraintSystem:
                 assert len(inputs) == len(table_expressions)
         self.lookups.append((name, list(table_expressions), [[list(i) for i in st] for st in input_expressions_sets]))
 
+    # -- the traced front end and its chunking passes -----------------------------------------------------------
+    def lookup(self, name, pairs):
+        """`lookup_any` (plonk/circuit.rs:1377-1406): pairs = [(input Expression, table Expression)]; lookups into the
+        same table expressions are collected under one tracer entry"""
+        inputs, table = [i for i, _ in pairs], [t for _, t in pairs]
+        ident = "".join(t.identifier() for t in table)
+        if ident in self.lookup_tracer:
+            self.lookup_tracer[ident][2].append((name, inputs))
+        else:
+            self.lookup_tracer[ident] = (name, table, [(name, inputs)])
+        return len(self.lookup_tracer) - 1
+
+    def chunk_lookups(self):
+        """circuit.rs:1411-1424 + ArgumentTracer::chunks (plonk/logup.rs:73-153): pack the inputs of every table into
+        sets whose polynomial fits the constraint system's degree; set 0 also carries the table term"""
+        if not self.lookup_tracer:
+            return self
+        degree = self.degree()
+        assert degree > 2
+        max_degree = degree - 2
+        deg = lambda exprs: max(e.degree() for e in exprs)  # noqa: E731
+        self.lookups = []
+        for ident in sorted(self.lookup_tracer):              # BTreeMap<String, _> iteration order
+            name, table, traced = self.lookup_tracer[ident]
+            first, extra = [traced[0][1]], []
+            for _, inputs in traced[1:]:
+                d = deg(inputs)
+                if deg(table) + sum(deg(i) for i in first) + d <= max_degree:
+                    first.append(inputs)
+                    continue
+                for st in extra:
+                    if sum(deg(i) for i in st) + d <= max_degree:
+                        st.append(inputs)
+                        break
+                else:
+                    extra.append([inputs])
+            self.lookups.append((name, list(table), [first] + extra))
+        return self
+
+    def shuffle(self, name, pairs):
+        """circuit.rs:1430-1442: pairs = [(input Expression, shuffle Expression)]"""
+        self.shuffle_tracer.append((name, [i for i, _ in pairs], [s_ for _, s_ in pairs]))
+        return len(self.shuffle_tracer) - 1
+
+    def chunk_shuffles(self):
+        """circuit.rs:1445-1451 + shuffle::chunk (plonk/shuffle.rs:57-103): first-fit grouping by summed degree"""
+        if not self.shuffle_tracer:
+            return self
+        degree = self.degree()
+        assert degree > 2
+        max_degree = degree - 2
+        udeg = lambda u: max([1] + [e.degree() for e in u[1] + u[2]])  # noqa: E731
+        groups = [[self.shuffle_tracer[0]]]
+        for unit in self.shuffle_tracer[1:]:
+            for group in groups:
+                if sum(udeg(u) for u in group) + udeg(unit) <= max_degree:
+                    group.append(unit)
+                    break
+            else:
+                groups.append([unit])
+        self.shuffles = groups
+        return self
+
     def shuffle_group(self, units):
         """units: [(name, [input Expression], [shuffle Expression])] sharing one product polynomial"""
         for _, inp, shf in units:
@@ -195,7 +279,11 @@ class ConstraintSystem:
             tdeg = max([1] + [e.degree() for e in table])
             ideg = max([1] + [e.degree() for st in sets for inputs in st for e in inputs])
             d = max(d, 4, 2 + ideg + tdeg)
-        for group in self.shuffles:              # shuffle::ArgumentUnit::required_degree (plonk/shuffle.rs:43-54)
+        for _, table, traced in self.lookup_tracer.values():   # ArgumentTracer::required_degree (plonk/logup.rs:155-176)
+            tdeg = max([1] + [e.degree() for e in table])
+            ideg = max([1] + [e.degree() for _, inputs in traced for e in inputs])
+            d = max(d, 4, 2 + ideg + tdeg)
+        for group in list(self.shuffles) + [[u] for u in self.shuffle_tracer]:   # ArgumentUnit::required_degree (shuffle.rs:43-54)
             for _, inp, shf in group:
                 d = max(d, 2 + max([1] + [e.degree() for e in inp + shf]))
         d = max(d, self.minimum_degree or 1)

@@ -218,3 +218,22 @@ def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
     bad[10][1] += 1
     with pytest.raises(ValueError, match="shuffle"):
         prover.create_proof_with_shplonk(device, params, pk, cols_to_arr(bad), ProverRng(1), instances=inst)
+
+
+def test_lookup_proof_at_a_multi_workgroup_size_is_accepted(oracle, device):
+    """the lookup / shuffle / instance circuit at k = 12 (hash table, additive and multiplicative scans and the
+    logup kernels of evaluate_h beyond one workgroup), checked by the reference verifier on the device keygen's
+    commitments"""
+    from halo2_gpu_specific_amd import prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 12
+    adv, fixed, copies, inst = rp.LookupShuffle.synthesize(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, lookup_shuffle_cs(), cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    vk = rp.Keys()
+    vk.cs, vk.dom, vk.s = rp.LookupShuffle, rp.Domain(k, 6), S_TRAPDOOR
+    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+    proof = prover.create_proof_with_shplonk(device, params, pk, cols_to_arr(adv), ProverRng(3), instances=inst)
+    assert rp.verify_proof(vk, proof, instances=inst)
+    assert not rp.verify_proof(vk, proof, instances=[[42, 8]])

@@ -335,3 +335,48 @@ def test_prover_refuses_to_run_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         prover.Device()
+
+
+def test_chunk_lookups_like_the_reference():
+    """plonk/logup.rs:203-281 (`test_chunks_normal`, `test_chunks_order`) restated on the host mirror"""
+    cs = hc.ConstraintSystem()
+    input_0, input_1, _l0, _l1 = (cs.advice_column() for _ in range(4))
+    s_0, _s1, table_0, _t1 = (cs.fixed_column() for _ in range(4))
+    cs.lookup("table1", [(cs.query_advice(input_0), cs.query_fixed(table_0))])
+    cs.lookup("table2", [(cs.query_advice(input_1), cs.query_fixed(table_0))])
+    cs.chunk_lookups()                                            # degree = 4
+    assert cs.degree() == 4 and len(cs.lookups) == 1
+    assert len(cs.lookups[0][1]) == 1 and len(cs.lookups[0][2]) == 2
+    t0 = cs.query_fixed(table_0)
+    cs.lookup("table3", [(cs.query_advice(input_1) * cs.query_fixed(s_0), t0), (cs.query_advice(input_1), t0)])
+    cs.chunk_lookups()                                            # degree = 5
+    assert cs.degree() == 5 and len(cs.lookups) == 2
+    assert len(cs.lookups[0][1]) == 1 and len(cs.lookups[0][2]) == 1
+    assert len(cs.lookups[1][1]) == 2 and len(cs.lookups[1][2]) == 1
+    # the big-degree expression in the middle
+    cs = hc.ConstraintSystem()
+    input_0, input_1 = cs.advice_column(), cs.advice_column()
+    s_0, table_0 = cs.fixed_column(), cs.fixed_column()
+    cs.lookup("table1", [(cs.query_advice(input_0), cs.query_fixed(table_0))])
+    cs.lookup("table2", [(cs.query_advice(input_1) * cs.query_fixed(s_0), cs.query_fixed(table_0))])
+    cs.lookup("table3", [(cs.query_advice(input_1), cs.query_fixed(table_0))])
+    cs.chunk_lookups()
+    assert len(cs.lookups) == 1 and len(cs.lookups[0][1]) == 1 and len(cs.lookups[0][2]) == 2
+    hc.compile_evaluator(cs)                                      # and the result feeds the evaluator
+
+
+def test_chunk_shuffles_first_fit():
+    cs = hc.ConstraintSystem()
+    cols = [cs.advice_column() for _ in range(8)]
+    q = [cs.query_advice(c) for c in cols]
+    s0 = cs.query_fixed(cs.fixed_column())
+    cs.shuffle("a", [(q[0], q[1])])
+    cs.shuffle("b", [(q[2] * s0, q[3])])          # degree 2
+    cs.shuffle("c", [(q[4], q[5])])
+    cs.shuffle("d", [(q[6], q[7])])
+    cs.chunk_shuffles()                            # cs degree 4 -> at most summed degree 2 per group
+    assert cs.degree() == 4
+    assert [[u[0] for u in g] for g in cs.shuffles] == [["a", "c"], ["b"], ["d"]]
+    cs.set_minimum_degree(6)
+    cs.chunk_shuffles()
+    assert [[u[0] for u in g] for g in cs.shuffles] == [["a", "b", "c"], ["d"]]
