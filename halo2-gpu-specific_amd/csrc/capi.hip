@@ -372,6 +372,24 @@ int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
     });
 }
 
+int h2_dev_points_decompress(const void* d_bytes, size_t n, void* d_points, void* stream) {
+    if (n && (!d_bytes || !d_points)) return bad("h2_dev_points_decompress: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        uint32_t* d_bad = (uint32_t*)ctx->buf_d.get(256);
+        return points_decompress_launch(d_bytes, n, (uint64_t*)d_points, d_bad, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_points_compress(const void* d_points, size_t n, void* d_bytes, void* stream) {
+    if (n && (!d_bytes || !d_points)) return bad("h2_dev_points_compress: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return points_compress_launch((const uint64_t*)d_points, n, d_bytes, pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_random_fr(uint64_t seed, size_t n, void* d_out, void* stream) {
     if (!d_out && n) return bad("h2_dev_random_fr: null argument");
     return guarded([&] {

@@ -558,6 +558,110 @@ int random_points_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t s
     return H2_OK;
 }
 
+// ---------------------------------------------------------------- compressed points (Params::{read, write})
+// poly/commitment.rs:241-294 stores g and g_lagrange as `to_bytes()` = 32 bytes per point.  Convention (the layout of
+// pairing_bn256@30b052f cannot be checked without its sources -- "parity unpinned"): x little-endian, bit 7 of byte 31 =
+// parity of canonical y, identity = 32 zero bytes.  Decompression is one square root (y = rhs^((q+1)/4), q = 3 mod 4)
+// per point: the reference does it with a rayon `parallelize` over `from_bytes`, here it is one lane per point.
+__device__ __forceinline__ Fq fq_sqrt_candidate(const Fq& rhs) {
+    // (q + 1) / 4, little-endian u32 limbs
+    const uint32_t E[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u,
+                           0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    Fq y = fp_one<FqParams>();
+    for (int bit = 253; bit >= 0; bit--) {
+        y = fp_sqr(y);
+        if ((E[bit >> 5] >> (bit & 31)) & 1) y = fp_mul(y, rhs);
+    }
+    return y;
+}
+
+__global__ void __launch_bounds__(256) k_points_decompress(const uint32_t* bytes, size_t n, Affine* out, uint32_t* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq x;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        x.l[k] = bytes[8 * i + k];
+        any |= x.l[k];
+    }
+    Fq zero = fp_zero<FqParams>();
+    if (any == 0) {  // identity
+        fp_store(&out[i].x, zero);
+        fp_store(&out[i].y, zero);
+        return;
+    }
+    const uint32_t sign = x.l[7] >> 31;
+    x.l[7] &= 0x7fffffffu;
+    // x must be a canonical residue (< q)
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        if (!decided && x.l[k] != FqParams::MOD[k]) {
+            lt = x.l[k] < FqParams::MOD[k];
+            decided = true;
+        }
+    }
+    if (!lt) {
+        atomicAdd(bad, 1u);
+        fp_store(&out[i].x, zero);
+        fp_store(&out[i].y, zero);
+        return;
+    }
+    Fq xm = fp_to_mont(x);
+    Fq three = fp_add(fp_add(fp_one<FqParams>(), fp_one<FqParams>()), fp_one<FqParams>());
+    Fq rhs = fp_add(fp_mul(fp_sqr(xm), xm), three);
+    Fq y = fq_sqrt_candidate(rhs);
+    if (!fp_eq(fp_sqr(y), rhs)) {  // x is not the abscissa of a curve point
+        atomicAdd(bad, 1u);
+        fp_store(&out[i].x, zero);
+        fp_store(&out[i].y, zero);
+        return;
+    }
+    if ((fp_from_mont(y).l[0] & 1u) != sign) y = fp_neg(y);
+    fp_store(&out[i].x, xm);
+    fp_store(&out[i].y, y);
+}
+
+__global__ void __launch_bounds__(256) k_points_compress(const Affine* pts, size_t n, uint32_t* bytes) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p = affine_load(pts + i);
+    Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
+    if (fp_is_zero(x) && fp_is_zero(y)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) bytes[8 * i + k] = 0;
+        return;
+    }
+    x.l[7] |= (y.l[0] & 1u) << 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) bytes[8 * i + k] = x.l[k];
+}
+
+int points_decompress_launch(const void* d_bytes, size_t n, uint64_t* d_out, uint32_t* d_bad, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    H2_HIP(hipMemsetAsync(d_bad, 0, 4, stream));
+    hipLaunchKernelGGL(k_points_decompress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const uint32_t*)d_bytes, n, (Affine*)d_out, d_bad);
+    H2_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    H2_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
+    H2_HIP(hipStreamSynchronize(stream));
+    if (bad) {
+        set_last_error("points_decompress: " + std::to_string(bad) + " encoding(s) are not curve points");
+        return H2_ERR_INVALID;
+    }
+    return H2_OK;
+}
+
+int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_points_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const Affine*)d_points, n, (uint32_t*)d_bytes);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 // ---------------------------------------------------------------- drivers
 void msm_identity(uint64_t out_xyz[12]) {
     Jacobian j = xyzz_to_jacobian(xyzz_identity());

@@ -21,4 +21,6 @@ int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_
                               uint32_t max_bits, uint64_t out_xyz[12]);
 int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]);
 int random_points_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream);
+int points_decompress_launch(const void* d_bytes, size_t n, uint64_t* d_out, uint32_t* d_bad, hipStream_t stream);
+int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hipStream_t stream);
 }  // namespace h2

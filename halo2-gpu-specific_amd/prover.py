@@ -105,7 +105,11 @@ class Device:
             src = self._pinned.get(a.ctypes.data)
             if src is not None and src.numel() == a.size:
                 return src.to(self.dev, non_blocking=True)
-            return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+            import warnings
+
+            with warnings.catch_warnings():      # read-only sources (a memory-mapped witness file) are only read
+                warnings.simplefilter("ignore", UserWarning)
+                return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
 
     def download(self, t):
         with self.torch.cuda.stream(self.tstream):
@@ -489,10 +493,16 @@ def _compress(D, dom, program, theta, fixed, advice, instance):
     return out
 
 
-def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=()):
-    """plonk/prover.rs:206-850.  advice: list of canonical (n, 4) u64 columns (rows past the usable range are
-    overwritten with blinding values); instances: one list of canonical integers per instance column;
-    rng: a rng.ProverRng.  Returns the proof bytes."""
+def create_proof_from_witness(device, params, pk, witness, rng, use_gwc=True, timings=None, instances=()):
+    """plonk/prover.rs:916-1500: the advice columns come from a witness file (formats.witness_fetch), i.e. in the
+    in-memory Montgomery representation"""
+    return create_proof_ext(device, params, pk, witness, rng, use_gwc, timings, instances, montgomery=True)
+
+
+def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=(), montgomery=False):
+    """plonk/prover.rs:206-850.  advice: list of (n, 4) u64 columns, canonical integers (or Montgomery residues with
+    montgomery=True); rows past the usable range are overwritten with blinding values; instances: one list of
+    canonical integers per instance column; rng: a rng.ProverRng.  Returns the proof bytes."""
     import time
 
     D, L = device, device.L
@@ -529,7 +539,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     max_bits = 0
     advice_dev = []
     for col in advice:
-        t = D.upload(col)                                        # canonical; DMA when the column is pinned memory
+        t = D.upload(col)                                        # DMA when the column is pinned memory
+        if montgomery:                                           # find_max_scalar_bits needs the canonical values
+            check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
         D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
         max_bits = max(max_bits, D.max_scalar_bits(t))
         check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")

@@ -168,6 +168,14 @@ size_t h2_logup_scratch_bytes(size_t n);
 int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
 
+/* Compressed G1 points of the SRS file -- Params::{write, read}, poly/commitment.rs:241-294 (`to_bytes` / `from_bytes`
+ * per point; the reference decompresses with a rayon `parallelize`).  32 bytes per point: x little-endian, bit 7 of
+ * byte 31 = parity of the canonical y, identity = zeros (convention of this build: the encoding of pairing_bn256@30b052f
+ * could not be checked).  d_points: n x 64 B affine Montgomery.  Decompress is synchronous and returns H2_ERR_INVALID
+ * when an encoding is not a curve point (the reference unwraps `from_bytes`). */
+int h2_dev_points_decompress(const void *d_bytes, size_t n, void *d_points, void *stream);
+int h2_dev_points_compress(const void *d_points, size_t n, void *d_bytes, void *stream);
+
 /* ---- evaluate_h: the quotient numerator h(X) on the extended coset ------------------------------
  * Evaluator::evaluate_h -- plonk/evaluation.rs:778-1226 (CPU twin) / :1229-1985 (cuda).
  * The Rust side flattens its `Evaluator` (plonk/evaluation.rs:270-296) into this plain descriptor:

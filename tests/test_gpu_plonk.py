@@ -237,3 +237,53 @@ def test_lookup_proof_at_a_multi_workgroup_size_is_accepted(oracle, device):
     proof = prover.create_proof_with_shplonk(device, params, pk, cols_to_arr(adv), ProverRng(3), instances=inst)
     assert rp.verify_proof(vk, proof, instances=inst)
     assert not rp.verify_proof(vk, proof, instances=[[42, 8]])
+
+
+def test_params_file_and_witness_file_round_trip(oracle, device, tmp_path):
+    """N4: Params::{write, read} with device-side point (de)compression, store_witness / fetch_witness, and
+    create_proof_from_witness producing the same bytes as create_proof on the in-memory inputs"""
+    from halo2_gpu_specific_amd import circuits, formats, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+    from halo2_gpu_specific_amd.transcript import point_to_bytes
+    from h2util import arr_to_points, to_mont
+
+    k = 7
+    params = srs(oracle, device, k)
+    path = tmp_path / "params.bin"
+    formats.params_write(device, params, path, additional_data=b"\x01" * 64)
+    raw = path.read_bytes()
+    assert len(raw) == 4 + 2 * 32 * (1 << k) + 4 + 64 and raw[:4] == bytes([k, 0, 0, 0])
+    # the stored encodings, point by point, against the host encoder on the oracle's normalised points
+    g_pts = arr_to_points(device.download(params.g).reshape(-1, 8))
+    for i in (0, 1, 5, (1 << k) - 1):
+        assert raw[4 + 32 * i:4 + 32 * i + 32] == point_to_bytes(g_pts[i])
+    back, extra = formats.params_read(device, path)
+    assert extra == b"\x01" * 64 and back.k == k
+    assert np.array_equal(device.download(back.g), device.download(params.g))
+    assert np.array_equal(device.download(back.g_lagrange), device.download(params.g_lagrange))
+    # a corrupted abscissa is rejected (the reference unwraps from_bytes)
+    bad = bytearray(raw)
+    bad[4 + 32 * 3] ^= 1
+    good_count = 0
+    for tweak in range(1, 6):             # about half of all x are not on the curve: one of a few tweaks must fail
+        bad[4 + 32 * 3 + 1] = (raw[4 + 32 * 3 + 1] + tweak) & 0xFF
+        (tmp_path / "bad.bin").write_bytes(bytes(bad))
+        try:
+            formats.params_read(device, tmp_path / "bad.bin")
+            good_count += 1
+        except Exception as e:  # noqa: BLE001
+            assert "not curve points" in str(e)
+    assert good_count < 5
+    # witness file -> create_proof_from_witness
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    pk = prover.keygen(device, back, circuits.mini_plonk(), fixed, copies)
+    want = prover.create_proof(device, back, pk, adv, ProverRng(6))
+    from h2util import from_mont  # noqa: F401
+
+    mont_cols = [to_mont([int(v) for v in c[:, 0]]) for c in adv]
+    wpath = tmp_path / "witness.bin"
+    formats.witness_store(wpath, k, mont_cols)
+    assert wpath.stat().st_size == 4 + 3 * (32 << k)
+    cols = formats.witness_fetch(wpath, k)
+    assert len(cols) == 3 and np.array_equal(cols[1], mont_cols[1])
+    assert prover.create_proof_from_witness(device, back, pk, cols, ProverRng(6)) == want
