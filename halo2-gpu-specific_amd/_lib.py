@@ -94,6 +94,15 @@ def lib():
                 "libhalo2_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C halo2-gpu-specific_amd/csrc`; there is no CPU fallback" % path
             )
+        # torch ships its own HIP runtime; when both live in one process torch has to initialise first, then the
+        # library binds to the same runtime instance (the other order leaves one of them without a device)
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
