@@ -399,10 +399,22 @@ __global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const ui
         if (e == bnext) {  // bucket boundary inside the slice (rare: once per ~n/2^(c-1) entries)
             xyzz_store(partials + (b + s), acc);
             acc = xyzz_identity();
-            do {
-                b++;
+            b++;
+            bnext = starts[b + 1];
+            if (bnext == e) {
+                // a run of empty buckets (sparse columns: a few distinct values spread over 2^(c-1) buckets): locate the
+                // bucket that owns entry e by bisection instead of walking the run one dependent load at a time
+                uint32_t l2 = b, h2 = nbt;  // starts[l2] <= e < starts[h2]
+                while (h2 - l2 > 1) {
+                    uint32_t mid = (l2 + h2) >> 1;
+                    if (starts[mid] <= e)
+                        l2 = mid;
+                    else
+                        h2 = mid;
+                }
+                b = l2;
                 bnext = starts[b + 1];
-            } while (bnext == e);  // skip empty buckets
+            }
         }
         uint32_t ref = sorted[e];
         Affine p = affine_load(bases + (ref & ~SIGN_BIT));
@@ -662,6 +674,21 @@ int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hi
     return H2_OK;
 }
 
+// The per-window partial sums (W * G points, tens of KB) go back to the host through a store kernel into mapped pinned
+// memory rather than hipMemcpyAsync: a DMA-engine copy queues behind whatever bulk transfer is in flight (the prover
+// uploads the next witness column while it commits the current one) and would stall the MSM for the whole transfer.
+__global__ void __launch_bounds__(256) k_export(const uint4* src, uint4* dst, size_t count16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count16) dst[i] = src[i];
+}
+
+static void export_to_host(const XYZZ* d_src, XYZZ* h_dst, size_t count, hipStream_t stream) {
+    const size_t count16 = count * sizeof(XYZZ) / 16;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((count16 + 255) / 256)), dim3(256), 0, stream, (const uint4*)d_src,
+                       (uint4*)h_dst, count16);
+    H2_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- drivers
 void msm_identity(uint64_t out_xyz[12]) {
     Jacobian j = xyzz_to_jacobian(xyzz_identity());
@@ -737,10 +764,12 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         return H2_ERR_INVALID;
     }
     msm_launch(s, d_scalars, (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
-    std::vector<XYZZ> winpart((size_t)s.W * s.G);
-    H2_HIP(hipMemcpyAsync(winpart.data(), (char*)d_scratch + s.off_winpart, winpart.size() * sizeof(XYZZ),
-                          hipMemcpyDeviceToHost, stream));
+    const size_t wp = (size_t)s.W * s.G;
+    static thread_local PinnedBuf staging;  // per calling thread: this entry point takes no context lock
+    XYZZ* h_win = (XYZZ*)staging.get(wp * sizeof(XYZZ));
+    export_to_host((const XYZZ*)((char*)d_scratch + s.off_winpart), h_win, wp, stream);
     H2_HIP(hipStreamSynchronize(stream));
+    std::vector<XYZZ> winpart(h_win, h_win + wp);
     msm_host_tail(s, winpart, out_xyz);
     return H2_OK;
 }
@@ -777,7 +806,7 @@ int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, c
         char* scratch = (char*)d_scratch + (i & 1) * per;
         hipStream_t q = st[i & 1];
         msm_launch(s, d_scalars[i], (const Affine*)d_bases, max_bits, scratch, q);
-        H2_HIP(hipMemcpyAsync(h_win + i * wp, scratch + s.off_winpart, wp * sizeof(XYZZ), hipMemcpyDeviceToHost, q));
+        export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp, wp, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         H2_HIP(hipEventRecord(done[i], q));
     }

@@ -81,6 +81,7 @@ class Device:
         torch.cuda.set_device(self.dev)
         self.L = lib()
         self.tstream = torch.cuda.Stream(device=self.dev)
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.stream = _vp(self.tstream.cuda_stream)
         self._scratch = None
         self._pinned = {}
@@ -110,6 +111,21 @@ class Device:
             with warnings.catch_warnings():      # read-only sources (a memory-mapped witness file) are only read
                 warnings.simplefilter("ignore", UserWarning)
                 return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+
+    def upload_async(self, a):
+        """-> (device tensor, event or None): a pinned source is copied by DMA on the copy stream and the event marks
+        its arrival; anything else goes through the synchronous path"""
+        a = np.ascontiguousarray(a)
+        src = self._pinned.get(a.ctypes.data)
+        if src is None or src.numel() != a.size:
+            return self.upload(a), None
+        torch = self.torch
+        with torch.cuda.stream(self.copy_stream):
+            t = src.to(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        t.record_stream(self.tstream)          # allocated under the copy stream, consumed on the compute stream
+        return t, ev
 
     def download(self, t):
         with self.torch.cuda.stream(self.tstream):
@@ -536,18 +552,19 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     instance_polys = [D.intt(D.clone(t), dom) for t in instance_dev]
 
     # ---- advice columns: blinding rows, bounded commitments (prover.rs:255-312) ----------------------------
-    max_bits = 0
+    # Every column is queued for upload on the copy stream first (DMA when it lives in pinned memory); column i is then
+    # blinded, measured and committed while columns i+1.. are still in flight.  Per-column max_bits, as the reference.
     advice_dev = []
-    for col in advice:
-        t = D.upload(col)                                        # DMA when the column is pinned memory
+    for t, arrived in [D.upload_async(col) for col in advice]:
+        if arrived is not None:
+            D.tstream.wait_event(arrived)
         if montgomery:                                           # find_max_scalar_bits needs the canonical values
             check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
         D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
-        max_bits = max(max_bits, D.max_scalar_bits(t))
+        max_bits = D.max_scalar_bits(t)
         check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+        transcript.write_point(D.msm(t, params.g_lagrange, n, max(max_bits, 1)))
         advice_dev.append(t)
-    for P in D.msm_batch(advice_dev, params.g_lagrange, n, max(max_bits, 1)):
-        transcript.write_point(P)
     mark("advice commit")
     theta = transcript.squeeze_challenge_scalar()
 
