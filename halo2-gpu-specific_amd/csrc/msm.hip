@@ -47,7 +47,8 @@ static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce thread
 static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
 
 struct MsmShape {
-    uint32_t c, W, nb, nbt, G;  // window bits, windows, buckets/window, total buckets, reduce groups/window
+    uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, reduce groups/window
+    uint32_t Wt;                // windows the pipeline runs: W, + 1 when a dominant scalar has its own window (see k_digits)
     uint32_t log_s;             // slice length S = 2^log_s entries
     uint32_t lo_bits, hi_bits;  // bucket id = hi (partition inside the window) : lo (bin inside the partition)
     uint32_t np;                // partitions = W << hi_bits
@@ -59,7 +60,7 @@ struct MsmShape {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static MsmShape msm_shape(size_t n, uint32_t max_bits) {
+static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot) {
     MsmShape s{};
     if (max_bits > 254) max_bits = 254;
     if (max_bits == 0) max_bits = 1;
@@ -81,11 +82,12 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     }
     s.c = best_c;
     s.W = (max_bits + 1 + s.c - 1) / s.c;
+    s.Wt = s.W + (hot ? 1u : 0u);
     s.nb = 1u << (s.c - 1);
-    s.nbt = s.W * s.nb;
+    s.nbt = s.Wt * s.nb;
     uint32_t per_group = REDUCE_T * REDUCE_M;
     s.G = (s.nb + per_group - 1) / per_group;
-    s.entries = n * s.W;
+    s.entries = n * s.Wt;
     // slice length: aim at >= 2^18 slices (one resident round of the chip at 4 waves/SIMD), 8 <= S <= 64
     s.log_s = 6;
     while (s.log_s > 3 && (s.entries >> s.log_s) < (1u << 18)) s.log_s--;
@@ -97,9 +99,9 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     // high bits select one of 2^hi_bits partitions per window (k_partition); W << hi_bits <= 16384 so
     // the per-workgroup partition histogram of k_digits fits in 64 KiB of LDS
     s.lo_bits = (s.c - 1 < 8) ? (s.c - 1) : 8;
-    while (((size_t)s.W << (s.c - 1 - s.lo_bits)) > 16384) s.lo_bits++;
+    while (((size_t)s.Wt << (s.c - 1 - s.lo_bits)) > 16384) s.lo_bits++;
     s.hi_bits = s.c - 1 - s.lo_bits;
-    s.np = s.W << s.hi_bits;
+    s.np = s.Wt << s.hi_bits;
     s.max_items = (s.entries >> s.log_s) + s.nbt + 2;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -117,14 +119,17 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits) {
     s.off_heavy = take(((size_t)s.nbt + 2) * 4);
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
-    s.off_winpart = take((size_t)s.W * s.G * sizeof(XYZZ));
+    s.off_winpart = take((size_t)s.Wt * s.G * sizeof(XYZZ));
     s.total = o;
     return s;
 }
 
-size_t msm_scratch_bytes(size_t n, uint32_t max_bits) { return msm_shape(n, max_bits).total; }
+// sized for the larger of the two shapes (with the extra window of a dominant scalar)
+size_t msm_scratch_bytes(size_t n, uint32_t max_bits) {
+    return std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
+}
 void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
-    MsmShape s = msm_shape(n, max_bits);
+    MsmShape s = msm_shape(n, max_bits, false);
     if (c) *c = s.c;
     if (windows) *windows = s.W;
     if (buckets_per_window) *buckets_per_window = s.nb;
@@ -134,17 +139,35 @@ void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows
 // One thread per scalar (grid-stride): Montgomery -> canonical, signed c-bit digits, keys[w][i] =
 // bucket | sign (KEY_INVALID for a zero digit), and the histogram of (window, bucket >> lo_bits)
 // partitions, privatised in LDS and flushed once per workgroup.
+//
+// Dominant scalar.  Committed columns are often constant over most rows -- a grand-product / grand-sum column over
+// the padding rows of a circuit, a default value -- and Pippenger would pay W additions for each of those rows.  When
+// sampling finds a value v on >= 1/4 of the rows (`hot_on`), the rows holding v contribute no digits at all; instead
+// they enter bucket 0 of one extra window (index W), whose sum E = sum of their points is multiplied by v once on the
+// host: sum_i s_i P_i = sum_{s_i != v} s_i P_i + v * E.  One addition per such row instead of W.
 extern __shared__ __attribute__((aligned(16))) uint32_t h2_msm_smem[];
 
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
-                                                uint32_t* keys, uint32_t* pcount) {
+                                                uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot) {
     uint32_t* hist = h2_msm_smem;
     for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = fp_from_mont(fp_load(scalars + i));  // canonical little-endian integer (to_repr, arithmetic.rs:21)
+        const Fr raw = fp_load(scalars + i);
+        if (hot_on) {  // wave-uniform branch
+            const bool is_hot = fp_eq(raw, hot);
+            const uint64_t m = __ballot(is_hot);
+            if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
+                atomicAdd(&hist[W << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
+            keys[(size_t)W * n + i] = is_hot ? 0u : KEY_INVALID;
+            if (is_hot) {
+                for (uint32_t w = 0; w < W; w++) keys[(size_t)w * n + i] = KEY_INVALID;
+                continue;
+            }
+        }
+        Fr s = fp_from_mont(raw);  // canonical little-endian integer (to_repr, arithmetic.rs:21)
         // keep only the low max_bits bits (multiexp_bound contract)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -304,11 +327,18 @@ __device__ __forceinline__ uint32_t lds_count_aggregated(uint32_t* bins, uint32_
 
 __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
                                                         uint32_t hi_bits, uint32_t nb, uint32_t skew_threshold,
-                                                        uint32_t* starts, uint32_t* sorted) {
+                                                        uint32_t hot_partition, uint32_t* starts, uint32_t* sorted) {
     uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
     __shared__ uint32_t sh[4];
     const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
     const uint32_t e0 = pbase[p], e1 = pbase[p + 1];
+    if (p == hot_partition) {
+        // the dominant scalar's window: every entry sits in bin 0, so there is nothing to sort -- k_copy_hot moves the
+        // references with the whole chip instead of this one workgroup; only the bucket starts are written here
+        const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
+        for (uint32_t b = threadIdx.x; b < nbins; b += SORT_T) starts[(size_t)w * nb + ((hi << lo_bits) | b)] = b ? e1 : e0;
+        return;
+    }
     const bool skewed = (e1 - e0) > skew_threshold;  // uniform over the workgroup
     for (uint32_t k = threadIdx.x; k < nbins; k += SORT_T) bins[k] = 0;
     __syncthreads();
@@ -372,6 +402,12 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_copy_hot(const uint2* tmp, const uint32_t* pbase, uint32_t hot_partition,
+                                                  uint32_t* sorted) {
+    const uint32_t e0 = pbase[hot_partition], e1 = pbase[hot_partition + 1];
+    for (uint32_t e = e0 + blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += gridDim.x * blockDim.x) sorted[e] = tmp[e].x;
 }
 
 // ---------------------------------------------------------------- k_acc_slice (hot loop)
@@ -689,14 +725,45 @@ static void export_to_host(const XYZZ* d_src, XYZZ* h_dst, size_t count, hipStre
     H2_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------- dominant-scalar detection
+static constexpr uint32_t HOT_SAMPLES = 64;
+static constexpr uint32_t HOT_MIN = 16;  // a value on >= 16 of 64 sampled rows gets its own window
+
+__global__ void __launch_bounds__(HOT_SAMPLES) k_sample(const Fr* scalars, size_t n, Fr* out) {
+    size_t idx = ((size_t)threadIdx.x * 0x9E3779B1ull + 0x7F4A7C15ull) % n;
+    fp_store(out + threadIdx.x, fp_load(scalars + idx));
+}
+
+struct Hot {
+    bool on = false;
+    Fr value{};  // Montgomery form, as stored in the column
+};
+
+static Hot detect_hot(const Fr* samples) {
+    Hot h;
+    uint32_t best = 0;
+    for (uint32_t i = 0; i < HOT_SAMPLES; i++) {
+        uint32_t cnt = 0;
+        for (uint32_t j = 0; j < HOT_SAMPLES; j++) cnt += fp_eq(samples[i], samples[j]) ? 1u : 0u;
+        if (cnt > best && !fp_is_zero(samples[i])) {  // zero scalars are free already
+            best = cnt;
+            h.value = samples[i];
+        }
+    }
+    h.on = best >= HOT_MIN;
+    if (const char* env = getenv("H2_MSM_NO_HOT"))
+        if (env[0] == '1') h.on = false;
+    return h;
+}
+
 // ---------------------------------------------------------------- drivers
 void msm_identity(uint64_t out_xyz[12]) {
     Jacobian j = xyzz_to_jacobian(xyzz_identity());
     memcpy(out_xyz, &j, 96);
 }
 
-static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_bases, uint32_t max_bits, char* scratch,
-                       hipStream_t stream) {
+static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, const Affine* d_bases, uint32_t max_bits,
+                       char* scratch, hipStream_t stream) {
     uint32_t* keys = (uint32_t*)(scratch + s.off_keys);
     uint32_t* sorted = (uint32_t*)(scratch + s.off_sorted);
     uint2* tmp = (uint2*)(scratch + s.off_tmp);
@@ -714,14 +781,17 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
     unsigned nblk = (unsigned)((s.n + 255) / 256);
     unsigned dblk = nblk < 1024 ? nblk : 1024;  // grid-stride: one LDS histogram flush per workgroup
     hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
-                       max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount);
+                       max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
+                       hot.value);
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
-    hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.W), dim3(256),
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wt), dim3(256),
                        (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
+    const uint32_t hot_partition = hot.on ? (s.W << s.hi_bits) : 0xffffffffu;
     hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
-                       s.hi_bits, s.nb, skew_threshold, starts, sorted);
+                       s.hi_bits, s.nb, skew_threshold, hot_partition, starts, sorted);
+    if (hot.on) hipLaunchKernelGGL(k_copy_hot, dim3(2048), dim3(256), 0, stream, tmp, pbase, hot_partition, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
                        s.log_s, partials);
@@ -731,18 +801,29 @@ static void msm_launch(const MsmShape& s, const Fr* d_scalars, const Affine* d_b
                        heavy);
     hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
-    hipLaunchKernelGGL(k_reduce, dim3(s.G, s.W), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
+    hipLaunchKernelGGL(k_reduce, dim3(s.G, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
     H2_HIP(hipGetLastError());
 }
 
 // host tail: add the G partials of each window, then Horner over the windows
-static void msm_host_tail(const MsmShape& s, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12]) {
+static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12]) {
     XYZZ acc = xyzz_identity();
     for (int w = (int)s.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < s.c; k++) acc = xyzz_double(acc);
         XYZZ ws = xyzz_identity();
         for (uint32_t g = 0; g < s.G; g++) ws = xyzz_add(ws, winpart[(size_t)w * s.G + g]);
         acc = xyzz_add(acc, ws);
+    }
+    if (hot.on) {  // + v * E, E = the extra window's sum (bucket 0 carries weight 1)
+        XYZZ e = xyzz_identity();
+        for (uint32_t g = 0; g < s.G; g++) e = xyzz_add(e, winpart[(size_t)s.W * s.G + g]);
+        const Fr v = fp_from_mont(hot.value);
+        XYZZ r = xyzz_identity();
+        for (int bit = 253; bit >= 0; bit--) {
+            r = xyzz_double(r);
+            if ((v.l[bit >> 5] >> (bit & 31)) & 1) r = xyzz_add(r, e);
+        }
+        acc = xyzz_add(acc, r);
     }
     Jacobian j = xyzz_to_jacobian(acc);
     memcpy(out_xyz, &j, 96);
@@ -758,19 +839,24 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         set_last_error("h2 msm: n must be < 2^31");
         return H2_ERR_INVALID;
     }
-    MsmShape s = msm_shape(n, max_bits);
-    if (!d_scratch || scratch_bytes < s.total) {
+    if (!d_scratch || scratch_bytes < msm_scratch_bytes(n, max_bits)) {
         set_last_error("h2 msm: scratch too small (see h2_msm_scratch_bytes)");
         return H2_ERR_INVALID;
     }
-    msm_launch(s, d_scalars, (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
-    const size_t wp = (size_t)s.W * s.G;
     static thread_local PinnedBuf staging;  // per calling thread: this entry point takes no context lock
+    // 64 sampled scalars decide whether a dominant value gets its own window
+    Fr* h_samples = (Fr*)staging.get(HOT_SAMPLES * sizeof(Fr));
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars, n, (Fr*)h_samples);
+    H2_HIP(hipStreamSynchronize(stream));
+    const Hot hot = detect_hot(h_samples);
+    MsmShape s = msm_shape(n, max_bits, hot.on);
+    msm_launch(s, hot, d_scalars, (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
+    const size_t wp = (size_t)s.Wt * s.G;
     XYZZ* h_win = (XYZZ*)staging.get(wp * sizeof(XYZZ));
     export_to_host((const XYZZ*)((char*)d_scratch + s.off_winpart), h_win, wp, stream);
     H2_HIP(hipStreamSynchronize(stream));
     std::vector<XYZZ> winpart(h_win, h_win + wp);
-    msm_host_tail(s, winpart, out_xyz);
+    msm_host_tail(s, hot, winpart, out_xyz);
     return H2_OK;
 }
 
@@ -790,32 +876,39 @@ int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, c
         set_last_error("h2 msm: n must be < 2^31");
         return H2_ERR_INVALID;
     }
-    MsmShape s = msm_shape(n, max_bits);
-    const size_t per = align_up(s.total, 256);
+    const size_t per = align_up(msm_scratch_bytes(n, max_bits), 256);
     if (!d_scratch || scratch_bytes < 2 * per) {
         set_last_error("h2 msm batch: scratch too small (need 2 x h2_msm_scratch_bytes, 256-byte aligned)");
         return H2_ERR_INVALID;
     }
-    const size_t wp = (size_t)s.W * s.G;
-    // pinned staging for the per-MSM window partials (async read-back)
-    XYZZ* h_win = (XYZZ*)ctx->pinned.get(count * wp * sizeof(XYZZ));
+    const MsmShape shapes[2] = {msm_shape(n, max_bits, false), msm_shape(n, max_bits, true)};
+    const size_t wp_max = (size_t)shapes[1].Wt * shapes[1].G;
+    // pinned staging: the sampled scalars of every column, then the per-MSM window partials (async read-back)
+    char* pinned = (char*)ctx->pinned.get(count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ)));
+    Fr* h_samples = (Fr*)pinned;
+    XYZZ* h_win = (XYZZ*)(pinned + count * HOT_SAMPLES * sizeof(Fr));
     hipStream_t st[2] = {ctx->stream, ctx->copy_stream};
-    H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete
+    for (size_t i = 0; i < count; i++)
+        hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[i], n, h_samples + i * HOT_SAMPLES);
+    H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
+    std::vector<Hot> hots(count);
+    for (size_t i = 0; i < count; i++) hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);
     std::vector<hipEvent_t> done(count);
     for (size_t i = 0; i < count; i++) {
+        const MsmShape& s = shapes[hots[i].on ? 1 : 0];
         char* scratch = (char*)d_scratch + (i & 1) * per;
         hipStream_t q = st[i & 1];
-        msm_launch(s, d_scalars[i], (const Affine*)d_bases, max_bits, scratch, q);
-        export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp, wp, q);
+        msm_launch(s, hots[i], d_scalars[i], (const Affine*)d_bases, max_bits, scratch, q);
+        export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         H2_HIP(hipEventRecord(done[i], q));
     }
-    std::vector<XYZZ> winpart(wp);
     for (size_t i = 0; i < count; i++) {
+        const MsmShape& s = shapes[hots[i].on ? 1 : 0];
         H2_HIP(hipEventSynchronize(done[i]));
         H2_HIP(hipEventDestroy(done[i]));
-        memcpy(winpart.data(), h_win + i * wp, wp * sizeof(XYZZ));
-        msm_host_tail(s, winpart, out_xyz + 12 * i);
+        std::vector<XYZZ> winpart(h_win + i * wp_max, h_win + i * wp_max + (size_t)s.Wt * s.G);
+        msm_host_tail(s, hots[i], winpart, out_xyz + 12 * i);
     }
     return H2_OK;
 }

@@ -2,6 +2,8 @@
 the committed golden vectors.  Bit-exact: everything here is integer / finite-field work.
 MSM results are compared after affine normalisation (the reference's own `==` on C::Curve is
 projective-aware, poly/commitment.rs:494)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -363,3 +365,55 @@ def test_concurrent_callers(oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n", [64, 1000, 1 << 13, 70001])
+def test_msm_dominant_scalar(oracle, n):
+    """columns that are constant over most rows (grand products over padding rows): the dominant value gets its own
+    window -- one addition per row and one host scalar multiplication -- and the result is the same group element"""
+    import random
+
+    rnd = random.Random(n)
+    pts = oracle.random_g1(123, n)
+    rand = from_mont(oracle.random_fr(321, n))
+    hot = rnd.randrange(R_MOD)
+    cases = {
+        "7/8 hot": [hot if i >= n // 8 else rand[i] for i in range(n)],
+        "all hot": [hot] * n,
+        "hot = r - 1": [R_MOD - 1 if i % 4 else rand[i] for i in range(n)],
+        "hot = 1, rest zero": [1 if i % 3 else 0 for i in range(n)],
+        "two frequent values": [(hot, 77, rand[i])[i % 3] for i in range(n)],
+        "30 % hot, interleaved": [hot if (i * 7) % 10 < 3 else rand[i] for i in range(n)],
+        "hot small, 16-bit bound": [5 if i % 8 else (i * 31) % 65536 for i in range(n)],
+    }
+    for name, vals in cases.items():
+        scalars = to_mont(vals)
+        want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+        bits = 16 if "16-bit" in name else 254
+        assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, bits)) == want, name
+        assert _affine(oracle, ar.gpu_multiexp_bound(scalars, pts, bits)) == want, name + " (multi)"
+
+
+def test_msm_batch_mixes_dominant_and_uniform_columns(oracle):
+    import torch
+
+    L = h2.lib()
+    n = 1 << 12
+    pts = oracle.random_g1(55, n)
+    rand = [from_mont(oracle.random_fr(60 + j, n)) for j in range(4)]
+    cols = [
+        to_mont(rand[0]),
+        to_mont([0xABCDEF0123456789 if i > 100 else rand[1][i] for i in range(n)]),
+        to_mont(rand[2]),
+        to_mont([3] * n),
+        to_mont([rand[3][0] if i % 2 else rand[3][i] for i in range(n)]),
+    ]
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    per = (L.h2_msm_scratch_bytes(n, 254) + 255) // 256 * 256
+    scratch = torch.empty(2 * per, dtype=torch.uint8, device="cuda")
+    ptrs = (ctypes.c_void_p * len(cols))(*[t.data_ptr() for t in d_cols])
+    out = np.zeros((len(cols), 12), dtype=np.uint64)
+    assert L.h2_dev_msm_batch(ptrs, len(cols), d_pts.data_ptr(), n, 254, scratch.data_ptr(), 2 * per, out.ctypes.data, None) == 0
+    for j, c in enumerate(cols):
+        assert _affine(oracle, out[j]) == _affine(oracle, oracle.best_multiexp(c, pts)), j

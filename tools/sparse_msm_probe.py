@@ -1,20 +1,55 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
-import torch; torch.cuda.init()
-from halo2_gpu_specific_amd import circuits, prover
-from halo2_gpu_specific_amd._lib import check
-k = 22; n = 1 << k
-D = prover.Device(); L = D.L
+"""MSM timing on the scalar distributions a proof actually commits (one MI355X):
+   uniform | sparse small values (a witness column) | mostly-constant 254-bit (a grand-product column with padding rows)
+usage: python tools/sparse_msm_probe.py [k]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+torch.cuda.init()
+import numpy as np  # noqa: E402
+
+from halo2_gpu_specific_amd import prover  # noqa: E402
+from halo2_gpu_specific_amd._lib import check  # noqa: E402
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+n = 1 << k
+D = prover.Device()
+L = D.L
 params = prover.Params.synthetic(D, k)
-adv, fixed, copies = circuits.mini_plonk_synthesize(k, alloc=D.pinned_columns)
-def once(name, f):
-    D.sync(); t0 = time.perf_counter(); r = f(); D.sync(); print("%-44s %.2f ms" % (name, (time.perf_counter() - t0) * 1e3)); return r
-for rep in range(2):
-    for ci in range(3):
-        t, ev = D.upload_async(adv[ci]); D.tstream.wait_event(ev); D.sync(); ev.synchronize()
-        once("col %d msm raw canonical (no mont) bits16" % ci, lambda: D.msm(t, params.g_lagrange, n, 16))
-        D.set_rows_raw(t, n - 6, [60000, 2, 3, 4, 5, 6])
-        b = D.max_scalar_bits(t); print("bits", b)
-        check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "m")
-        once("col %d msm after mont, bits=%d" % (ci, b), lambda: D.msm(t, params.g_lagrange, n, b))
-        once("col %d msm again" % ci, lambda: D.msm(t, params.g_lagrange, n, b))
+
+
+def timed(name, col, bits, reps=3):
+    D.msm(col, params.g_lagrange, n, bits)
+    D.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        D.msm(col, params.g_lagrange, n, bits)
+    D.sync()
+    print("%-52s %7.2f ms" % (name, (time.perf_counter() - t0) / reps * 1e3))
+
+
+uniform = D.empty(n)
+check(L.h2_dev_random_fr(1, n, uniform.data_ptr(), D.stream), "rnd")
+timed("uniform 254-bit", uniform, 254)
+small = np.zeros((n, 4), dtype=np.uint64)
+small[: n // 8, 0] = np.tile(np.array([5, 25, 30, 5], dtype=np.uint64), n // 32)
+small[n - 6:, 0] = [60000, 12345, 3, 40000, 5, 65535]
+t = D.upload(small)
+check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "mont")
+timed("sparse small values (16-bit bound)", t, 16)
+timed("sparse small values (254-bit bound)", t, 254)
+mostly = D.clone(uniform)
+with torch.cuda.stream(D.tstream):
+    mostly[n // 8:] = mostly[0]
+timed("7/8 of the rows one 254-bit value", mostly, 254)
+with torch.cuda.stream(D.tstream):
+    mostly[:] = mostly[0]
+timed("every row the same 254-bit value", mostly, 254)
+boolean = np.zeros((n, 4), dtype=np.uint64)
+boolean[::2, 0] = 1
+t = D.upload(boolean)
+check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "mont")
+timed("boolean column (254-bit bound)", t, 254)
