@@ -420,10 +420,6 @@ def keygen(device, params, cs, fixed, copies):
     return pk
 
 
-def _column(kind, idx, advice, fixed):
-    return {"advice": advice, "fixed": fixed}[kind][idx]
-
-
 def _intermediate_sets(queries):
     """construct_intermediate_sets (poly/multiopen/shplonk.rs:58-135) on (key, rotation, point, eval) tuples:
     BTreeMap / BTreeSet iteration orders become sorted()."""
