@@ -290,3 +290,24 @@ def test_params_file_and_witness_file_round_trip(oracle, device, tmp_path):
     cols = formats.witness_fetch(wpath, k)
     assert len(cols) == 3 and np.array_equal(cols[1], mont_cols[1])
     assert prover.create_proof_from_witness(device, back, pk, cols, ProverRng(6)) == want
+
+
+def test_device_prover_reproduces_committed_proofs(oracle, device):
+    """the committed proof fixtures (tests/golden/proof_kat.json, made by the reference prover): same bytes from the
+    device prover"""
+    from h2util import load_golden
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+    from test_plonk_host import _golden_case
+
+    product_cs = {"mini-plonk": circuits.mini_plonk, "rot-gate": rot_gate_cs, "lookup-shuffle": lookup_shuffle_cs}
+    for case in load_golden("proof_kat.json"):
+        assert int(case["trapdoor"], 16) == S_TRAPDOOR
+        _, adv, fixed, copies, inst = _golden_case(case)
+        params = srs(oracle, device, case["k"])
+        pk = prover.keygen(device, params, product_cs[case["circuit"]](), cols_to_arr(fixed),
+                           [(l[0], l[1], r[0], r[1]) for l, r in copies])
+        assert pk.transcript_repr == int(case["vk_digest"], 16)
+        proof = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(case["seed"]),
+                                        case["scheme"] == "gwc", instances=inst)
+        assert proof.hex() == case["proof"], (case["circuit"], case["scheme"])

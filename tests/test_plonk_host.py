@@ -380,3 +380,24 @@ def test_chunk_shuffles_first_fit():
     cs.set_minimum_degree(6)
     cs.chunk_shuffles()
     assert [[u[0] for u in g] for g in cs.shuffles] == [["a", "b", "c"], ["d"]]
+
+
+def _golden_case(case):
+    cs = {"mini-plonk": rp.MiniPlonk, "rot-gate": rp.RotGate, "lookup-shuffle": rp.LookupShuffle}[case["circuit"]]
+    syn = cs.synthesize(case["k"])
+    inst = [[int(v, 16) for v in col] for col in case["instances"]]
+    return cs, syn[0], syn[1], syn[2], inst
+
+
+def test_reference_prover_reproduces_committed_proofs():
+    """tests/golden/proof_kat.json (gen_proof_golden.py): the reference prover's conventions are pinned byte for byte"""
+    from h2util import load_golden
+
+    for case in load_golden("proof_kat.json"):
+        cs, adv, fixed, copies, inst = _golden_case(case)
+        pk = rp.keygen(cs, case["k"], int(case["trapdoor"], 16), fixed, copies)
+        assert pk.transcript_repr == int(case["vk_digest"], 16)
+        gwc = case["scheme"] == "gwc"
+        proof = rp.create_proof(pk, adv, ProverRng(case["seed"]), use_gwc=gwc, instances=inst)
+        assert proof.hex() == case["proof"], (case["circuit"], case["scheme"])
+        assert rp.verify_proof(pk, bytes.fromhex(case["proof"]), use_gwc=gwc, instances=inst)
