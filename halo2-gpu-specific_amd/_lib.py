@@ -54,6 +54,7 @@ SYMBOLS = {
     "h2_msm_shape": (ctypes.c_int, [_sz, _u32, _vp, _vp, _vp]),
     "h2_dev_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
     "h2_dev_msm_batch": (ctypes.c_int, [_vp, _sz, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
+    "h2_dev_msm_batch_ex": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "h2_dev_eval_op": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i32, _i32, _sz, _vp, _vp]),
     "h2_dev_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "h2_dev_batch_mont": (ctypes.c_int, [_vp, _sz, _vp]),

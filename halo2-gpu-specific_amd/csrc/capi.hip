@@ -372,6 +372,17 @@ int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
     });
 }
 
+int h2_dev_msm_batch_ex(const void* const* d_scalars, const void* const* d_bases_each, const uint32_t* max_bits_each,
+                        size_t count, size_t n, void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, void* stream) {
+    if (count && (!d_scalars || !d_bases_each || !max_bits_each || !out_xyz)) return bad("h2_dev_msm_batch_ex: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);  // uses the context's two internal streams and pinned staging
+        return msm_device_batch_ex(ctx, (const Fr* const*)d_scalars, (const uint64_t* const*)d_bases_each, max_bits_each,
+                                   count, nullptr, n, 0, d_scratch, scratch_bytes, out_xyz, pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_points_decompress(const void* d_bytes, size_t n, void* d_points, void* stream) {
     if (n && (!d_bytes || !d_points)) return bad("h2_dev_points_decompress: null argument");
     return guarded([&] {

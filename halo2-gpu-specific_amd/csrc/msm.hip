@@ -867,22 +867,39 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
 // window combine of MSM i runs while the GPU works on i+1, i+2.
 int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, const uint64_t* d_bases, size_t n,
                      uint32_t max_bits, void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream) {
+    return msm_device_batch_ex(ctx, d_scalars, nullptr, nullptr, count, d_bases, n, max_bits, d_scratch, scratch_bytes,
+                               out_xyz, stream);
+}
+
+// bases_each / bits_each (either may be null): per-column base table and scalar bound -- the prover's batches mix
+// g_lagrange with g (the vanishing argument's random polynomial) and 16-bit witness columns with full-width ones
+int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64_t* const* bases_each,
+                        const uint32_t* bits_each, size_t count, const uint64_t* d_bases, size_t n, uint32_t max_bits,
+                        void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream) {
     if (count == 0) return H2_OK;
-    if (n == 0 || max_bits == 0) {
-        for (size_t i = 0; i < count; i++) msm_identity(out_xyz + 12 * i);
-        return H2_OK;
-    }
     if (n > 0x7fffffffu) {
         set_last_error("h2 msm: n must be < 2^31");
         return H2_ERR_INVALID;
     }
-    const size_t per = align_up(msm_scratch_bytes(n, max_bits), 256);
+    uint32_t top_bits = 0;
+    for (size_t i = 0; i < count; i++) top_bits = std::max(top_bits, bits_each ? bits_each[i] : max_bits);
+    if (n == 0 || top_bits == 0) {
+        for (size_t i = 0; i < count; i++) msm_identity(out_xyz + 12 * i);
+        return H2_OK;
+    }
+    size_t per = 0, wp_max = 0;
+    std::vector<MsmShape> shapes(2 * count);
+    for (size_t i = 0; i < count; i++) {
+        const uint32_t bits = bits_each ? bits_each[i] : max_bits;
+        shapes[2 * i] = msm_shape(n, bits ? bits : 1, false);
+        shapes[2 * i + 1] = msm_shape(n, bits ? bits : 1, true);
+        per = std::max(per, align_up(std::max(shapes[2 * i].total, shapes[2 * i + 1].total), 256));
+        wp_max = std::max(wp_max, (size_t)shapes[2 * i + 1].Wt * shapes[2 * i + 1].G);
+    }
     if (!d_scratch || scratch_bytes < 2 * per) {
-        set_last_error("h2 msm batch: scratch too small (need 2 x h2_msm_scratch_bytes, 256-byte aligned)");
+        set_last_error("h2 msm batch: scratch too small (need 2 x h2_msm_scratch_bytes of the widest column, 256-byte aligned)");
         return H2_ERR_INVALID;
     }
-    const MsmShape shapes[2] = {msm_shape(n, max_bits, false), msm_shape(n, max_bits, true)};
-    const size_t wp_max = (size_t)shapes[1].Wt * shapes[1].G;
     // pinned staging: the sampled scalars of every column, then the per-MSM window partials (async read-back)
     char* pinned = (char*)ctx->pinned.get(count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ)));
     Fr* h_samples = (Fr*)pinned;
@@ -893,18 +910,25 @@ int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, c
     H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
     std::vector<Hot> hots(count);
     for (size_t i = 0; i < count; i++) hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);
-    std::vector<hipEvent_t> done(count);
+    std::vector<hipEvent_t> done(count, nullptr);
     for (size_t i = 0; i < count; i++) {
-        const MsmShape& s = shapes[hots[i].on ? 1 : 0];
+        const uint32_t bits = bits_each ? bits_each[i] : max_bits;
+        if (bits == 0) continue;  // identity (arithmetic.rs:346)
+        const MsmShape& s = shapes[2 * i + (hots[i].on ? 1 : 0)];
+        const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
         char* scratch = (char*)d_scratch + (i & 1) * per;
         hipStream_t q = st[i & 1];
-        msm_launch(s, hots[i], d_scalars[i], (const Affine*)d_bases, max_bits, scratch, q);
+        msm_launch(s, hots[i], d_scalars[i], (const Affine*)bases, bits, scratch, q);
         export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         H2_HIP(hipEventRecord(done[i], q));
     }
     for (size_t i = 0; i < count; i++) {
-        const MsmShape& s = shapes[hots[i].on ? 1 : 0];
+        if (!done[i]) {
+            msm_identity(out_xyz + 12 * i);
+            continue;
+        }
+        const MsmShape& s = shapes[2 * i + (hots[i].on ? 1 : 0)];
         H2_HIP(hipEventSynchronize(done[i]));
         H2_HIP(hipEventDestroy(done[i]));
         std::vector<XYZZ> winpart(h_win + i * wp_max, h_win + i * wp_max + (size_t)s.Wt * s.G);

@@ -23,4 +23,7 @@ int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uin
 int random_points_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream);
 int points_decompress_launch(const void* d_bytes, size_t n, uint64_t* d_out, uint32_t* d_bad, hipStream_t stream);
 int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hipStream_t stream);
+int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64_t* const* bases_each,
+                        const uint32_t* bits_each, size_t count, const uint64_t* d_bases, size_t n, uint32_t max_bits,
+                        void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
 }  // namespace h2

@@ -216,8 +216,8 @@ class Device:
         return self.msm_batch([scalars], bases, n, max_bits)[0]
 
     def msm_batch(self, columns, bases, n, max_bits=254, also=None):
-        """one MSM per column over the same bases, pipelined inside the library; `also` = (scalars, other bases) is
-        one more MSM over a different table.  With a process group (one process per GPU, every rank holding the same
+        """one MSM per column over the same bases (max_bits: one bound or one per column), pipelined inside the
+        library; `also` = (scalars, other bases) is one more MSM over a different table in the same pipeline.  With a process group (one process per GPU, every rank holding the same
         polynomials) each MSM is split into contiguous ranges over the ranks -- gpu_multiexp_bound's split
         (arithmetic.rs:413-440) -- and the partial points are all-gathered and folded (parallel.py)."""
         if not columns and not also:
@@ -234,21 +234,26 @@ class Device:
         return [jacobian_to_affine(r) for r in out]
 
     def msm_partial(self, columns, bases, lo, hi, max_bits=254, also=None):
-        """the MSMs restricted to the index range [lo, hi): raw Jacobian results, (count (+1), 12) u64"""
-        count, m = len(columns), hi - lo
-        per = (self.L.h2_msm_scratch_bytes(m, max_bits) + 255) // 256 * 256
-        scratch = self.scratch(2 * per)
-        out = np.zeros((count + (1 if also else 0), 12), dtype=np.uint64)
-        if count == 1:
-            check(self.L.h2_dev_msm(columns[0].data_ptr() + 32 * lo, bases.data_ptr() + 64 * lo, m, max_bits,
-                                    scratch.data_ptr(), per, out.ctypes.data, self.stream), "h2_dev_msm")
-        elif count > 1:
-            ptrs = (_vp * count)(*[c.data_ptr() + 32 * lo for c in columns])
-            check(self.L.h2_dev_msm_batch(ptrs, count, bases.data_ptr() + 64 * lo, m, max_bits, scratch.data_ptr(),
-                                          2 * per, out.ctypes.data, self.stream), "h2_dev_msm_batch")
+        """the MSMs restricted to the index range [lo, hi): raw Jacobian results, (count (+1), 12) u64.
+        max_bits: one bound for every column or a list with one bound per column."""
+        items = [(c, bases, b) for c, b in zip(columns, max_bits if isinstance(max_bits, (list, tuple)) else
+                                               [max_bits] * len(columns))]
         if also:
-            check(self.L.h2_dev_msm(also[0].data_ptr() + 32 * lo, also[1].data_ptr() + 64 * lo, m, max_bits,
-                                    scratch.data_ptr(), per, out[count:].ctypes.data, self.stream), "h2_dev_msm")
+            items.append((also[0], also[1], 254))
+        count, m = len(items), hi - lo
+        per = max((self.L.h2_msm_scratch_bytes(m, b) + 255) // 256 * 256 for b in {b for _, _, b in items})
+        scratch = self.scratch(2 * per)
+        out = np.zeros((count, 12), dtype=np.uint64)
+        if count == 1:
+            c, bs, b = items[0]
+            check(self.L.h2_dev_msm(c.data_ptr() + 32 * lo, bs.data_ptr() + 64 * lo, m, b, scratch.data_ptr(), per,
+                                    out.ctypes.data, self.stream), "h2_dev_msm")
+        elif count > 1:
+            sp = (_vp * count)(*[c.data_ptr() + 32 * lo for c, _, _ in items])
+            bp = (_vp * count)(*[bs.data_ptr() + 64 * lo for _, bs, _ in items])
+            bits = (ctypes.c_uint32 * count)(*[b for _, _, b in items])
+            check(self.L.h2_dev_msm_batch_ex(sp, bp, bits, count, m, scratch.data_ptr(), 2 * per, out.ctypes.data,
+                                             self.stream), "h2_dev_msm_batch_ex")
         return out
 
     # -- elementwise / scans ----------------------------------------------------------------------------
@@ -548,19 +553,27 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     instance_polys = [D.intt(D.clone(t), dom) for t in instance_dev]
 
     # ---- advice columns: blinding rows, bounded commitments (prover.rs:255-312) ----------------------------
-    # Every column is queued for upload on the copy stream first (DMA when it lives in pinned memory); column i is then
-    # blinded, measured and committed while columns i+1.. are still in flight.  Per-column max_bits, as the reference.
+    # Every column is queued for upload on the copy stream first (DMA when it lives in pinned memory); the columns are
+    # then blinded, measured (per-column max_bits, as the reference) and committed in small groups -- one pipelined
+    # batch per group -- while the later groups are still in flight.
+    uploads = [D.upload_async(col) for col in advice]
+    group = max(1, min(4, len(uploads) // 3))
     advice_dev = []
-    for t, arrived in [D.upload_async(col) for col in advice]:
-        if arrived is not None:
-            D.tstream.wait_event(arrived)
-        if montgomery:                                           # find_max_scalar_bits needs the canonical values
-            check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
-        D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
-        max_bits = D.max_scalar_bits(t)
-        check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
-        transcript.write_point(D.msm(t, params.g_lagrange, n, max(max_bits, 1)))
-        advice_dev.append(t)
+    for g0 in range(0, len(uploads), group):
+        cols_, bits_ = [], []
+        for t, arrived in uploads[g0:g0 + group]:
+            if arrived is not None:
+                D.tstream.wait_event(arrived)
+            if montgomery:                                       # find_max_scalar_bits needs the canonical values
+                check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
+            D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
+            bits_.append(max(D.max_scalar_bits(t), 1))
+            check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+            cols_.append(t)
+        for P in D.msm_batch(cols_, params.g_lagrange, n, bits_):
+            transcript.write_point(P)
+        advice_dev += cols_
+    del uploads
     mark("advice commit")
     theta = transcript.squeeze_challenge_scalar()
 

@@ -276,6 +276,12 @@ int h2_dev_msm(const void *d_scalars, const void *d_bases, size_t n, uint32_t ma
  * one's accumulation.  out_xyz: count x 12 u64 in HOST memory.  Synchronous. */
 int h2_dev_msm_batch(const void *const *d_scalars, size_t count, const void *d_bases, size_t n, uint32_t max_bits,
                      void *d_scratch, size_t scratch_bytes, uint64_t *out_xyz, void *stream);
+/* The same pipeline with a base table and a scalar bound PER COLUMN (host arrays of `count` entries): one call commits
+ * 16-bit witness columns next to full-width ones (plonk/prover.rs:293-299 computes max_bits per column) and columns over
+ * g_lagrange next to one over g.  scratch_bytes >= 2 * max over the columns of round_up(h2_msm_scratch_bytes(n, max_bits_each[i]), 256)
+ * (the layout depends on the window size picked for the bound: it is not monotonic in max_bits). */
+int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases_each, const uint32_t *max_bits_each,
+                        size_t count, size_t n, void *d_scratch, size_t scratch_bytes, uint64_t *out_xyz, void *stream);
 int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,
                    const uint64_t c[4], void *stream);
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);

@@ -358,7 +358,7 @@ class LookupShuffle:
             r = (5 * i + 2) % (usable - 1)
             adv[2][i], adv[3][i] = t0[r], t1[r]
             adv[4][i] = u[(i * i) % usable]
-            adv[5][i], adv[6][i] = i + 1, 1000 - i
+            adv[5][i], adv[6][i] = i + 1, (1000 - i) % R
             adv[9][i] = i * i + 5
         for i in range(usable):
             adv[7][i], adv[8][i] = adv[5][usable - 1 - i], adv[6][usable - 1 - i]

@@ -417,3 +417,33 @@ def test_msm_batch_mixes_dominant_and_uniform_columns(oracle):
     assert L.h2_dev_msm_batch(ptrs, len(cols), d_pts.data_ptr(), n, 254, scratch.data_ptr(), 2 * per, out.ctypes.data, None) == 0
     for j, c in enumerate(cols):
         assert _affine(oracle, out[j]) == _affine(oracle, oracle.best_multiexp(c, pts)), j
+
+
+def test_msm_batch_ex_per_column_bases_and_bounds(oracle):
+    """h2_dev_msm_batch_ex: one pipelined call over columns with their own base table and max_bits (16-bit witness
+    columns next to full-width ones, g_lagrange next to g); a zero bound yields the identity"""
+    import torch
+
+    L = h2.lib()
+    n = 1 << 12
+    tables = [oracle.random_g1(91, n), oracle.random_g1(92, n)]
+    small = to_mont([(i * 2654435761) % 65536 for i in range(n)])
+    cols = [oracle.random_fr(93, n), small, oracle.random_fr(94, n), small, oracle.random_fr(95, n)]
+    which = [0, 0, 1, 1, 0]
+    bits = [254, 16, 254, 17, 0]
+    d_tab = [torch.from_numpy(t.view(np.int64)).cuda() for t in tables]
+    d_cols = [torch.from_numpy(np.ascontiguousarray(c).view(np.int64)).cuda() for c in cols]
+    per = max((L.h2_msm_scratch_bytes(n, b) + 255) // 256 * 256 for b in bits)
+    scratch = torch.empty(2 * per, dtype=torch.uint8, device="cuda")
+    count = len(cols)
+    sp = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_cols])
+    bp = (ctypes.c_void_p * count)(*[d_tab[w].data_ptr() for w in which])
+    bb = (ctypes.c_uint32 * count)(*bits)
+    out = np.zeros((count, 12), dtype=np.uint64)
+    assert L.h2_dev_msm_batch_ex(sp, bp, bb, count, n, scratch.data_ptr(), 2 * per, out.ctypes.data, None) == 0, L.h2_last_error()
+    for j in range(count):
+        if bits[j] == 0:
+            assert _affine(oracle, out[j]) == (0, 0)
+        else:
+            assert _affine(oracle, out[j]) == _affine(oracle, oracle.best_multiexp(cols[j], tables[which[j]])), j
+    assert L.h2_dev_msm_batch_ex(sp, bp, bb, count, n, scratch.data_ptr(), per, out.ctypes.data, None) == 1
