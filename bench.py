@@ -175,6 +175,14 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_per_transform / passes,
             "avg_launch_ms": avg_launch_ms,
             "launches_per_transform": passes,
+            "alu": {
+                "bound": "integer multiplier",
+                "achieved_mul_per_s": (log_n / 2.0 + passes) * n / (passes * avg_launch_ms * 1e-3),
+                "peak_mul_per_s": MUL_CEILING,
+                "frac": (log_n / 2.0 + passes) * n / (passes * avg_launch_ms * 1e-3) / MUL_CEILING,
+                "note": "multiplications per transform = (n/2) log2 n butterflies + one inter-pass / scaling twiddle "
+                "per element per pass (the last pass forms its twiddle from two table entries: one more, not counted)",
+            },
             "note": "VALU-bound in practice: ~15n 254-bit Montgomery multiplications per transform against a measured "
             "chip ceiling of 1.31e11 multiplications/s (tools/mulbench.hip, profiles/r1_mulbench.txt); see DESIGN.md",
         },
