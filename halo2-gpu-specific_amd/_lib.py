@@ -62,6 +62,7 @@ SYMBOLS = {
     "h2_dev_random_points": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
     "h2_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
+    "h2_dev_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "h2_batch_invert": (ctypes.c_int, [_vp, _sz]),
     "h2_dev_batch_invert": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "h2_kate_division": (ctypes.c_int, [_vp, _sz, _vp, _vp]),

@@ -449,6 +449,17 @@ int h2_dev_eval_polynomial(const void* d_poly, size_t n, const uint64_t point[4]
     });
 }
 
+int h2_dev_eval_polynomial_batch(const void* const* d_polys, size_t count, size_t n, const uint64_t* points, uint64_t* out,
+                                 void* stream) {
+    if (count && (!d_polys || !points || !out)) return bad("h2_dev_eval_polynomial_batch: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        Fr* tmp = (Fr*)ctx->buf_d.get(eval_polynomial_batch_tmp_bytes(count, n));
+        return eval_polynomial_batch_launch((const Fr* const*)d_polys, count, n, points, tmp, out, pick_stream(ctx, stream));
+    });
+}
+
 int h2_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]) {
     if (!point || !out || (n && !poly)) return bad("h2_eval_polynomial: null argument");
     return guarded([&] {

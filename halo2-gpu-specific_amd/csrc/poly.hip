@@ -181,13 +181,9 @@ __global__ void __launch_bounds__(256) k_eval_poly(EvalPolyArgs a) {
 }
 
 // result (host) = sum_i poly[i] * x^i.  d_tmp: ceil(n / 4096) + ceil(n / 4096^2) + 2 elements of scratch.
-int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],
-                           hipStream_t stream) {
+// enqueue the levels of one evaluation; the value lands in d_tmp's last level, whose address is returned
+static Fr* eval_polynomial_enqueue(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, hipStream_t stream) {
     Fr x = fr_host(point);
-    if (n == 0) {
-        memset(out, 0, 32);
-        return H2_OK;
-    }
     const Fr* in = d_poly;
     Fr* dst = d_tmp;
     size_t cnt = n;
@@ -212,10 +208,55 @@ int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], 
         dst = dst + blocks;
         cnt = blocks;
     }
+    return dst;
+}
+
+int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],
+                           hipStream_t stream) {
+    if (n == 0) {
+        memset(out, 0, 32);
+        return H2_OK;
+    }
+    Fr* dst = eval_polynomial_enqueue(d_poly, n, point, d_tmp, stream);
     H2_HIP(hipGetLastError());
     H2_HIP(hipMemcpyAsync(out, dst, 32, hipMemcpyDeviceToHost, stream));
     H2_HIP(hipStreamSynchronize(stream));
     return H2_OK;
+}
+
+// `count` evaluations (polynomial j at point j) enqueued back to back, one read-back and one synchronisation for all
+// of them: the prover evaluates every committed polynomial at x, omega x, ... (plonk/prover.rs:700-790, a rayon
+// par_iter over eval_polynomial_st there).  d_tmp: count * eval_polynomial_tmp_elems(n) elements.
+__global__ void __launch_bounds__(64) k_gather_results(const Fr* const* slots, uint32_t count, Fr* out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) fp_store(out + j, fp_load(slots[j]));
+}
+
+int eval_polynomial_batch_launch(const Fr* const* d_polys, size_t count, size_t n, const uint64_t* points, Fr* d_tmp,
+                                 uint64_t* out, hipStream_t stream) {
+    if (count == 0) return H2_OK;
+    if (n == 0) {
+        memset(out, 0, 32 * count);
+        return H2_OK;
+    }
+    const size_t per = eval_polynomial_tmp_elems(n);
+    std::vector<const Fr*> slots(count);
+    for (size_t j = 0; j < count; j++)
+        slots[j] = eval_polynomial_enqueue(d_polys[j], n, points + 4 * j, d_tmp + j * per, stream);
+    H2_HIP(hipGetLastError());
+    // gather the result slots: pointer table and packed results live behind the per-evaluation scratch
+    const Fr** d_slots = (const Fr**)(d_tmp + count * per);
+    Fr* d_out = (Fr*)(d_slots + count + (count & 1));  // keep 16-byte alignment
+    H2_HIP(hipMemcpyAsync(d_slots, slots.data(), count * sizeof(Fr*), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_gather_results, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, d_slots, (uint32_t)count,
+                       d_out);
+    H2_HIP(hipMemcpyAsync(out, d_out, 32 * count, hipMemcpyDeviceToHost, stream));
+    H2_HIP(hipStreamSynchronize(stream));  // also keeps `slots` alive until the upload has been consumed
+    return H2_OK;
+}
+
+size_t eval_polynomial_batch_tmp_bytes(size_t count, size_t n) {
+    return count * eval_polynomial_tmp_elems(n ? n : 1) * sizeof(Fr) + (count + 2) * sizeof(void*) + count * sizeof(Fr) + 64;
 }
 
 size_t eval_polynomial_tmp_elems(size_t n) {

@@ -10,6 +10,9 @@ int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream);
 int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],
                            hipStream_t stream);
 size_t eval_polynomial_tmp_elems(size_t n);
+int eval_polynomial_batch_launch(const Fr* const* d_polys, size_t count, size_t n, const uint64_t* points, Fr* d_tmp,
+                                 uint64_t* out, hipStream_t stream);
+size_t eval_polynomial_batch_tmp_bytes(size_t count, size_t n);
 int batch_invert_launch(Fr* d_a, Fr* d_tmp, size_t n, hipStream_t stream);
 int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size_t count, size_t size, hipStream_t stream);
 int perm_sigma_launch(Fr* out, const uint32_t* map_col, const uint32_t* map_row, size_t n, const uint64_t delta[4],

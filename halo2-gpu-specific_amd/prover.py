@@ -269,6 +269,18 @@ class Device:
         check(self.L.h2_dev_eval_polynomial(t.data_ptr(), n, _fr(x), out, self.stream), "h2_dev_eval_polynomial")
         return fr_from_mont_limbs(out)
 
+    def eval_polynomial_batch(self, polys, n, points):
+        """[poly_j(point_j)]: enqueued back to back, one read-back (the par_iter of plonk/prover.rs:731-737)"""
+        count = len(polys)
+        if count == 0:
+            return []
+        ptrs = (_vp * count)(*[p.data_ptr() for p in polys])
+        pts = np.array([fr_to_mont_limbs(x % R_MOD) for x in points], dtype=np.uint64)
+        out = np.zeros((count, 4), dtype=np.uint64)
+        check(self.L.h2_dev_eval_polynomial_batch(ptrs, count, n, pts.ctypes.data, out.ctypes.data, self.stream),
+              "h2_dev_eval_polynomial_batch")
+        return [fr_from_mont_limbs(r) for r in out]
+
     def lincomb(self, res, polys, coeffs, size):
         ptrs = (_vp * len(polys))(*[p.data_ptr() for p in polys])
         cf = np.array([fr_to_mont_limbs(c % R_MOD) for c in coeffs], dtype=np.uint64)
@@ -724,41 +736,49 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     xn = pow(x, n, R_MOD)
     mark("vanishing construct")
 
-    # ---- evaluations (prover.rs:700-790) ------------------------------------------------------------------
-    evals = {}
-
-    def evaluate(key, poly, rot):
-        pt = dom.rotate_omega(x, rot)
-        if (key, rot) not in evals:
-            evals[(key, rot)] = (pt, D.eval_polynomial(poly, n, pt))
-        return evals[(key, rot)][1]
-
-    def write_set_evals(name, polys_):
-        for i, p in enumerate(polys_):
-            transcript.write_scalar(evaluate((name, i), p, 0))
-            transcript.write_scalar(evaluate((name, i), p, 1))
-            if i + 1 < len(polys_):
-                transcript.write_scalar(evaluate((name, i), p, last_rot))
-
-    for c, rot in cs.instance_queries:
-        transcript.write_scalar(evaluate(("instance", c), instance_polys[c], rot))
-    for c, rot in cs.advice_queries:
-        transcript.write_scalar(evaluate(("advice", c), advice_polys[c], rot))
-    for c, rot in cs.fixed_queries:
-        transcript.write_scalar(evaluate(("fixed", c), pk.fixed_polys[c], rot))
+    # ---- evaluations (prover.rs:700-790): every (polynomial, point) pair of the proof in one batched launch ------
     # h(X) = sum_i x^(n i) piece_i (vanishing/prover.rs:120-124)
     h_poly = D.lincomb(D.empty(n), pieces, [pow(xn, i, R_MOD) for i in range(len(pieces))], n)
-    transcript.write_scalar(evaluate(("random",), random_poly, 0))
+    wanted, written = [], []            # (key, poly, rotation); the subset the transcript receives, in its order
+
+    def want(key, poly, rot, write=True):
+        if (key, rot) not in [(k_, r_) for k_, _, r_ in wanted]:
+            wanted.append((key, poly, rot))
+        if write:
+            written.append((key, rot))
+
+    def want_set_evals(name, polys_):
+        for i, p in enumerate(polys_):
+            want((name, i), p, 0)
+            want((name, i), p, 1)
+            if i + 1 < len(polys_):
+                want((name, i), p, last_rot)
+
+    for c, rot in cs.instance_queries:
+        want(("instance", c), instance_polys[c], rot)
+    for c, rot in cs.advice_queries:
+        want(("advice", c), advice_polys[c], rot)
+    for c, rot in cs.fixed_queries:
+        want(("fixed", c), pk.fixed_polys[c], rot)
+    want(("random",), random_poly, 0)
     for i, p in enumerate(pk.sigma_polys):
-        transcript.write_scalar(evaluate(("sigma", i), p, 0))
-    write_set_evals("z", z_polys)
+        want(("sigma", i), p, 0)
+    want_set_evals("z", z_polys)
     for li, st in enumerate(lookups):                                  # logup/prover.rs:419-446
-        transcript.write_scalar(evaluate(("lookup_m", li), st["m_poly"], 0))
-        write_set_evals("lookup_z%d" % li, st["z_polys"])
+        want(("lookup_m", li), st["m_poly"], 0)
+        want_set_evals("lookup_z%d" % li, st["z_polys"])
     for i, p in enumerate(shuffle_polys):                              # shuffle/prover.rs:196-212
-        transcript.write_scalar(evaluate(("shuffle_z", i), p, 0))
-        transcript.write_scalar(evaluate(("shuffle_z", i), p, 1))
+        want(("shuffle_z", i), p, 0)
+        want(("shuffle_z", i), p, 1)
+    want(("h",), h_poly, 0, write=False)                               # opened, not written (vanishing/prover.rs:140-155)
+    values = D.eval_polynomial_batch([p for _, p, _ in wanted], n, [dom.rotate_omega(x, r) for _, _, r in wanted])
+    evals = {(key, rot): v for (key, _, rot), v in zip(wanted, values)}
+    for key, rot in written:
+        transcript.write_scalar(evals[(key, rot)])
     mark("evaluations")
+
+    def evaluate(key, poly, rot):
+        return evals[(key, rot)]
 
     # ---- multiopen query list in the reference's order (prover.rs:792-840) -----------------------------------
     polys, queries = {}, []

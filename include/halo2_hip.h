@@ -117,6 +117,11 @@ int h2_divide_by_vanishing_poly(uint64_t *a, size_t size, const uint64_t *t_eval
  * at x).  out = sum_i poly[i] * point^i.  Synchronous (the result is host memory). */
 int h2_eval_polynomial(const uint64_t *poly, size_t n, const uint64_t point[4], uint64_t out[4]);
 int h2_dev_eval_polynomial(const void *d_poly, size_t n, const uint64_t point[4], uint64_t out[4], void *stream);
+/* `count` evaluations, polynomial j (n coefficients, device) at points[4 j .. 4 j + 3], enqueued back to back with one
+ * read-back: the rayon `par_iter` over eval_polynomial_st of plonk/prover.rs:731-737.  d_polys: HOST array of device
+ * pointers; out: count x 4 u64 on the host.  Synchronous. */
+int h2_dev_eval_polynomial_batch(const void *const *d_polys, size_t count, size_t n, const uint64_t *points,
+                                 uint64_t *out, void *stream);
 /* batch_invert: arithmetic.rs:840-844 -- every non-zero element replaced by its inverse, zeros kept
  * (ff::BatchInvert).  d_tmp: n Fr of scratch. */
 int h2_batch_invert(uint64_t *a, size_t n);

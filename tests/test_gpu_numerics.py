@@ -233,3 +233,17 @@ def test_random_fr_matches_host_twin():
         d = _dev(np.zeros((n, 4), dtype=np.uint64))
         assert L.h2_dev_random_fr(seed, n, d.data_ptr(), None) == 0 and L.h2_synchronize() == 0
         assert np.array_equal(_host(d), ProverRng.random_poly_limbs(seed, n))
+
+
+def test_eval_polynomial_batch(oracle):
+    L = h2.lib()
+    for n, count in ((1, 3), (300, 5), (5000, 7), (1 << 18, 4)):
+        polys = [oracle.random_fr(700 + j, n) for j in range(count)]
+        pts = oracle.random_fr(800 + n % 97, count)
+        d = [_dev(p) for p in polys]
+        ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d])
+        out = np.zeros((count, 4), dtype=np.uint64)
+        assert L.h2_dev_eval_polynomial_batch(ptrs, count, n, pts.ctypes.data, out.ctypes.data, None) == 0
+        for j in range(count):
+            assert np.array_equal(out[j], _oracle_eval(oracle, polys[j], pts[j])), (n, j)
+    assert L.h2_dev_eval_polynomial_batch(None, 0, 5, None, None, None) == 0
