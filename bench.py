@@ -348,6 +348,21 @@ def main():
             "2^%d NTT, %d reps, %.3f s each (includes the oracle wrapper's input copy)" % (clog, reps, ct),
         }
 
+        # the MSM leg's CPU twin: best_multiexp (arithmetic.rs:465-492, c = ceil(ln n) per thread chunk) on a bounded sample
+        if "msm" in out:
+            mlog_c = min(args.msm_log_n, 18)
+            ms, mp = oracle.random_fr(11, 1 << mlog_c), oracle.random_g1(12, 1 << mlog_c)
+            oracle.best_multiexp(ms, mp, threads=best_th)
+            c0 = time.perf_counter()
+            oracle.best_multiexp(ms, mp, threads=best_th)
+            mt = time.perf_counter() - c0
+            out["msm"]["cpu_baseline"] = {
+                "pairs_per_s": (1 << mlog_c) / mt,
+                "cores": best_th,
+                "kind": "port",
+                "sample": "oracle best_multiexp on 2^%d uniform pairs, %.3f s" % (mlog_c, mt),
+            }
+
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
