@@ -184,7 +184,12 @@ proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(9))
 sys.stdout.write("PROOF " + proof.hex() + "\n")
 dist.destroy_process_group()
 """ % (ROOT, k, str(g_path), str(gl_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout + res.stderr
     line = [l for l in res.stdout.splitlines() if l.startswith("PROOF ")][0]
