@@ -447,3 +447,22 @@ def test_msm_batch_ex_per_column_bases_and_bounds(oracle):
         else:
             assert _affine(oracle, out[j]) == _affine(oracle, oracle.best_multiexp(cols[j], tables[which[j]])), j
     assert L.h2_dev_msm_batch_ex(sp, bp, bb, count, n, scratch.data_ptr(), per, out.ctypes.data, None) == 1
+
+
+def test_msm_2p20_proof_shaped_columns(oracle):
+    """BASELINE config 2's size on the scalar distributions a proof commits: a grand-product column (constant over
+    7/8 of the rows: dominant-scalar window + skew path) and a sparse witness column (a few small values, 16-bit
+    blinding rows: the empty-bucket bisection), against the oracle"""
+    n = 1 << 20
+    pts = oracle.random_g1(2020, n)
+    z = oracle.random_fr(2021, n)
+    z[n // 8:] = z[5]
+    want = _affine(oracle, oracle.best_multiexp(z, pts))
+    assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(z, pts, 254)) == want
+    w = np.zeros((n, 4), dtype=np.uint64)
+    w[: n // 8, 0] = np.tile(np.array([5, 25, 30, 5], dtype=np.uint64), n // 32)
+    w[n - 6:, 0] = [60000, 12345, 3, 40000, 5, 65535]
+    w = to_mont([int(v) for v in w[:, 0]])
+    want = _affine(oracle, oracle.best_multiexp(w, pts))
+    for bits in (16, 254):
+        assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(w, pts, bits)) == want, bits
