@@ -340,7 +340,9 @@ class GraphEvaluator:
         if isinstance(e, Constant):
             return self.add_constant(e.v)
         if isinstance(e, Query):
-            return self._calc(ev.CALC_STORE, ev.vs(e.kind, e.column, self.add_rotation(e.rotation)))
+            # the reference wraps every query in a Store calculation (evaluation.rs add_expression); the device
+            # interpreter takes column operands directly, which saves one intermediate round trip per query
+            return ev.vs(e.kind, e.column, self.add_rotation(e.rotation))
         if isinstance(e, Negated):
             return self._calc(ev.CALC_NEGATE, self.add_expression(e.e))
         if isinstance(e, Sum):

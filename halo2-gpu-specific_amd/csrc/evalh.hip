@@ -51,11 +51,17 @@ struct Interp {
     const Fr* inter;  // this thread's column of the intermediates array
     size_t stride;    // distance between consecutive intermediates of one thread
     size_t idx;
+    // the most recent intermediate stays in registers: expression trees flattened depth-first consume the previous
+    // result in the very next calculation most of the time, which then skips the round trip through memory
+    uint32_t last_index = 0xffffffffu;
+    Fr last{};
 
     __device__ __forceinline__ Fr get(const h2_value_source& v) const {
         switch (v.kind) {
             case H2_VS_CONSTANT: return fp_load(p.constants + v.index);
-            case H2_VS_INTERMEDIATE: return fp_load(inter + (size_t)v.index * stride);
+            case H2_VS_INTERMEDIATE:
+                if (v.index == last_index) return last;
+                return fp_load(inter + (size_t)v.index * stride);
             case H2_VS_FIXED: return fp_load(p.fixed[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
             case H2_VS_ADVICE: return fp_load(p.advice[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
             default: return fp_load(p.instance[v.index] + rot_idx(idx, p.rotations[v.rot], p.rot_scale, p.extended_k));
@@ -90,7 +96,12 @@ __global__ void __launch_bounds__(256) k_evalh_expr(EvalhProgram p, Fr* inter, F
     Fr* my = inter + t;
     for (size_t idx = t; idx < size; idx += nthreads) {
         Interp in{p, my, nthreads, idx};
-        for (uint32_t i = 0; i < p.n_calcs; i++) fp_store(my + (size_t)i * nthreads, in.eval(p.calcs[i]));
+        for (uint32_t i = 0; i < p.n_calcs; i++) {
+            Fr r = in.eval(p.calcs[i]);
+            fp_store(my + (size_t)i * nthreads, r);
+            in.last = r;
+            in.last_index = i;
+        }
         Fr value = fp_zero<FrParams>();
         for (uint32_t i = 0; i < p.n_value_parts; i++) value = fp_add(fp_mul(value, p.y), in.get(p.value_parts[i]));
         fp_store(values + idx, value);
