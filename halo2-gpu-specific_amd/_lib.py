@@ -78,6 +78,7 @@ SYMBOLS = {
     "h2_dev_logup_multiplicity": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
     "h2_dev_points_decompress": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_points_compress": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_jit_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _vp]),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_dev_evaluate_h": (ctypes.c_int, [_vp, _vp, _vp]),
     "h2_timer_start": (ctypes.c_int, [_vp]),

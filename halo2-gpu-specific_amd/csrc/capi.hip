@@ -608,6 +608,19 @@ int h2_dev_logup_multiplicity(const void* d_table, const void* const* d_inputs, 
     });
 }
 
+int h2_jit_load(const char* code_object_path, const char* kernel_name, const void** function_out) {
+    if (!code_object_path || !kernel_name || !function_out) return bad("h2_jit_load: null argument");
+    return guarded([&] {
+        current_ctx();  // the device of this thread is initialised
+        hipModule_t mod = nullptr;
+        H2_HIP(hipModuleLoad(&mod, code_object_path));
+        hipFunction_t fn = nullptr;
+        H2_HIP(hipModuleGetFunction(&fn, mod, kernel_name));
+        *function_out = (const void*)fn;
+        return (int)H2_OK;
+    });
+}
+
 // ------------------------------------------------------------------ evaluate_h
 int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h: null argument");

@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "evalh.hpp"
+#include "evalh_jit.hpp"
 #include "ntt.hpp"
 
 namespace h2 {
@@ -288,7 +289,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     // ---- work space: interpreter intermediates + lookup / shuffle compressed expressions
     const unsigned blocks = 256 * 8, threads = 256;
     const size_t nthreads = (size_t)blocks * threads;
-    size_t inter_bytes = (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
+    size_t inter_bytes = d->jit_function ? 256 : (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
     size_t lk_bytes = (n_lookup_calcs ? n_lookup_calcs : 1) * size * sizeof(Fr);
     size_t sh_bytes = (d->n_shuffles ? 2 * (size_t)d->n_shuffles : 1) * size * sizeof(Fr);
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -344,7 +345,28 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     p.gamma = fr_from_u64x4(d->gamma);
     p.theta = fr_from_u64x4(d->theta);
 
-    hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
+    if (d->jit_function != nullptr) {
+        // the program as generated straight-line code (evalh_jit.hpp): same outputs, intermediates in registers
+        JitArgs ja{};
+        ja.constants = p.constants;
+        ja.fixed = p.fixed;
+        ja.advice = p.advice;
+        ja.instance = p.instance;
+        ja.values = d_values;
+        ja.lk_out = d_lk;
+        ja.sh_out = d_sh;
+        ja.extended_k = p.extended_k;
+        ja.rot_scale = p.rot_scale;
+        ja.y = p.y;
+        ja.beta = p.beta;
+        ja.gamma = p.gamma;
+        ja.theta = p.theta;
+        void* kargs[] = {&ja};
+        const unsigned jblocks = (unsigned)std::min<size_t>((size + 255) / 256, 256 * 16);
+        H2_HIP(hipModuleLaunchKernel((hipFunction_t)d->jit_function, jblocks, 1, 1, 256, 1, 1, 0, stream, kargs, nullptr));
+    } else {
+        hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
+    }
 
     const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
     unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 256 * 16);

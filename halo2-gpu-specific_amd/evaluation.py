@@ -43,6 +43,7 @@ class EvalHDesc(ctypes.Structure):
         ("shuffle_z", _vp),
         ("y", _fr), ("beta", _fr), ("gamma", _fr), ("theta", _fr),
         ("delta", _fr), ("zeta", _fr), ("extended_omega", _fr),
+        ("jit_function", _vp),
     ]
 
 
@@ -89,7 +90,7 @@ class Builder:
     def build(self, *, k, extended_k, blinding_factors, chunk_len, constants, rotations, calculations, value_parts,
               lookups=(), shuffles=(), fixed=(), advice=(), instance=(), l0=None, l_last=None, l_active_row=None,
               perm_z=(), perm_columns=(), perm_sigma=(), lookup_z=(), lookup_m=(), shuffle_z=(), y, beta, gamma, theta,
-              delta, zeta, extended_omega):
+              delta, zeta, extended_omega, jit_function=None):
         """lookups: list of (table_calc, [product_calcs], [sum_calcs]); shuffles: list of (input_calc, shuffle_calc);
         perm_columns: list of (ANY_*, index)."""
         d = self.desc
@@ -121,6 +122,7 @@ class Builder:
         d.perm_sigma = self._ptrs(perm_sigma)
         assert len(lookup_z) == sum(sets) and len(lookup_m) == len(sets) and len(shuffle_z) == len(shuffles)
         d.lookup_z, d.lookup_m, d.shuffle_z = self._ptrs(lookup_z), self._ptrs(lookup_m), self._ptrs(shuffle_z)
+        d.jit_function = jit_function
         for name, val in (("y", y), ("beta", beta), ("gamma", gamma), ("theta", theta), ("delta", delta), ("zeta", zeta),
                           ("extended_omega", extended_omega)):
             setattr(d, name, _fr(*[int(x) for x in val]))

@@ -432,6 +432,11 @@ def keygen(device, params, cs, fixed, copies):
                           for _, table, sets in cs.lookups]
     pk.shuffle_programs = [[(compile_compress(inp), compile_compress(shf)) for _, inp, shf in group]
                            for group in cs.shuffles]
+    # the same program as generated straight-line HIP (jit.py): None = keep the interpreter
+    from . import jit
+
+    pk.evalh_code_object = jit.compile_program(pk.graph.rotations, pk.graph.calculations, pk.value_parts,
+                                               pk.lookup_calcs, pk.shuffle_calcs)
     pk.transcript_repr = vk_digest(cs, params.k, pk.fixed_commitments, pk.perm_commitments)
     D.sync()
     return pk
@@ -520,6 +525,15 @@ def _compress(D, dom, program, theta, fixed, advice, instance):
     out = D.empty(dom.n)
     check(D.L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h (compress)")
     return out
+
+
+def _jit_function(pk):
+    path = getattr(pk, "evalh_code_object", None)
+    if not path:
+        return None
+    from . import jit
+
+    return jit.load(path)
 
 
 def create_proof_from_witness(device, params, pk, witness, rng, use_gwc=True, timings=None, instances=()):
@@ -719,7 +733,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         lookup_z=[t.data_ptr() for t in lookup_z_cosets], lookup_m=[t.data_ptr() for t in lookup_m_cosets],
         shuffle_z=[t.data_ptr() for t in shuffle_cosets],
         y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
-        delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.extended_omega))
+        delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.extended_omega),
+        jit_function=_jit_function(pk))
     h = D.empty(en)
     check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), h.data_ptr(), D.stream), "h2_dev_evaluate_h")
     del advice_cosets, instance_cosets, z_cosets, lookup_z_cosets, lookup_m_cosets, shuffle_cosets

@@ -241,6 +241,8 @@ typedef struct {
     /* challenges and field constants */
     uint64_t y[4], beta[4], gamma[4], theta[4];
     uint64_t delta[4], zeta[4], extended_omega[4]; /* FieldExt::DELTA, ::ZETA, domain.get_extended_omega() */
+    /* optional: a kernel generated for exactly this program (h2_jit_load); NULL = the interpreter */
+    const void *jit_function;
 } h2_evalh_desc;
 
 /* Host buffers everywhere (descriptor and every pointer in it); values: 2^extended_k Fr out. */
@@ -249,6 +251,12 @@ int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);
  * arrays -- constants, rotations, calculations, ... and the pointer tables -- stay in host memory).
  * d_values: 2^extended_k Fr on the device.  Work space is taken from the library's arena. */
 int h2_dev_evaluate_h(const h2_evalh_desc *desc, void *d_values, void *stream);
+
+/* Loads a code object produced for one gate program (halo2-gpu-specific_amd/jit.py: straight-line HIP generated from the
+ * `Calculation` list, compiled with `hipcc --genco`) on the current device and returns its kernel, to be passed as
+ * h2_evalh_desc.jit_function.  The kernel must have been generated from the same constants / rotations / calculations /
+ * value parts / lookup and shuffle calculations as the descriptor it is used with.  The module stays loaded. */
+int h2_jit_load(const char *code_object_path, const char *kernel_name, const void **function_out);
 
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for

@@ -401,3 +401,24 @@ def test_reference_prover_reproduces_committed_proofs():
         proof = rp.create_proof(pk, adv, ProverRng(case["seed"]), use_gwc=gwc, instances=inst)
         assert proof.hex() == case["proof"], (case["circuit"], case["scheme"])
         assert rp.verify_proof(pk, bytes.fromhex(case["proof"]), use_gwc=gwc, instances=inst)
+
+
+def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
+    """jit.py: the straight-line HIP generated from a gate program (all three test circuits, with their lookup and
+    shuffle result calculations) cross-compiles with hipcc; the Horner fold is interleaved with the calculations"""
+    import shutil
+
+    from halo2_gpu_specific_amd import jit
+
+    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    monkeypatch.setenv("H2_JIT_CACHE", str(tmp_path))
+    for make in (circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs):
+        g, parts, lookups, shuffles = hc.compile_evaluator(make())
+        src = jit.generate_source(g.rotations, g.calculations, parts, lookups, shuffles)
+        assert src.count("fp_store(a.values") == 1 and "h2_evalh_jit" in src
+        path = jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles)
+        assert path and path.startswith(str(tmp_path)) and __import__("os").path.getsize(path) > 1000
+        assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) == path   # cached
+    monkeypatch.setenv("H2_EVALH_JIT", "0")
+    assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) is None
