@@ -277,7 +277,9 @@ def main():
             # N > 1: ONE proof over all ranks -- every rank holds the same polynomials, each MSM is range-split over the
             # ranks and folded after an all-gather of the partial points (config 5's "RCCL final reduce over xGMI")
             D = prover.Device(local_rank, force_collective=dist is not None)
-            params = prover.Params.synthetic(D, pk_k)  # timing-only SRS: same work, proofs do not verify
+            # Params::unsafe_setup on the device with a fixed toxic scalar: a real (insecure, test-only) SRS, so the timed proofs
+            # are valid proofs (tests/test_gpu_plonk.py has the same k = 22 flow accepted by the reference verifier)
+            params = prover.Params.unsafe_setup(D, pk_k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
             adv, fixed, copies = circuits.mini_plonk_synthesize(pk_k, alloc=D.pinned_columns)
             pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
             proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))  # warm-up (arena growth, plan caches)
@@ -306,8 +308,8 @@ def main():
                 "proof_bytes": len(proof),
                 "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
                 "steps": args.prove_steps,
-                "srs": "synthetic points (timing only); tests/test_gpu_plonk.py proves with a real SRS and checks the bytes "
-                "against the big-integer reference prover and verifier",
+                "srs": "Params::unsafe_setup on the device with a fixed trapdoor (g[i] = [s^i]G, g_lagrange[i] = [l_i(s)]G); "
+                "tests/test_gpu_plonk.py checks proof bytes against the reference prover and verifies the k = 22 proof",
             }
             del D, params, pk, adv, fixed
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed

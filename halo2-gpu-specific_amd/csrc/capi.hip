@@ -383,6 +383,15 @@ int h2_dev_msm_batch_ex(const void* const* d_scalars, const void* const* d_bases
     });
 }
 
+int h2_dev_fixed_base_mul(const void* d_scalars, const void* d_table, size_t n, void* d_points, void* stream) {
+    if (n && (!d_scalars || !d_table || !d_points)) return bad("h2_dev_fixed_base_mul: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return fixed_base_mul_launch((const Fr*)d_scalars, (const uint64_t*)d_table, n, (uint64_t*)d_points,
+                                     pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_points_decompress(const void* d_bytes, size_t n, void* d_points, void* stream) {
     if (n && (!d_bytes || !d_points)) return bad("h2_dev_points_decompress: null argument");
     return guarded([&] {

@@ -710,6 +710,53 @@ int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hi
     return H2_OK;
 }
 
+// ---------------------------------------------------------------- fixed-base multiplication (Params::unsafe_setup)
+// out[i] = [scalars[i]] B for one base B given as the table T[j] = [2^j] B, j < 254 (affine): the setup's
+// g[i] = [s^i] G and g_lagrange[i] = [l_i(s)] G (poly/commitment.rs:67-112, a rayon `parallelize` with one variable-
+// base multiplication per point there).  One lane per point: ~127 mixed additions against the shared table (every
+// lane reads the same entry: a broadcast), then one Fq inversion (a^(q-2)) to normalise.
+__device__ __forceinline__ Fq fq_inv_device(const Fq& a) {
+    // q - 2, little-endian u32 limbs
+    const uint32_t E[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                           0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    Fq acc = fp_one<FqParams>();
+#pragma unroll 1
+    for (int bit = 253; bit >= 0; bit--) {
+        acc = fp_sqr(acc);
+        if ((E[bit >> 5] >> (bit & 31)) & 1) acc = fp_mul(acc, a);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_fixed_base_mul(const Fr* scalars, const Affine* table, size_t n, Affine* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr s = fp_from_mont(fp_load(scalars + i));
+    XYZZ acc = xyzz_identity();
+#pragma unroll 1
+    for (int bit = 0; bit < 254; bit++)
+        if ((s.l[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_madd(acc, affine_load(table + bit), false);
+    Fq zero = fp_zero<FqParams>();
+    if (fp_is_zero(acc.zz)) {  // scalar 0: the identity
+        fp_store(&out[i].x, zero);
+        fp_store(&out[i].y, zero);
+        return;
+    }
+    // x = X / ZZ, y = Y / ZZZ with one inversion: t = 1 / ZZZ, 1 / ZZ = (ZZ * t)^2  (ZZ^3 = ZZZ^2)
+    const Fq t = fq_inv_device(acc.zzz);
+    const Fq u = fp_mul(acc.zz, t);
+    fp_store(&out[i].x, fp_mul(acc.x, fp_sqr(u)));
+    fp_store(&out[i].y, fp_mul(acc.y, t));
+}
+
+int fixed_base_mul_launch(const Fr* d_scalars, const uint64_t* d_table, size_t n, uint64_t* d_out, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_fixed_base_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_scalars,
+                       (const Affine*)d_table, n, (Affine*)d_out);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 // The per-window partial sums (W * G points, tens of KB) go back to the host through a store kernel into mapped pinned
 // memory rather than hipMemcpyAsync: a DMA-engine copy queues behind whatever bulk transfer is in flight (the prover
 // uploads the next witness column while it commits the current one) and would stall the MSM for the whole transfer.

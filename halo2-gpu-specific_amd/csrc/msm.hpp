@@ -26,4 +26,5 @@ int points_compress_launch(const uint64_t* d_points, size_t n, void* d_bytes, hi
 int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64_t* const* bases_each,
                         const uint32_t* bits_each, size_t count, const uint64_t* d_bases, size_t n, uint32_t max_bits,
                         void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
+int fixed_base_mul_launch(const Fr* d_scalars, const uint64_t* d_table, size_t n, uint64_t* d_out, hipStream_t stream);
 }  // namespace h2

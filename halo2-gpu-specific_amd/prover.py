@@ -313,6 +313,51 @@ class Params:
         assert self.g.shape[0] == self.n and self.g_lagrange.shape[0] == self.n
 
     @staticmethod
+    def unsafe_setup(device, k, s):
+        """Params::unsafe_setup (poly/commitment.rs:56-124) with the toxic scalar `s` supplied by the caller instead of
+        OsRng -- tests and benchmarks only, MUST NOT be used in production (as the reference says).
+        g[i] = [s^i] G (:67-83), g_lagrange[i] = [(s^n - 1)/n * w^i / (s - w^i)] G (:85-112), all on the device."""
+        from .transcript import Q_MOD
+
+        D, L = device, device.L
+        n = 1 << k
+        s %= R_MOD
+        omega = pow(ROOT_OF_UNITY, 1 << (S - k), R_MOD)
+        # table of [2^j] G, j < 254 (affine; host big integers, 254 doublings)
+        pts, P = [], (1, 2)
+        for _ in range(254):
+            pts.append(P)
+            lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, Q_MOD) % Q_MOD
+            x3 = (lam * lam - 2 * P[0]) % Q_MOD
+            P = (x3, (lam * (P[0] - x3) - P[1]) % Q_MOD)
+        mq = lambda v: [((v << 256) % Q_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]  # noqa: E731
+        table = D.upload(np.array([mq(x) + mq(y) for x, y in pts], dtype=np.uint64))
+
+        def powers(base):                       # [base^i]: the running product of a constant column
+            f = D.eval_op(8, D.empty(n), c=base)                                # H2_OP_CONSTANT
+            out = D.empty(n)
+            check(L.h2_dev_prefix_product(f.data_ptr(), n, _fr(1), out.data_ptr(), D.stream), "h2_dev_prefix_product")
+            return out
+
+        def fixed_base(scalars):
+            with D.torch.cuda.stream(D.tstream):
+                out = D.torch.empty((n, 8), dtype=D.torch.int64, device=D.dev)
+            check(L.h2_dev_fixed_base_mul(scalars.data_ptr(), table.data_ptr(), n, out.data_ptr(), D.stream),
+                  "h2_dev_fixed_base_mul")
+            return out
+
+        g = fixed_base(powers(s))
+        w = powers(omega)
+        t = D.eval_op(1, D.empty(n), w, c=-s)                                   # w^i - s
+        check(L.h2_dev_batch_invert(t.data_ptr(), D.empty(n).data_ptr(), n, D.stream), "h2_dev_batch_invert")
+        D.eval_op(3, t, t, w)                                                   # w^i / (w^i - s)
+        multiplier = (pow(s, n, R_MOD) - 1) * pow(n, -1, R_MOD) % R_MOD
+        D.eval_op(0, t, t, c=-multiplier)                                       # multiplier * w^i / (s - w^i)
+        g_lagrange = fixed_base(t)
+        D.sync()
+        return Params(D, k, g, g_lagrange)
+
+    @staticmethod
     def synthetic(device, k, seed=0x48414C4F32):
         """Timing-only parameters: two tables of valid curve points with no common trapdoor, so proofs made
         with them exercise exactly the same work but cannot verify."""

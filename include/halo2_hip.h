@@ -173,6 +173,12 @@ size_t h2_logup_scratch_bytes(size_t n);
 int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
 
+/* Fixed-base multiplication, the work of Params::unsafe_setup (poly/commitment.rs:56-124: g[i] = [s^i] G,
+ * g_lagrange[i] = [l_i(s)] G, one variable-base multiplication per point under `parallelize` there):
+ * points[i] = [scalars[i]] B, with B given as d_table[j] = [2^j] B for j < 254 (affine Montgomery, 64 B each);
+ * scalars Montgomery Fr, output affine Montgomery ((0,0) for a zero scalar).  Asynchronous on `stream`. */
+int h2_dev_fixed_base_mul(const void *d_scalars, const void *d_table, size_t n, void *d_points, void *stream);
+
 /* Compressed G1 points of the SRS file -- Params::{write, read}, poly/commitment.rs:241-294 (`to_bytes` / `from_bytes`
  * per point; the reference decompresses with a rayon `parallelize`).  32 bytes per point: x little-endian, bit 7 of
  * byte 31 = parity of the canonical y, identity = zeros (convention of this build: the encoding of pairing_bn256@30b052f

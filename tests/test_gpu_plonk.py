@@ -22,9 +22,13 @@ def device():
 
 
 def srs(oracle, device, k):
-    """Params::unsafe_setup with the fixed trapdoor (oracle restatement, pinned by tests/golden/setup_kat.json)"""
+    """Params::unsafe_setup with the fixed trapdoor: the oracle restatement (pinned by tests/golden/setup_kat.json) up
+    to 2^16 points, the device setup (checked against the oracle in test_device_unsafe_setup_matches_oracle, and by
+    every verified proof: a wrong SRS cannot satisfy the trapdoor / pairing checks) above"""
     from halo2_gpu_specific_amd import prover
 
+    if k > 16:
+        return prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
     n = 1 << k
     g = np.zeros((n, 8), dtype=np.uint64)
     gl = np.zeros((n, 8), dtype=np.uint64)
@@ -316,3 +320,32 @@ def test_device_prover_reproduces_committed_proofs(oracle, device):
         proof = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(case["seed"]),
                                         case["scheme"] == "gwc", instances=inst)
         assert proof.hex() == case["proof"], (case["circuit"], case["scheme"])
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 13])
+def test_device_unsafe_setup_matches_oracle(oracle, device, k):
+    """Params::unsafe_setup on the device (powers by the prefix-product scan, l_i(s) by the elementwise kernels and the
+    batch inversion, h2_dev_fixed_base_mul) against the oracle's restatement of poly/commitment.rs:56-124"""
+    from halo2_gpu_specific_amd import prover
+
+    n = 1 << k
+    g = np.zeros((n, 8), dtype=np.uint64)
+    gl = np.zeros((n, 8), dtype=np.uint64)
+    s = fr_mont(S_TRAPDOOR)
+    oracle.lib.oracle_unsafe_setup(k, s.ctypes.data, g.ctypes.data, gl.ctypes.data)
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    assert np.array_equal(device.download(params.g).reshape(n, 8), g)
+    assert np.array_equal(device.download(params.g_lagrange).reshape(n, 8), gl)
+
+
+def test_fixed_base_mul_edge_scalars(oracle, device):
+    """scalars 0, 1, 2, r - 1 and random ones against the reference curve arithmetic"""
+    from halo2_gpu_specific_amd import prover
+    from h2util import arr_to_points
+
+    params = prover.Params.unsafe_setup(device, 2, 5)          # g = [1, 5, 25, 125] G
+    pts = arr_to_points(device.download(params.g).reshape(4, 8))
+    assert pts == [rp.g1_mul(rp.G1, e) for e in (1, 5, 25, 125)]
+    params = prover.Params.unsafe_setup(device, 1, rp.R - 1)   # g = [1, -1] G
+    pts = arr_to_points(device.download(params.g).reshape(2, 8))
+    assert pts == [rp.G1, rp.g1_neg(rp.G1)]

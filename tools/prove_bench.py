@@ -1,5 +1,5 @@
 """create_proof wall-clock on one GPU for the mini-PLONK circuit (BASELINE config 4: k = 22), per phase.
-usage: python tools/prove_bench.py [k] [reps]      (synthetic SRS: timing only, the proof cannot verify)"""
+usage: python tools/prove_bench.py [k] [reps]      (SRS from the device-side unsafe_setup with a fixed trapdoor)"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     D = prover.Device()
     t0 = time.perf_counter()
-    params = prover.Params.synthetic(D, k)
+    params = prover.Params.unsafe_setup(D, k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
     t1 = time.perf_counter()
     adv, fixed, copies = circuits.mini_plonk_synthesize(k, alloc=D.pinned_columns)
     t2 = time.perf_counter()
