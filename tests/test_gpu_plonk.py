@@ -349,3 +349,32 @@ def test_fixed_base_mul_edge_scalars(oracle, device):
     params = prover.Params.unsafe_setup(device, 1, rp.R - 1)   # g = [1, -1] G
     pts = arr_to_points(device.download(params.g).reshape(2, 8))
     assert pts == [rp.G1, rp.g1_neg(rp.G1)]
+
+
+def test_proof_parity_over_random_trapdoors_sizes_and_seeds(oracle, device):
+    """a sweep instead of fixed cases: other SRS trapdoors, sizes 4..9, blinding seeds, all three circuits, both
+    multiopen schemes -- device bytes == reference bytes, and accepted"""
+    import random
+
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    rnd = random.Random(20261002)
+    makers = {"mini": (rp.MiniPlonk, circuits.mini_plonk), "rot": (rp.RotGate, rot_gate_cs),
+              "lookup": (rp.LookupShuffle, lookup_shuffle_cs)}
+    for trial in range(8):
+        which = rnd.choice(sorted(makers))
+        ref_cs, make = makers[which]
+        k = rnd.randrange(5 if which != "mini" else 4, 10 if which != "lookup" else 8)
+        trapdoor, seed, use_gwc = rnd.randrange(2, rp.R), rnd.randrange(1 << 30), rnd.random() < 0.5
+        syn = ref_cs.synthesize(k)
+        adv, fixed, copies = syn[:3]
+        inst = syn[3] if len(syn) > 3 else []
+        params = prover.Params.unsafe_setup(device, k, trapdoor)
+        pk = prover.keygen(device, params, make(), cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+        rpk = rp.keygen(ref_cs, k, trapdoor, fixed, copies)
+        assert pk.fixed_commitments == rpk.fixed_commitments and pk.perm_commitments == rpk.perm_commitments
+        proof = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(seed), use_gwc, instances=inst)
+        want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=inst)
+        assert proof == want, (trial, which, k, use_gwc)
+        assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=inst)
