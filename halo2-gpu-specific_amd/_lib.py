@@ -51,6 +51,7 @@ SYMBOLS = {
     "h2_dev_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "h2_dev_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "h2_msm_scratch_bytes": (_sz, [_sz, _u32]),
+    "h2_msm_batch_scratch_bytes": (_sz, [_sz, _u32, _sz]),
     "h2_msm_shape": (ctypes.c_int, [_sz, _u32, _vp, _vp, _vp]),
     "h2_dev_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),
     "h2_dev_msm_batch": (ctypes.c_int, [_vp, _sz, _vp, _sz, _u32, _vp, _sz, _vp, _vp]),

@@ -338,6 +338,7 @@ int h2_dev_extended_to_coeff(void* d_a, void* d_tmp, uint32_t extended_k, const 
 }
 
 size_t h2_msm_scratch_bytes(size_t n, uint32_t max_bits) { return msm_scratch_bytes(n, max_bits); }
+size_t h2_msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count) { return msm_batch_scratch_bytes(n, max_bits, count); }
 int h2_msm_shape(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
     msm_shape_query(n, max_bits, c, windows, buckets_per_window);
     return H2_OK;

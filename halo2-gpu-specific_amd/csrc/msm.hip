@@ -49,6 +49,8 @@ static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgro
 struct MsmShape {
     uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, reduce groups/window
     uint32_t Wt;                // windows the pipeline runs: W, + 1 when a dominant scalar has its own window (see k_digits)
+    uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
+    size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
     uint32_t log_s;             // slice length S = 2^log_s entries
     uint32_t lo_bits, hi_bits;  // bucket id = hi (partition inside the window) : lo (bin inside the partition)
     uint32_t np;                // partitions = W << hi_bits
@@ -60,7 +62,7 @@ struct MsmShape {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot) {
+static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols = 0) {
     MsmShape s{};
     if (max_bits > 254) max_bits = 254;
     if (max_bits == 0) max_bits = 1;
@@ -83,6 +85,9 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot) {
     s.c = best_c;
     s.W = (max_bits + 1 + s.c - 1) / s.c;
     s.Wt = s.W + (hot ? 1u : 0u);
+    s.cols = cols;
+    s.Wc = s.W + 1;
+    if (cols) s.Wt = cols * s.Wc;  // every column keeps a slot for its dominant-scalar window
     s.nb = 1u << (s.c - 1);
     s.nbt = s.Wt * s.nb;
     uint32_t per_group = REDUCE_T * REDUCE_M;
@@ -120,6 +125,7 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot) {
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
     s.off_winpart = take((size_t)s.Wt * s.G * sizeof(XYZZ));
+    s.off_coltab = take((size_t)(cols ? cols : 1) * 64);
     s.total = o;
     return s;
 }
@@ -128,6 +134,9 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot) {
 size_t msm_scratch_bytes(size_t n, uint32_t max_bits) {
     return std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
 }
+// scratch that lets h2_dev_msm_batch(_ex) fuse `count` columns of bound `max_bits` over one base table
+size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
+
 void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
     MsmShape s = msm_shape(n, max_bits, false);
     if (c) *c = s.c;
@@ -147,17 +156,29 @@ void msm_shape_query(size_t n, uint32_t max_bits, uint32_t* c, uint32_t* windows
 // host: sum_i s_i P_i = sum_{s_i != v} s_i P_i + v * E.  One addition per such row instead of W.
 extern __shared__ __attribute__((aligned(16))) uint32_t h2_msm_smem[];
 
+// Fused multi-column form (col_scalars != nullptr): blockIdx.y is the column; its scalars, its dominant value and its
+// flag come from the tables, its W + 1 windows start at window blockIdx.y * (W + 1), and `np` counts the partitions of
+// ONE column -- the rest of the pipeline just sees more windows over the same bases.
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
-                                                uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot) {
+                                                uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
+                                                const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask) {
+    if (col_scalars != nullptr) {
+        const uint32_t col = blockIdx.y;
+        scalars = col_scalars[col];
+        hot_on = (int)((col_hot_mask >> col) & 1);
+        if (hot_on) hot = fp_load(col_hot + col);
+        keys += (size_t)col * (W + 1) * n;
+        pcount += (size_t)col * np;
+    }
     uint32_t* hist = h2_msm_smem;
     for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const Fr raw = fp_load(scalars + i);
-        if (hot_on) {  // wave-uniform branch
-            const bool is_hot = fp_eq(raw, hot);
+        if (hot_on || col_scalars != nullptr) {  // wave-uniform branch; a fused column always owns the extra window
+            const bool is_hot = hot_on && fp_eq(raw, hot);
             const uint64_t m = __ballot(is_hot);
             if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
                 atomicAdd(&hist[W << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
@@ -327,12 +348,18 @@ __device__ __forceinline__ uint32_t lds_count_aggregated(uint32_t* bins, uint32_
 
 __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
                                                         uint32_t hi_bits, uint32_t nb, uint32_t skew_threshold,
-                                                        uint32_t hot_partition, uint32_t* starts, uint32_t* sorted) {
+                                                        uint32_t hot_partition, uint32_t hot_wc, uint64_t hot_mask,
+                                                        uint32_t* starts, uint32_t* sorted) {
     uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
     __shared__ uint32_t sh[4];
     const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
     const uint32_t e0 = pbase[p], e1 = pbase[p + 1];
-    if (p == hot_partition) {
+    bool is_hot_partition = p == hot_partition;
+    if (hot_wc) {  // fused shape: the dominant-scalar window of column j is window j * hot_wc + hot_wc - 1
+        const uint32_t w = p >> hi_bits;
+        is_hot_partition = (p & ((1u << hi_bits) - 1)) == 0 && (w % hot_wc) == hot_wc - 1 && ((hot_mask >> (w / hot_wc)) & 1);
+    }
+    if (is_hot_partition) {
         // the dominant scalar's window: every entry sits in bin 0, so there is nothing to sort -- k_copy_hot moves the
         // references with the whole chip instead of this one workgroup; only the bucket starts are written here
         const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
@@ -809,8 +836,16 @@ void msm_identity(uint64_t out_xyz[12]) {
     memcpy(out_xyz, &j, 96);
 }
 
+// `fused`: non-null for the multi-column shape (s.cols columns): device table of scalar pointers, then of dominant
+// values, and the bit mask of the columns that have one
+struct FusedCols {
+    const Fr* const* scalars;
+    const Fr* hot_values;
+    uint64_t hot_mask;
+};
+
 static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, const Affine* d_bases, uint32_t max_bits,
-                       char* scratch, hipStream_t stream) {
+                       char* scratch, hipStream_t stream, const FusedCols* fused = nullptr) {
     uint32_t* keys = (uint32_t*)(scratch + s.off_keys);
     uint32_t* sorted = (uint32_t*)(scratch + s.off_sorted);
     uint2* tmp = (uint2*)(scratch + s.off_tmp);
@@ -827,18 +862,31 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     H2_HIP(hipMemsetAsync(heavy, 0, 4, stream));
     unsigned nblk = (unsigned)((s.n + 255) / 256);
     unsigned dblk = nblk < 1024 ? nblk : 1024;  // grid-stride: one LDS histogram flush per workgroup
-    hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
-                       max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
-                       hot.value);
+    if (fused) {
+        const uint32_t np_col = s.Wc << s.hi_bits;
+        hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
+                           s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask);
+    } else {
+        hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
+                           max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
+                           hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0);
+    }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wt), dim3(256),
                        (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
-    const uint32_t hot_partition = hot.on ? (s.W << s.hi_bits) : 0xffffffffu;
+    const uint32_t hot_partition = (!fused && hot.on) ? (s.W << s.hi_bits) : 0xffffffffu;
     hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
-                       s.hi_bits, s.nb, skew_threshold, hot_partition, starts, sorted);
-    if (hot.on) hipLaunchKernelGGL(k_copy_hot, dim3(2048), dim3(256), 0, stream, tmp, pbase, hot_partition, sorted);
+                       s.hi_bits, s.nb, skew_threshold, hot_partition, fused ? s.Wc : 0u, fused ? fused->hot_mask : 0ull,
+                       starts, sorted);
+    if (!fused && hot.on) hipLaunchKernelGGL(k_copy_hot, dim3(2048), dim3(256), 0, stream, tmp, pbase, hot_partition, sorted);
+    if (fused)
+        for (uint32_t col = 0; col < s.cols; col++)
+            if ((fused->hot_mask >> col) & 1)
+                hipLaunchKernelGGL(k_copy_hot, dim3(1024), dim3(256), 0, stream, tmp, pbase,
+                                   (col * s.Wc + s.W) << s.hi_bits, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
                        s.log_s, partials);
@@ -853,17 +901,18 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
 }
 
 // host tail: add the G partials of each window, then Horner over the windows
-static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12]) {
+static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12],
+                          size_t w0 = 0) {  // w0: first window of the column inside a fused shape
     XYZZ acc = xyzz_identity();
     for (int w = (int)s.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < s.c; k++) acc = xyzz_double(acc);
         XYZZ ws = xyzz_identity();
-        for (uint32_t g = 0; g < s.G; g++) ws = xyzz_add(ws, winpart[(size_t)w * s.G + g]);
+        for (uint32_t g = 0; g < s.G; g++) ws = xyzz_add(ws, winpart[(w0 + (size_t)w) * s.G + g]);
         acc = xyzz_add(acc, ws);
     }
     if (hot.on) {  // + v * E, E = the extra window's sum (bucket 0 carries weight 1)
         XYZZ e = xyzz_identity();
-        for (uint32_t g = 0; g < s.G; g++) e = xyzz_add(e, winpart[(size_t)s.W * s.G + g]);
+        for (uint32_t g = 0; g < s.G; g++) e = xyzz_add(e, winpart[(w0 + (size_t)s.W) * s.G + g]);
         const Fr v = fp_from_mont(hot.value);
         XYZZ r = xyzz_identity();
         for (int bit = 253; bit >= 0; bit--) {
@@ -907,6 +956,63 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     return H2_OK;
 }
 
+// `cols` MSMs over the SAME bases and with the same scalar bound as ONE pass of the pipeline: column j's windows are
+// windows j * (W + 1) ... of a single wide MSM (k_digits reads each column's scalars, everything after it only sees
+// more windows), so the fixed costs -- sampling, sort launches, the latency-bound finish / reduce, the synchronisation
+// and the read-back -- are paid once for the group instead of once per column.  This is what a witness with many
+// narrow columns needs: at 2^18 a single MSM is ~1 ms of mostly fixed latency.
+static int msm_device_fused(DeviceCtx* ctx, const Fr* const* d_scalars, uint32_t cols, const uint64_t* d_bases, size_t n,
+                            uint32_t bits, char* scratch, uint64_t* const* outs, hipStream_t stream) {
+    const MsmShape s = msm_shape(n, bits, false, cols);
+    const size_t wp = (size_t)s.Wt * s.G;
+    char* pinned = (char*)ctx->pinned.get((size_t)cols * HOT_SAMPLES * sizeof(Fr) + wp * sizeof(XYZZ));
+    Fr* h_samples = (Fr*)pinned;
+    XYZZ* h_win = (XYZZ*)(pinned + (size_t)cols * HOT_SAMPLES * sizeof(Fr));
+    for (uint32_t j = 0; j < cols; j++)
+        hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[j], n, h_samples + (size_t)j * HOT_SAMPLES);
+    H2_HIP(hipStreamSynchronize(stream));
+    std::vector<Hot> hots(cols);
+    std::vector<uint64_t> tab((size_t)cols * 8);  // cols pointers, then cols x 4 u64 dominant values
+    FusedCols fc{};
+    for (uint32_t j = 0; j < cols; j++) {
+        hots[j] = detect_hot(h_samples + (size_t)j * HOT_SAMPLES);
+        if (hots[j].on) fc.hot_mask |= 1ull << j;
+        tab[j] = (uint64_t)(uintptr_t)d_scalars[j];
+    }
+    std::vector<Fr> hv(cols);
+    for (uint32_t j = 0; j < cols; j++) hv[j] = hots[j].value;
+    char* d_tab = scratch + s.off_coltab;
+    H2_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)cols * 8, hipMemcpyHostToDevice, stream));
+    H2_HIP(hipMemcpyAsync(d_tab + (size_t)cols * 8 + ((cols & 1) ? 8 : 0), hv.data(), (size_t)cols * sizeof(Fr), hipMemcpyHostToDevice, stream));
+    fc.scalars = (const Fr* const*)d_tab;
+    fc.hot_values = (const Fr*)(d_tab + (size_t)cols * 8 + ((cols & 1) ? 8 : 0));
+    msm_launch(s, Hot{}, nullptr, (const Affine*)d_bases, bits, scratch, stream, &fc);
+    export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win, wp, stream);
+    H2_HIP(hipStreamSynchronize(stream));  // also keeps `tab` / `hv` alive until their uploads are done
+    std::vector<XYZZ> winpart(h_win, h_win + wp);
+    for (uint32_t j = 0; j < cols; j++) msm_host_tail(s, hots[j], winpart, outs[j], (size_t)j * s.Wc);
+    return H2_OK;
+}
+
+// largest fused group (<= 64 columns) whose sort still fits the LDS histograms and whose keys stay below 2^28 entries
+static uint32_t fused_group_limit(size_t n, uint32_t bits) {
+    const MsmShape one = msm_shape(n, bits, true);
+    // Fusing pays while a column is dominated by fixed latencies (measured, 8 uniform columns: 2^14 0.26 vs 0.51 ms per
+    // MSM, 2^16 0.40 vs 0.69, 2^18 0.90 vs 0.86, 2^20 2.35 vs 2.0); past ~4M (scalar, window) entries per column the
+    // two-stream pipeline, which hides every column's host tail under the next column's kernels, is the better shape.
+    // Columns with a short scalar bound have one or two windows: the slot every fused column keeps for its
+    // dominant-scalar window would double their finish / reduce work -- they stay in the pipeline too.
+    if ((size_t)one.Wt * n > ((size_t)1 << 22) || one.W < 8) return 1;
+    uint32_t best = 1;
+    for (uint32_t g = 2; g <= 64; g++) {
+        const size_t wt = (size_t)g * (one.W + 1);
+        if (wt * n > ((size_t)1 << 28)) break;
+        if ((wt << (one.c - 1 - 9)) > 16384 && one.c - 1 > 9) break;  // lo_bits would exceed 9 (512 bins per partition)
+        best = g;
+    }
+    return best;
+}
+
 // Batch of MSMs over ONE set of bases (the prover commits every advice / fixed / z column against the
 // same g_lagrange: plonk/prover.rs:293-299, :477-487, keygen.rs:288-291).  Consecutive MSMs alternate
 // between two streams with their own scratch halves, so the latency-bound tail of one MSM (k_finish,
@@ -934,10 +1040,44 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         for (size_t i = 0; i < count; i++) msm_identity(out_xyz + 12 * i);
         return H2_OK;
     }
+    // columns that share their base table and their bound are committed as fused groups when the caller's scratch
+    // allows it (h2_msm_batch_scratch_bytes); the rest goes through the two-stream pipeline below
+    std::vector<char> done_fused(count, 0);
+    if (getenv("H2_MSM_NO_FUSE") == nullptr) {
+        H2_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < count; i++) {
+            if (done_fused[i]) continue;
+            const uint32_t bits = bits_each ? bits_each[i] : max_bits;
+            if (bits == 0) continue;
+            const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
+            std::vector<size_t> members{i};
+            for (size_t j = i + 1; j < count; j++) {
+                const uint32_t bj = bits_each ? bits_each[j] : max_bits;
+                const uint64_t* basej = bases_each && bases_each[j] ? bases_each[j] : d_bases;
+                if (!done_fused[j] && bj == bits && basej == bases) members.push_back(j);
+            }
+            const uint32_t limit = fused_group_limit(n, bits);
+            for (size_t m0 = 0; m0 < members.size(); m0 += limit) {
+                const uint32_t g = (uint32_t)std::min<size_t>(limit, members.size() - m0);
+                if (g < 2) break;
+                if (msm_shape(n, bits, false, g).total > scratch_bytes) break;  // caller sized the scratch for the pipeline only
+                std::vector<const Fr*> sc(g);
+                std::vector<uint64_t*> outs(g);
+                for (uint32_t t = 0; t < g; t++) {
+                    sc[t] = d_scalars[members[m0 + t]];
+                    outs[t] = out_xyz + 12 * members[m0 + t];
+                    done_fused[members[m0 + t]] = 1;
+                }
+                int rc = msm_device_fused(ctx, sc.data(), g, bases, n, bits, (char*)d_scratch, outs.data(), stream);
+                if (rc != H2_OK) return rc;
+            }
+        }
+    }
     size_t per = 0, wp_max = 0;
     std::vector<MsmShape> shapes(2 * count);
     for (size_t i = 0; i < count; i++) {
         const uint32_t bits = bits_each ? bits_each[i] : max_bits;
+        if (done_fused[i]) continue;
         shapes[2 * i] = msm_shape(n, bits ? bits : 1, false);
         shapes[2 * i + 1] = msm_shape(n, bits ? bits : 1, true);
         per = std::max(per, align_up(std::max(shapes[2 * i].total, shapes[2 * i + 1].total), 256));
@@ -960,7 +1100,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     std::vector<hipEvent_t> done(count, nullptr);
     for (size_t i = 0; i < count; i++) {
         const uint32_t bits = bits_each ? bits_each[i] : max_bits;
-        if (bits == 0) continue;  // identity (arithmetic.rs:346)
+        if (bits == 0 || done_fused[i]) continue;  // identity (arithmetic.rs:346) / already committed in a fused group
         const MsmShape& s = shapes[2 * i + (hots[i].on ? 1 : 0)];
         const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
         char* scratch = (char*)d_scratch + (i & 1) * per;
@@ -971,6 +1111,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         H2_HIP(hipEventRecord(done[i], q));
     }
     for (size_t i = 0; i < count; i++) {
+        if (done_fused[i]) continue;
         if (!done[i]) {
             msm_identity(out_xyz + 12 * i);
             continue;
@@ -982,6 +1123,13 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         msm_host_tail(s, hots[i], winpart, out_xyz + 12 * i);
     }
     return H2_OK;
+}
+
+size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count) {
+    const size_t pipeline = 2 * align_up(msm_scratch_bytes(n, max_bits), 256);
+    if (count < 2 || n == 0 || max_bits == 0) return pipeline;
+    const uint32_t g = (uint32_t)std::min<size_t>(count, fused_group_limit(n, max_bits));
+    return g >= 2 ? std::max(pipeline, msm_shape(n, max_bits, false, g).total) : pipeline;
 }
 
 // ---- resident SRS: host ranges the caller promised not to modify (h2_bases_register).  The reference

@@ -242,7 +242,11 @@ class Device:
             items.append((also[0], also[1], 254))
         count, m = len(items), hi - lo
         per = max((self.L.h2_msm_scratch_bytes(m, b) + 255) // 256 * 256 for b in {b for _, _, b in items})
-        scratch = self.scratch(2 * per)
+        groups = {}
+        for _, bs, b in items:                      # columns over one table with one bound can be fused by the library
+            groups[(bs.data_ptr(), b)] = groups.get((bs.data_ptr(), b), 0) + 1
+        nbytes = max([2 * per] + [self.L.h2_msm_batch_scratch_bytes(m, b, cnt) for (_, b), cnt in groups.items()])
+        scratch = self.scratch(nbytes)
         out = np.zeros((count, 12), dtype=np.uint64)
         if count == 1:
             c, bs, b = items[0]
@@ -252,7 +256,7 @@ class Device:
             sp = (_vp * count)(*[c.data_ptr() + 32 * lo for c, _, _ in items])
             bp = (_vp * count)(*[bs.data_ptr() + 64 * lo for _, bs, _ in items])
             bits = (ctypes.c_uint32 * count)(*[b for _, _, b in items])
-            check(self.L.h2_dev_msm_batch_ex(sp, bp, bits, count, m, scratch.data_ptr(), 2 * per, out.ctypes.data,
+            check(self.L.h2_dev_msm_batch_ex(sp, bp, bits, count, m, scratch.data_ptr(), nbytes, out.ctypes.data,
                                              self.stream), "h2_dev_msm_batch_ex")
         return out
 

@@ -299,6 +299,11 @@ int h2_dev_msm_batch(const void *const *d_scalars, size_t count, const void *d_b
  * 16-bit witness columns next to full-width ones (plonk/prover.rs:293-299 computes max_bits per column) and columns over
  * g_lagrange next to one over g.  scratch_bytes >= 2 * max over the columns of round_up(h2_msm_scratch_bytes(n, max_bits_each[i]), 256)
  * (the layout depends on the window size picked for the bound: it is not monotonic in max_bits). */
+/* Scratch that lets the batch entry points commit `count` columns sharing one base table and one bound as a FUSED group
+ * (their windows become the windows of one wide MSM: sampling, sort launches, finish / reduce latency, synchronisation
+ * and read-back are paid once per group -- what a witness of many narrow columns needs).  With less scratch (but at
+ * least the 2 x h2_msm_scratch_bytes of the pipeline) the calls still succeed, column by column. */
+size_t h2_msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
 int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases_each, const uint32_t *max_bits_each,
                         size_t count, size_t n, void *d_scratch, size_t scratch_bytes, uint64_t *out_xyz, void *stream);
 int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,

@@ -466,3 +466,37 @@ def test_msm_2p20_proof_shaped_columns(oracle):
     want = _affine(oracle, oracle.best_multiexp(w, pts))
     for bits in (16, 254):
         assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(w, pts, bits)) == want, bits
+
+
+@pytest.mark.parametrize("n", [1 << 8, 1 << 12, 5000])
+def test_msm_fused_group(oracle, n):
+    """h2_dev_msm_batch with h2_msm_batch_scratch_bytes of scratch: the columns become the windows of ONE wide MSM
+    (uniform, dominant-scalar, all-equal, zero and sparse columns side by side), same points as the oracle; with the
+    pipeline-sized scratch the same call takes the two-stream path and returns the same points"""
+    import torch
+
+    L = h2.lib()
+    pts = oracle.random_g1(55, n)
+    rand = [from_mont(oracle.random_fr(160 + j, n)) for j in range(3)]
+    cols = [
+        to_mont(rand[0]),
+        to_mont([0xABCDEF0123456789ABCDEF if i > n // 10 else rand[1][i] for i in range(n)]),
+        to_mont([R_MOD - 1] * n),
+        to_mont([0] * n),
+        to_mont(rand[2]),
+        to_mont([7 if i % 5 == 0 else 0 for i in range(n)]),
+        to_mont([rand[2][3] if i % 2 else rand[2][i] for i in range(n)]),
+    ]
+    d_pts = torch.from_numpy(pts.view(np.int64)).cuda()
+    d_cols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    count = len(cols)
+    ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_cols])
+    want = [_affine(oracle, oracle.best_multiexp(c, pts)) for c in cols]
+    fused_bytes = L.h2_msm_batch_scratch_bytes(n, 254, count)
+    pipe_bytes = 2 * ((L.h2_msm_scratch_bytes(n, 254) + 255) // 256 * 256)
+    assert fused_bytes > pipe_bytes
+    for nbytes in (fused_bytes, pipe_bytes):
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        out = np.zeros((count, 12), dtype=np.uint64)
+        assert L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 254, scratch.data_ptr(), nbytes, out.ctypes.data, None) == 0
+        assert [_affine(oracle, out[j]) for j in range(count)] == want, nbytes
