@@ -70,7 +70,10 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     // cost model: W * (n + 3 * 2^(c-1)) group additions
     double best = 1e300;
     uint32_t best_c = 4;
-    for (uint32_t c = 2; c <= 20; c++) {
+    // windows wider than 17 bits lose more in the bucket-proportional kernels than they save in additions (measured at
+    // 2^22 / 2^24: c = 17 8.4 / 28.8 ms, c = 18 13.7 / 46.3 ms, c = 20 - / 40.7 ms: k_bucket_sort's partitions get small
+    // and numerous, k_reduce walks 2^c * W buckets), so the model only ranks c <= 17
+    for (uint32_t c = 2; c <= 17; c++) {
         uint32_t W = (max_bits + 1 + c - 1) / c;
         double cost = (double)W * ((double)n + 3.0 * (double)(1u << (c - 1)));
         if (cost < best) {
@@ -96,6 +99,9 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     // slice length: aim at >= 2^18 slices (one resident round of the chip at 4 waves/SIMD), 8 <= S <= 64
     s.log_s = 6;
     while (s.log_s > 3 && (s.entries >> s.log_s) < (1u << 18)) s.log_s--;
+    // large MSMs: keep the partials per bucket low (k_finish folds <= FINISH_SERIAL of them per thread, more go through
+    // the heavy-bucket path) by lengthening the slices while at least 2^20 of them remain
+    while (s.log_s < 10 && (s.entries >> (s.log_s + 1)) >= (1u << 20) && ((n / s.nb) >> s.log_s) > 2) s.log_s++;
     if (const char* env = getenv("H2_MSM_SLICE_LOG")) {
         int v = atoi(env);
         if (v >= 1 && v <= 10) s.log_s = (uint32_t)v;
