@@ -682,21 +682,28 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     cols = cs.perm_columns
     colvals = {"advice": advice_dev, "fixed": pk.fixed_values, "instance": instance_dev}
     z_dev, last_z = [], 1
-    num, den, tmp = D.empty(n), D.empty(n), D.empty(n)
-    for si in range(0, len(cols), chunk):
+    # numerators / denominators of every set first, then ONE batch inversion over all sets: the inversion's serial
+    # a^(r-2) chain (~0.3 ms of pure latency) is paid once instead of once per set; only the running products chain
+    nsets = (len(cols) + chunk - 1) // chunk
+    nums, dens = D.empty(max(nsets, 1) * n), D.empty(max(nsets, 1) * n)
+    for k_, si in enumerate(range(0, len(cols), chunk)):
         for ci in range(si, min(si + chunk, len(cols))):
             values = colvals[cols[ci][0]][cols[ci][1]]
-            check(L.h2_dev_permutation_terms(num.data_ptr(), den.data_ptr(), values.data_ptr(),
+            check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), dens[k_ * n:].data_ptr(), values.data_ptr(),
                                              pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
                                              _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
                                              D.stream), "h2_dev_permutation_terms")
-        check(L.h2_dev_batch_invert(den.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
-        D.eval_op(3, num, num, den)                                                   # H2_OP_MUL
+    if nsets:
+        check(L.h2_dev_batch_invert(dens.data_ptr(), D.empty(nsets * n).data_ptr(), nsets * n, D.stream), "h2_dev_batch_invert")
+        D.eval_op(3, nums, nums, dens)                                                # H2_OP_MUL over all sets
+    for k_ in range(nsets):
         z = D.empty(n)
-        check(L.h2_dev_prefix_product(num.data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+        check(L.h2_dev_prefix_product(nums[k_ * n:].data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
         D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
         last_z = D.get_rows(z, usable, 1)[0]
         z_dev.append(z)
+    del nums, dens
+    num, den, tmp = D.empty(n), D.empty(n), D.empty(n)
     # ---- lookup grand sums (logup/prover.rs:243-415; blinding prover.rs:446-465) -------------------------------
     for st in lookups:
         st["z"] = []
