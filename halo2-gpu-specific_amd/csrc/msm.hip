@@ -32,18 +32,19 @@
 #include <thread>
 
 #include "common.hpp"
-#include "ec.hpp"
+#include "ec_quad.hpp"
 #include "msm.hpp"
 
 namespace h2 {
 
-static constexpr uint32_t FINISH_SERIAL = 8; // partials a single thread folds in k_finish
+static constexpr uint32_t FINISH_SERIAL = 32; // partials a single quad folds in k_finish
 static constexpr uint32_t SORT_T = 1024;      // threads of a k_bucket_sort workgroup (one partition each)
 static constexpr uint32_t HEAVY_SPLIT = 64;   // workgroups sharing one heavy bucket in k_finish_heavy
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 256;    // threads per k_reduce workgroup
-static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce thread
+static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce lane: a quad walks REDUCE_QM = 4 * REDUCE_M of them
+static constexpr uint32_t REDUCE_QM = 4 * REDUCE_M;
 static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
 
 struct MsmShape {
@@ -493,24 +494,50 @@ __global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const ui
 }
 
 // ---------------------------------------------------------------- k_finish / k_finish_heavy
+// These kernels and k_reduce are chains and trees of dependent point additions with few of them in flight: they run on
+// QUADS (ec_quad.hpp) -- four lanes share one chain and each addition costs 4 dependent field products instead of 14.
+// `q` = lane inside the quad, `qd` = quad inside the workgroup; loads are replicated over the quad, lane k stores
+// coordinate k.
+__device__ __forceinline__ void xyzz_store_q(XYZZ* p, const XYZZ& v, uint32_t q) {
+    fp_store(&p->x + q, quad_pick(q, v.x, v.y, v.zz, v.zzz));
+}
+
+// sum over the QUADS quads of a workgroup, result in quad 0 (sh: one XYZZ per quad)
+template <uint32_t QUADS>
+__device__ __forceinline__ XYZZ quad_tree_sum(XYZZ acc, XYZZ* sh, uint32_t qd, uint32_t q) {
+    for (uint32_t off = QUADS / 2; off >= 1; off >>= 1) {
+        if (qd >= off && qd < 2 * off) xyzz_store_q(sh + qd, acc, q);
+        __syncthreads();
+        if (qd < off) acc = xyzz_add_q(acc, xyzz_load(sh + qd + off), q);
+        __syncthreads();
+    }
+    return acc;
+}
+
 // bucket b's partials are slots b + first .. b + last, first/last = slices of its first/last entry
 __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint32_t* starts, uint32_t nbt,
                                                 uint32_t log_s, XYZZ* buckets, uint32_t* heavy_list,
                                                 uint32_t* heavy_count) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = threadIdx.x & 3;
+    uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     if (b >= nbt) return;
     uint32_t e0 = starts[b], e1 = starts[b + 1];
     XYZZ acc = xyzz_identity();
     if (e1 > e0) {
         uint32_t first = e0 >> log_s, last = (e1 - 1) >> log_s;
         if (last - first + 1 > FINISH_SERIAL) {
-            heavy_list[atomicAdd(heavy_count, 1u)] = b;
+            if (q == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
             return;
         }
         acc = xyzz_load(partials + (b + first));
-        for (uint32_t sl = first + 1; sl <= last; sl++) acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
+        XYZZ nxt = first < last ? xyzz_load(partials + (b + first + 1)) : xyzz_identity();
+        for (uint32_t sl = first + 1; sl <= last; sl++) {
+            const XYZZ cur = nxt;
+            if (sl < last) nxt = xyzz_load(partials + (b + sl + 1));  // in flight during the addition below
+            acc = xyzz_add_q(acc, cur, q);
+        }
     }
-    xyzz_store(buckets + b, acc);
+    xyzz_store_q(buckets + b, acc, q);
 }
 
 // Heavy bucket h, part y (of HEAVY_SPLIT): folds the partial slots first + y, first + y + HEAVY_SPLIT, ... and
@@ -518,74 +545,63 @@ __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint
 // bucket never race.  k_finish_heavy2 then folds the (at most HEAVY_SPLIT) leading slots.
 __global__ void __launch_bounds__(256) k_finish_heavy(XYZZ* partials, const uint32_t* starts, uint32_t log_s,
                                                       const uint32_t* heavy_list, const uint32_t* heavy_count) {
-    __shared__ XYZZ sh[256];
-    const uint32_t tid = threadIdx.x, part = blockIdx.y;
+    __shared__ XYZZ sh[64];
+    const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2, part = blockIdx.y;
     uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
         if (first + part > last) continue;  // uniform over the workgroup
         XYZZ acc = xyzz_identity();
-        for (uint32_t sl = first + part + tid * HEAVY_SPLIT; sl <= last; sl += 256 * HEAVY_SPLIT)
-            acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
-        sh[tid] = acc;
-        __syncthreads();
-        for (uint32_t off = 128; off >= 1; off >>= 1) {
-            if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
-            __syncthreads();
-        }
-        if (tid == 0) xyzz_store(partials + (b + first + part), sh[0]);
-        __syncthreads();
+        for (uint32_t sl = first + part + qd * HEAVY_SPLIT; sl <= last; sl += 64 * HEAVY_SPLIT)
+            acc = xyzz_add_q(acc, xyzz_load(partials + (b + sl)), q);
+        acc = quad_tree_sum<64>(acc, sh, qd, q);
+        if (qd == 0) xyzz_store_q(partials + (b + first + part), acc, q);
     }
 }
 
-__global__ void __launch_bounds__(HEAVY_SPLIT) k_finish_heavy2(const XYZZ* partials, const uint32_t* starts,
-                                                                uint32_t log_s, const uint32_t* heavy_list,
-                                                                const uint32_t* heavy_count, XYZZ* buckets) {
+__global__ void __launch_bounds__(4 * HEAVY_SPLIT) k_finish_heavy2(const XYZZ* partials, const uint32_t* starts,
+                                                                    uint32_t log_s, const uint32_t* heavy_list,
+                                                                    const uint32_t* heavy_count, XYZZ* buckets) {
     __shared__ XYZZ sh[HEAVY_SPLIT];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2;
     uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
-        sh[tid] = (first + tid <= last) ? xyzz_load(partials + (b + first + tid)) : xyzz_identity();
-        __syncthreads();
-        for (uint32_t off = HEAVY_SPLIT / 2; off >= 1; off >>= 1) {
-            if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
-            __syncthreads();
-        }
-        if (tid == 0) xyzz_store(buckets + b, sh[0]);
-        __syncthreads();
+        XYZZ acc = (first + qd <= last) ? xyzz_load(partials + (b + first + qd)) : xyzz_identity();
+        acc = quad_tree_sum<HEAVY_SPLIT>(acc, sh, qd, q);
+        if (qd == 0) xyzz_store_q(buckets + b, acc, q);
     }
 }
 
 // ---------------------------------------------------------------- k_reduce
-// window w, group g: sum over this group's buckets of (b + 1) * B_b   (b = index inside the window)
+// window w, group g: sum over this group's buckets of (b + 1) * B_b   (b = index inside the window).  A quad walks
+// REDUCE_QM consecutive buckets by summation by parts (arithmetic.rs:98-106), lifts its sum by the offset of its first
+// bucket, and the 64 quads of the workgroup are folded by a tree.
 __global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32_t nb, uint32_t G, XYZZ* winpart) {
-    __shared__ XYZZ sh[REDUCE_T];
-    const uint32_t tid = threadIdx.x, g = blockIdx.x, w = blockIdx.y;
+    __shared__ XYZZ sh[REDUCE_T / 4];
+    const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2, g = blockIdx.x, w = blockIdx.y;
     const XYZZ* B = buckets + (size_t)w * nb;
-    uint32_t k0 = (g * REDUCE_T + tid) * REDUCE_M;
+    uint32_t k0 = (g * (REDUCE_T / 4) + qd) * REDUCE_QM;
     XYZZ res = xyzz_identity();
     if (k0 < nb) {
-        uint32_t k1 = k0 + REDUCE_M;
+        uint32_t k1 = k0 + REDUCE_QM;
         if (k1 > nb) k1 = nb;
         XYZZ running = xyzz_identity(), acc = xyzz_identity();
-        for (uint32_t b = k1; b-- > k0;) {  // summation by parts (arithmetic.rs:98-106)
-            running = xyzz_add(running, xyzz_load(B + b));
-            acc = xyzz_add(acc, running);
+        XYZZ nxt = xyzz_load(B + (k1 - 1));
+        for (uint32_t b = k1; b-- > k0;) {
+            const XYZZ cur = nxt;
+            if (b > k0) nxt = xyzz_load(B + (b - 1));  // in flight during the two additions below
+            running = xyzz_add_q(running, cur, q);
+            acc = xyzz_add_q(acc, running, q);
         }
         // acc = sum (b - k0 + 1) * B_b ;  running = sum B_b
         res = acc;
-        if (k0 != 0 && !xyzz_is_identity(running)) res = xyzz_add(res, xyzz_mul_u32(running, k0));
+        if (k0 != 0 && !xyzz_is_identity(running)) res = xyzz_add_q(res, xyzz_mul_u32_q(running, k0, q), q);
     }
-    sh[tid] = res;
-    __syncthreads();
-    for (uint32_t off = REDUCE_T / 2; off >= 1; off >>= 1) {
-        if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
-        __syncthreads();
-    }
-    if (tid == 0) xyzz_store(winpart + (size_t)w * G + g, sh[0]);
+    res = quad_tree_sum<REDUCE_T / 4>(res, sh, qd, q);
+    if (qd == 0) xyzz_store_q(winpart + (size_t)w * G + g, res, q);
 }
 
 // ---------------------------------------------------------------- synthetic bases (bench / tests)
@@ -896,11 +912,11 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
                        s.log_s, partials);
-    hipLaunchKernelGGL(k_finish, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
+    hipLaunchKernelGGL(k_finish, dim3((s.nbt + 63) / 64), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
                        buckets, heavy + 1, heavy);
     hipLaunchKernelGGL(k_finish_heavy, dim3(64, HEAVY_SPLIT), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy);
-    hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
+    hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(4 * HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
     hipLaunchKernelGGL(k_reduce, dim3(s.G, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
     H2_HIP(hipGetLastError());

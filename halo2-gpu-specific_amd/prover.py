@@ -428,8 +428,10 @@ class ProvingKey:
     pass
 
 
-def keygen(device, params, cs, fixed, copies):
-    """keygen_vk + keygen_pk.  fixed: list of canonical (n, 4) u64 columns; copies: see permutation_mapping."""
+def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=False):
+    """keygen_vk + keygen_pk.  fixed: list of canonical (n, 4) u64 columns; copies: see permutation_mapping.
+    `mapping` = (map_col, map_row) replaces `copies` and `fixed_montgomery` marks columns already in the in-memory
+    representation: the two things a CircuitData file holds (keygen_pk_from_info, plonk/keygen.rs:458-553)."""
     D, L = device, device.L
     dom = Domain(params.k, cs.degree())
     n, bf = dom.n, cs.blinding_factors()
@@ -440,20 +442,23 @@ def keygen(device, params, cs, fixed, copies):
     pk.fixed_values = []
     for col in fixed:
         t = D.upload(col)
-        check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+        if not fixed_montgomery:
+            check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
         pk.fixed_values.append(t)
     pk.fixed_commitments = D.msm_batch(pk.fixed_values, params.g_lagrange, n, 254)
     pk.fixed_polys = [D.intt(D.clone(t), dom) for t in pk.fixed_values]
     pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys]
     # permutation: sigma columns (Lagrange), polys, cosets
     ncols = len(cs.perm_columns)
-    map_col, map_row = permutation_mapping(ncols, n, copies)
+    map_col, map_row = mapping if mapping is not None else permutation_mapping(ncols, n, copies)
+    assert len(map_col) == ncols and all(len(c) == n for c in map_col)
+    pk.mapping = (map_col, map_row)
     pk.sigma_values = []
     for i in range(ncols):
         out = D.empty(n)
         with D.torch.cuda.stream(D.tstream):
-            mc = D.torch.from_numpy(map_col[i].view(np.int32)).to(D.dev)
-            mr = D.torch.from_numpy(map_row[i].view(np.int32)).to(D.dev)
+            mc = D.torch.from_numpy(np.ascontiguousarray(map_col[i], dtype=np.uint32).view(np.int32)).to(D.dev)
+            mr = D.torch.from_numpy(np.ascontiguousarray(map_row[i], dtype=np.uint32).view(np.int32)).to(D.dev)
         check(L.h2_dev_permutation_sigma(out.data_ptr(), mc.data_ptr(), mr.data_ptr(), n, _fr(DELTA), _fr(dom.omega),
                                          D.stream), "h2_dev_permutation_sigma")
         D.sync()
@@ -488,6 +493,18 @@ def keygen(device, params, cs, fixed, copies):
                                                pk.lookup_calcs, pk.shuffle_calcs)
     pk.transcript_repr = vk_digest(cs, params.k, pk.fixed_commitments, pk.perm_commitments)
     D.sync()
+    return pk
+
+
+def keygen_from_info(device, params, info):
+    """CircuitData::into_proving_key (plonk.rs:196-198): `info` = formats.circuit_data_read(path).  The commitments
+    are recomputed from the columns and must equal the ones the file carries."""
+    if info["k"] != params.k:
+        raise ValueError("circuit data for k = %d under params of k = %d" % (info["k"], params.k))
+    pk = keygen(device, params, info["cs"], info["fixed"], None, mapping=info["mapping"], fixed_montgomery=True)
+    have = [point_to_bytes(P) for P in list(pk.fixed_commitments) + list(pk.perm_commitments)]
+    if have != list(info["fixed_commitments"]) + list(info["perm_commitments"]):
+        raise ValueError("circuit data: the verifying key's commitments do not match its columns under these params")
     return pk
 
 

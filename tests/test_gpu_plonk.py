@@ -378,3 +378,39 @@ def test_proof_parity_over_random_trapdoors_sizes_and_seeds(oracle, device):
         want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=inst)
         assert proof == want, (trial, which, k, use_gwc)
         assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=inst)
+
+
+def test_circuit_data_file_to_proving_key(oracle, device, tmp_path):
+    """N4: CircuitData::write -> read -> into_proving_key (plonk.rs:126-204): a key rebuilt from the file (constraint
+    system, raw fixed columns, permutation mapping) proves to the same bytes as the key it was written from -- and as
+    the reference prover; a file whose columns disagree with its commitments is refused"""
+    from halo2_gpu_specific_amd import formats, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 6
+    adv, fixed, copies, inst = rp.LookupShuffle.synthesize(k)
+    params = srs(oracle, device, k)
+    cs = lookup_shuffle_cs()
+    pk = prover.keygen(device, params, cs, cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    path = str(tmp_path / "circuit.data")
+    formats.circuit_data_write(path, device, params, pk)
+    info = formats.circuit_data_read(path, cs.name)
+    assert (info["j"], info["k"]) == (cs.degree(), k)
+    pk2 = prover.keygen_from_info(device, params, info)
+    assert pk2.transcript_repr == pk.transcript_repr
+    rpk = rp.keygen(rp.LookupShuffle, k, S_TRAPDOOR, fixed, copies)
+    for seed, use_gwc in ((3, False), (4, True)):
+        a = prover.create_proof_ext(device, params, pk, cols_to_arr(adv), ProverRng(seed), use_gwc, instances=inst)
+        b = prover.create_proof_ext(device, params, pk2, cols_to_arr(adv), ProverRng(seed), use_gwc, instances=inst)
+        assert a == b == rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=inst)
+    # one fixed value changed in the file: the commitments no longer match
+    raw = bytearray(open(path, "rb").read())
+    n = 1 << k
+    tail = len(info["mapping"][0]) * (4 + 8 * n) + 4           # mapping section
+    first_fixed = len(raw) - tail - len(info["fixed"]) * (4 + 32 * n) + 4
+    raw[first_fixed + 32 * 3] ^= 1
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="do not match"):
+        prover.keygen_from_info(device, params, formats.circuit_data_read(path, cs.name))
+    with pytest.raises(ValueError, match="under params"):
+        prover.keygen_from_info(device, srs(oracle, device, k + 1), info)

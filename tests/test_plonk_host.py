@@ -422,3 +422,110 @@ def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
         assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) == path   # cached
     monkeypatch.setenv("H2_EVALH_JIT", "0")
     assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) is None
+
+
+# ---- CircuitData (plonk.rs:126-204, helpers.rs write_cs / read_cs) ------------------------------------------------
+def _u32s(*vals):
+    import struct
+
+    return b"".join(struct.pack("<I", v & 0xFFFFFFFF) for v in vals)
+
+
+def test_constraint_system_bytes_follow_write_cs():
+    """the mini-PLONK constraint system, byte for byte as helpers.rs:406-456 / :687-757 lay it out (written out by hand
+    from those functions: every integer a little-endian u32, rotation as i32, Any = {Advice 0, Fixed 1, Instance 2},
+    expression codes Constant 0 .. Scaled 7)"""
+    from halo2_gpu_specific_amd import formats
+
+    cs = hc.ConstraintSystem("tiny")
+    a, b = cs.advice_column(), cs.advice_column()
+    s = cs.fixed_column()
+    cs.enable_equality(a)
+    cs.enable_equality(b)
+    qa, qb1, qs = cs.query_advice(a), cs.query_advice(b, -1), cs.query_fixed(s)
+    cs.create_gate("g", [qs * (qa + qb1 * 5)])
+    want = _u32s(2, 0, 0, 1)                        # advice, instance, selectors, fixed
+    want += _u32s(2, 1, 2)                          # num_advice_queries: a once, b twice (cur + prev)
+    want += _u32s(0) + _u32s(0)                     # selector_map, constants
+    want += _u32s(3, 0, 0, 1, 0, 1, -1)             # advice queries (a,0) (b,0) (b,-1)
+    want += _u32s(0)                                # instance queries
+    want += _u32s(1, 0, 0)                          # fixed queries (s,0)
+    want += _u32s(2, 0, 0, 1, 0)                    # permutation columns: (index, Any::Advice) x 2
+    want += _u32s(0) + _u32s(0) + _u32s(0) + _u32s(0)   # lookups, shuffles, range checks, named advices
+    want += _u32s(1)                                # gates
+    want += _u32s(1)                                # one polynomial: Product(Fixed, Sum(Advice, Scaled(Advice, 5)))
+    want += _u32s(6) + _u32s(1, 0, 0, 0)            # Product, Fixed{query 0, column 0, rot 0}
+    want += _u32s(5) + _u32s(2, 0, 0, 0)            # Sum, Advice{query 0, column 0, rot 0}
+    want += _u32s(7) + _u32s(2, 2, 1, -1) + (5).to_bytes(32, "little")   # Scaled(Advice{query 2, column 1, rot -1}, 5)
+    want += _u32s(3) + _u32s(0, 1, 0) + _u32s(0, 0, 0) + _u32s(1, 0, -1)  # queried cells: (column, Any, rotation)
+    assert formats.cs_store(cs) == want
+
+
+@pytest.mark.parametrize("make", [circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs])
+def test_constraint_system_round_trip(make):
+    from halo2_gpu_specific_amd import formats
+
+    cs = make()
+    raw = formats.cs_store(cs)
+    r = formats._Reader(raw)
+    back = formats.cs_fetch(r, cs.name)
+    assert r.pos == len(raw)
+    back.set_minimum_degree(cs.degree())
+    assert formats.cs_store(back) == raw
+    assert (back.degree(), back.blinding_factors(), back.perm_columns) == (cs.degree(), cs.blinding_factors(), cs.perm_columns)
+    # the prover sees the same program: Evaluator::new on the fetched system
+    g0, parts0, lk0, sh0 = hc.compile_evaluator(cs)
+    g1, parts1, lk1, sh1 = hc.compile_evaluator(back)
+    key = lambda g: ([(c.op, c.a.kind, c.a.index, c.a.rot, c.b.kind, c.b.index, c.b.rot) for c in g.calculations],  # noqa: E731
+                     g.constants, g.rotations)
+    assert key(g0) == key(g1) and len(parts0) == len(parts1) and len(lk0) == len(lk1) and len(sh0) == len(sh1)
+    with pytest.raises(IOError):
+        formats.cs_fetch(formats._Reader(raw[:-5]))
+
+
+def test_circuit_data_file_round_trip(tmp_path):
+    """CircuitData::write / read around a key whose device tensors are stood in by arrays (no GPU here): layout of
+    the commitments, the raw fixed columns and the (u32, u32) mapping pairs"""
+    from halo2_gpu_specific_amd import formats
+
+    k, n = 4, 16
+    cs = rot_gate_cs()
+    rng = random.Random(9)
+
+    class FakeDevice:
+        def download(self, t):
+            return t
+
+    class PK:
+        pass
+
+    pk = PK()
+    pk.cs = cs
+    pk.fixed_values = [np.array([[rng.getrandbits(64) for _ in range(4)] for _ in range(n)], dtype=np.uint64) for _ in range(2)]
+    pk.fixed_commitments = [rp.g1_mul(rp.G1, 5), None]
+    pk.perm_commitments = [rp.g1_mul(rp.G1, 7 + i) for i in range(4)]
+    copies = [(0, 1, 2, 3), (1, 0, 3, 5), (2, 3, 0, 7)]
+    pk.mapping = prover.permutation_mapping(4, n, copies)
+
+    class P:
+        pass
+
+    params = P()
+    params.k, params.n = k, n
+    path = str(tmp_path / "circuit.data")
+    formats.circuit_data_write(path, FakeDevice(), params, pk)
+    info = formats.circuit_data_read(path, "rot-gate")
+    assert (info["j"], info["k"]) == (cs.degree(), k)
+    assert info["fixed_commitments"] == [transcript.point_to_bytes(P_) for P_ in pk.fixed_commitments]
+    assert info["perm_commitments"] == [transcript.point_to_bytes(P_) for P_ in pk.perm_commitments]
+    assert all((x == y).all() for x, y in zip(info["fixed"], pk.fixed_values))
+    assert all((x == y).all() for x, y in zip(info["mapping"][0], pk.mapping[0]))
+    assert all((x == y).all() for x, y in zip(info["mapping"][1], pk.mapping[1]))
+    raw = open(path, "rb").read()
+    # the tail is the mapping: 4 columns x 16 pairs x 8 bytes after the u32 count and the 4 u32 lengths
+    tail = raw[-(4 * n * 8):]
+    assert raw[-(4 * n * 8) - 20:-(4 * n * 8)] == _u32s(4, n, n, n, n)
+    assert tail[8 * 1:8 * 2] == _u32s(int(pk.mapping[0][0][1]), int(pk.mapping[1][0][1]))
+    with pytest.raises(IOError):
+        open(path, "wb").write(raw[:-3])
+        formats.circuit_data_read(path)
