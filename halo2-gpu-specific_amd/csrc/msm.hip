@@ -42,13 +42,13 @@ static constexpr uint32_t SORT_T = 1024;      // threads of a k_bucket_sort work
 static constexpr uint32_t HEAVY_SPLIT = 64;   // workgroups sharing one heavy bucket in k_finish_heavy
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
-static constexpr uint32_t REDUCE_T = 256;    // threads per k_reduce workgroup
-static constexpr uint32_t REDUCE_M = 8;      // buckets per k_reduce lane: a quad walks REDUCE_QM = 4 * REDUCE_M of them
-static constexpr uint32_t REDUCE_QM = 4 * REDUCE_M;
+static constexpr uint32_t REDUCE_T = 512;    // threads per k_reduce workgroup = 128 quads (two waves per SIMD)
+static constexpr uint32_t REDUCE_QM = 16;    // consecutive buckets a quad walks
 static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
 
 struct MsmShape {
-    uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, reduce groups/window
+    uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, points exported per window (1)
+    uint32_t RG;                // k_reduce workgroups per window (folded on the device by the last one to finish)
     uint32_t Wt;                // windows the pipeline runs: W, + 1 when a dominant scalar has its own window (see k_digits)
     uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
     size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
@@ -58,7 +58,7 @@ struct MsmShape {
     size_t n, entries, max_items;
     // scratch offsets (bytes)
     size_t off_keys, off_sorted, off_tmp, off_pcount, off_pbase, off_pcursor, off_starts, off_heavy, off_partials,
-        off_buckets, off_winpart, total;
+        off_buckets, off_winpart, off_rcount, total;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -84,7 +84,7 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     }
     if (const char* env = getenv("H2_MSM_WINDOW")) {
         int v = atoi(env);
-        if (v >= 2 && v <= 20) best_c = (uint32_t)v;
+        if (v >= 2 && v <= 18) best_c = (uint32_t)v;  // k_reduce folds <= 128 groups per window
     }
     s.c = best_c;
     s.W = (max_bits + 1 + s.c - 1) / s.c;
@@ -94,8 +94,9 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     if (cols) s.Wt = cols * s.Wc;  // every column keeps a slot for its dominant-scalar window
     s.nb = 1u << (s.c - 1);
     s.nbt = s.Wt * s.nb;
-    uint32_t per_group = REDUCE_T * REDUCE_M;
-    s.G = (s.nb + per_group - 1) / per_group;
+    uint32_t per_group = REDUCE_T / 4 * REDUCE_QM;
+    s.RG = (s.nb + per_group - 1) / per_group;
+    s.G = 1;
     s.entries = n * s.Wt;
     // slice length: aim at >= 2^18 slices (one resident round of the chip at 4 waves/SIMD), 8 <= S <= 64
     s.log_s = 6;
@@ -131,7 +132,8 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     s.off_heavy = take(((size_t)s.nbt + 2) * 4);
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
-    s.off_winpart = take((size_t)s.Wt * s.G * sizeof(XYZZ));
+    s.off_winpart = take((size_t)s.Wt * (1 + s.RG) * sizeof(XYZZ));  // window sums, then the RG group partials of each
+    s.off_rcount = take((size_t)s.Wt * 4);
     s.off_coltab = take((size_t)(cols ? cols : 1) * 64);
     s.total = o;
     return s;
@@ -578,9 +580,26 @@ __global__ void __launch_bounds__(4 * HEAVY_SPLIT) k_finish_heavy2(const XYZZ* p
 // ---------------------------------------------------------------- k_reduce
 // window w, group g: sum over this group's buckets of (b + 1) * B_b   (b = index inside the window).  A quad walks
 // REDUCE_QM consecutive buckets by summation by parts (arithmetic.rs:98-106), lifts its sum by the offset of its first
-// bucket, and the 64 quads of the workgroup are folded by a tree.
-__global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32_t nb, uint32_t G, XYZZ* winpart) {
+// bucket, and the quads of the workgroup are folded by a tree.  The last workgroup of a window to finish (a counter per
+// window) folds the RG group results, so the host reads one point per window.
+__device__ __forceinline__ XYZZ xyzz_load_coherent(const XYZZ* p) {  // written by other workgroups of this launch
+    XYZZ r;
+    const volatile uint4* src = (const volatile uint4*)p;
+    uint4* dst = (uint4*)&r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        dst[i].x = src[i].x;
+        dst[i].y = src[i].y;
+        dst[i].z = src[i].z;
+        dst[i].w = src[i].w;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32_t nb, uint32_t RG, XYZZ* groups,
+                                                     XYZZ* winsum, uint32_t* rcount) {
     __shared__ XYZZ sh[REDUCE_T / 4];
+    __shared__ uint32_t last_flag;
     const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2, g = blockIdx.x, w = blockIdx.y;
     const XYZZ* B = buckets + (size_t)w * nb;
     uint32_t k0 = (g * (REDUCE_T / 4) + qd) * REDUCE_QM;
@@ -601,7 +620,20 @@ __global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32
         if (k0 != 0 && !xyzz_is_identity(running)) res = xyzz_add_q(res, xyzz_mul_u32_q(running, k0, q), q);
     }
     res = quad_tree_sum<REDUCE_T / 4>(res, sh, qd, q);
-    if (qd == 0) xyzz_store_q(winpart + (size_t)w * G + g, res, q);
+    if (RG == 1) {
+        if (qd == 0) xyzz_store_q(winsum + w, res, q);
+        return;
+    }
+    if (qd == 0) xyzz_store_q(groups + (size_t)w * RG + g, res, q);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_flag = atomicAdd(rcount + w, 1u) == RG - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    res = qd < RG ? xyzz_load_coherent(groups + (size_t)w * RG + qd) : xyzz_identity();
+    res = quad_tree_sum<REDUCE_T / 4>(res, sh, qd, q);
+    if (qd == 0) xyzz_store_q(winsum + w, res, q);
 }
 
 // ---------------------------------------------------------------- synthetic bases (bench / tests)
@@ -918,7 +950,9 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
                        heavy);
     hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(4 * HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
-    hipLaunchKernelGGL(k_reduce, dim3(s.G, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.G, winpart);
+    if (s.RG > 1) H2_HIP(hipMemsetAsync(scratch + s.off_rcount, 0, (size_t)s.Wt * 4, stream));
+    hipLaunchKernelGGL(k_reduce, dim3(s.RG, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, winpart + s.Wt, winpart,
+                       (uint32_t*)(scratch + s.off_rcount));
     H2_HIP(hipGetLastError());
 }
 
