@@ -43,12 +43,13 @@ static constexpr uint32_t HEAVY_SPLIT = 64;   // workgroups sharing one heavy bu
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 512;    // threads per k_reduce workgroup = 128 quads (two waves per SIMD)
-static constexpr uint32_t REDUCE_QM = 16;    // consecutive buckets a quad walks
+static constexpr uint32_t REDUCE_QM = 32;    // consecutive buckets a quad walks (fewer when that still fits the chip)
 static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
 
 struct MsmShape {
     uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, points exported per window (1)
-    uint32_t RG;                // k_reduce workgroups per window (folded on the device by the last one to finish)
+    uint32_t RG, qm;            // k_reduce: workgroups per window (folded on the device by the last one to finish) and
+                                // consecutive buckets per quad
     uint32_t Wt;                // windows the pipeline runs: W, + 1 when a dominant scalar has its own window (see k_digits)
     uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
     size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
@@ -94,7 +95,20 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     if (cols) s.Wt = cols * s.Wc;  // every column keeps a slot for its dominant-scalar window
     s.nb = 1u << (s.c - 1);
     s.nbt = s.Wt * s.nb;
-    uint32_t per_group = REDUCE_T / 4 * REDUCE_QM;
+    // k_reduce is a chain of 2 * qm additions per quad: the shortest chains whose workgroups still fit the chip once
+    s.qm = REDUCE_QM;
+    for (uint32_t qm = 4; qm < REDUCE_QM; qm *= 2) {
+        uint32_t rg = (s.nb + REDUCE_T / 4 * qm - 1) / (REDUCE_T / 4 * qm);
+        if ((size_t)s.Wt * rg <= 256 && rg <= REDUCE_T / 4) {  // one workgroup per CU: a CU with two runs both at half speed
+            s.qm = qm;
+            break;
+        }
+    }
+    if (const char* env = getenv("H2_MSM_REDUCE_QM")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64 && (s.nb + REDUCE_T / 4 * v - 1) / (REDUCE_T / 4 * v) <= REDUCE_T / 4) s.qm = (uint32_t)v;
+    }
+    uint32_t per_group = REDUCE_T / 4 * s.qm;
     s.RG = (s.nb + per_group - 1) / per_group;
     s.G = 1;
     s.entries = n * s.Wt;
@@ -596,16 +610,16 @@ __device__ __forceinline__ XYZZ xyzz_load_coherent(const XYZZ* p) {  // written 
     return r;
 }
 
-__global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32_t nb, uint32_t RG, XYZZ* groups,
-                                                     XYZZ* winsum, uint32_t* rcount) {
+__global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32_t nb, uint32_t RG, uint32_t qm,
+                                                     XYZZ* groups, XYZZ* winsum, uint32_t* rcount) {
     __shared__ XYZZ sh[REDUCE_T / 4];
     __shared__ uint32_t last_flag;
     const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2, g = blockIdx.x, w = blockIdx.y;
     const XYZZ* B = buckets + (size_t)w * nb;
-    uint32_t k0 = (g * (REDUCE_T / 4) + qd) * REDUCE_QM;
+    uint32_t k0 = (g * (REDUCE_T / 4) + qd) * qm;
     XYZZ res = xyzz_identity();
     if (k0 < nb) {
-        uint32_t k1 = k0 + REDUCE_QM;
+        uint32_t k1 = k0 + qm;
         if (k1 > nb) k1 = nb;
         XYZZ running = xyzz_identity(), acc = xyzz_identity();
         XYZZ nxt = xyzz_load(B + (k1 - 1));
@@ -951,7 +965,7 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(4 * HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
     if (s.RG > 1) H2_HIP(hipMemsetAsync(scratch + s.off_rcount, 0, (size_t)s.Wt * 4, stream));
-    hipLaunchKernelGGL(k_reduce, dim3(s.RG, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, winpart + s.Wt, winpart,
+    hipLaunchKernelGGL(k_reduce, dim3(s.RG, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, s.qm, winpart + s.Wt, winpart,
                        (uint32_t*)(scratch + s.off_rcount));
     H2_HIP(hipGetLastError());
 }
