@@ -699,69 +699,87 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     cols = cs.perm_columns
     colvals = {"advice": advice_dev, "fixed": pk.fixed_values, "instance": instance_dev}
     z_dev, last_z = [], 1
-    # numerators / denominators of every set first, then ONE batch inversion over all sets: the inversion's serial
-    # a^(r-2) chain (~0.3 ms of pure latency) is paid once instead of once per set; only the running products chain
+    # Everything that has to be inverted before the grand products / sums can run -- the permutation denominators of
+    # every set, (beta + f) of every lookup input and table, the shuffle products -- depends only on beta and gamma: it
+    # is laid out in ONE buffer and inverted by ONE batch inversion, so the inversion's serial a^(r-2) chain (~0.3 ms
+    # of pure latency per call) is paid once per proof instead of once per column.
     nsets = (len(cols) + chunk - 1) // chunk
-    nums, dens = D.empty(max(nsets, 1) * n), D.empty(max(nsets, 1) * n)
+    slots = nsets + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
+    nums = D.empty(max(nsets, 1) * n)
+    inv = D.empty(max(slots, 1) * n)
+    slot = lambda i: inv[i * n:(i + 1) * n]  # noqa: E731
     for k_, si in enumerate(range(0, len(cols), chunk)):
         for ci in range(si, min(si + chunk, len(cols))):
             values = colvals[cols[ci][0]][cols[ci][1]]
-            check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), dens[k_ * n:].data_ptr(), values.data_ptr(),
+            check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), slot(k_).data_ptr(), values.data_ptr(),
                                              pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
                                              _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
                                              D.stream), "h2_dev_permutation_terms")
+    at = nsets
+    for st in lookups:
+        st["inv_inputs"] = []
+        for cols_in in st["inputs"]:
+            st["inv_inputs"].append([])
+            for col in cols_in:                                     # beta + f_i
+                st["inv_inputs"][-1].append(D.eval_op(1, slot(at), col, c=beta))          # H2_OP_SUM_C
+                at += 1
+        st["inv_table"] = D.eval_op(1, slot(at), st["table"], c=beta)  # beta + t
+        at += 1
+    shuffle_inv = []
+    for group in shuffles:                                          # prod_i (beta^(i+1) + shuffle_i)
+        dst = slot(at)
+        for i, (_, shf) in enumerate(group):
+            if i == 0:
+                D.eval_op(1, dst, shf, c=beta)
+            else:
+                D.eval_op(6, dst, shf, dst, c=pow(beta, i + 1, R_MOD))       # H2_OP_LCBETA: (l + c) * r
+        shuffle_inv.append(dst)
+        at += 1
+    assert at == slots
+    if slots:
+        check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * n).data_ptr(), slots * n, D.stream), "h2_dev_batch_invert")
+    # ---- permutation grand products (permutation/prover.rs:89-165) ------------------------------------------
     if nsets:
-        check(L.h2_dev_batch_invert(dens.data_ptr(), D.empty(nsets * n).data_ptr(), nsets * n, D.stream), "h2_dev_batch_invert")
-        D.eval_op(3, nums, nums, dens)                                                # H2_OP_MUL over all sets
+        D.eval_op(3, nums, nums, inv[:nsets * n])                                     # H2_OP_MUL over all sets
     for k_ in range(nsets):
         z = D.empty(n)
         check(L.h2_dev_prefix_product(nums[k_ * n:].data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
         D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
         last_z = D.get_rows(z, usable, 1)[0]
         z_dev.append(z)
-    del nums, dens
-    num, den, tmp = D.empty(n), D.empty(n), D.empty(n)
+    del nums
+    num = D.empty(n)
     # ---- lookup grand sums (logup/prover.rs:243-415; blinding prover.rs:446-465) -------------------------------
     for st in lookups:
         st["z"] = []
         last = 0
-        for si, cols_in in enumerate(st["inputs"]):
-            for j, col in enumerate(cols_in):                       # sum_i 1 / (beta + f_i)
-                dst = num if j == 0 else den
-                D.eval_op(1, dst, col, c=beta)                      # H2_OP_SUM_C
-                check(L.h2_dev_batch_invert(dst.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
-                if j:
-                    D.eval_op(2, num, num, den)                     # H2_OP_SUM
+        for si, inverted in enumerate(st["inv_inputs"]):
+            src = inverted[0]                                       # sum_i 1 / (beta + f_i)
+            for other in inverted[1:]:
+                src = D.eval_op(2, num, src, other)                 # H2_OP_SUM
             if si == 0:                                             # - m / (beta + t)
-                D.eval_op(1, den, st["table"], c=beta)
-                check(L.h2_dev_batch_invert(den.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
-                D.eval_op(3, den, den, st["m"])
-                D.eval_op(4, num, num, den)                         # H2_OP_SUB
+                D.eval_op(3, st["inv_table"], st["inv_table"], st["m"])
+                src = D.eval_op(4, num, src, st["inv_table"])       # H2_OP_SUB
             z = D.empty(n)
-            check(L.h2_dev_prefix_sum(num.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
+            check(L.h2_dev_prefix_sum(src.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
             last = D.get_rows(z, usable, 1)[0]
             D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
             st["z"].append(z)
         if last != 0:
             raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
+        del st["inv_inputs"], st["inv_table"]
     # ---- shuffle products (shuffle/prover.rs:82-150; blinding prover.rs:512-530) -------------------------------
     shuffle_z = []
-    for group in shuffles:
-        for i, (_, shf) in enumerate(group):                        # prod_i (beta^(i+1) + shuffle_i), inverted
-            if i == 0:
-                D.eval_op(1, num, shf, c=beta)
-            else:
-                D.eval_op(6, num, shf, num, c=pow(beta, i + 1, R_MOD))      # H2_OP_LCBETA: (l + c) * r
-        check(L.h2_dev_batch_invert(num.data_ptr(), tmp.data_ptr(), n, D.stream), "h2_dev_batch_invert")
+    for group, inverted in zip(shuffles, shuffle_inv):
         for i, (inp, _) in enumerate(group):
-            D.eval_op(6, num, inp, num, c=pow(beta, i + 1, R_MOD))
+            D.eval_op(6, inverted, inp, inverted, c=pow(beta, i + 1, R_MOD))
         z = D.empty(n)
-        check(L.h2_dev_prefix_product(num.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+        check(L.h2_dev_prefix_product(inverted.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
         if D.get_rows(z, usable, 1)[0] != 1:
             raise ValueError("shuffle product does not return to one")
         D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
         shuffle_z.append(z)
-    del num, den, tmp
+    del num, inv, shuffle_inv
     # vanishing argument: the random polynomial (vanishing/prover.rs:40-67), generated on the device
     random_poly = D.empty(n)
     check(L.h2_dev_random_fr(rng.random_poly_seed(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
