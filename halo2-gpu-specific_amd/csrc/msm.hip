@@ -50,7 +50,9 @@ struct MsmShape {
     uint32_t c, W, nb, nbt, G;  // window bits, digit windows, buckets/window, total buckets, points exported per window (1)
     uint32_t RG, qm;            // k_reduce: workgroups per window (folded on the device by the last one to finish) and
                                 // consecutive buckets per quad
-    uint32_t Wt;                // windows the pipeline runs: W, + 1 when a dominant scalar has its own window (see k_digits)
+    uint32_t Wt;                // windows the pipeline runs: R * W, + 1 when a dominant scalar has its own window (see k_digits)
+    uint32_t Wk;                // key arrays k_digits writes (n keys each): W, + 1 with a dominant scalar; cols * Wc when fused
+    uint32_t R, range_shift;    // row ranges: rows i >> range_shift = r use windows r * W .. r * W + W - 1 (see msm_shape)
     uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
     size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
     uint32_t log_s;             // slice length S = 2^log_s entries
@@ -90,10 +92,30 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     s.c = best_c;
     s.W = (max_bits + 1 + s.c - 1) / s.c;
     s.Wt = s.W + (hot ? 1u : 0u);
+    s.R = 1;
+    s.range_shift = 31;
     s.cols = cols;
     s.Wc = s.W + 1;
     if (cols) s.Wt = cols * s.Wc;  // every column keeps a slot for its dominant-scalar window
+    s.Wk = s.Wt;
     s.nb = 1u << (s.c - 1);
+    // Row ranges.  A narrow column (booleans, bytes, a 10-bit opcode) has ONE window of a few buckets: one or a handful
+    // of sort partitions (= workgroups) for all n entries, thousands of entries per bucket, everything after the sort on
+    // the heavy-bucket path.  Its rows are cut into R ranges that act as separate windows -- range r of window w is
+    // window r * W + w, with its own buckets and partitions -- and the host adds the R sums of each window.
+    if (!cols && n >= (1u << 15)) {
+        const uint32_t lo0 = (s.c - 1 < 8) ? (s.c - 1) : 8;
+        const uint32_t base_np = s.W << (s.c - 1 - lo0);
+        uint32_t R = 1;
+        while (R * base_np < 128 && (size_t)2 * R * s.W * s.nb * 4 <= n && (n / (2 * R)) >= 2048) R *= 2;
+        if (R > 1) {
+            uint32_t shift = 11;
+            while (((size_t)1 << shift) * R < n) shift++;
+            s.range_shift = shift;
+            s.R = (uint32_t)((n + ((size_t)1 << shift) - 1) >> shift);
+            s.Wt = s.R * s.W + (hot ? 1u : 0u);
+        }
+    }
     s.nbt = s.Wt * s.nb;
     // k_reduce is a chain of 2 * qm additions per quad: the shortest chains whose workgroups still fit the chip once
     s.qm = REDUCE_QM;
@@ -111,7 +133,7 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     uint32_t per_group = REDUCE_T / 4 * s.qm;
     s.RG = (s.nb + per_group - 1) / per_group;
     s.G = 1;
-    s.entries = n * s.Wt;
+    s.entries = n * s.Wk;
     // slice length: aim at >= 2^18 slices (one resident round of the chip at 4 waves/SIMD), 8 <= S <= 64
     s.log_s = 6;
     while (s.log_s > 3 && (s.entries >> s.log_s) < (1u << 18)) s.log_s--;
@@ -185,7 +207,8 @@ extern __shared__ __attribute__((aligned(16))) uint32_t h2_msm_smem[];
 __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uint32_t c, uint32_t W, uint32_t nb,
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
                                                 uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
-                                                const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask) {
+                                                const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
+                                                uint32_t range_shift, uint32_t R) {
     if (col_scalars != nullptr) {
         const uint32_t col = blockIdx.y;
         scalars = col_scalars[col];
@@ -204,7 +227,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             const bool is_hot = hot_on && fp_eq(raw, hot);
             const uint64_t m = __ballot(is_hot);
             if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
-                atomicAdd(&hist[W << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
+                atomicAdd(&hist[(R * W) << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
             keys[(size_t)W * n + i] = is_hot ? 0u : KEY_INVALID;
             if (is_hot) {
                 for (uint32_t w = 0; w < W; w++) keys[(size_t)w * n + i] = KEY_INVALID;
@@ -224,6 +247,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
         uint64_t buf = 0;
         int nbits = 0;
         uint32_t w = 0, carry = 0;
+        const uint32_t vw0 = (uint32_t)(i >> range_shift) * W;  // first window of this row's range
         auto emit = [&](uint32_t raw) {
             raw += carry;
             uint32_t neg = 0, mag = raw;
@@ -238,7 +262,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             if (mag != 0) {
                 uint32_t bucket = mag - 1;
                 out = bucket | neg;
-                atomicAdd(&hist[(w << hi_bits) + (bucket >> lo_bits)], 1u);
+                atomicAdd(&hist[((vw0 + w) << hi_bits) + (bucket >> lo_bits)], 1u);
             }
             keys[(size_t)w * n + i] = out;
             w++;
@@ -312,9 +336,13 @@ __global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint
 // non-empty partition costs ONE global atomic per workgroup (space reservation), and the entries of a
 // partition land in a contiguous run, so the 8-byte stores of a workgroup merge into full lines.
 __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t hi_bits,
-                                                   uint32_t* pcursor, uint2* tmp) {
+                                                   uint32_t* pcursor, uint2* tmp, uint32_t range_shift, uint32_t W,
+                                                   uint32_t R) {
     uint32_t* cnt = h2_msm_smem;               // 2^hi_bits local counters, then the reserved bases
     const uint32_t nparts = 1u << hi_bits, w = blockIdx.y;
+    // window of these PART_T rows: ranges are multiples of PART_T rows; key array W (if present) is the dominant-scalar
+    // window, which is not cut into ranges
+    const uint32_t vw = (R > 1) ? (w == W ? R * W : (uint32_t)(((size_t)blockIdx.x * PART_T) >> range_shift) * W + w) : w;
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
     const uint32_t ITEMS = PART_T / 256;
@@ -330,7 +358,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) {
         uint32_t v = cnt[k];
-        cnt[k] = v ? atomicAdd(&pcursor[(w << hi_bits) + k], v) : 0;
+        cnt[k] = v ? atomicAdd(&pcursor[(vw << hi_bits) + k], v) : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -934,18 +962,18 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
         const uint32_t np_col = s.Wc << s.hi_bits;
         hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
                            s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
-                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask);
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u);
     } else {
         hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
                            max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
-                           hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0);
+                           hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
-    hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wt), dim3(256),
-                       (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp);
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
+                       (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W, s.R);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
-    const uint32_t hot_partition = (!fused && hot.on) ? (s.W << s.hi_bits) : 0xffffffffu;
+    const uint32_t hot_partition = (!fused && hot.on) ? ((s.R * s.W) << s.hi_bits) : 0xffffffffu;
     hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
                        s.hi_bits, s.nb, skew_threshold, hot_partition, fused ? s.Wc : 0u, fused ? fused->hot_mask : 0ull,
                        starts, sorted);
@@ -977,12 +1005,12 @@ static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<X
     for (int w = (int)s.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < s.c; k++) acc = xyzz_double(acc);
         XYZZ ws = xyzz_identity();
-        for (uint32_t g = 0; g < s.G; g++) ws = xyzz_add(ws, winpart[(w0 + (size_t)w) * s.G + g]);
+        for (uint32_t r = 0; r < s.R; r++) ws = xyzz_add(ws, winpart[w0 + (size_t)r * s.W + w]);  // the row ranges of window w
         acc = xyzz_add(acc, ws);
     }
     if (hot.on) {  // + v * E, E = the extra window's sum (bucket 0 carries weight 1)
         XYZZ e = xyzz_identity();
-        for (uint32_t g = 0; g < s.G; g++) e = xyzz_add(e, winpart[(w0 + (size_t)s.W) * s.G + g]);
+        e = winpart[w0 + (size_t)s.R * s.W];
         const Fr v = fp_from_mont(hot.value);
         XYZZ r = xyzz_identity();
         for (int bit = 253; bit >= 0; bit--) {

@@ -500,3 +500,27 @@ def test_msm_fused_group(oracle, n):
         out = np.zeros((count, 12), dtype=np.uint64)
         assert L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 254, scratch.data_ptr(), nbytes, out.ctypes.data, None) == 0
         assert [_affine(oracle, out[j]) for j in range(count)] == want, nbytes
+
+
+@pytest.mark.parametrize("n", [1 << 15, (1 << 17) + 4321])
+def test_msm_narrow_columns_row_ranges(oracle, n):
+    """narrow witness columns (booleans, bytes, a 10- / 12-bit code): one window of a few buckets, which the library
+    cuts into row ranges acting as separate windows (msm_shape) -- with and without a dominant value, ragged n, and the
+    bound given exactly or loosely; against the oracle"""
+    pts = oracle.random_g1(3030 + n, n)
+    rows = np.arange(n, dtype=np.uint64)
+    cases = {
+        "boolean_sparse": ((rows * 2654435761 >> 7) % 16 == 0).astype(np.uint64),        # 1/16 ones: not dominant
+        "boolean_dense": ((rows * 2654435761 >> 7) % 4 != 0).astype(np.uint64),           # 3/4 ones: dominant value
+        "bytes": (rows * 40503 >> 3) % 256,
+        "ten_bits": (rows * 2654435761 >> 5) % 1000,
+        "twelve_bits_mostly_seven": np.where(rows % 3 == 0, (rows * 48271) % 4096, 7).astype(np.uint64),
+    }
+    for name, vals in cases.items():
+        scalars = to_mont([int(v) for v in vals])
+        want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+        top = max(1, int(vals.max()).bit_length())
+        for bits in (top, top + 1, 13):
+            if bits < top:
+                continue
+            assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, bits)) == want, (name, bits)
