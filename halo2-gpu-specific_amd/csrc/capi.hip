@@ -441,6 +441,18 @@ int h2_dev_batch_mont(void* d_a, size_t n, void* stream) {
         return batch_mont_launch((Fr*)d_a, n, true, pick_stream(ctx, stream));
     });
 }
+int h2_dev_max_scalar_bits(const void* const* d_cols, size_t count, size_t n, void* d_words, uint32_t* out_bits,
+                           void* stream) {
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        if (count && (!d_cols || !d_words || !out_bits)) {
+            set_last_error("h2_dev_max_scalar_bits: null argument");
+            return (int)H2_ERR_INVALID;
+        }
+        return max_scalar_bits_launch((const Fr* const*)d_cols, count, n, (uint32_t*)d_words, out_bits,
+                                      pick_stream(ctx, stream));
+    });
+}
 int h2_dev_batch_unmont(void* d_a, size_t n, void* stream) {
     return guarded([&] {
         DeviceCtx* ctx = current_ctx();

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include <vector>
 #include "common.hpp"
 #include "poly.hpp"
 
@@ -137,6 +138,64 @@ int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream) {
     return H2_OK;
 }
 
+
+// ---------------------------------------------------------------- find_max_scalar_bits for a group of columns
+// plonk/prover.rs:237-254 takes the maximum of a column and its bit length; the bit length of the maximum is the bit
+// length of the OR of all values, and an OR needs no ordering: one launch ORs the limbs of up to 16 canonical columns
+// (blockIdx.y = column) into 8 words each.
+static constexpr int MAXBITS_COLS = 16;
+struct MaxBitsArgs {
+    const Fr* col[MAXBITS_COLS];
+};
+
+__global__ void __launch_bounds__(256) k_or_limbs(MaxBitsArgs a, size_t n, uint32_t* words) {
+    const Fr* col = a.col[blockIdx.y];
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const Fr v = fp_load(col + i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] |= v.l[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[k] |= __shfl_xor(acc[k], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (acc[k]) atomicOr(&words[blockIdx.y * 8 + k], acc[k]);
+    }
+}
+
+int max_scalar_bits_launch(const Fr* const* d_cols, size_t count, size_t n, uint32_t* d_words, uint32_t* out_bits,
+                           hipStream_t stream) {
+    if (count == 0) return H2_OK;
+    H2_HIP(hipMemsetAsync(d_words, 0, count * 8 * sizeof(uint32_t), stream));
+    if (n) {
+        unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 512);
+        for (size_t c0 = 0; c0 < count; c0 += MAXBITS_COLS) {
+            MaxBitsArgs a{};
+            const size_t m = std::min<size_t>(MAXBITS_COLS, count - c0);
+            for (size_t j = 0; j < m; j++) a.col[j] = d_cols[c0 + j];
+            hipLaunchKernelGGL(k_or_limbs, dim3(blocks, (unsigned)m), dim3(256), 0, stream, a, n, d_words + c0 * 8);
+        }
+        H2_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> words(count * 8);
+    H2_HIP(hipMemcpyAsync(words.data(), d_words, count * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    H2_HIP(hipStreamSynchronize(stream));
+    for (size_t c = 0; c < count; c++) {
+        uint32_t bits = 0;
+        for (int k = 7; k >= 0; k--)
+            if (words[c * 8 + k]) {
+                bits = 32 * k + (32 - __builtin_clz(words[c * 8 + k]));
+                break;
+            }
+        out_bits[c] = bits;
+    }
+    return H2_OK;
+}
 
 // ---------------------------------------------------------------- eval_polynomial (Horner) on device
 // arithmetic.rs:707-735 evaluates p(x) by per-thread Horner over contiguous chunks + powers of x.  Here a

@@ -161,6 +161,18 @@ class Device:
                 return 64 * limb + v.bit_length()
         return 0
 
+    def max_scalar_bits_many(self, cols, n):
+        """find_max_scalar_bits of several canonical columns resident on the device: one launch, one synchronisation"""
+        count = len(cols)
+        if not count:
+            return []
+        ptrs = (ctypes.c_void_p * count)(*[c.data_ptr() for c in cols])
+        out = (ctypes.c_uint32 * count)()
+        with self.torch.cuda.stream(self.tstream):
+            words = self.torch.empty((count, 8), dtype=self.torch.int32, device=self.dev)
+        check(self.L.h2_dev_max_scalar_bits(ptrs, count, n, words.data_ptr(), out, self.stream), "h2_dev_max_scalar_bits")
+        return list(out)
+
     def pinned_columns(self, count, n):
         """`count` zeroed (n, 4) u64 numpy columns in page-locked host memory: a witness synthesised into them
         reaches the device by DMA instead of through the driver's staging copies"""
@@ -649,22 +661,31 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # then blinded, measured (per-column max_bits, as the reference) and committed in small groups -- one pipelined
     # batch per group -- while the later groups are still in flight.
     uploads = [D.upload_async(col) for col in advice]
+    # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
+    blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
+    for ci in range(len(uploads)):
+        blind[ci, :, 0] = [rng.u16() for _ in range(usable, n)]
+    with D.torch.cuda.stream(D.tstream):
+        blind_dev = D.torch.from_numpy(blind).to(D.dev)
     group = max(1, min(4, len(uploads) // 3))
     advice_dev = []
     for g0 in range(0, len(uploads), group):
-        cols_, bits_ = [], []
-        for t, arrived in uploads[g0:g0 + group]:
+        cols_ = []
+        for ci, (t, arrived) in enumerate(uploads[g0:g0 + group], start=g0):
             if arrived is not None:
                 D.tstream.wait_event(arrived)
             if montgomery:                                       # find_max_scalar_bits needs the canonical values
                 check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
-            D.set_rows_raw(t, usable, [rng.u16() for _ in range(usable, n)])
-            bits_.append(max(D.max_scalar_bits(t), 1))
-            check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+            with D.torch.cuda.stream(D.tstream):
+                t[usable:] = blind_dev[ci]
             cols_.append(t)
+        bits_ = [max(b, 1) for b in D.max_scalar_bits_many(cols_, n)]
+        for t in cols_:
+            check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
         for P in D.msm_batch(cols_, params.g_lagrange, n, bits_):
             transcript.write_point(P)
         advice_dev += cols_
+    del blind_dev
     del uploads
     mark("advice commit")
     theta = transcript.squeeze_challenge_scalar()

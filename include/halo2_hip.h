@@ -311,6 +311,11 @@ int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);
 int h2_dev_batch_mont(void *d_a, size_t n, void *stream);
 int h2_dev_batch_unmont(void *d_a, size_t n, void *stream);
+/* find_max_scalar_bits (plonk/prover.rs:237-254) for `count` CANONICAL columns of n scalars resident on the device, in
+ * one launch and one synchronisation: out_bits[i] (host) = bit length of the largest value of column i (0 for an all-zero
+ * column) -- the `max_bits` of commit_lagrange_with_bound.  d_words: count * 32 bytes of device scratch. */
+int h2_dev_max_scalar_bits(const void *const *d_cols, size_t count, size_t n, void *d_words, uint32_t *out_bits,
+                           void *stream);
 
 /* ---- synthetic workload (bench.py / tests; not a reference entry point) --------------------- */
 /* n deterministic valid G1Affine points (try-and-increment on y^2 = x^3 + 3) into d_out (n x 64 B). */

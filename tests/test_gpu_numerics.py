@@ -247,3 +247,33 @@ def test_eval_polynomial_batch(oracle):
         for j in range(count):
             assert np.array_equal(out[j], _oracle_eval(oracle, polys[j], pts[j])), (n, j)
     assert L.h2_dev_eval_polynomial_batch(None, 0, 5, None, None, None) == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 70001])
+def test_max_scalar_bits_of_column_groups(oracle, n):
+    """find_max_scalar_bits (plonk/prover.rs:237-254) for a group of canonical columns in one launch: the bit length of
+    each column's largest value, 0 for an all-zero column; more than 16 columns take several launches"""
+    import torch
+
+    L = h2.lib()
+    rows = np.arange(n, dtype=np.uint64)
+    cols, want = [], []
+    for bits in (0, 1, 7, 16, 31, 32, 33, 64, 65, 130, 200, 253, 254, 12, 1, 40, 90, 255):   # 18 columns
+        top = min(bits, 254)
+        vals = [0] * n
+        if bits:
+            for i in range(n):
+                vals[i] = (int(rows[i]) * 0x9E3779B97F4A7C15F39CC0605CEDC8341082276BF3A27251 + 12345) % (1 << max(top - 1, 0) or 1)
+            vals[(7 * n) // 11] = (1 << (top - 1)) | 1 if top > 1 else 1      # one value with the top bit set
+        a = np.zeros((n, 4), dtype=np.uint64)
+        for limb in range(4):
+            a[:, limb] = np.array([(v >> (64 * limb)) & (2 ** 64 - 1) for v in vals], dtype=np.uint64)
+        cols.append(_dev(a))
+        want.append(max(v.bit_length() for v in vals))
+    count = len(cols)
+    ptrs = (ctypes.c_void_p * count)(*[c.data_ptr() for c in cols])
+    out = (ctypes.c_uint32 * count)()
+    words = torch.empty((count, 8), dtype=torch.int32, device="cuda")
+    assert L.h2_dev_max_scalar_bits(ptrs, count, n, words.data_ptr(), out, None) == 0, L.h2_last_error()
+    assert list(out) == want
+    assert L.h2_dev_max_scalar_bits(ptrs, 0, n, None, None, None) == 0
