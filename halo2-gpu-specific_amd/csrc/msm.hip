@@ -584,9 +584,13 @@ __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint
     xyzz_store_q(buckets + b, acc, q);
 }
 
-// Heavy bucket h, part y (of HEAVY_SPLIT): folds the partial slots first + y, first + y + HEAVY_SPLIT, ... and
-// leaves the result in slot first + y -- a slot of its own set, written after its last read, so the parts of one
-// bucket never race.  k_finish_heavy2 then folds the (at most HEAVY_SPLIT) leading slots.
+// Heavy bucket h with P partials is shared by NP = ceil(P / 256) (at most HEAVY_SPLIT) workgroups: part y folds the
+// slots first + y, first + y + NP, ... and leaves the result in slot first + y -- a slot of its own set, written after
+// its last read, so the parts of one bucket never race.  k_finish_heavy2 then folds the NP leading slots.
+__device__ __forceinline__ uint32_t heavy_parts(uint32_t first, uint32_t last) {
+    const uint32_t np = (last - first + 256) / 256;  // ceil((last - first + 1) / 256)
+    return np < HEAVY_SPLIT ? np : HEAVY_SPLIT;
+}
 __global__ void __launch_bounds__(256) k_finish_heavy(XYZZ* partials, const uint32_t* starts, uint32_t log_s,
                                                       const uint32_t* heavy_list, const uint32_t* heavy_count) {
     __shared__ XYZZ sh[64];
@@ -595,9 +599,10 @@ __global__ void __launch_bounds__(256) k_finish_heavy(XYZZ* partials, const uint
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
-        if (first + part > last) continue;  // uniform over the workgroup
+        const uint32_t np = heavy_parts(first, last);
+        if (part >= np) continue;  // uniform over the workgroup
         XYZZ acc = xyzz_identity();
-        for (uint32_t sl = first + part + qd * HEAVY_SPLIT; sl <= last; sl += 64 * HEAVY_SPLIT)
+        for (uint32_t sl = first + part + qd * np; sl <= last; sl += 64 * np)
             acc = xyzz_add_q(acc, xyzz_load(partials + (b + sl)), q);
         acc = quad_tree_sum<64>(acc, sh, qd, q);
         if (qd == 0) xyzz_store_q(partials + (b + first + part), acc, q);
@@ -613,7 +618,7 @@ __global__ void __launch_bounds__(4 * HEAVY_SPLIT) k_finish_heavy2(const XYZZ* p
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t first = starts[b] >> log_s, last = (starts[b + 1] - 1) >> log_s;
-        XYZZ acc = (first + qd <= last) ? xyzz_load(partials + (b + first + qd)) : xyzz_identity();
+        XYZZ acc = qd < heavy_parts(first, last) ? xyzz_load(partials + (b + first + qd)) : xyzz_identity();
         acc = quad_tree_sum<HEAVY_SPLIT>(acc, sh, qd, q);
         if (qd == 0) xyzz_store_q(buckets + b, acc, q);
     }

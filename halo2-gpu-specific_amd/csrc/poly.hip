@@ -149,7 +149,10 @@ struct MaxBitsArgs {
 };
 
 __global__ void __launch_bounds__(256) k_or_limbs(MaxBitsArgs a, size_t n, uint32_t* words) {
+    __shared__ uint32_t sh[8];
     const Fr* col = a.col[blockIdx.y];
+    if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const Fr v = fp_load(col + i);
@@ -164,8 +167,10 @@ __global__ void __launch_bounds__(256) k_or_limbs(MaxBitsArgs a, size_t n, uint3
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (acc[k]) atomicOr(&words[blockIdx.y * 8 + k], acc[k]);
+            if (acc[k]) atomicOr(&sh[k], acc[k]);
     }
+    __syncthreads();
+    if (threadIdx.x < 8 && sh[threadIdx.x]) atomicOr(&words[blockIdx.y * 8 + threadIdx.x], sh[threadIdx.x]);
 }
 
 int max_scalar_bits_launch(const Fr* const* d_cols, size_t count, size_t n, uint32_t* d_words, uint32_t* out_bits,
@@ -173,7 +178,7 @@ int max_scalar_bits_launch(const Fr* const* d_cols, size_t count, size_t n, uint
     if (count == 0) return H2_OK;
     H2_HIP(hipMemsetAsync(d_words, 0, count * 8 * sizeof(uint32_t), stream));
     if (n) {
-        unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 512);
+        unsigned blocks = (unsigned)std::min<size_t>((n + 2047) / 2048, 256);  // 8 global atomics per workgroup
         for (size_t c0 = 0; c0 < count; c0 += MAXBITS_COLS) {
             MaxBitsArgs a{};
             const size_t m = std::min<size_t>(MAXBITS_COLS, count - c0);
