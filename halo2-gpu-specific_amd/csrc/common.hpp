@@ -59,6 +59,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;      // compute stream for host-API calls
     hipStream_t copy_stream = nullptr; // H2D/D2H overlap
+    hipStream_t aux_stream[2] = {nullptr, nullptr};  // third / fourth lane of the batched-MSM pipeline
     std::mutex mu;                     // one in-flight host-API op per device
     DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
     DevBuf msm_scratch;

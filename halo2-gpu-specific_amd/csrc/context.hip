@@ -95,6 +95,7 @@ DeviceCtx* ctx_for(int idx) {
         H2_HIP(hipGetDeviceProperties(&c->prop, dev));
         H2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         H2_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) H2_HIP(hipStreamCreateWithFlags(&c->aux_stream[k], hipStreamNonBlocking));
         p.ctxs[dev] = c;
     }
     return p.ctxs[dev];

@@ -1105,7 +1105,12 @@ static uint32_t fused_group_limit(size_t n, uint32_t bits) {
     // two-stream pipeline, which hides every column's host tail under the next column's kernels, is the better shape.
     // Columns with a short scalar bound have one or two windows: the slot every fused column keeps for its
     // dominant-scalar window would double their finish / reduce work -- they stay in the pipeline too.
-    if ((size_t)one.Wt * n > ((size_t)1 << 22) || one.W < 8) return 1;
+    uint32_t fuse_log = 22;
+    if (const char* env = getenv("H2_MSM_FUSE_LOG")) {
+        int v = atoi(env);
+        if (v >= 10 && v <= 28) fuse_log = (uint32_t)v;
+    }
+    if ((size_t)one.Wt * n > ((size_t)1 << fuse_log) || one.W < 8) return 1;
     uint32_t best = 1;
     for (uint32_t g = 2; g <= 64; g++) {
         const size_t wt = (size_t)g * (one.W + 1);
@@ -1194,20 +1199,29 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     char* pinned = (char*)ctx->pinned.get(count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ)));
     Fr* h_samples = (Fr*)pinned;
     XYZZ* h_win = (XYZZ*)(pinned + count * HOT_SAMPLES * sizeof(Fr));
-    hipStream_t st[2] = {ctx->stream, ctx->copy_stream};
+    // pipeline lanes: one stream + one scratch slice each.  Two: a third and fourth lane (H2_MSM_LANES, when the scratch
+    // holds them) were measured and do not pay -- 2^18: 0.78 (2) / 0.76 (3) / 0.84 (4) ms per MSM, 2^20: 2.06 / 2.08 / 2.17
+    hipStream_t st[4] = {ctx->stream, ctx->copy_stream, ctx->aux_stream[0], ctx->aux_stream[1]};
+    size_t lanes = 2;
+    if (const char* env = getenv("H2_MSM_LANES")) {
+        int v = atoi(env);
+        if (v >= 2 && v <= 4 && per && (size_t)v * per <= scratch_bytes) lanes = (size_t)v;
+    }
     for (size_t i = 0; i < count; i++)
         hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[i], n, h_samples + i * HOT_SAMPLES);
     H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
     std::vector<Hot> hots(count);
     for (size_t i = 0; i < count; i++) hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);
     std::vector<hipEvent_t> done(count, nullptr);
+    size_t lane_of = 0;
     for (size_t i = 0; i < count; i++) {
         const uint32_t bits = bits_each ? bits_each[i] : max_bits;
         if (bits == 0 || done_fused[i]) continue;  // identity (arithmetic.rs:346) / already committed in a fused group
         const MsmShape& s = shapes[2 * i + (hots[i].on ? 1 : 0)];
         const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
-        char* scratch = (char*)d_scratch + (i & 1) * per;
-        hipStream_t q = st[i & 1];
+        char* scratch = (char*)d_scratch + (lane_of % lanes) * per;
+        hipStream_t q = st[lane_of % lanes];
+        lane_of++;
         msm_launch(s, hots[i], d_scalars[i], (const Affine*)bases, bits, scratch, q);
         export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));

@@ -159,7 +159,8 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
     // batch of 8 MSMs over the same bases (pipelined on two internal streams)
     const int BATCH = 8;
     void* d_scr2;
-    size_t sb2 = 2 * ((sb + 255) / 256 * 256);
+    const char* lanes_env = getenv("H2BENCH_LANES");  // pipeline lanes the scratch allows (2..4)
+    size_t sb2 = (size_t)(lanes_env ? atoi(lanes_env) : 2) * ((sb + 255) / 256 * 256);
     CK(hipMalloc(&d_scr2, sb2));
     const void* ptrs[BATCH];
     for (int b = 0; b < BATCH; b++) ptrs[b] = d_s;
