@@ -215,8 +215,7 @@ struct EvalPolyArgs {
     Fr xpow[8];  // x^(2^l), l = 0..7
 };
 
-__global__ void __launch_bounds__(256) k_eval_poly(EvalPolyArgs a) {
-    __shared__ uint4 sh_lo[256], sh_hi[256];
+__device__ __forceinline__ void eval_poly_block(const EvalPolyArgs& a, uint4* sh_lo, uint4* sh_hi) {
     const uint32_t t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * 4096;
     Fr acc = fp_zero<FrParams>();
@@ -242,6 +241,22 @@ __global__ void __launch_bounds__(256) k_eval_poly(EvalPolyArgs a) {
         __syncthreads();
     }
     if (t == 0) fp_store(a.out + blockIdx.x, acc);
+}
+
+__global__ void __launch_bounds__(256) k_eval_poly(EvalPolyArgs a) {
+    __shared__ uint4 sh_lo[256], sh_hi[256];
+    eval_poly_block(a, sh_lo, sh_hi);
+}
+
+// blockIdx.y = evaluation: one level of EVERY evaluation of a batch in one launch (table in device memory)
+__global__ void __launch_bounds__(256) k_eval_poly_multi(const EvalPolyArgs* table) {
+    __shared__ uint4 sh_lo[256], sh_hi[256];
+    __shared__ EvalPolyArgs a;
+    const uint32_t* src = (const uint32_t*)(table + blockIdx.y);
+    for (uint32_t k = threadIdx.x; k < sizeof(EvalPolyArgs) / 4; k += 256) ((uint32_t*)&a)[k] = src[k];
+    __syncthreads();
+    if ((size_t)blockIdx.x * 4096 >= a.n) return;
+    eval_poly_block(a, sh_lo, sh_hi);
 }
 
 // result (host) = sum_i poly[i] * x^i.  d_tmp: ceil(n / 4096) + ceil(n / 4096^2) + 2 elements of scratch.
@@ -288,14 +303,11 @@ int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], 
     return H2_OK;
 }
 
-// `count` evaluations (polynomial j at point j) enqueued back to back, one read-back and one synchronisation for all
-// of them: the prover evaluates every committed polynomial at x, omega x, ... (plonk/prover.rs:700-790, a rayon
-// par_iter over eval_polynomial_st there).  d_tmp: count * eval_polynomial_tmp_elems(n) elements.
-__global__ void __launch_bounds__(64) k_gather_results(const Fr* const* slots, uint32_t count, Fr* out) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < count) fp_store(out + j, fp_load(slots[j]));
-}
-
+// `count` evaluations (polynomial j at point j), one read-back and one synchronisation for all of them: the prover
+// evaluates every committed polynomial at x, omega x, ... (plonk/prover.rs:700-790, a rayon par_iter over
+// eval_polynomial_st there).  Every level of the fold is ONE launch over all evaluations (a single evaluation is a
+// latency-bound chain on a quarter of the chip; sixty of them back to back were 2 ms of a 36 ms proof).
+// d_tmp: eval_polynomial_batch_tmp_bytes(count, n).
 int eval_polynomial_batch_launch(const Fr* const* d_polys, size_t count, size_t n, const uint64_t* points, Fr* d_tmp,
                                  uint64_t* out, hipStream_t stream) {
     if (count == 0) return H2_OK;
@@ -304,23 +316,56 @@ int eval_polynomial_batch_launch(const Fr* const* d_polys, size_t count, size_t 
         return H2_OK;
     }
     const size_t per = eval_polynomial_tmp_elems(n);
-    std::vector<const Fr*> slots(count);
-    for (size_t j = 0; j < count; j++)
-        slots[j] = eval_polynomial_enqueue(d_polys[j], n, points + 4 * j, d_tmp + j * per, stream);
+    Fr* d_out = d_tmp + count * per;                        // packed results
+    EvalPolyArgs* d_table = (EvalPolyArgs*)(d_out + count);  // one table per level
+    std::vector<std::vector<EvalPolyArgs>> levels;
+    std::vector<Fr> x(count);
+    std::vector<const Fr*> in(count);
+    std::vector<Fr*> dst(count);
+    for (size_t j = 0; j < count; j++) {
+        x[j] = fr_host(points + 4 * j);
+        in[j] = d_polys[j];
+        dst[j] = d_tmp + j * per;
+    }
+    size_t cnt = n;
+    for (;;) {
+        const size_t blocks = (cnt + 4095) / 4096;
+        std::vector<EvalPolyArgs> table(count);
+        for (size_t j = 0; j < count; j++) {
+            EvalPolyArgs& a = table[j];
+            a.in = in[j];
+            a.out = blocks == 1 ? d_out + j : dst[j];
+            a.n = cnt;
+            Fr p = x[j];
+            for (int l = 0; l < 8; l++) {
+                a.xpow[l] = p;
+                p = fp_sqr(p);
+            }
+            a.x256 = p;
+            for (int l = 0; l < 4; l++) p = fp_sqr(p);  // x^256 -> x^4096: the next level's variable
+            x[j] = p;
+            in[j] = dst[j];
+            dst[j] += blocks;
+        }
+        EvalPolyArgs* d_level = d_table + levels.size() * count;
+        levels.push_back(std::move(table));
+        H2_HIP(hipMemcpyAsync(d_level, levels.back().data(), count * sizeof(EvalPolyArgs), hipMemcpyHostToDevice, stream));
+        for (size_t j0 = 0; j0 < count; j0 += 32768)
+            hipLaunchKernelGGL(k_eval_poly_multi, dim3((unsigned)blocks, (unsigned)std::min<size_t>(32768, count - j0)),
+                               dim3(256), 0, stream, d_level + j0);
+        if (blocks == 1) break;
+        cnt = blocks;
+    }
     H2_HIP(hipGetLastError());
-    // gather the result slots: pointer table and packed results live behind the per-evaluation scratch
-    const Fr** d_slots = (const Fr**)(d_tmp + count * per);
-    Fr* d_out = (Fr*)(d_slots + count + (count & 1));  // keep 16-byte alignment
-    H2_HIP(hipMemcpyAsync(d_slots, slots.data(), count * sizeof(Fr*), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_gather_results, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, d_slots, (uint32_t)count,
-                       d_out);
     H2_HIP(hipMemcpyAsync(out, d_out, 32 * count, hipMemcpyDeviceToHost, stream));
-    H2_HIP(hipStreamSynchronize(stream));  // also keeps `slots` alive until the upload has been consumed
+    H2_HIP(hipStreamSynchronize(stream));  // also keeps the level tables alive until their uploads have been consumed
     return H2_OK;
 }
 
 size_t eval_polynomial_batch_tmp_bytes(size_t count, size_t n) {
-    return count * eval_polynomial_tmp_elems(n ? n : 1) * sizeof(Fr) + (count + 2) * sizeof(void*) + count * sizeof(Fr) + 64;
+    size_t levels = 1, c = n ? n : 1;
+    while ((c = (c + 4095) / 4096) > 1) levels++;
+    return count * (eval_polynomial_tmp_elems(n ? n : 1) + 1) * sizeof(Fr) + (levels + 1) * count * sizeof(EvalPolyArgs) + 64;
 }
 
 size_t eval_polynomial_tmp_elems(size_t n) {
