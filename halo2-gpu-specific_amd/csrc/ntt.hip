@@ -73,6 +73,7 @@ struct PassArgs {
     uint32_t prevB[4];    // their bit widths
     uint32_t prevT[4];    // their T_q logs
     uint32_t is_last, in_len, log_c;
+    uint32_t zskip;  // first pass of a zero-padded transform: rows rho >= R >> zskip are zero (see the load loop)
 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
@@ -161,6 +162,10 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
             K = (tile_id << log_c) + c;
             idx = (K_to_hi(K, a) << B) + rho;
         }
+        // Zero padding by 2^z (coeff_to_extended): the rows rho >= R >> z of the first pass are zero, so its first z
+        // stages are butterflies (u, 0) -> (u, u) whatever the twiddle: each loaded element is written to the 2^z rows
+        // those stages would copy it to (the low z bits of the bit-reversed row index) and the stage loop starts at z.
+        if (a.zskip && rho >= (R >> a.zskip)) continue;
         Fr x = (idx < a.in_len) ? fp_load(a.in + idx) : fp_zero<FrParams>();
         if (a.has_pre3) {
             uint32_t m = idx % 3;
@@ -175,13 +180,17 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                 x = fp_mul(x, twiddle_pow(a, ex));
             }
         }
-        lds_put(t_lo, t_hi, (bitrev(rho, B) << log_c) + c, x);
+        if (a.zskip) {
+            for (uint32_t m = 0; m < (1u << a.zskip); m++) lds_put(t_lo, t_hi, ((bitrev(rho, B) | m) << log_c) + c, x);
+        } else {
+            lds_put(t_lo, t_hi, (bitrev(rho, B) << log_c) + c, x);
+        }
     }
     __syncthreads();
 
     // ---- B radix-2 DIT stages in LDS
     const uint32_t nbf = total >> 1;
-    for (uint32_t s = 0; s < B; s++) {
+    for (uint32_t s = a.zskip; s < B; s++) {
         const uint32_t h = 1u << s;
         const uint32_t log_per = (B - 1 + log_c) - s;  // butterflies that share one twiddle index r: 2^log_per
         const bool by_r = s != 0 && log_per >= 6 && (nthreads & 63) == 0;
@@ -363,6 +372,11 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         }
         a.is_last = last ? 1 : 0;
         a.in_len = (p == 0) ? in_len : (1u << L);
+        if (p == 0 && !last && in_len && in_len < (1u << L) && (in_len & (in_len - 1)) == 0 && getenv("H2_NTT_NO_ZSKIP") == nullptr) {
+            uint32_t z = 0;
+            while ((in_len << z) < (1u << L)) z++;  // padded by 2^z
+            a.zskip = z < B ? z : B;               // in_len = (R >> z) * S rows exactly when z <= B
+        }
         if (last && p > 0 && a.post3_uniform && L > LO_BITS) {
             // iNTT: fold the divisor into the high twiddle table used by the last pass's inter-pass twiddles
             char key[80];
