@@ -140,7 +140,7 @@ def main():
     # --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); null when the file is absent
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_v3_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r1_v10_hbm_traffic.json")) as f:
             if log_n == 24:
                 traffic = json.load(f)["kernels"]["h2::k_ntt_pass"]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
