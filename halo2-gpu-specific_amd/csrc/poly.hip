@@ -380,8 +380,8 @@ size_t eval_polynomial_tmp_elems(size_t n) {
 
 // ---------------------------------------------------------------- batch_invert on device
 // arithmetic.rs:840-844 (`parallelize` + ff::BatchInvert per chunk).  Montgomery's trick per lane over a
-// strided set of <= 64 elements (coalesced across lanes); zeros stay zero.  3 multiplications per element
-// plus one field inversion (a^(r-2), ~390 multiplications) per lane.
+// strided set of 8..64 elements (coalesced across lanes); zeros stay zero.  3 multiplications per element
+// plus one field inversion (a^(r-2), ~390 multiplications) per workgroup.
 __device__ __forceinline__ Fr fr_inv_device(const Fr& a) {
     // exponent r - 2, little-endian u32 limbs
     const uint32_t E[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
@@ -394,18 +394,68 @@ __device__ __forceinline__ Fr fr_inv_device(const Fr& a) {
     return acc;
 }
 
+// One inversion per WORKGROUP: the lanes' chain products are multiplied up by two LDS scans (prefix and suffix, 8 steps
+// each), wave 0 inverts the workgroup's total, and lane t recovers the inverse of its own product as
+// total^-1 * (product of the lanes before it) * (product of the lanes after it) -- 18 multiplications per lane instead
+// of the ~390 of a private a^(r-2) chain (which made two thirds of this kernel's work).
+__device__ __forceinline__ void binv_put(uint4* lo, uint4* hi, uint32_t i, const Fr& v) {
+    lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ Fr binv_get(const uint4* lo, const uint4* hi, uint32_t i) {
+    const uint4 x = lo[i], y = hi[i];
+    Fr r;
+    r.l[0] = x.x; r.l[1] = x.y; r.l[2] = x.z; r.l[3] = x.w;
+    r.l[4] = y.x; r.l[5] = y.y; r.l[6] = y.z; r.l[7] = y.w;
+    return r;
+}
+
 __global__ void __launch_bounds__(256) k_batch_invert(Fr* a, Fr* prefix, size_t n, size_t nthreads) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
+    __shared__ uint4 sh_lo[256], sh_hi[256];
+    const uint32_t tid = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + tid;
+    const bool active = t < nthreads;
     Fr acc = fp_one<FrParams>();
     size_t last = t;
-    for (size_t i = t; i < n; i += nthreads) {
-        Fr v = fp_load(a + i);
-        fp_store(prefix + i, acc);
-        if (!fp_is_zero(v)) acc = fp_mul(acc, v);
-        last = i;
+    if (active) {
+        for (size_t i = t; i < n; i += nthreads) {
+            Fr v = fp_load(a + i);
+            fp_store(prefix + i, acc);
+            if (!fp_is_zero(v)) acc = fp_mul(acc, v);
+            last = i;
+        }
     }
-    Fr inv = fr_inv_device(acc);
+    // before = product of the chain products of lanes < tid, after = of lanes > tid (Hillis-Steele, inclusive then shifted)
+    Fr incl = acc;
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        binv_put(sh_lo, sh_hi, tid, incl);
+        __syncthreads();
+        if (tid >= off) incl = fp_mul(incl, binv_get(sh_lo, sh_hi, tid - off));
+        __syncthreads();
+    }
+    binv_put(sh_lo, sh_hi, tid, incl);
+    __syncthreads();
+    const Fr before = tid ? binv_get(sh_lo, sh_hi, tid - 1) : fp_one<FrParams>();
+    const Fr total = binv_get(sh_lo, sh_hi, 255);
+    __syncthreads();
+    Fr sfx = acc;
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        binv_put(sh_lo, sh_hi, tid, sfx);
+        __syncthreads();
+        if (tid + off < 256) sfx = fp_mul(sfx, binv_get(sh_lo, sh_hi, tid + off));
+        __syncthreads();
+    }
+    binv_put(sh_lo, sh_hi, tid, sfx);
+    __syncthreads();
+    const Fr after = tid < 255 ? binv_get(sh_lo, sh_hi, tid + 1) : fp_one<FrParams>();
+    __syncthreads();
+    if (tid < 64) {  // one wave inverts (its lanes all hold `total`), the others wait at the barrier
+        const Fr tinv = fr_inv_device(total);
+        if (tid == 0) binv_put(sh_lo, sh_hi, 0, tinv);
+    }
+    __syncthreads();
+    if (!active) return;
+    Fr inv = fp_mul(fp_mul(binv_get(sh_lo, sh_hi, 0), before), after);
     for (size_t i = last;; i -= nthreads) {
         Fr v = fp_load(a + i);
         if (!fp_is_zero(v)) {
@@ -418,7 +468,11 @@ __global__ void __launch_bounds__(256) k_batch_invert(Fr* a, Fr* prefix, size_t 
 
 int batch_invert_launch(Fr* d_a, Fr* d_tmp, size_t n, hipStream_t stream) {
     if (n == 0) return H2_OK;
-    size_t nthreads = (n + 63) / 64;
+    // elements per lane: 64 when that still fills the chip, down to 8 for small inputs (the chain of 3 multiplications
+    // per element is pure latency there; the shared inversion costs a lane 18 multiplications whatever the chunk)
+    size_t chunk = 64;
+    while (chunk > 8 && n / chunk < 65536) chunk /= 2;
+    size_t nthreads = (n + chunk - 1) / chunk;
     if (nthreads < 256) nthreads = n < 256 ? n : 256;
     hipLaunchKernelGGL(k_batch_invert, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, d_a, d_tmp, n,
                        nthreads);
