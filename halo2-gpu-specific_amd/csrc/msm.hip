@@ -1034,8 +1034,8 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         msm_identity(out_xyz);
         return H2_OK;
     }
-    if (n > 0x7fffffffu) {
-        set_last_error("h2 msm: n must be < 2^31");
+    if (n > 0x7fffffffu || msm_shape(n, max_bits, true).entries >= ((size_t)1 << 32)) {
+        set_last_error("h2 msm: n * windows must be < 2^32 (sorted entries are indexed with 32 bits): split the MSM");
         return H2_ERR_INVALID;
     }
     if (!d_scratch || scratch_bytes < msm_scratch_bytes(n, max_bits)) {
@@ -1138,12 +1138,12 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
                         const uint32_t* bits_each, size_t count, const uint64_t* d_bases, size_t n, uint32_t max_bits,
                         void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream) {
     if (count == 0) return H2_OK;
-    if (n > 0x7fffffffu) {
-        set_last_error("h2 msm: n must be < 2^31");
-        return H2_ERR_INVALID;
-    }
     uint32_t top_bits = 0;
     for (size_t i = 0; i < count; i++) top_bits = std::max(top_bits, bits_each ? bits_each[i] : max_bits);
+    if (n > 0x7fffffffu || (top_bits && msm_shape(n, top_bits, true).entries >= ((size_t)1 << 32))) {
+        set_last_error("h2 msm: n * windows must be < 2^32 (sorted entries are indexed with 32 bits): split the MSM");
+        return H2_ERR_INVALID;
+    }
     if (n == 0 || top_bits == 0) {
         for (size_t i = 0; i < count; i++) msm_identity(out_xyz + 12 * i);
         return H2_OK;
