@@ -52,6 +52,7 @@ struct MsmShape {
                                 // consecutive buckets per quad
     uint32_t Wt;                // windows the pipeline runs: R * W, + 1 when a dominant scalar has its own window (see k_digits)
     uint32_t Wk;                // key arrays k_digits writes (n keys each): W, + 1 with a dominant scalar; cols * Wc when fused
+    uint32_t wfull;             // windows 0 .. wfull - 1 are c bits wide, the rest c - 1 (see msm_shape)
     uint32_t R, range_shift;    // row ranges: rows i >> range_shift = r use windows r * W .. r * W + W - 1 (see msm_shape)
     uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
     size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
@@ -91,6 +92,15 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     }
     s.c = best_c;
     s.W = (max_bits + 1 + s.c - 1) / s.c;
+    // Balanced windows.  max_bits + 1 bits cut into W digits of c bits leave the top window whatever remains -- 7 bits
+    // at c = 13, 2 bits at c = 12, 5 at c = 10: a window whose n digits share a handful of buckets, i.e. one sort
+    // partition (one workgroup) and nothing but heavy buckets.  The same W windows get (max_bits + 1) / W bits each
+    // instead, the first `wfull` of them one more: widths c and c - 1, every window with >= 2^(c-2) buckets.
+    {
+        const uint32_t T = max_bits + 1, base = T / s.W, rem = T % s.W;
+        s.c = rem ? base + 1 : base;
+        s.wfull = rem ? rem : s.W;
+    }
     s.Wt = s.W + (hot ? 1u : 0u);
     s.R = 1;
     s.range_shift = 31;
@@ -208,7 +218,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
                                                 uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
                                                 const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
-                                                uint32_t range_shift, uint32_t R) {
+                                                uint32_t range_shift, uint32_t R, uint32_t wfull) {
     if (col_scalars != nullptr) {
         const uint32_t col = blockIdx.y;
         scalars = col_scalars[col];
@@ -220,7 +230,6 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
     uint32_t* hist = h2_msm_smem;
     for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) hist[k] = 0;
     __syncthreads();
-    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const Fr raw = fp_load(scalars + i);
         if (hot_on || col_scalars != nullptr) {  // wave-uniform branch; a fused column always owns the extra window
@@ -248,11 +257,11 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
         int nbits = 0;
         uint32_t w = 0, carry = 0;
         const uint32_t vw0 = (uint32_t)(i >> range_shift) * W;  // first window of this row's range
-        auto emit = [&](uint32_t raw) {
+        auto emit = [&](uint32_t raw, uint32_t cw) {  // cw: width of window w
             raw += carry;
             uint32_t neg = 0, mag = raw;
-            if (raw > half) {  // digit = raw - 2^c  (negative)
-                mag = (1u << c) - raw;
+            if (raw > (1u << (cw - 1))) {  // digit = raw - 2^cw  (negative)
+                mag = (1u << cw) - raw;
                 neg = SIGN_BIT;
                 carry = 1;
             } else {
@@ -271,15 +280,18 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
         for (int k = 0; k < 8; k++) {
             buf |= (uint64_t)s.l[k] << nbits;
             nbits += 32;
-            while (nbits >= (int)c && w < W) {
-                emit((uint32_t)buf & mask);
-                buf >>= c;
-                nbits -= c;
+            for (;;) {
+                const uint32_t cw = c - (w >= wfull ? 1u : 0u);
+                if (nbits < (int)cw || w >= W) break;
+                emit((uint32_t)buf & ((1u << cw) - 1), cw);
+                buf >>= cw;
+                nbits -= cw;
             }
         }
         while (w < W) {
-            emit((uint32_t)buf & mask);
-            buf >>= c;
+            const uint32_t cw = c - (w >= wfull ? 1u : 0u);
+            emit((uint32_t)buf & ((1u << cw) - 1), cw);
+            buf >>= cw;
         }
     }
     __syncthreads();
@@ -967,11 +979,12 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
         const uint32_t np_col = s.Wc << s.hi_bits;
         hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
                            s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
-                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u);
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull);
     } else {
         hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
                            max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
-                           hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R);
+                           hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R,
+                           s.wfull);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
@@ -1008,7 +1021,8 @@ static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<X
                           size_t w0 = 0) {  // w0: first window of the column inside a fused shape
     XYZZ acc = xyzz_identity();
     for (int w = (int)s.W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < s.c; k++) acc = xyzz_double(acc);
+        const uint32_t cw = s.c - ((uint32_t)w >= s.wfull ? 1u : 0u);  // the windows above w sit 2^cw higher
+        for (uint32_t k = 0; k < cw; k++) acc = xyzz_double(acc);
         XYZZ ws = xyzz_identity();
         for (uint32_t r = 0; r < s.R; r++) ws = xyzz_add(ws, winpart[w0 + (size_t)r * s.W + w]);  // the row ranges of window w
         acc = xyzz_add(acc, ws);
