@@ -53,3 +53,21 @@ boolean[::2, 0] = 1
 t = D.upload(boolean)
 check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "mont")
 timed("boolean column (254-bit bound)", t, 254)
+# a few distinct wide values (an opcode / state column of field-sized constants): heavy buckets in every window
+for distinct in (4, 16, 256, 4096):
+    col = D.clone(uniform)
+    with torch.cuda.stream(D.tstream):
+        idx = (torch.arange(n, device=D.dev) * 2654435761 % distinct)
+        col[:] = uniform[idx]
+    timed("%d distinct 254-bit values" % distinct, col, 254)
+# sparse wide values: 1/10 of the rows random, the rest zero
+col = D.clone(uniform)
+with torch.cuda.stream(D.tstream):
+    mask = (torch.arange(n, device=D.dev) % 10) != 0
+    col[mask] = 0
+timed("1/10 of the rows 254-bit, rest zero", col, 254)
+# half the rows one value, half uniform (dominant value + uniform remainder)
+col = D.clone(uniform)
+with torch.cuda.stream(D.tstream):
+    col[::2] = uniform[7]
+timed("half the rows one 254-bit value", col, 254)
