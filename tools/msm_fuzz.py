@@ -1,0 +1,81 @@
+"""Randomised MSM parity: random sizes (1 .. 2^19, ragged), scalar bounds (1 .. 254 bits) and value distributions
+(uniform under the bound, a few distinct values, one dominant value, sparse, booleans, P / -P pairs in the bases) through
+the C ABI against the CPU oracle, for a time budget.   usage: python tools/msm_fuzz.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+torch.cuda.init()
+import numpy as np  # noqa: E402
+
+from h2util import Oracle, to_mont  # noqa: E402
+from halo2_gpu_specific_amd import arithmetic as ar  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+oracle = Oracle.get()
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def aff(j):
+    return tuple(oracle.to_affine(j).tolist())
+
+
+def rand_ints(count, bits):
+    """`count` uniform integers below min(2^bits, r) as Python ints"""
+    words = rng.integers(0, 1 << 62, size=(count, 5), dtype=np.uint64)
+    out = []
+    for row in words:
+        v = 0
+        for w in row:
+            v = (v << 62) | int(w)
+        out.append((v & ((1 << bits) - 1)) % R_MOD)
+    return out
+
+
+cases = 0
+t_end = time.time() + budget
+all_pts = oracle.random_g1(seed, 1 << 19)
+while time.time() < t_end:
+    log_n = int(rng.integers(0, 20))
+    n = int(rng.integers(max(1, (1 << log_n) // 2), (1 << log_n) + 1))
+    bits = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 31, 32, 33, 48, 64, 65, 100, 127, 128, 129, 200, 253, 254]))
+    kind = int(rng.integers(0, 6))
+    pool = rand_ints(min(n, 4096), bits)
+    idx = rng.integers(0, len(pool), size=n)
+    if kind == 0:      # uniform (from a pool of <= 4096 values when n is larger: cheap to build, still spread)
+        vals = [pool[i] for i in idx]
+    elif kind == 1:    # a few distinct values
+        d = int(rng.choice([1, 2, 3, 16, 200]))
+        vals = [pool[i % d] for i in idx]
+    elif kind == 2:    # one dominant value + uniform remainder
+        keep = rng.random(n) < float(rng.choice([0.05, 0.3, 0.6]))
+        vals = [pool[i] if k else pool[0] for i, k in zip(idx, keep)]
+    elif kind == 3:    # sparse: mostly zero
+        keep = rng.random(n) < 0.08
+        vals = [pool[i] if k else 0 for i, k in zip(idx, keep)]
+    elif kind == 4:    # booleans / tiny values whatever the bound says
+        vals = [int(v) for v in rng.integers(0, 3, size=n)]
+    else:              # edge values
+        edge = [0, 1, (1 << bits) - 1 if bits < 254 else R_MOD - 1, R_MOD - 1 if bits == 254 else 1]
+        vals = [edge[i % 4] % R_MOD for i in idx]
+    top = max(vals).bit_length()
+    use_bits = max(bits, top) if rng.random() < 0.8 else 254
+    scalars = to_mont(vals)
+    start = int(rng.integers(0, (1 << 19) - n + 1))
+    pts = all_pts[start:start + n].copy()
+    if rng.random() < 0.2 and n >= 4:  # repeated points: P + P and bucket collisions
+        pts[n // 2:] = pts[: n - n // 2]
+    want = aff(oracle.best_multiexp(scalars, pts))
+    got = aff(ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, use_bits))
+    cases += 1
+    if got != want:
+        print("MISMATCH n=%d bits=%d use_bits=%d kind=%d seed=%d case=%d" % (n, bits, use_bits, kind, seed, cases))
+        sys.exit(1)
+print("msm_fuzz: %d cases in %.0f s, all equal to the oracle (seed %d)" % (cases, budget, seed))
