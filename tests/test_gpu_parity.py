@@ -3,6 +3,7 @@ the committed golden vectors.  Bit-exact: everything here is integer / finite-fi
 MSM results are compared after affine normalisation (the reference's own `==` on C::Curve is
 projective-aware, poly/commitment.rs:494)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
