@@ -40,7 +40,7 @@ namespace h2 {
 static constexpr uint32_t FINISH_SERIAL = 32; // partials a single quad folds in k_finish
 static constexpr uint32_t SORT_T = 1024;      // threads of a k_bucket_sort workgroup (one partition each)
 static constexpr uint32_t HEAVY_SPLIT = 64;   // workgroups sharing one heavy bucket in k_finish_heavy
-static constexpr uint32_t MID_MAX = 256;      // partials of a bucket one wave folds in k_finish_mid
+static constexpr uint32_t MID_MAX = 512;      // partials of a bucket one wave folds in k_finish_mid
 static constexpr uint32_t KEY_INVALID = 0xffffffffu;
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 512;    // threads per k_reduce workgroup = 128 quads (two waves per SIMD)
@@ -118,7 +118,12 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
         const uint32_t lo0 = (s.c - 1 < 8) ? (s.c - 1) : 8;
         const uint32_t base_np = s.W << (s.c - 1 - lo0);
         uint32_t R = 1;
-        while (R * base_np < 128 && (size_t)2 * R * s.W * s.nb * 4 <= n && (n / (2 * R)) >= 2048) R *= 2;
+        // ... until there are >= 128 partitions and a bucket holds <= 2048 entries on average (k_finish_mid's range of
+        // slice partials even when half the buckets go unused, as with booleans), while the buckets stay few against
+        // the entries and a range keeps >= 2048 rows
+        while ((R * base_np < 128 || n / ((size_t)R * s.W * s.nb) > 2048) && (size_t)2 * R * s.W * s.nb * 4 <= n &&
+               (n / (2 * R)) >= 2048)
+            R *= 2;
         if (R > 1) {
             uint32_t shift = 11;
             while (((size_t)1 << shift) * R < n) shift++;
@@ -1098,7 +1103,10 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     Fr* h_samples = (Fr*)staging.get(HOT_SAMPLES * sizeof(Fr));
     hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars, n, (Fr*)h_samples);
     H2_HIP(hipStreamSynchronize(stream));
-    const Hot hot = detect_hot(h_samples);
+    Hot hot = detect_hot(h_samples);
+    // the extra window trades W additions per dominant row for one: with one or two windows there is nothing to gain,
+    // only a giant bucket to fold and a 254-bit multiplication on the host
+    if (hot.on && msm_shape(n, max_bits, false).W <= 2) hot.on = false;
     MsmShape s = msm_shape(n, max_bits, hot.on);
     msm_launch(s, hot, d_scalars, (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
     const size_t wp = (size_t)s.Wt * s.G;
@@ -1262,7 +1270,10 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[i], n, h_samples + i * HOT_SAMPLES);
     H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
     std::vector<Hot> hots(count);
-    for (size_t i = 0; i < count; i++) hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);
+    for (size_t i = 0; i < count; i++) {
+        hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);
+        if (hots[i].on && !done_fused[i] && shapes[2 * i].W <= 2) hots[i].on = false;  // nothing to gain (see msm_device)
+    }
     std::vector<hipEvent_t> done(count, nullptr);
     size_t lane_of = 0;
     for (size_t i = 0; i < count; i++) {
