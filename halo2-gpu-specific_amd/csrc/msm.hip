@@ -7,16 +7,20 @@
 // (results are compared after affine normalisation, like the reference's own `==`).
 //
 // Pipeline (one stream, no host round trip until the final 1-2 KB read-back):
-//   k_digits      scalar -> canonical (one Montgomery mul), signed c-bit digits, bucket histogram
-//   k_scan_*      3-launch exclusive scan of the histogram -> bucket start offsets
-//   k_scatter     counting sort of (point index, sign) by (window, bucket)
+//   k_sample      64 scalars -> host: does one value dominate the column? (it then gets its own window, see k_digits)
+//   k_digits      scalar -> canonical (one Montgomery mul), signed digits of BALANCED width (c or c - 1 bits), keys, and
+//                 the histogram of (window, bucket >> lo_bits) partitions; narrow columns: rows cut into ranges = windows
+//   k_scan_parts / k_partition / k_bucket_sort   two-level counting sort of (point index, sign) by (window, bucket)
 //   k_acc_slice   one thread per fixed-size SLICE of the sorted list: exactly S mixed XYZZ
 //                 additions per lane whatever the bucket sizes are; a partial sum is emitted at
 //                 every bucket boundary inside the slice                              [hot loop]
-//   k_finish      per bucket: fold its slice partials (serial when few, else queued)
-//   k_finish_heavy HEAVY_SPLIT workgroups per heavy bucket (strided fold + LDS tree), k_finish_heavy2 folds their results
-//   k_reduce      per window: sum_b (b+1) * B_b by chunked running sums + small scalar mul + LDS tree
-//   host          adds the <= W*G partial window sums and runs the W*c doublings (Horner)
+//   k_finish      a QUAD per bucket folds its slice partials (<= 32), heavier buckets are queued
+//   k_finish_mid  queued buckets with <= 512 partials: one wave each (strided fold + shuffle tree)
+//   k_finish_heavy / _heavy2   the rest: ceil(P / 256) workgroups per bucket (strided fold + quad tree), then their fold
+//   k_reduce      per window: sum_b (b+1) * B_b by chunked running sums on quads + small scalar mul + quad tree; the last
+//                 workgroup of a window folds its groups
+//   host          W window sums -> Horner (W additions, max_bits + 1 doublings); the dominant scalar's multiplication
+// Everything after k_acc_slice runs on quads (ec_quad.hpp): four lanes per chain of dependent additions.
 // Slicing the *sorted list* evenly (instead of giving each bucket to a thread) keeps every lane of
 // the hot loop busy for any digit distribution: Poisson-sized buckets of a uniform MSM as well as
 // the skewed columns real witnesses have (boolean / small-valued columns put most points into a
@@ -938,7 +942,7 @@ int fixed_base_mul_launch(const Fr* d_scalars, const uint64_t* d_table, size_t n
     return H2_OK;
 }
 
-// The per-window partial sums (W * G points, tens of KB) go back to the host through a store kernel into mapped pinned
+// The window sums (one point per window, a few KB) go back to the host through a store kernel into mapped pinned
 // memory rather than hipMemcpyAsync: a DMA-engine copy queues behind whatever bulk transfer is in flight (the prover
 // uploads the next witness column while it commits the current one) and would stall the MSM for the whole transfer.
 __global__ void __launch_bounds__(256) k_export(const uint4* src, uint4* dst, size_t count16) {
