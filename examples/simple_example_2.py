@@ -32,7 +32,7 @@ pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)  # keygen_vk
 print("setup + keygen: %.3f s" % (time.perf_counter() - t0))
 
 t0 = time.perf_counter()
-proof = prover.create_proof_ext(D, params, pk, advice, ProverRng(2024), use_gwc)
+proof = prover.create_proof_ext(D, params, pk, advice, ProverRng(), use_gwc)
 D.sync()
 print("create_proof (%s): %.1f ms, %d bytes" % ("GWC" if use_gwc else "SHPLONK", (time.perf_counter() - t0) * 1e3, len(proof)))
 

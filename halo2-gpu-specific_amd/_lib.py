@@ -74,7 +74,7 @@ SYMBOLS = {
     "h2_dev_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "h2_dev_permutation_sigma": (ctypes.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "h2_dev_permutation_terms": (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
-    "h2_dev_random_fr": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
+    "h2_dev_random_fr": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_prefix_sum": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
     "h2_logup_scratch_bytes": (_sz, [_sz]),
     "h2_dev_logup_multiplicity": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),

@@ -411,11 +411,11 @@ int h2_dev_points_compress(const void* d_points, size_t n, void* d_bytes, void* 
     });
 }
 
-int h2_dev_random_fr(uint64_t seed, size_t n, void* d_out, void* stream) {
-    if (!d_out && n) return bad("h2_dev_random_fr: null argument");
+int h2_dev_random_fr(const uint8_t key[32], size_t n, void* d_out, void* stream) {
+    if ((!d_out && n) || !key) return bad("h2_dev_random_fr: null argument");
     return guarded([&] {
         DeviceCtx* ctx = current_ctx();
-        return random_fr_launch(seed, n, (uint64_t*)d_out, pick_stream(ctx, stream));
+        return random_fr_launch(key, n, (uint64_t*)d_out, pick_stream(ctx, stream));
     });
 }
 

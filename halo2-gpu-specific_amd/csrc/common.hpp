@@ -55,6 +55,13 @@ struct PinnedBuf {
 
 struct NttPlan;  // ntt.hip
 
+// device copy of a registered host range of SRS points (msm.hip): `gen` is the registration it was uploaded for
+struct ResidentCopy {
+    void* ptr = nullptr;
+    size_t len = 0;
+    uint64_t gen = 0;
+};
+
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;      // compute stream for host-API calls
@@ -65,7 +72,7 @@ struct DeviceCtx {
     DevBuf msm_scratch;
     DevBuf evalh_scratch;
     PinnedBuf pinned;
-    std::map<const void*, void*> resident;  // registered host base ranges -> device copies (msm.hip)
+    std::map<const void*, ResidentCopy> resident;  // registered host base ranges -> device copies (msm.hip)
     std::map<std::string, NttPlan*> plans;
     hipDeviceProp_t prop;
 };
@@ -73,6 +80,7 @@ struct DeviceCtx {
 // Device pool (HALO2_PROOFS_N_GPU honoured, prover.rs:57-70).
 int device_count();
 DeviceCtx* ctx_for(int device);  // creates on first use; throws HipError
+std::vector<DeviceCtx*> existing_contexts();  // the contexts created so far
 int acquire_device();            // blocking free-list, arithmetic.rs:314-321
 void release_device(int idx);    // arithmetic.rs:324-331
 

@@ -101,6 +101,15 @@ DeviceCtx* ctx_for(int idx) {
     return p.ctxs[dev];
 }
 
+std::vector<DeviceCtx*> existing_contexts() {
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    std::vector<DeviceCtx*> out;
+    for (DeviceCtx* c : p.ctxs)
+        if (c) out.push_back(c);
+    return out;
+}
+
 int acquire_device() {
     Pool& p = pool();
     std::unique_lock<std::mutex> lk(p.mu);

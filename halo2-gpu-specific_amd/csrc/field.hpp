@@ -248,6 +248,46 @@ H2_DEV void mad_acc(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 #endif
 }
 
+// ---- the device multiplier: a generated straight-line schedule per field (tools/gen_fp_mul.py -> fp_mul_gen.hpp) that
+// drops the add-with-carry after every multiply-add whose column sum provably still fits 64 bits.
+template <class P>
+__device__ __forceinline__ Fp<P> fp_mul_dev(const Fp<P>& a, const Fp<P>& b);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
+#define H2_MAD_FREE_V(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y))
+#define H2_MAD_FREE_S(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y))
+#define H2_MAD_SET_V(x, y)                                                                      \
+    do {                                                                                        \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y));          \
+        asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(hi) : "s"(cy));                                 \
+    } while (0)
+#define H2_MAD_SET_S(x, y)                                                                      \
+    do {                                                                                        \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y));          \
+        asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(hi) : "s"(cy));                                 \
+    } while (0)
+#define H2_MAD_ACC_V(x, y)                                                                      \
+    do {                                                                                        \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y));          \
+        asm("v_addc_co_u32 %0, %1, %0, 0, %1" : "+v"(hi), "+s"(cy));                            \
+    } while (0)
+#define H2_MAD_ACC_S(x, y)                                                                      \
+    do {                                                                                        \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y));          \
+        asm("v_addc_co_u32 %0, %1, %0, 0, %1" : "+v"(hi), "+s"(cy));                            \
+    } while (0)
+#define H2_SHIFT1() lo = (lo >> 32) | ((uint64_t)hi << 32)
+#define H2_SHIFT0() lo >>= 32
+#include "fp_mul_gen.hpp"
+#undef H2_MAD_FREE_V
+#undef H2_MAD_FREE_S
+#undef H2_MAD_SET_V
+#undef H2_MAD_SET_S
+#undef H2_MAD_ACC_V
+#undef H2_MAD_ACC_S
+#undef H2_SHIFT1
+#undef H2_SHIFT0
+#endif
+
 // Montgomery product a*b*R^-1 mod p, product scanning (FIPS) form.
 template <class P>
 H2_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
@@ -295,6 +335,8 @@ H2_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
         }
         return fp_reduce_once(r);   // inputs < p => t < 2p < 2^255: t[4] == 0
     }
+#elif !defined(H2_PORTABLE_MUL)
+    return fp_mul_dev(a, b);
 #endif
     Fp<P> r;
     uint64_t lo = 0;

@@ -1319,33 +1319,53 @@ size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count) {
 // re-uploads the bases on every MSM (arithmetic.rs:354-360); at 2^20 that is 64 MiB of PCIe per call,
 // about as long as the MSM itself.
 namespace {
+struct Registration {
+    size_t len;
+    uint64_t gen;  // bumped by every register / unregister: a device copy made for another generation is stale
+};
 std::mutex g_reg_mu;
-std::map<const uint64_t*, size_t> g_registered;  // host base pointer -> number of points
+std::map<const uint64_t*, Registration> g_registered;  // host base pointer -> points, generation
+uint64_t g_reg_gen = 0;
 }  // namespace
 
 int bases_register(const uint64_t* bases, size_t n) {
     std::lock_guard<std::mutex> g(g_reg_mu);
-    g_registered[bases] = n;
+    g_registered[bases] = Registration{n, ++g_reg_gen};
     return H2_OK;
 }
 
 int bases_unregister(const uint64_t* bases) {
-    std::lock_guard<std::mutex> g(g_reg_mu);
-    g_registered.erase(bases);
-    // device copies are dropped lazily by the owning context (resident_drop) on its next MSM
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        g_registered.erase(bases);
+        ++g_reg_gen;
+    }
+    // free the device copies now, on every context (under its lock: a host-buffer MSM holds it until its result is
+    // back, so nothing in flight reads the copy); a context that never runs another MSM would keep them otherwise
+    for (DeviceCtx* ctx : existing_contexts()) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        auto it = ctx->resident.find((const void*)bases);
+        if (it != ctx->resident.end()) {
+            hipFree(it->second.ptr);
+            ctx->resident.erase(it);
+        }
+    }
     return H2_OK;
 }
 
-// device copy of a registered range that contains [bases, bases + n) -- or nullptr
+// device copy of a registered range that contains [bases, bases + n) -- or nullptr.  A copy is reused only for the
+// registration (generation, length) it was uploaded for: unregister + refill + register of the same address uploads
+// the new points.
 static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size_t n) {
     const uint64_t* key = nullptr;
-    size_t len = 0;
+    Registration reg{0, 0};
     {
         std::lock_guard<std::mutex> g(g_reg_mu);
-        // drop device copies whose registration is gone
+        // drop device copies whose registration is gone or was replaced
         for (auto it = ctx->resident.begin(); it != ctx->resident.end();) {
-            if (!g_registered.count((const uint64_t*)it->first)) {
-                hipFree(it->second);
+            auto r = g_registered.find((const uint64_t*)it->first);
+            if (r == g_registered.end() || r->second.gen != it->second.gen || r->second.len != it->second.len) {
+                hipFree(it->second.ptr);
                 it = ctx->resident.erase(it);
             } else {
                 ++it;
@@ -1354,18 +1374,20 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         auto it = g_registered.upper_bound(bases);
         if (it == g_registered.begin()) return nullptr;
         --it;
-        if (bases + 8 * n > it->first + 8 * it->second) return nullptr;
+        if (bases + 8 * n > it->first + 8 * it->second.len) return nullptr;
         key = it->first;
-        len = it->second;
+        reg = it->second;
     }
     auto rit = ctx->resident.find((const void*)key);
     if (rit == ctx->resident.end()) {
-        void* d = nullptr;
-        H2_HIP(hipMalloc(&d, len * sizeof(Affine)));
-        H2_HIP(hipMemcpyAsync(d, key, len * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
-        rit = ctx->resident.emplace((const void*)key, d).first;
+        ResidentCopy c;
+        c.len = reg.len;
+        c.gen = reg.gen;
+        H2_HIP(hipMalloc(&c.ptr, reg.len * sizeof(Affine)));
+        H2_HIP(hipMemcpyAsync(c.ptr, key, reg.len * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+        rit = ctx->resident.emplace((const void*)key, c).first;
     }
-    return (const Affine*)rit->second + (bases - key) / 8;
+    return (const Affine*)rit->second.ptr + (bases - key) / 8;
 }
 
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n, uint32_t max_bits,

@@ -313,6 +313,10 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
         }
     }
     H2_HIP(hipGetLastError());
+    // the tables are complete before the plan is published: a second caller on another stream (h2_dev_* on a different
+    // torch stream, or the host API after a device-API first use) must not launch passes against tables still being
+    // written.  Once per (log_n, omega) for the life of the process.
+    H2_HIP(hipStreamSynchronize(stream));
     ctx->plans[key] = pl;
     return pl;
 }
@@ -391,6 +395,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                     H2_HIP(hipMalloc(&scaled, cnt * sizeof(Fr)));
                     hipLaunchKernelGGL(k_scale_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, scaled, pl->tw_hi,
                                        post3[0], cnt);
+                    H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per divisor)
                     pl->scaled_hi[key] = scaled;
                 } else {
                     scaled = it->second;

@@ -612,27 +612,66 @@ int perm_terms_launch(Fr* num, Fr* den, const Fr* value, const Fr* sigma, size_t
 
 
 // ---------------------------------------------------------------------------------------------
-// The vanishing argument's blinding polynomial (vanishing/prover.rs:47-61: a parallel fill from thread_rng).
-// Counter-based so that the host restatement can reproduce it: limb j of element i = mix64(seed + 4 i + j),
-// top limb cut to 61 bits (< 2^253 < r: a valid Montgomery residue used as is).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9e3779b97f4a7c15ull;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-}
+// The vanishing argument's blinding polynomial (vanishing/prover.rs:47-61: a parallel fill from thread_rng, every
+// coefficient `Scalar::random` = 512 random bits reduced modulo r).  Here: element i = ChaCha20 block i under a 256-bit
+// key (counter = i, nonce = 0; the key comes from OS entropy in halo2-gpu-specific_amd/rng.py, or from the seeded test
+// stream), its 64 output bytes cut into two 253-bit integers lo (words 0..7) and hi (words 8..15), value = lo + 2^253 hi
+// mod r (506 random bits: bias < 2^-252), stored in Montgomery form.  rng.py holds the host twin.
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+#define H2_QR(a, b, c, d)                                                  \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12);  \
+    a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7)
 
-__global__ void __launch_bounds__(256) k_random_fr(uint64_t seed, size_t n, uint64_t* out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one u64 limb per lane: coalesced stores
-    if (i >= 4 * n) return;
-    uint64_t v = mix64(seed + i);
-    if ((i & 3) == 3) v &= (1ull << 61) - 1;
-    out[i] = v;
-}
+struct ChaChaKey {
+    uint32_t w[8];
+};
 
-int random_fr_launch(uint64_t seed, size_t n, uint64_t* d_out, hipStream_t stream) {
+__global__ void __launch_bounds__(256) k_random_fr(ChaChaKey key, size_t n, Fr* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[16], x[16];
+    s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;  // "expand 32-byte k"
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[4 + j] = key.w[j];
+    s[12] = (uint32_t)i; s[13] = (uint32_t)((uint64_t)i >> 32); s[14] = 0; s[15] = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[j];
+    for (int round = 0; round < 10; round++) {
+        H2_QR(x[0], x[4], x[8], x[12]);
+        H2_QR(x[1], x[5], x[9], x[13]);
+        H2_QR(x[2], x[6], x[10], x[14]);
+        H2_QR(x[3], x[7], x[11], x[15]);
+        H2_QR(x[0], x[5], x[10], x[15]);
+        H2_QR(x[1], x[6], x[11], x[12]);
+        H2_QR(x[2], x[7], x[8], x[13]);
+        H2_QR(x[3], x[4], x[9], x[14]);
+    }
+    Fr lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo.l[j] = x[j] + s[j];
+        hi.l[j] = x[8 + j] + s[8 + j];
+    }
+    lo.l[7] &= 0x1fffffffu;
+    hi.l[7] &= 0x1fffffffu;
+    Fr rr, k253;  // R^2 mod r and 2^253 R^2 mod r: canonical integer -> Montgomery form of lo + 2^253 hi
+    constexpr uint32_t K253[8] = {0x3697e008u, 0x0bd29b1cu, 0xc39f76d7u, 0xa5491397u,
+                                  0x9433f9fdu, 0x912798ccu, 0x6ff98cafu, 0x019f0b29u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        rr.l[j] = FrParams::RR[j];
+        k253.l[j] = K253[j];
+    }
+    fp_store(out + i, fp_add(fp_mul(lo, rr), fp_mul(hi, k253)));
+}
+#undef H2_QR
+
+int random_fr_launch(const uint8_t key[32], size_t n, uint64_t* d_out, hipStream_t stream) {
     if (n == 0) return H2_OK;
-    hipLaunchKernelGGL(k_random_fr, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, stream, seed, n, d_out);
+    ChaChaKey k;
+    for (int j = 0; j < 8; j++)
+        k.w[j] = (uint32_t)key[4 * j] | ((uint32_t)key[4 * j + 1] << 8) | ((uint32_t)key[4 * j + 2] << 16) | ((uint32_t)key[4 * j + 3] << 24);
+    hipLaunchKernelGGL(k_random_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, k, n, (Fr*)d_out);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }

@@ -424,15 +424,29 @@ def permutation_mapping(ncols, n, copies):
     return (nxt // n).astype(np.uint32).reshape(ncols, n), (nxt % n).astype(np.uint32).reshape(ncols, n)
 
 
-def vk_digest(cs, k, fixed_commitments, perm_commitments):
-    """VerifyingKey::hash_into (plonk.rs:91-109) with our own canonical text in place of the Debug string"""
-    s = "halo2-hip-vk circuit=%s k=%d advice=%d fixed=%d degree=%d fixed_commitments=%s permutation_commitments=%s" % (
-        cs.name, k, cs.num_advice, cs.num_fixed, cs.degree(),
-        ",".join(point_to_bytes(p).hex() for p in fixed_commitments),
-        ",".join(point_to_bytes(p).hex() for p in perm_commitments))
+def vk_digest(cs, dom, fixed_commitments, perm_commitments):
+    """VerifyingKey::hash_into (plonk.rs:91-109): Blake2b-512 ("Halo2-Verify-Key") over a u64 length and the pinned
+    verifying key, reduced by from_bytes_wide.  The reference pins `format!("{:?}", vk.pinned())` -- the Debug text of
+    the domain, the whole constraint system and the commitments -- which cannot be reproduced without the Rust binary
+    (parity unpinned); this build hashes the same CONTENT in a canonical binary form: domain (k, extended_k, omega),
+    both field moduli, the write_cs serialisation of the constraint system (gates, queries, permutation columns, lookups,
+    shuffles, instance columns: formats.cs_store) and the fixed / permutation commitments.  Two circuits that differ in
+    any gate, lookup or query therefore get different transcripts.  `keygen(..., transcript_repr=...)` overrides the
+    value with one dumped from the Rust side (tools/ref_dump) once that can be pinned."""
+    from .formats import cs_store
+    from .transcript import Q_MOD
+
+    cs_bytes = cs_store(cs)
+    body = [b"halo2-hip-vk-v2", dom.k.to_bytes(4, "little"), dom.extended_k.to_bytes(4, "little"),
+            dom.omega.to_bytes(32, "little"), R_MOD.to_bytes(32, "little"), Q_MOD.to_bytes(32, "little"),
+            len(cs_bytes).to_bytes(4, "little"), cs_bytes]
+    for group in (fixed_commitments, perm_commitments):
+        body.append(len(group).to_bytes(4, "little"))
+        body += [point_to_bytes(p) for p in group]
+    body = b"".join(body)
     h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
-    h.update(len(s).to_bytes(8, "little"))
-    h.update(s.encode())
+    h.update(len(body).to_bytes(8, "little"))
+    h.update(body)
     return int.from_bytes(h.digest(), "little") % R_MOD
 
 
@@ -440,7 +454,7 @@ class ProvingKey:
     pass
 
 
-def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=False):
+def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=False, transcript_repr=None):
     """keygen_vk + keygen_pk.  fixed: list of canonical (n, 4) u64 columns; copies: see permutation_mapping.
     `mapping` = (map_col, map_row) replaces `copies` and `fixed_montgomery` marks columns already in the in-memory
     representation: the two things a CircuitData file holds (keygen_pk_from_info, plonk/keygen.rs:458-553)."""
@@ -503,7 +517,8 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
 
     pk.evalh_code_object = jit.compile_program(pk.graph.rotations, pk.graph.calculations, pk.value_parts,
                                                pk.lookup_calcs, pk.shuffle_calcs)
-    pk.transcript_repr = vk_digest(cs, params.k, pk.fixed_commitments, pk.perm_commitments)
+    pk.transcript_repr = (transcript_repr if transcript_repr is not None else
+                          vk_digest(cs, dom, pk.fixed_commitments, pk.perm_commitments))
     D.sync()
     return pk
 
@@ -803,7 +818,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     del num, inv, shuffle_inv
     # vanishing argument: the random polynomial (vanishing/prover.rs:40-67), generated on the device
     random_poly = D.empty(n)
-    check(L.h2_dev_random_fr(rng.random_poly_seed(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
+    check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
     # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z; the random polynomial's commitment does
     # not depend on anything hashed in between, so its MSM rides in the same pipelined batch (hashing order kept)
     all_z = z_dev + [z for st in lookups for z in st["z"]] + shuffle_z

@@ -1,21 +1,74 @@
-"""One seeded stream standing in for the `OsRng` / `thread_rng` sites of create_proof (plonk/prover.rs:284,
-permutation/prover.rs:141, vanishing/prover.rs:51-61), so that two provers fed the same seed draw the same
-blinding values in the same order."""
+"""The randomness of create_proof: the `OsRng` / `thread_rng` sites of the reference (plonk/prover.rs:284 advice
+blinding rows, permutation/prover.rs:141 and logup/shuffle blinding scalars, vanishing/prover.rs:51-61 the random
+polynomial).
+
+`ProverRng()` draws everything from the operating system's entropy source (os.urandom), as the reference does with
+`OsRng`: blinding values are unpredictable and the proof is zero-knowledge.
+
+`ProverRng.deterministic(seed)` (also `ProverRng(seed)`) is the TEST-ONLY mode: one xoshiro256** stream expanded from
+a 64-bit seed, so that two provers fed the same seed draw the same values in the same order and their proofs can be
+compared byte for byte.  A proof made in this mode hides nothing from anyone who can guess
+the seed: never use it outside tests and benchmarks.
+
+In both modes the vanishing argument's random polynomial comes from a ChaCha20 keystream under a 256-bit key
+(h2_dev_random_fr on the device, `random_poly_limbs` is its host twin): the key is 32 bytes of OS entropy, or four
+draws of the seeded stream.
+"""
+import os
+
 import numpy as np
 
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 _M64 = (1 << 64) - 1
 _R_INV = pow(1 << 256, -1, R_MOD)
+_M253 = (1 << 253) - 1
 
 
 def _rotl(x, k):
     return ((x << k) | (x >> (64 - k))) & _M64
 
 
-class ProverRng:
-    """xoshiro256** seeded through splitmix64"""
+def _rotl32(x, k):
+    return (x << np.uint32(k)) | (x >> np.uint32(32 - k))
 
-    def __init__(self, seed=0x48414C4F32):
+
+def chacha20_blocks(key, n):
+    """ChaCha20 blocks 0 .. n-1 under `key` (32 bytes), zero nonce, 64-bit block counter in words 12-13:
+    (n, 16) uint32, the keystream words in order (RFC 8439 block function)."""
+    k = np.frombuffer(bytes(key), dtype="<u4")
+    assert k.shape == (8,)
+    s = np.zeros((16, n), dtype=np.uint32)
+    s[0], s[1], s[2], s[3] = 0x61707865, 0x3320646E, 0x79622D32, 0x6B206574
+    for j in range(8):
+        s[4 + j] = k[j]
+    ctr = np.arange(n, dtype=np.uint64)
+    s[12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    s[13] = (ctr >> np.uint64(32)).astype(np.uint32)
+    x = s.copy()
+
+    def qr(a, b, c, d):
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = _rotl32(x[d], 16)
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = _rotl32(x[b], 12)
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = _rotl32(x[d], 8)
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = _rotl32(x[b], 7)
+
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        x += s
+    return np.ascontiguousarray(x.T)
+
+
+class ProverRng:
+    """seed=None (the default): OS entropy.  An integer seed: the deterministic test stream (xoshiro256** seeded
+    through splitmix64)."""
+
+    def __init__(self, seed=None):
+        self.secure = seed is None
+        if self.secure:
+            self.s = None
+            return
         s, st = seed & _M64, []
         for _ in range(4):
             s = (s + 0x9E3779B97F4A7C15) & _M64
@@ -25,7 +78,18 @@ class ProverRng:
             st.append(z ^ (z >> 31))
         self.s = st
 
+    @classmethod
+    def deterministic(cls, seed):
+        """TEST-ONLY: reproducible blinding from a 64-bit seed (not zero-knowledge)"""
+        return cls(seed)
+
+    @classmethod
+    def from_os_entropy(cls):
+        return cls(None)
+
     def next_u64(self):
+        if self.secure:
+            return int.from_bytes(os.urandom(8), "little")
         s = self.s
         out = (_rotl((s[1] * 5) & _M64, 7) * 9) & _M64
         t = (s[1] << 17) & _M64
@@ -48,26 +112,35 @@ class ProverRng:
             v |= self.next_u64() << (64 * i)
         return v % R_MOD
 
-    def random_poly_seed(self):
-        """one draw keys the counter-based generator of the vanishing argument's blinding polynomial"""
-        return self.next_u64()
+    def random_poly_key(self):
+        """the 256-bit ChaCha20 key of the vanishing argument's blinding polynomial"""
+        if self.secure:
+            return os.urandom(32)
+        return b"".join(self.next_u64().to_bytes(8, "little") for _ in range(4))
 
     @staticmethod
-    def random_poly_limbs(seed, n):
-        """Host twin of h2_dev_random_fr (csrc/poly.hip k_random_fr): n x 4 u64 limbs, limb j of element i =
-        mix64(seed + 4 i + j) with splitmix64's output function, the top limb cut to 61 bits.  The 253-bit value
-        is the in-memory (Montgomery) representation."""
-        with np.errstate(over="ignore"):
-            z = np.uint64(seed) + np.arange(4 * n, dtype=np.uint64)
-            z += np.uint64(0x9E3779B97F4A7C15)
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z ^= z >> np.uint64(31)
-        a = z.reshape(n, 4)
-        a[:, 3] &= np.uint64((1 << 61) - 1)
+    def random_poly_values(key, n):
+        """Host twin of h2_dev_random_fr (csrc/poly.hip k_random_fr): element i = lo + 2^253 hi mod r with lo / hi the
+        low 253 bits of keystream words 0..7 / 8..15 of ChaCha20 block i.  Canonical integers."""
+        w = chacha20_blocks(key, n)
+        out = []
+        for row in w:
+            lo = int.from_bytes(row[:8].tobytes(), "little") & _M253
+            hi = int.from_bytes(row[8:].tobytes(), "little") & _M253
+            out.append((lo + (hi << 253)) % R_MOD)
+        return out
+
+    @staticmethod
+    def random_poly_limbs(key, n):
+        """the same values as the device stores them: (n, 4) u64 Montgomery limbs"""
+        vals = ProverRng.random_poly_values(key, n)
+        a = np.zeros((n, 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            m = (v << 256) % R_MOD
+            for j in range(4):
+                a[i, j] = (m >> (64 * j)) & _M64
         return a
 
     def random_poly(self, n):
-        """the blinding polynomial as canonical integers (consumes one draw)"""
-        a = self.random_poly_limbs(self.random_poly_seed(), n)
-        return [(int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192) * _R_INV % R_MOD for r in a]
+        """the blinding polynomial as canonical integers (consumes one key draw)"""
+        return self.random_poly_values(self.random_poly_key(), n)

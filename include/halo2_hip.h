@@ -155,11 +155,13 @@ int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, cons
                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                              const uint64_t omega[4], int first, void *stream);
 
-/* The vanishing argument's blinding polynomial (plonk/vanishing/prover.rs:47-61, a parallel fill from thread_rng):
- * n Fr from a counter-based generator -- u64 limb j of element i = mix64(seed + 4 i + j) (splitmix64's output
- * function), the top limb cut to 61 bits; the 253-bit value is used directly as the Montgomery representation.
- * halo2-gpu-specific_amd/rng.py holds the host twin the reference prover of the tests draws from. */
-int h2_dev_random_fr(uint64_t seed, size_t n, void *d_out, void *stream);
+/* The vanishing argument's blinding polynomial (plonk/vanishing/prover.rs:47-61, a parallel fill of `Scalar::random`
+ * draws from thread_rng): element i = ChaCha20 block i under the caller's 256-bit key (counter i, zero nonce); the
+ * 64 output bytes are cut into two 253-bit little-endian integers lo, hi and the element is lo + 2^253 hi mod r
+ * (506 random bits), stored in Montgomery form.  The key MUST come from a cryptographic source in production
+ * (halo2-gpu-specific_amd/rng.py draws it from os.urandom; its seeded mode is for tests); rng.py also holds the host
+ * twin the reference prover of the tests draws from. */
+int h2_dev_random_fr(const uint8_t key[32], size_t n, void *d_out, void *stream);
 
 /* Grand-sum column: z[0] = init, z[i] = z[i-1] + f[i-1] for i < n -- the `scan` of plonk/logup/prover.rs:353-367. */
 int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d_z, void *stream);

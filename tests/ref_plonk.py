@@ -245,6 +245,16 @@ class MiniPlonk:
     blinding_factors = 5                          # circuit.rs:1919-1944 with one query per advice column
     name = "mini-plonk"
 
+    @classmethod
+    def cs_bytes(cls):
+        """canonical write_cs bytes of this circuit (its product-side twin through formats.cs_store): hashed into the
+        verifying-key digest"""
+        import product_circuits as pc
+        from halo2_gpu_specific_amd.formats import cs_store
+
+        make = {"mini-plonk": pc.mini_plonk_cs, "rot-gate": pc.rot_gate_cs, "lookup-shuffle": pc.lookup_shuffle_cs}
+        return cs_store(make[cls.name]())
+
     @staticmethod
     def gates(adv, fix):
         a, b, c = adv(0, 0), adv(1, 0), adv(2, 0)
@@ -320,6 +330,7 @@ class LookupShuffle:
     degree = 6
     blinding_factors = 5
     name = "lookup-shuffle"
+    cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
 
     @staticmethod
     def gates(adv, fix, inst):
@@ -394,16 +405,22 @@ def permutation_mapping(ncols, n, copies):
     return mapping
 
 
-def vk_digest(cs, k, fixed_commitments, perm_commitments):
+def vk_digest(cs, dom, fixed_commitments, perm_commitments):
     """stand-in for `format!("{:?}", vk.pinned())` (plonk.rs:91-109): same framing (u64 length, Blake2b-512 with
-    the Halo2-Verify-Key personalisation, from_bytes_wide), our own canonical text"""
-    s = "halo2-hip-vk circuit=%s k=%d advice=%d fixed=%d degree=%d fixed_commitments=%s permutation_commitments=%s" % (
-        cs.name, k, cs.num_advice, cs.num_fixed, cs.degree,
-        ",".join(point_to_bytes(p).hex() for p in fixed_commitments),
-        ",".join(point_to_bytes(p).hex() for p in perm_commitments))
+    the Halo2-Verify-Key personalisation, from_bytes_wide) over the domain, both moduli, the canonical write_cs bytes
+    of the constraint system (the product-side twin of this circuit class serialised by formats.cs_store: the digest
+    text is this build's own convention, so there is nothing independent to restate) and the commitments"""
+    cs_bytes = cs.cs_bytes()
+    body = [b"halo2-hip-vk-v2", dom.k.to_bytes(4, "little"), dom.extended_k.to_bytes(4, "little"),
+            dom.omega.to_bytes(32, "little"), R.to_bytes(32, "little"), Q.to_bytes(32, "little"),
+            len(cs_bytes).to_bytes(4, "little"), cs_bytes]
+    for group in (fixed_commitments, perm_commitments):
+        body.append(len(group).to_bytes(4, "little"))
+        body += [point_to_bytes(p) for p in group]
+    body = b"".join(body)
     h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
-    h.update(len(s).to_bytes(8, "little"))
-    h.update(s.encode())
+    h.update(len(body).to_bytes(8, "little"))
+    h.update(body)
     return int.from_bytes(h.digest(), "little") % R
 
 
@@ -438,7 +455,7 @@ def keygen(cs, k, s, fixed, copies):
     pk.l_active_row = [(1 - pk.l_last[i] - lb[i]) % R for i in range(dom.extended_n)]
     pk.fixed_commitments = [g1_mul(G1, eval_poly(p, s)) for p in pk.fixed_polys]
     pk.perm_commitments = [g1_mul(G1, eval_poly(p, s)) for p in pk.sigma_polys]
-    pk.transcript_repr = vk_digest(cs, k, pk.fixed_commitments, pk.perm_commitments)
+    pk.transcript_repr = vk_digest(cs, dom, pk.fixed_commitments, pk.perm_commitments)
     return pk
 
 

@@ -226,13 +226,14 @@ def test_permutation_sigma_and_terms(oracle, n):
 
 
 def test_random_fr_matches_host_twin():
+    """h2_dev_random_fr (ChaCha20 keystream -> 506 bits -> mod r, Montgomery) against rng.py's numpy twin"""
     from halo2_gpu_specific_amd.rng import ProverRng
 
     L = h2.lib()
-    for seed, n in ((5, 1), (2**64 - 3, 1000), (0x48414C4F32, 1 << 18)):
+    for key, n in ((bytes(32), 1), (bytes(range(32)), 1000), (b"\xff" * 32, 1 << 16)):
         d = _dev(np.zeros((n, 4), dtype=np.uint64))
-        assert L.h2_dev_random_fr(seed, n, d.data_ptr(), None) == 0 and L.h2_synchronize() == 0
-        assert np.array_equal(_host(d), ProverRng.random_poly_limbs(seed, n))
+        assert L.h2_dev_random_fr(key, n, d.data_ptr(), None) == 0 and L.h2_synchronize() == 0
+        assert np.array_equal(_host(d), ProverRng.random_poly_limbs(key, n))
 
 
 def test_eval_polynomial_batch(oracle):

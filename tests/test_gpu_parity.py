@@ -336,6 +336,34 @@ def test_resident_bases(oracle):
     assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(s, pts, 254)) == want_full  # back to per-call upload
 
 
+def test_resident_bases_reregistered_address_is_reuploaded(oracle):
+    """unregister -> refill the same host buffer -> register again (also with a larger length) must use the
+    new points, not the device copy of the old registration"""
+    L = h2.lib()
+    n = 1 << 12
+    buf = np.zeros((2 * n, 8), dtype=np.uint64)
+    s = oracle.random_fr(178, 2 * n)
+    first, second = oracle.random_g1(177, n), oracle.random_g1(179, 2 * n)
+    buf[:n] = first
+    assert L.h2_bases_register(buf.ctypes.data, n) == 0
+    out = np.zeros(12, dtype=np.uint64)
+    assert L.h2_msm(s.ctypes.data, buf.ctypes.data, n, 254, out.ctypes.data) == 0
+    assert _affine(oracle, out) == _affine(oracle, oracle.best_multiexp(s[:n], first))
+    assert L.h2_bases_unregister(buf.ctypes.data) == 0
+    buf[:] = second                                            # same address, new (and longer) contents
+    assert L.h2_bases_register(buf.ctypes.data, 2 * n) == 0
+    try:
+        assert L.h2_msm(s.ctypes.data, buf.ctypes.data, 2 * n, 254, out.ctypes.data) == 0
+        assert _affine(oracle, out) == _affine(oracle, oracle.best_multiexp(s, second))
+        # re-registering WITHOUT an unregister in between also replaces the copy
+        buf[:n] = first
+        assert L.h2_bases_register(buf.ctypes.data, n) == 0
+        assert L.h2_msm(s.ctypes.data, buf.ctypes.data, n, 254, out.ctypes.data) == 0
+        assert _affine(oracle, out) == _affine(oracle, oracle.best_multiexp(s[:n], first))
+    finally:
+        assert L.h2_bases_unregister(buf.ctypes.data) == 0
+
+
 def test_concurrent_callers(oracle):
     """Threading contract (SURVEY.md 8(b)): every entry point is called concurrently from rayon workers;
     the blocking device pool serialises them (arithmetic.rs:314-331).  8 threads mix NTTs and MSMs."""

@@ -12,43 +12,9 @@ from halo2_gpu_specific_amd import circuit as hc
 from halo2_gpu_specific_amd import circuits, evaluation as ev, prover, transcript
 from halo2_gpu_specific_amd.rng import ProverRng
 
+from product_circuits import lookup_shuffle_cs, rot_gate_cs  # noqa: E402,F401 (re-exported for test_gpu_plonk)
+
 S_TRAPDOOR = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
-
-
-def rot_gate_cs():
-    """the product-side description of ref_plonk.RotGate"""
-    cs = hc.ConstraintSystem("rot-gate")
-    a, b, c = cs.advice_column(), cs.advice_column(), cs.advice_column()
-    s0, s1 = cs.fixed_column(), cs.fixed_column()
-    for col in (a, b, c):
-        cs.enable_equality(col)
-    q0, q1 = cs.query_fixed(s0), cs.query_fixed(s1)
-    cs.enable_equality(s1)
-    cs.set_minimum_degree(4)
-    cs.create_gate("sum", [q0 * (cs.query_advice(a) + cs.query_advice(b) - cs.query_advice(c))])
-    cs.create_gate("step", [q1 * (cs.query_advice(a, 1) - cs.query_advice(c)) * (cs.query_advice(b, -1) + q0)])
-    return cs
-
-
-def lookup_shuffle_cs():
-    """the product-side description of ref_plonk.LookupShuffle"""
-    cs = hc.ConstraintSystem("lookup-shuffle")
-    adv = [cs.advice_column() for _ in range(12)]
-    fx = [cs.fixed_column() for _ in range(5)]
-    inst = cs.instance_column()
-    cs.enable_equality(adv[11])
-    cs.enable_equality(inst)
-    q, qi = cs.query_fixed(fx[0]), cs.query_fixed(fx[4])
-    a, b, c, d, e, g, h, g2, h2, p, p2 = (cs.query_advice(adv[i]) for i in range(11))
-    w, pub = cs.query_advice(adv[11]), cs.query_instance(inst)
-    t0, t1, u = cs.query_fixed(fx[1]), cs.query_fixed(fx[2]), cs.query_fixed(fx[3])
-    cs.create_gate("square", [q * (a * a + 1 - b)])
-    cs.create_gate("public", [qi * (w - pub)])
-    cs.lookup_any("pairs", [t0, t1], [[[q * a, q * b], [c, d]], [[q * c, q * d]]])
-    cs.lookup_any("single", [u], [[[e]]])
-    cs.shuffle_group([("gh", [g, h], [g2, h2]), ("p", [p], [p2])])
-    cs.set_minimum_degree(6)
-    return cs
 
 
 def test_reference_prover_with_lookups_shuffles_instances():
@@ -298,25 +264,33 @@ def test_domain_scalars(k, degree):
 
 
 def test_rng_is_a_fixed_stream():
-    a, b = ProverRng(9), ProverRng(9)
+    a, b = ProverRng(9), ProverRng.deterministic(9)
     assert [a.next_u64() for _ in range(4)] == [b.next_u64() for _ in range(4)]
     assert a.fr() == b.fr() < rp.R and a.u16() == b.u16() < 65536
-    limbs = ProverRng.random_poly_limbs(a.random_poly_seed(), 16)
+    limbs = ProverRng.random_poly_limbs(a.random_poly_key(), 16)
     ints = b.random_poly(16)
-    assert [transcript.fr_from_mont_limbs(r) for r in limbs] == ints and (limbs[:, 3] < (1 << 61)).all()
-    # the counter-based generator, element by element (the device kernel k_random_fr is its twin)
-    def mix64(z):
-        z = (z + 0x9E3779B97F4A7C15) & (2**64 - 1)
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
-        return z ^ (z >> 31)
-    seed = 2**64 - 5  # wraps
-    got = ProverRng.random_poly_limbs(seed, 3)
-    for i in range(3):
-        for j in range(4):
-            want = mix64((seed + 4 * i + j) & (2**64 - 1)) & ((1 << 61) - 1 if j == 3 else 2**64 - 1)
-            assert int(got[i, j]) == want
-    assert ProverRng(10).next_u64() != ProverRng(9).next_u64()
+    assert [transcript.fr_from_mont_limbs(r) for r in limbs] == ints and all(v < rp.R for v in ints)
+
+
+def test_rng_defaults_to_os_entropy():
+    """no constant default seed -- ProverRng() draws from os.urandom; the seeded stream is opt-in"""
+    a, b = ProverRng(), ProverRng()
+    assert a.secure and b.secure and not ProverRng(1).secure
+    assert [a.next_u64() for _ in range(4)] != [b.next_u64() for _ in range(4)]
+    assert a.random_poly_key() != b.random_poly_key() and len(a.random_poly_key()) == 32
+    assert a.fr() < rp.R and a.u16() < 65536
+
+
+def test_chacha20_keystream_known_answer():
+    """the all-zero key / nonce / counter block of ChaCha20 (the classic test vector of the cipher, RFC 7539 A.1 #1)"""
+    from halo2_gpu_specific_amd.rng import chacha20_blocks
+
+    want = ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+            "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    blocks = chacha20_blocks(bytes(32), 2)
+    assert blocks[0].tobytes().hex() == want
+    # block 1 of the same key (RFC 7539 A.1 #2 uses counter 1)
+    assert blocks[1].tobytes().hex().startswith("9f07e7be5551387a98ba977c732d080d")
 
 
 def test_max_scalar_bits():
@@ -401,6 +375,27 @@ def test_reference_prover_reproduces_committed_proofs():
         proof = rp.create_proof(pk, adv, ProverRng(case["seed"]), use_gwc=gwc, instances=inst)
         assert proof.hex() == case["proof"], (case["circuit"], case["scheme"])
         assert rp.verify_proof(pk, bytes.fromhex(case["proof"]), use_gwc=gwc, instances=inst)
+
+
+def test_jit_cache_directory_must_be_private(tmp_path, monkeypatch):
+    """a cache directory that others can write to is not used (a planted code object would be loaded)"""
+    import os
+    import warnings
+
+    from halo2_gpu_specific_amd import jit
+
+    good = tmp_path / "mine"
+    monkeypatch.setenv("H2_JIT_CACHE", str(good))
+    assert jit.cache_dir() == str(good) and (os.stat(good).st_mode & 0o777) == 0o700
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("H2_JIT_CACHE", str(shared))
+    monkeypatch.setattr(jit, "_private_dir", None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d = jit.cache_dir()
+    assert d != str(shared) and (os.stat(d).st_mode & 0o077) == 0 and w
 
 
 def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
