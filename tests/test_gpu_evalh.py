@@ -29,6 +29,14 @@ def test_evaluate_h_k16(oracle):
     assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
 
 
+@pytest.mark.timeout(900)
+def test_evaluate_h_k20(oracle):
+    """the size class of the proofs (2^20 rows, 2^22 extended points, permutation + lookups + shuffles)"""
+    kw = random_case(23, 20, 22, oracle, n_calcs=40)
+    b = ev.Builder().build(**kw)
+    assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
+
+
 @pytest.mark.parametrize("seed,k,ek,kwargs", [
     (1, 2, 3, {}), (2, 5, 7, {}), (4, 10, 12, {}), (6, 13, 13, {}), (7, 6, 8, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=3)),
     (8, 9, 11, dict(lookup_sets=(2,), n_shuffles=1, n_calcs=80)), (9, 16, 18, dict(n_calcs=60))])

@@ -287,6 +287,56 @@ def test_commit_lagrange_and_ifft(oracle):
     assert _affine(oracle, c_lagrange) == _affine(oracle, oracle.best_multiexp(a, gl))
 
 
+@pytest.mark.parametrize("k", [16, 20])
+@pytest.mark.timeout(600)
+def test_commit_lagrange_and_ifft_large(oracle, k):
+    """h2_msm_intt at the sizes the prover calls it with (one z-polynomial at 2^16 / 2^20): the in-place iNTT equals the
+    oracle's `ifft` on every element and the commitment equals the oracle's MSM over random bases; a bounded column
+    (max_bits = 40) goes through the same entry point"""
+    n = 1 << k
+    d, _ = oracle.domain(1, k)
+    pts = oracle.random_g1(600 + k, n)
+    for bits in (254, 40):
+        a = oracle.random_fr(610 + k + bits, n)
+        if bits < 254:                                   # canonical values below 2^40, stored Montgomery
+            a = to_mont_array(oracle, a, bits)
+        vals = a.copy()
+        got = ar.gpu_multiexp_bound_and_fft(vals, pts, 254, d.fr("omega_inv"), d.fr("ifft_divisor"), k)
+        assert np.array_equal(vals, oracle.ifft(a, d.fr("omega_inv"), k, d.fr("ifft_divisor")))
+        assert _affine(oracle, got) == _affine(oracle, oracle.best_multiexp(a, pts))
+
+
+def to_mont_array(oracle, a, bits):
+    """(n, 4) u64 random limbs -> Montgomery form of (value mod 2^bits)"""
+    small = a.copy()
+    full, rem = divmod(bits, 64)
+    small[:, full + (1 if rem else 0):] = 0
+    if rem:
+        small[:, full] &= np.uint64((1 << rem) - 1)
+    return ar.gpu_mont(small)
+
+
+@pytest.mark.parametrize("j,k", [(3, 22), (5, 22)])
+@pytest.mark.timeout(900)
+def test_coset_divide_inverse_vs_oracle_large(oracle, j, k):
+    """coeff_to_extended, divide_by_vanishing_poly and extended_to_coeff against the oracle at the prover's sizes:
+    2^22 rows extended to 2^23 (degree 3, BASELINE configs[3]) / 2^24 (degree 5); every element"""
+    d, t = oracle.domain(j, k)
+    coeffs = oracle.random_fr(j * 100 + k, 1 << k)
+    ext = ar.coeff_to_extended(coeffs, d.k, d.extended_k, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega"))
+    want = oracle.coeff_to_extended(coeffs, d)
+    assert np.array_equal(ext, want)
+    del want
+    div = ar.divide_by_vanishing_poly(ext.copy(), t)
+    oracle.lib.oracle_divide_by_vanishing_poly(ext.ctypes.data, len(ext), t.ctypes.data, len(t), 64)
+    assert np.array_equal(div, ext)
+    got_c = ar.extended_to_coeff(
+        div, d.k, d.extended_k, d.quotient_poly_degree, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega_inv"),
+        d.fr("extended_ifft_divisor"),
+    )
+    assert np.array_equal(got_c, oracle.extended_to_coeff(ext, d))
+
+
 def test_msm_batch_shared_bases(oracle):
     """h2_dev_msm_batch: several columns committed against the same bases (plonk/prover.rs:293-299),
     pipelined on two streams; each result must equal the oracle's MSM of that column."""
