@@ -29,7 +29,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-MUL_CEILING = 1.31e11  # 254-bit Montgomery multiplications/s, whole chip (tools/mulbench.hip, profiles/r1_mulbench.txt)
+# Integer-ALU bound of the 254-bit Montgomery product, from HARDWARE rates (tools/mulbench.hip, profiles/r2_mulbench.txt):
+# v_mad_u64_u32 issues at 3.046e13 lane-ops/s on the whole chip; a product needs 136 of them (64 + 64 + 8); nothing
+# else credited.  The multiplier itself reaches 1.60e11/s (0.71 of this bound: the add-with-carry after the
+# multiply-adds that can carry, and the final conditional subtraction, share the same issue port).
+MAD_RATE = 3.046e13
+MUL_HW_BOUND = MAD_RATE / 136.0   # 2.24e11 products/s
+MUL_MEASURED = 1.60e11            # the multiplier in a loop, >= 2 waves/SIMD
 
 
 def fr_limbs(v):
@@ -67,6 +73,7 @@ def main():
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--prove-k", type=int, default=22, help="create_proof leg: mini-PLONK with 2^k rows (0 = skip)")
     ap.add_argument("--prove-steps", type=int, default=3)
+    ap.add_argument("--k24", type=int, default=1, help="1: also run the k = 24 legs (MSM 2^24, create_proof k = 24) the metric is quoted at")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +137,7 @@ def main():
 
     # roofline of the dominant kernel (k_ntt_pass): algorithmic bytes per SURVEY.md 8(d) =
     # 64 * n * ceil(log_n / 12) per transform, spread over the passes this build launches per transform
-    passes = (log_n + 7) // 8 if log_n else 1
+    passes = ((log_n + 8) // 9 if log_n >= 12 else (log_n + 7) // 8) if log_n else 1   # csrc/ntt.hip ntt_split
     alg_bytes_per_transform = 64 * n * ((log_n + 11) // 12)
     launches = args.steps * 2 * passes
     avg_launch_ms = ev_ms.value / launches
@@ -140,12 +147,23 @@ def main():
     # --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); null when the file is absent
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_v10_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")) as f:
             if log_n == 24:
-                traffic = json.load(f)["kernels"]["h2::k_ntt_pass"]["hbm_bytes_per_launch_corrected"]
-    except (OSError, KeyError, ValueError):
+                kern = json.load(f)["kernels"]
+                name = [k for k in kern if "k_ntt_r8" in k][0]
+                traffic = kern[name]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError, IndexError):
         traffic = None
 
+    # products per transform of the register-resident passes (csrc/ntt.hip k_ntt_r8): small-DFT constants + per-element
+    # twiddles of the 8 x 8 x 2^B3 split, + 1 (tabulated) / 2 (lo x hi) inter-pass products per element
+    per_pass = {6: (5 + 7 + 5) / 8.0, 7: (5 + 7 + 5 + 4) / 8.0, 8: (5 + 7 + 5 + 6 + 2) / 8.0, 9: (5 + 7 + 5 + 7 + 5) / 8.0}
+    if log_n >= 12:
+        lo_b, rem = log_n // passes, log_n % passes
+        bits = [lo_b + (1 if p >= passes - rem else 0) for p in range(passes)]
+        mults_per_transform = n * (sum(per_pass[b] for b in bits) + max(passes - 2, 0) + (2 if passes > 1 else 0))
+    else:
+        mults_per_transform = (log_n / 2.0 + passes) * n
     out = {
         "metric": "NTT Fr-ops/s @ k=24 (forward+inverse 2^24 BN254 Fr NTT; MSM G1-adds/s under 'msm')",
         "value": value,
@@ -166,7 +184,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_ntt_pass",
+            "kernel": "k_ntt_r8" if log_n >= 12 else "k_ntt_pass",
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -175,145 +193,172 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_per_transform / passes,
             "avg_launch_ms": avg_launch_ms,
             "launches_per_transform": passes,
+            "limiter": "integer VALU (254-bit modular multiplication), not HBM: the HBM figure above is the contract's "
+            "definition; the ALU accounting follows",
             "alu": {
-                "bound": "integer multiplier",
-                "achieved_mul_per_s": (log_n / 2.0 + passes) * n / (passes * avg_launch_ms * 1e-3),
-                "peak_mul_per_s": MUL_CEILING,
-                "frac": (log_n / 2.0 + passes) * n / (passes * avg_launch_ms * 1e-3) / MUL_CEILING,
-                "note": "multiplications per transform = (n/2) log2 n butterflies + one inter-pass / scaling twiddle "
-                "per element per pass (the last pass forms its twiddle from two table entries: one more, not counted)",
+                "bound": "v_mad_u64_u32 issue rate / 136 multiply-adds per product (hardware rates, tools/mulbench.hip)",
+                "achieved_mul_per_s": mults_per_transform / (passes * avg_launch_ms * 1e-3),
+                "peak_mul_per_s": MUL_HW_BOUND,
+                "frac": mults_per_transform / (passes * avg_launch_ms * 1e-3) / MUL_HW_BOUND,
+                "multiplier_in_a_loop_per_s": MUL_MEASURED,
+                "note": "products per transform: 3.18 per element per 8-bit pass (8 x 8 x 4 Cooley-Tukey: 5 + 7 + 5 + 6 + 2 "
+                "per 8 elements) + one inter-pass twiddle product per element in the middle passes and two in the last",
             },
-            "note": "VALU-bound in practice: ~15n 254-bit Montgomery multiplications per transform against a measured "
-            "chip ceiling of 1.31e11 multiplications/s (tools/mulbench.hip, profiles/r1_mulbench.txt); see DESIGN.md",
         },
     }
 
-    # ---------------------------------------------------------------- MSM leg (secondary)
-    if not args.no_msm:
-        mlog, mn = args.msm_log_n, 1 << args.msm_log_n
-        sc = torch.randint(-(2**63), 2**63 - 1, (mn, 4), dtype=torch.int64, device=dev, generator=g)
-        sc[:, 3] &= 0x1FFFFFFFFFFFFFFF
+    # ---------------------------------------------------------------- MSM legs: 2^20 (configs[1]) and 2^24 (the k = 24 size)
+    def msm_leg(mlog, steps, batch):
+        mn = 1 << mlog
         bases = torch.empty((mn, 8), dtype=torch.int64, device=dev)
         check(L.h2_dev_random_points(0x48414C4F32, mn, bases.data_ptr(), stream), "h2_dev_random_points")
+        cols = []
+        for j in range(max(batch, 1)):          # DISTINCT uniform columns (a batch of one repeated column is cache-friendly)
+            sc = torch.randint(-(2**63), 2**63 - 1, (mn, 4), dtype=torch.int64, device=dev, generator=g)
+            sc[:, 3] &= 0x1FFFFFFFFFFFFFFF
+            cols.append(sc)
         sbytes = L.h2_msm_scratch_bytes(mn, 254)
         scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
         res = np.zeros(12, dtype=np.uint64)
         c, W, nb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         L.h2_msm_shape(mn, 254, ctypes.byref(c), ctypes.byref(W), ctypes.byref(nb))
 
-        def msm_step():
-            check(L.h2_dev_msm(sc.data_ptr(), bases.data_ptr(), mn, 254, scratch.data_ptr(), sbytes, vp(res), stream), "h2_dev_msm")
+        def msm_step(j=0):
+            check(L.h2_dev_msm(cols[j].data_ptr(), bases.data_ptr(), mn, 254, scratch.data_ptr(), sbytes, vp(res), stream), "h2_dev_msm")
 
-        msm_step()
-        first = res.copy()
+        singles = []
+        for j in range(len(cols)):
+            msm_step(j)
+            singles.append(res.copy())
         barrier()
         m0 = time.perf_counter()
-        for _ in range(args.msm_steps):
-            msm_step()
+        for i in range(steps):
+            msm_step(i % len(cols))
         barrier()
-        m1 = time.perf_counter()
-        assert jac_eq(first, res), "MSM result changed between runs"
-        melapsed = m1 - m0
-        # batch leg: BATCH columns committed against the same bases (the prover's shape, plonk/prover.rs:293-299),
-        # pipelined by the library on two internal streams
-        BATCH = 8
-        per = (sbytes + 255) // 256 * 256
-        scratch2 = torch.empty(2 * per, dtype=torch.uint8, device=dev)
-        ptrs = (ctypes.c_void_p * BATCH)(*([sc.data_ptr()] * BATCH))
-        bres = np.zeros((BATCH, 12), dtype=np.uint64)
-
-        def batch_step():
-            check(L.h2_dev_msm_batch(ptrs, BATCH, bases.data_ptr(), mn, 254, scratch2.data_ptr(), 2 * per, vp(bres), stream), "h2_dev_msm_batch")
-
-        batch_step()
-        assert all(jac_eq(first, bres[i]) for i in range(BATCH)), "batched MSM differs from the single MSM"
-        barrier()
-        b0 = time.perf_counter()
-        for _ in range(args.msm_steps):
-            batch_step()
-        barrier()
-        b1 = time.perf_counter()
-        belapsed = b1 - b0
-        if dist is not None:
-            t = torch.tensor([melapsed, belapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            melapsed, belapsed = float(t[0].item()), float(t[1].item())
+        melapsed = time.perf_counter() - m0
+        assert jac_eq(singles[(steps - 1) % len(cols)], res), "MSM result changed between runs"
         adds = mn * W.value + 2 * nb.value * W.value + W.value * c.value
-        out["msm"] = {
-            "workload": "BASELINE configs[1]: 2^%d BN254 G1 MSM, uniform 254-bit scalars, resident in HBM" % mlog,
-            "g1_adds_per_s": world * args.msm_steps * BATCH * adds / belapsed,
-            "pairs_per_s": world * args.msm_steps * BATCH * mn / belapsed,
-            "ms_per_msm_batched": belapsed / (args.msm_steps * BATCH) * 1e3,
-            "batch": "%d MSMs over shared bases per call (h2_dev_msm_batch, two streams)" % BATCH,
-            "single_msm": {
-                "ms_per_msm": melapsed / args.msm_steps * 1e3,
-                "g1_adds_per_s": world * args.msm_steps * adds / melapsed,
-                "pairs_per_s": world * args.msm_steps * mn / melapsed,
-            },
-            "window_bits": c.value,
-            "windows": W.value,
-            "buckets_per_window": nb.value,
-            "g1_adds_per_msm": adds,
+        leg = {
+            "single_msm": {"ms_per_msm": None, "g1_adds_per_s": None, "pairs_per_s": None},
+            "window_bits": c.value, "windows": W.value, "buckets_per_window": nb.value, "g1_adds_per_msm": adds,
             "g1_adds_formula": "n*W + 2*2^(c-1)*W + W*c (bucket accumulate + running-sum reduce + window doublings)",
-            "alu_roofline": {
-                "bound": "integer multiplier (not HBM: 96 B per pair)",
-                "peak_adds_per_s": world * MUL_CEILING / 10.0,
-                "frac": (world * args.msm_steps * BATCH * adds / belapsed) / (world * MUL_CEILING / 10.0),
-                "note": "peak = measured chip ceiling of 1.31e11 254-bit Montgomery multiplications/s (profiles/r1_mulbench.txt) "
-                "/ 10 multiplications per mixed XYZZ addition; field additions, sorting and the bucket reduction are not credited",
-            },
-            "steps": args.msm_steps,
+            "steps": steps,
         }
-        del scratch2
-        del sc, bases, scratch
+        belapsed = None
+        if batch > 1:
+            # batch leg: `batch` distinct columns committed against the same bases (the prover's shape,
+            # plonk/prover.rs:293-299), pipelined by the library on two internal streams
+            per = (sbytes + 255) // 256 * 256
+            del scratch
+            scratch2 = torch.empty(2 * per, dtype=torch.uint8, device=dev)
+            ptrs = (ctypes.c_void_p * batch)(*[t.data_ptr() for t in cols])
+            bres = np.zeros((batch, 12), dtype=np.uint64)
 
-    # ---------------------------------------------------------------- create_proof leg (BASELINE configs[3])
-    if args.prove_k:
+            def batch_step():
+                check(L.h2_dev_msm_batch(ptrs, batch, bases.data_ptr(), mn, 254, scratch2.data_ptr(), 2 * per, vp(bres), stream), "h2_dev_msm_batch")
+
+            batch_step()
+            assert all(jac_eq(singles[i], bres[i]) for i in range(batch)), "batched MSM differs from the single MSMs"
+            barrier()
+            b0 = time.perf_counter()
+            for _ in range(steps):
+                batch_step()
+            barrier()
+            belapsed = time.perf_counter() - b0
+            del scratch2
+        if dist is not None:
+            t = torch.tensor([melapsed, belapsed or 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            melapsed, belapsed = float(t[0].item()), (float(t[1].item()) if belapsed is not None else None)
+        leg["single_msm"] = {"ms_per_msm": melapsed / steps * 1e3, "g1_adds_per_s": world * steps * adds / melapsed,
+                             "pairs_per_s": world * steps * mn / melapsed}
+        if belapsed is not None:
+            leg.update({
+                "g1_adds_per_s": world * steps * batch * adds / belapsed,
+                "pairs_per_s": world * steps * batch * mn / belapsed,
+                "ms_per_msm_batched": belapsed / (steps * batch) * 1e3,
+                "batch": "%d DISTINCT uniform columns over shared bases per call (h2_dev_msm_batch, two streams)" % batch,
+            })
+        best = leg.get("g1_adds_per_s") or leg["single_msm"]["g1_adds_per_s"]
+        leg["alu_roofline"] = {
+            "bound": "integer VALU (not HBM: 96 B per pair): v_mad_u64_u32 issue rate / 136 per product / 10 products per mixed XYZZ addition",
+            "peak_adds_per_s": world * MUL_HW_BOUND / 10.0,
+            "frac": best / (world * MUL_HW_BOUND / 10.0),
+            "note": "field additions, sorting and the bucket reduction are not credited",
+        }
+        return leg
+
+    if not args.no_msm:
+        out["msm"] = dict(workload="BASELINE configs[1]: 2^%d BN254 G1 MSM, uniform 254-bit scalars, resident in HBM" % args.msm_log_n,
+                          **msm_leg(args.msm_log_n, args.msm_steps, 8))
+        if args.k24 and args.msm_log_n != 24:
+            out["msm_k24"] = dict(workload="the metric's k = 24 size: 2^24 BN254 G1 MSM, uniform 254-bit scalars, resident in HBM",
+                                  **msm_leg(24, 3, 0))
+
+    # ---------------------------------------------------------------- create_proof legs (configs[3] k = 22; configs[4]'s k = 24)
+    def prove_leg(pk_k, steps, verify):
+        from halo2_gpu_specific_amd import circuits, prover
+        from halo2_gpu_specific_amd.rng import ProverRng
+
+        trapdoor = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
+        # N > 1: ONE proof over all ranks (config 5): prover.Device splits the work over the process group
+        D = prover.Device(local_rank, force_collective=dist is not None)
+        # Params::unsafe_setup on the device with a fixed toxic scalar: a real (insecure, test-only) SRS, so the timed
+        # proofs are valid proofs
+        params = prover.Params.unsafe_setup(D, pk_k, trapdoor)
+        adv, fixed, copies = circuits.mini_plonk_synthesize(pk_k, alloc=D.pinned_columns)
+        pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
+        proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))  # warm-up (arena growth, plan caches)
+        assert proof == prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1)), "create_proof is not deterministic"
+        verified = None
+        if verify and rank == 0:
+            # outside the timed region: the warm-up proof is accepted by the big-integer verifier of the tests (gate and
+            # permutation identities at x, opening equation through the trapdoor)
+            import ref_plonk as rp
+
+            vk = rp.Keys()
+            vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(pk_k, 3), trapdoor
+            vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+            verified = bool(rp.verify_proof(vk, proof))
+            assert verified, "the bench proof was rejected by the verifier"
+        phases = {}
+        barrier()
+        p0 = time.perf_counter()
+        for i in range(steps):
+            prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(2 + i))
+        D.sync()
+        barrier()
+        pelapsed = time.perf_counter() - p0
+        prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=phases)  # per-phase split (adds syncs: untimed)
+        if dist is not None:
+            t = torch.tensor([pelapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pelapsed = float(t[0].item())
+        peak_gib = torch.cuda.max_memory_allocated(dev) / 2**30
+        return {
+            "k": pk_k,
+            "seconds": pelapsed / steps,
+            "scaling": "strong" if world > 1 else "n/a",
+            "sharding": prover.sharding_description(D),
+            "proof_bytes": len(proof),
+            "verified": verified,
+            "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
+            "steps": steps,
+            "peak_device_memory_gib": round(peak_gib, 1),
+            "srs": "Params::unsafe_setup on the device with a fixed trapdoor (g[i] = [s^i]G, g_lagrange[i] = [l_i(s)]G)",
+        }
+
+    for key, kk, steps in (("create_proof", args.prove_k, args.prove_steps), ("create_proof_k24", 24 if args.k24 else 0, 2)):
+        if not kk or (key == "create_proof_k24" and args.prove_k == 24):
+            continue
         try:
-            from halo2_gpu_specific_amd import circuits, prover
-            from halo2_gpu_specific_amd.rng import ProverRng
-
-            pk_k = args.prove_k
-            # N > 1: ONE proof over all ranks -- every rank holds the same polynomials, each MSM is range-split over the
-            # ranks and folded after an all-gather of the partial points (config 5's "RCCL final reduce over xGMI")
-            D = prover.Device(local_rank, force_collective=dist is not None)
-            # Params::unsafe_setup on the device with a fixed toxic scalar: a real (insecure, test-only) SRS, so the timed proofs
-            # are valid proofs (tests/test_gpu_plonk.py has the same k = 22 flow accepted by the reference verifier)
-            params = prover.Params.unsafe_setup(D, pk_k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
-            adv, fixed, copies = circuits.mini_plonk_synthesize(pk_k, alloc=D.pinned_columns)
-            pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
-            proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))  # warm-up (arena growth, plan caches)
-            assert proof == prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1)), "create_proof is not deterministic"
-            phases = {}
-            barrier()
-            p0 = time.perf_counter()
-            for i in range(args.prove_steps):
-                prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(2 + i))
-            D.sync()
-            barrier()
-            pelapsed = time.perf_counter() - p0
-            prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=phases)  # per-phase split (adds syncs: untimed)
-            if dist is not None:
-                t = torch.tensor([pelapsed], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                pelapsed = float(t[0].item())
-            out["create_proof"] = {
-                "workload": "BASELINE configs[3]: mini-PLONK (examples/simple-example-2.rs) with 2^%d rows, KZG/SHPLONK, witness "
-                "in pinned host memory, SRS / proving key resident in HBM" % pk_k,
-                "k": pk_k,
-                "seconds": pelapsed / args.prove_steps,
-                "scaling": "strong" if world > 1 else "n/a",
-                "sharding": "one proof over %d rank(s): MSMs range-split + all-gather of partial points, transforms and "
-                "elementwise passes replicated" % world,
-                "proof_bytes": len(proof),
-                "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
-                "steps": args.prove_steps,
-                "srs": "Params::unsafe_setup on the device with a fixed trapdoor (g[i] = [s^i]G, g_lagrange[i] = [l_i(s)]G); "
-                "tests/test_gpu_plonk.py checks proof bytes against the reference prover and verifies the k = 22 proof",
-            }
-            del D, params, pk, adv, fixed
+            leg = prove_leg(kk, steps, verify=True)
+            leg["workload"] = ("BASELINE configs[%d]: mini-PLONK (examples/simple-example-2.rs) with 2^%d rows, KZG/SHPLONK, "
+                               "witness in pinned host memory, SRS / proving key resident in HBM" % (3 if kk != 24 else 4, kk))
+            out[key] = leg
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
-            out["create_proof"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:
@@ -321,22 +366,23 @@ def main():
 
         oracle = Oracle.get()
         cores = os.cpu_count() or 1
-        clog = min(log_n, 22)
+        clog = log_n                       # the GPU's own size (2^24): ~2 s per transform on a large host
         x = oracle.random_fr(7, 1 << clog)
         wc = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - clog), R_MOD))
-        # libgomp does not always scale to every hardware thread: probe a few team sizes once, then
-        # time the best one (`cores` in the report = the threads actually used)
+        # the restatement keeps the reference's serial bit-reversal and its task structure: it does not scale to every
+        # hardware thread; probe team sizes once, then time the best one (`cores` = the threads actually used)
         best_t, best_th = None, cores
-        for th in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32)}, reverse=True):
+        budget0 = time.perf_counter()
+        for th in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
             c0 = time.perf_counter()
             oracle.best_fft(x, wc, clog, threads=th)
             dt = time.perf_counter() - c0
             if best_t is None or dt < best_t:
                 best_t, best_th = dt, th
-            if time.perf_counter() - c0 > 20:
+            if time.perf_counter() - budget0 > 15:
                 break
         reps, c0 = 0, time.perf_counter()
-        while reps < 3 and (time.perf_counter() - c0) < 15.0:
+        while reps < 3 and (time.perf_counter() - c0) < 10.0:
             oracle.best_fft(x, wc, clog, threads=best_th)
             reps += 1
         ct = (time.perf_counter() - c0) / max(reps, 1)
@@ -347,22 +393,26 @@ def main():
             "host_threads_available": cores,
             "kind": "port",
             "sample": "oracle best_fft (C restatement of arithmetic.rs:556-705, OpenMP tasks ~ rayon) on one forward "
-            "2^%d NTT, %d reps, %.3f s each (includes the oracle wrapper's input copy)" % (clog, reps, ct),
+            "2^%d NTT (the GPU's size), %d reps, %.3f s each (includes the oracle wrapper's input copy)" % (clog, reps, ct),
         }
+        del x
 
-        # the MSM leg's CPU twin: best_multiexp (arithmetic.rs:465-492, c = ceil(ln n) per thread chunk) on a bounded sample
+        # the MSM leg's CPU twin: best_multiexp (arithmetic.rs:465-492, c = ceil(ln n) per thread chunk) at the GPU's 2^20
         if "msm" in out:
-            mlog_c = min(args.msm_log_n, 18)
+            mlog_c = min(args.msm_log_n, 20)
             ms, mp = oracle.random_fr(11, 1 << mlog_c), oracle.random_g1(12, 1 << mlog_c)
-            oracle.best_multiexp(ms, mp, threads=best_th)
-            c0 = time.perf_counter()
-            oracle.best_multiexp(ms, mp, threads=best_th)
-            mt = time.perf_counter() - c0
+            best_m, best_mth = None, cores
+            for th in sorted({cores, min(cores, 128), min(cores, 64)}, reverse=True):
+                c0 = time.perf_counter()
+                oracle.best_multiexp(ms, mp, threads=th)
+                dt = time.perf_counter() - c0
+                if best_m is None or dt < best_m:
+                    best_m, best_mth = dt, th
             out["msm"]["cpu_baseline"] = {
-                "pairs_per_s": (1 << mlog_c) / mt,
-                "cores": best_th,
+                "pairs_per_s": (1 << mlog_c) / best_m,
+                "cores": best_mth,
                 "kind": "port",
-                "sample": "oracle best_multiexp on 2^%d uniform pairs, %.3f s" % (mlog_c, mt),
+                "sample": "oracle best_multiexp on 2^%d uniform pairs (the GPU's size), best of 3 team sizes, %.3f s" % (mlog_c, best_m),
             }
 
     if rank == 0:

@@ -319,6 +319,14 @@ class Device:
         self.set_rows(t, 0, [(c - l) % R_MOD for c, l in zip(cur, low)])
 
 
+def sharding_description(device):
+    """how one proof is spread over the ranks of `device`'s process group (bench.py reports it)"""
+    if device.group_size <= 1 and not device.force_collective:
+        return "one proof on one device"
+    return ("one proof over %d rank(s): every MSM range-split over the ranks, partial points exchanged by one device-side "
+            "all-gather per batch and folded; transforms and elementwise passes replicated" % device.group_size)
+
+
 class Params:
     """poly/commitment.rs:23-29: k, n, g, g_lagrange -- both tables resident on the device"""
 
