@@ -137,7 +137,7 @@ def main():
 
     # roofline of the dominant kernel (k_ntt_pass): algorithmic bytes per SURVEY.md 8(d) =
     # 64 * n * ceil(log_n / 12) per transform, spread over the passes this build launches per transform
-    passes = ((log_n + 8) // 9 if log_n >= 12 else (log_n + 7) // 8) if log_n else 1   # csrc/ntt.hip ntt_split
+    passes = (log_n + 7) // 8 if log_n else 1   # csrc/ntt.hip ntt_split: 8-bit passes, the remainder first
     alg_bytes_per_transform = 64 * n * ((log_n + 11) // 12)
     launches = args.steps * 2 * passes
     avg_launch_ms = ev_ms.value / launches
@@ -150,20 +150,15 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")) as f:
             if log_n == 24:
                 kern = json.load(f)["kernels"]
-                name = [k for k in kern if "k_ntt_r8" in k][0]
+                name = [k for k in kern if "k_ntt_pass" in k][0]
                 traffic = kern[name]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError, IndexError):
         traffic = None
 
-    # products per transform of the register-resident passes (csrc/ntt.hip k_ntt_r8): small-DFT constants + per-element
-    # twiddles of the 8 x 8 x 2^B3 split, + 1 (tabulated) / 2 (lo x hi) inter-pass products per element
-    per_pass = {6: (5 + 7 + 5) / 8.0, 7: (5 + 7 + 5 + 4) / 8.0, 8: (5 + 7 + 5 + 6 + 2) / 8.0, 9: (5 + 7 + 5 + 7 + 5) / 8.0}
-    if log_n >= 12:
-        lo_b, rem = log_n // passes, log_n % passes
-        bits = [lo_b + (1 if p >= passes - rem else 0) for p in range(passes)]
-        mults_per_transform = n * (sum(per_pass[b] for b in bits) + max(passes - 2, 0) + (2 if passes > 1 else 0))
-    else:
-        mults_per_transform = (log_n / 2.0 + passes) * n
+    # products per transform (csrc/ntt.hip k_ntt_pass): (n/2) log2 n butterflies minus the twiddle-1 ones the early stages
+    # skip (stage 0 of every pass; the r = 0 waves of stages 1-3), one tabulated inter-pass twiddle per element in the
+    # middle passes and two (lo x hi, then the product) in the last
+    mults_per_transform = n * (passes * 3.2 + max(passes - 2, 0) + (2 if passes > 1 else 0)) if log_n >= 8 else (log_n / 2.0 + passes) * n
     out = {
         "metric": "NTT Fr-ops/s @ k=24 (forward+inverse 2^24 BN254 Fr NTT; MSM G1-adds/s under 'msm')",
         "value": value,
@@ -184,7 +179,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_ntt_r8" if log_n >= 12 else "k_ntt_pass",
+            "kernel": "k_ntt_pass",
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -201,8 +196,8 @@ def main():
                 "peak_mul_per_s": MUL_HW_BOUND,
                 "frac": mults_per_transform / (passes * avg_launch_ms * 1e-3) / MUL_HW_BOUND,
                 "multiplier_in_a_loop_per_s": MUL_MEASURED,
-                "note": "products per transform: 3.18 per element per 8-bit pass (8 x 8 x 4 Cooley-Tukey: 5 + 7 + 5 + 6 + 2 "
-                "per 8 elements) + one inter-pass twiddle product per element in the middle passes and two in the last",
+                "note": "products per transform: ~3.2 per element per 8-bit pass (4 butterflies, the twiddle-1 ones of the early "
+                "stages skipped) + one inter-pass twiddle product per element in the middle passes and two in the last",
             },
         },
     }

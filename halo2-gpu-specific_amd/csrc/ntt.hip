@@ -22,7 +22,6 @@
 //   * zeta-power coset pre-scale (distribute_powers_zeta, domain.rs:382-398)
 //   * 1/n and zeta^-1 post-scale (domain.rs:404-409, :341)
 #include <cstdlib>
-#include <utility>
 
 #include "common.hpp"
 #include "ntt.hpp"
@@ -65,7 +64,6 @@ struct PassArgs {
     const Fr* tw_lo;    // min(n, 4096) entries: w^i
     const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
     const Fr* tw_direct;  // non-null: inter-pass twiddle = tw_direct[(rho << consumed) | K] (no generation multiply)
-    const Fr* tw_full;    // k_ntt_r8: R entries (w^(n/R))^e
     uint32_t hi_scaled;  // tw_hi already carries the uniform post-scale (1/n): never skip, no post multiply
     Fr pre3[3];         // has_pre3: x *= pre3[idx % 3] on the first-pass load (idx % 3 == 0 skipped)
     Fr post3[3];        // has_post3: y *= post3[idx % 3] on the final store
@@ -238,231 +236,6 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
 }
 
 
-// ---------------------------------------------------------------- the register-resident pass (B = 6 .. 9)
-// k_ntt_pass above makes one LDS round trip and one barrier per radix-2 stage (8 per pass); measured in round 2 it
-// ran at 63 % of the multiplier rate whatever the multiplier cost -- bound by those round trips.  Here a thread keeps
-// 8 elements in registers and the R = 2^(6+B3)-point DFT of a tile column is the Cooley-Tukey product 8 x 8 x 2^B3:
-//   rho = rho1 2^(3+B3) + rho2 2^B3 + rho3 (row),  k = k1 + 8 k2 + 64 k3 (output),  w = w_R
-//   phase A: A[k1; rho2, rho3] = sum_rho1 x[rho] w_8^(rho1 k1)                              (8-point DFT, constants)
-//   phase B: Bv[k1, k2; rho3]  = sum_rho2 A w^(rho2 k1 2^B3) w_8^(rho2 k2)                  (twiddle + 8-point DFT)
-//   phase C: X[k]              = sum_rho3 Bv w^(rho3 (k1 + 8 k2)) w_{2^B3}^(rho3 k3)        (twiddle + 2^B3-point DFT)
-// with two exchanges through LDS (a transpose of 8 x 8 blocks each) instead of eight.  A block always holds 2048
-// elements (64 KiB of LDS, two blocks per CU): 2048 / (R C) tiles of R rows x C columns.  Global indexing, zero
-// padding, the zeta pre / post scale and the inter-pass twiddles are those of k_ntt_pass.
-// compile-time loop: the body is instantiated once per index, so register arrays are only ever indexed by constants
-// (a `#pragma unroll` loop is unrolled after scalar replacement has run and leaves the array in scratch memory)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-#define H2_INLINE_LAMBDA __attribute__((always_inline))
-
-__host__ __device__ constexpr int h2_bitrev_c(int i, int bits) {
-    int r = 0;
-    for (int b = 0; b < bits; b++) r |= ((i >> b) & 1) << (bits - 1 - b);
-    return r;
-}
-
-// One out-of-line copy of the multiplier: the pass below contains ~46 products per thread; inlined that is ~130 KB of
-// straight-line code per kernel against a 64 KB instruction cache shared by two CUs.  CALL = true routes every
-// product of the pass through this function (~25 KB of code); CALL = false keeps them inline.  H2_NTT_INLINE_MUL
-// selects the inline variant at run time (measured: see DESIGN.md).
-__device__ __noinline__ Fr ntt_mul_call(Fr x, Fr y) { return fp_mul(x, y); }
-template <bool CALL>
-__device__ __forceinline__ Fr ntt_mul(const Fr& x, const Fr& y) {
-    if constexpr (CALL)
-        return ntt_mul_call(x, y);
-    else
-        return fp_mul(x, y);
-}
-template <bool CALL>
-__device__ __forceinline__ Fr twiddle_pow_t(const PassArgs& a, uint32_t e) {
-    if (a.log_n <= LO_BITS) return fp_load(a.tw_lo + e);
-    return ntt_mul<CALL>(fp_load(a.tw_lo + (e & ((1u << LO_BITS) - 1))), fp_load(a.tw_hi + (e >> LO_BITS)));
-}
-
-// one radix-2 DIT butterfly of an LB-bit DFT held in v[] (bit-reversed naming): stage S, butterfly Bf
-template <bool CALL, int LB, int S, int Bf>
-__device__ __forceinline__ void small_bfly(Fr* v, const Fr& w8_1, const Fr& w8_2, const Fr& w8_3) {
-    constexpr int h = 1 << S;
-    constexpr int i = ((Bf >> S) << (S + 1)) | (Bf & (h - 1));
-    constexpr int e8 = (Bf & (h - 1)) * (8 / (2 * h));  // twiddle w_{2h}^r as a power of w_8
-    Fr t = v[i + h];
-    if (e8 == 1) t = ntt_mul<CALL>(t, w8_1);
-    if (e8 == 2) t = ntt_mul<CALL>(t, w8_2);
-    if (e8 == 3) t = ntt_mul<CALL>(t, w8_3);
-    const Fr u = v[i];
-    v[i] = fp_add(u, t);
-    v[i + h] = fp_sub(u, t);
-}
-template <bool CALL, int LB, int S, int... Bf>
-__device__ __forceinline__ void small_stage(Fr* v, const Fr& w8_1, const Fr& w8_2, const Fr& w8_3, std::integer_sequence<int, Bf...>) {
-    (small_bfly<CALL, LB, S, Bf>(v, w8_1, w8_2, w8_3), ...);
-}
-template <bool CALL, int LB, int... S>
-__device__ __forceinline__ void small_stages(Fr* v, const Fr& w8_1, const Fr& w8_2, const Fr& w8_3, std::integer_sequence<int, S...>) {
-    (small_stage<CALL, LB, S>(v, w8_1, w8_2, w8_3, std::make_integer_sequence<int, (1 << LB) / 2>{}), ...);
-}
-template <int LB, int OFF, int... I>
-__device__ __forceinline__ void small_gather(Fr* v, const Fr (&x)[8], std::integer_sequence<int, I...>) {
-    ((v[I] = x[OFF + h2_bitrev_c(I, LB)]), ...);
-}
-template <int OFF, int... I>
-__device__ __forceinline__ void small_scatter(const Fr* v, Fr (&x)[8], std::integer_sequence<int, I...>) {
-    ((x[OFF + I] = v[I]), ...);
-}
-// in-place DFT of x[OFF .. OFF + 2^LB) (natural order in and out), every index a compile-time constant
-template <bool CALL, int LB, int OFF>
-__device__ __forceinline__ void small_dft(Fr (&x)[8], const Fr& w8_1, const Fr& w8_2, const Fr& w8_3) {
-    if constexpr (LB > 0) {
-        Fr v[1 << LB];
-        small_gather<LB, OFF>(v, x, std::make_integer_sequence<int, 1 << LB>{});
-        small_stages<CALL, LB>(v, w8_1, w8_2, w8_3, std::make_integer_sequence<int, LB>{});
-        small_scatter<OFF>(v, x, std::make_integer_sequence<int, 1 << LB>{});
-    }
-}
-
-template <int B3, bool CALL>
-__global__ void __launch_bounds__(256) k_ntt_r8(PassArgs a) {
-    constexpr uint32_t B = 6 + B3, R = 1u << B, M3 = (1u << B3) - 1;
-    const uint32_t log_c = a.log_c, C = 1u << log_c;
-    const uint32_t U_log = B - 3 + log_c, U = 1u << U_log;  // threads per tile (8 elements each)
-    const uint32_t tid = threadIdx.x;
-    const uint32_t tau = tid >> U_log, u = tid & (U - 1);
-    const uint32_t tile_id = blockIdx.x * (256u >> U_log) + tau;
-    const uint32_t tile_base = tau << (B + log_c);
-    const uint32_t n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
-    uint4* t_lo = h2_smem;
-    uint4* t_hi = t_lo + 2048;
-    const Fr w8_1 = fp_load(a.tw_full + (R >> 3)), w8_2 = fp_load(a.tw_full + (R >> 2)), w8_3 = fp_load(a.tw_full + 3 * (R >> 3));
-
-    // field layout of the 8-element owner index u: non-last passes keep the column fastest (a row segment of C
-    // elements is contiguous in memory), the last pass keeps the row fastest (a DFT's rows are contiguous)
-    const bool last = a.is_last;
-    const uint32_t sh3 = last ? 0 : log_c;          // position of the rho3 field
-    const uint32_t sh2 = sh3 + B3;                   // position of the rho2 / k1 field
-    const uint32_t c_a = last ? (u >> (B3 + 3)) : (u & (C - 1));
-    const uint32_t f3 = (u >> sh3) & M3, f2 = (u >> sh2) & 7;
-
-    // ---- tile geometry (as k_ntt_pass)
-    uint32_t base = 0, K = 0, row0 = 0;
-    if (!last) {
-        const uint32_t chunks_per_hi = (1u << a.s_log) >> log_c;
-        const uint32_t hi = tile_id / chunks_per_hi, lo0 = (tile_id % chunks_per_hi) << log_c;
-        base = (hi << (B + a.s_log)) + lo0;
-        K = hi_to_K(hi, a);
-    } else {
-        K = (tile_id << log_c) + c_a;
-        row0 = K_to_hi(K, a) << B;
-    }
-
-    // ---- phase A: 8 rows rho1 2^(3+B3) + (rho2, rho3) of column c; pre-scale, inter-pass twiddle; DFT over rho1
-    Fr x[8];
-    {
-        const uint32_t rlow = (f2 << B3) | f3;
-        uint32_t idx[8];
-        static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            const uint32_t rho = ((uint32_t)j << (3 + B3)) | rlow;
-            idx[j] = last ? (row0 + rho) : (base + (rho << a.s_log) + c_a);
-            x[j] = (idx[j] < a.in_len) ? fp_load(a.in + idx[j]) : fp_zero<FrParams>();
-        });
-        static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            const uint32_t rho = ((uint32_t)j << (3 + B3)) | rlow;
-            if (a.has_pre3) {
-                const uint32_t m = idx[j] % 3;
-                if (m != 0) x[j] = ntt_mul<CALL>(x[j], m == 1 ? a.pre3[1] : a.pre3[2]);
-            }
-            if (a.nprev != 0) {
-                const uint32_t ex = (uint32_t)(((uint64_t)rho * K) << a.s_log) & n_mask;
-                if (a.tw_direct != nullptr) {
-                    if (ex != 0) x[j] = ntt_mul<CALL>(x[j], fp_load(a.tw_direct + ((rho << a.t_log) | K)));
-                } else if (ex != 0 || a.hi_scaled) {
-                    x[j] = ntt_mul<CALL>(x[j], twiddle_pow_t<CALL>(a, ex));
-                }
-            }
-        });
-    }
-    small_dft<CALL, 3, 0>(x, w8_1, w8_2, w8_3);
-    // ---- exchange 1: (k1; rho2) -> (rho2; k1)
-    static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-        constexpr int j = decltype(jc)::value;
-        lds_put(t_lo, t_hi, tile_base + u + (U * j), x[j]);
-    });
-    __syncthreads();
-    const uint32_t k1 = f2;  // the same field of u now names k1
-    {
-        const uint32_t u0 = u & ~(7u << sh2);
-        static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            x[j] = lds_get(t_lo, t_hi, tile_base + (u0 | ((uint32_t)j << sh2)) + U * k1);
-        });
-    }
-    // ---- phase B: twiddle w^(rho2 k1 2^B3), DFT over rho2
-    static_for<7>([&](auto jc) H2_INLINE_LAMBDA {
-        constexpr int j = decltype(jc)::value + 1;
-        x[j] = ntt_mul<CALL>(x[j], fp_load(a.tw_full + ((j * k1) << B3)));
-    });
-    small_dft<CALL, 3, 0>(x, w8_1, w8_2, w8_3);
-
-    auto store = [&](uint32_t k, uint32_t c, const Fr& v) H2_INLINE_LAMBDA {
-        const uint32_t o = last ? (((tile_id << log_c) + c) + (k << a.t_log)) : (base + (k << a.s_log) + c);
-        Fr y = v;
-        if (last && a.has_post3 && !a.hi_scaled) {
-            const uint32_t m = o % 3;
-            y = ntt_mul<CALL>(y, m == 0 ? a.post3[0] : (m == 1 ? a.post3[1] : a.post3[2]));
-        }
-        fp_store(a.out + o, y);
-    };
-
-    if constexpr (B3 == 0) {
-        // ---- R = 64: outputs k = k1 + 8 k2 straight from phase B
-        static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            store(k1 + 8 * j, c_a, x[j]);
-        });
-    } else {
-        // ---- exchange 2: (k2; rho3) -> (rho3; k2).  Readers keep the column fastest in both pass kinds (stores of C
-        // consecutive elements); the writers' index is recomputed from (k1, rho3, c).
-        __syncthreads();
-        static_for<8>([&](auto jc) H2_INLINE_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            lds_put(t_lo, t_hi, tile_base + u + (U * j), x[j]);
-        });
-        __syncthreads();
-        constexpr int N3 = 1 << B3, G = 8 >> B3;  // points of the last radix, DFTs of it per thread
-        const uint32_t c_c = u & (C - 1), q = (u >> log_c) & M3, k1c = u >> (log_c + B3);
-        static_for<8>([&](auto ec) H2_INLINE_LAMBDA {
-            constexpr int e = decltype(ec)::value, g = e / N3, r3 = e % N3;
-            const uint32_t k2 = q * G + g;
-            const uint32_t uw = last ? ((uint32_t)r3 | (k1c << B3) | (c_c << (B3 + 3)))
-                                     : (c_c | ((uint32_t)r3 << log_c) | (k1c << (log_c + B3)));
-            x[e] = lds_get(t_lo, t_hi, tile_base + uw + U * k2);
-        });
-        // ---- phase C: twiddle w^(rho3 (k1 + 8 k2)), DFT over rho3, store
-        static_for<8>([&](auto ec) H2_INLINE_LAMBDA {
-            constexpr int e = decltype(ec)::value, g = e / N3, r3 = e % N3;
-            if constexpr (r3 != 0) {
-                const uint32_t k12 = k1c + 8 * (q * G + g);
-                x[e] = ntt_mul<CALL>(x[e], fp_load(a.tw_full + r3 * k12));
-            }
-        });
-        static_for<G>([&](auto gc) H2_INLINE_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            small_dft<CALL, B3, g * N3>(x, w8_1, w8_2, w8_3);
-        });
-        static_for<8>([&](auto ec) H2_INLINE_LAMBDA {
-            constexpr int e = decltype(ec)::value, g = e / N3, k3 = e % N3;
-            store(k1c + 8 * (q * G + g) + 64 * k3, c_c, x[e]);
-        });
-    }
-}
-
 // ---------------------------------------------------------------- plans
 static std::string plan_key(uint32_t log_n, const uint64_t omega[4]) {
     char buf[128];
@@ -483,15 +256,7 @@ Fr fr_from_u64x4(const uint64_t v[4]) {
 void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits) {
     bits.clear();
     if (log_n == 0) return;
-    if (log_n >= 12) {
-        // passes of 6 .. 9 bits for the register-resident kernel (k_ntt_r8), as few as possible and balanced, the
-        // larger ones last (the middle passes' complete twiddle tables stay small): 24 -> 8 8 8, 23 -> 7 8 8,
-        // 18 -> 9 9, 25 -> 8 8 9
-        const uint32_t P = (log_n + 8) / 9, lo = log_n / P, rem = log_n % P;
-        for (uint32_t p = 0; p < P; p++) bits.push_back(lo + (p >= P - rem ? 1 : 0));
-        return;
-    }
-    // small transforms: as many 8-bit passes as possible, the remainder first (it needs no inter-pass twiddle)
+    // as many 8-bit passes as possible, the remainder first (it needs no inter-pass twiddle)
     uint32_t rem = log_n % 8;
     if (rem) bits.push_back(rem);
     for (uint32_t p = 0; p < log_n / 8; p++) bits.push_back(8);
@@ -510,14 +275,10 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
     uint32_t lo_count = n < (1u << LO_BITS) ? n : (1u << LO_BITS);
     uint32_t hi_count = log_n > LO_BITS ? (n >> LO_BITS) : 0;
     size_t total = lo_count + hi_count;
-    std::vector<uint32_t> bf_off, full_off;
+    std::vector<uint32_t> bf_off;
     for (uint32_t b : pl->bits) {
         bf_off.push_back((uint32_t)total);
         total += (1u << b) >> 1 ? (1u << b) >> 1 : 1;
-    }
-    for (uint32_t b : pl->bits) {  // complete tables (w^(n/R))^e, e < R, of the passes k_ntt_r8 can run
-        full_off.push_back((uint32_t)total);
-        if (b >= 6 && b <= 9) total += 1u << b;
     }
     H2_HIP(hipMalloc(&pl->tables, total * sizeof(Fr)));
     pl->tw_lo = pl->tables;
@@ -532,13 +293,6 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
         if (half)
             hipLaunchKernelGGL(k_pow_table, dim3((half + 255) / 256), dim3(256), 0, stream, pl->tables + bf_off[p], w,
                                n >> pl->bits[p], half);
-        if (pl->bits[p] >= 6 && pl->bits[p] <= 9) {
-            pl->tw_full.push_back(pl->tables + full_off[p]);
-            hipLaunchKernelGGL(k_pow_table, dim3((R + 255) / 256), dim3(256), 0, stream, pl->tables + full_off[p], w,
-                               n >> pl->bits[p], R);
-        } else {
-            pl->tw_full.push_back(nullptr);
-        }
     }
     // passes whose whole inter-pass twiddle set has <= 2^16 entries get it tabulated (2 MiB, L2-resident):
     // the pass then spends one multiplication per element on twiddles instead of two
@@ -548,7 +302,7 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
             const uint32_t B = pl->bits[p];
             const bool last = p + 1 == pl->bits.size();
             Fr* tab = nullptr;
-            if (p > 0 && !last && B + consumed <= 17) {
+            if (p > 0 && !last && B + consumed <= 16) {
                 uint32_t cnt = 1u << (B + consumed);
                 H2_HIP(hipMalloc(&tab, (size_t)cnt * sizeof(Fr)));
                 hipLaunchKernelGGL(k_direct_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, tab, w, consumed,
@@ -650,37 +404,12 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             a.tw_hi = scaled;
             a.hi_scaled = 1;
         }
-        static const bool env_r2 = getenv("H2_NTT_RADIX2") != nullptr;  // experiment knob: keep the radix-2 LDS kernel
-        const uint32_t avail = last ? consumed : a.s_log;  // last pass: number of DFTs = 2^consumed
-        if (!env_r2 && B >= 6 && B <= 9 && L >= 11 && pl->tw_full[p] != nullptr) {
-            // register-resident kernel: 2048 elements per block, C = 4 columns (128-byte row segments) when available
-            uint32_t log_c = 11 - B < 2 ? 11 - B : 2;
-            if (avail < log_c) log_c = avail;
-            a.log_c = log_c;
-            a.tw_full = pl->tw_full[p];
-            a.zskip = 0;
-            const uint32_t nblocks = (1u << L) >> 11;
-            const size_t lds = 2 * 2048 * sizeof(uint4);
-            static const bool inline_mul = getenv("H2_NTT_INLINE_MUL") != nullptr;
-#define H2_LAUNCH_R8(B3)                                                                                     \
-    do {                                                                                                     \
-        if (inline_mul)                                                                                      \
-            hipLaunchKernelGGL((k_ntt_r8<B3, false>), dim3(nblocks), dim3(256), lds, stream, a);             \
-        else                                                                                                 \
-            hipLaunchKernelGGL((k_ntt_r8<B3, true>), dim3(nblocks), dim3(256), lds, stream, a);              \
-    } while (0)
-            switch (B) {
-                case 6: H2_LAUNCH_R8(0); break;
-                case 7: H2_LAUNCH_R8(1); break;
-                case 8: H2_LAUNCH_R8(2); break;
-                default: H2_LAUNCH_R8(3); break;
-            }
-#undef H2_LAUNCH_R8
-        } else {
+        {
             // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
             static const int env_logc = getenv("H2_NTT_LOGC") ? atoi(getenv("H2_NTT_LOGC")) : -1;
-            uint32_t log_c = (B < 8) ? (10 - B) : (B == 8 ? 2 : 1);
+            uint32_t log_c = (B < 8) ? (10 - B) : 2;
             if (env_logc >= 0 && B == 8) log_c = (uint32_t)env_logc;
+            uint32_t avail = last ? consumed : a.s_log;  // last pass: number of DFTs = 2^consumed
             if (avail < log_c) log_c = avail;
             a.log_c = log_c;
             uint32_t R = 1u << B, C = 1u << log_c;

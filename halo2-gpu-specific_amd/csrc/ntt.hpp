@@ -13,7 +13,6 @@ struct NttPlan {
     const Fr* tw_lo = nullptr;         // w^i,        i < min(n, 4096)
     const Fr* tw_hi = nullptr;         // w^(i<<12),  i < n >> 12
     std::vector<const Fr*> tw_bfly;    // per pass: (w^(n/R))^e, e < R/2
-    std::vector<const Fr*> tw_full;    // per pass of 6 .. 9 bits: the same powers for e < R (k_ntt_r8), else nullptr
     std::vector<const Fr*> tw_direct;  // per pass: full inter-pass twiddle table or nullptr
     std::mutex mu;                     // guards scaled_hi
     std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)
