@@ -249,6 +249,14 @@ int h2_g1_sum(const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]) {
     return H2_OK;
 }
 
+int h2_dev_g1_fold(const void* d_points_xyz, uint32_t world, uint32_t count, void* d_out_xyz, void* stream) {
+    if (count && (!d_points_xyz || !d_out_xyz)) return bad("h2_dev_g1_fold: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return g1_fold_launch((const uint64_t*)d_points_xyz, world, count, (uint64_t*)d_out_xyz, pick_stream(ctx, stream));
+    });
+}
+
 int h2_msm_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits, uint64_t out_xyz[12]) {
     if (!out_xyz || (n && (!scalars || !bases))) return bad("h2_msm_multi: null argument");
     return guarded([&] {
@@ -604,6 +612,14 @@ int h2_dev_permutation_terms(void* d_num, void* d_den, const void* d_value, cons
         DeviceCtx* ctx = current_ctx();
         return perm_terms_launch((Fr*)d_num, (Fr*)d_den, (const Fr*)d_value, (const Fr*)d_sigma, n, beta, gamma,
                                  delta_pow, omega, first, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_distribute_powers(void* d_a, size_t n, const uint64_t g[4], void* stream) {
+    if ((n && !d_a) || !g) return bad("h2_dev_distribute_powers: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return distribute_powers_launch((Fr*)d_a, n, g, pick_stream(ctx, stream));
     });
 }
 

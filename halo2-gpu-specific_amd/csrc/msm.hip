@@ -1444,6 +1444,33 @@ int msm_host_multi(const uint64_t* scalars, const uint64_t* bases, size_t n, uin
 // host fold of `count` Jacobian points (12 x u64 each) -- the `reduce(|acc, x| acc + x)` of
 // arithmetic.rs:434 and the local add after an all-gather of per-rank partial points.
 // Jacobian (X, Y, Z) -> XYZZ (X, Y, Z^2, Z^3).
+// Device-side fold of gathered partial points (one proof over several ranks): points[r * count + j] = rank r's partial of
+// MSM j (Jacobian, 96 B), out[j] = sum over r in rank order -- the `.reduce(|acc, x| acc + x)` of arithmetic.rs:433-435
+// after an all-gather, without bringing world x count points back to the host.  One lane per MSM (count is ~10).
+__global__ void __launch_bounds__(64) k_g1_fold(const Jacobian* points, uint32_t world, uint32_t count, Jacobian* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    XYZZ acc = xyzz_identity();
+    for (uint32_t r = 0; r < world; r++) {
+        const Jacobian p = points[(size_t)r * count + j];
+        XYZZ q;
+        q.x = p.x;
+        q.y = p.y;
+        q.zz = fp_sqr(p.z);
+        q.zzz = fp_mul(q.zz, p.z);
+        acc = xyzz_add(acc, q);
+    }
+    out[j] = xyzz_to_jacobian(acc);
+}
+
+int g1_fold_launch(const uint64_t* d_points, uint32_t world, uint32_t count, uint64_t* d_out, hipStream_t stream) {
+    if (count == 0) return H2_OK;
+    hipLaunchKernelGGL(k_g1_fold, dim3((count + 63) / 64), dim3(64), 0, stream, (const Jacobian*)d_points, world, count,
+                       (Jacobian*)d_out);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 void g1_sum_host(const uint64_t* points, size_t count, uint64_t out_xyz[12]) {
     XYZZ acc = xyzz_identity();
     for (size_t p = 0; p < count; p++) {

@@ -8,6 +8,7 @@
 // and the CPU loops Polynomial +,-,*scalar (poly.rs:191-257) and
 // divide_by_vanishing_poly (poly/domain.rs:354-373).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <vector>
@@ -24,15 +25,38 @@ __device__ __forceinline__ size_t rot_index(size_t i, int32_t rot, size_t size) 
     return (size_t)v;
 }
 
-template <int OP>
+// streaming accesses: every operand is read once and the result written once, nothing is reused through the caches
+__device__ __forceinline__ Fr fr_load_stream(const Fr* p, bool nt) {
+    if (!nt) return fp_load(p);
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4* q = reinterpret_cast<const v4*>(p);
+    const v4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fr_store_stream(Fr* p, const Fr& v, bool nt) {
+    if (!nt) {
+        fp_store(p, v);
+        return;
+    }
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4* q = reinterpret_cast<v4*>(p);
+    v4 a = {v.l[0], v.l[1], v.l[2], v.l[3]}, b = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    __builtin_nontemporal_store(a, q);
+    __builtin_nontemporal_store(b, q + 1);
+}
+
+template <int OP, bool NT>
 __global__ void __launch_bounds__(256) k_eval_op(Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int32_t r_rot,
                                                  size_t size, Fr c) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) {
         Fr lv, rv, out;
-        if (OP != H2_OP_CONSTANT) lv = fp_load(l + rot_index(i, l_rot, size));
+        if (OP != H2_OP_CONSTANT) lv = fr_load_stream(l + rot_index(i, l_rot, size), NT);
         if (OP == H2_OP_SUM || OP == H2_OP_MUL || OP == H2_OP_SUB || OP == H2_OP_LCTHETA || OP == H2_OP_LCBETA)
-            rv = fp_load(r + rot_index(i, r_rot, size));
+            rv = fr_load_stream(r + rot_index(i, r_rot, size), NT);
         if (OP == H2_OP_MUL_C) out = fp_mul(lv, c);
         else if (OP == H2_OP_SUM_C || OP == H2_OP_ADDGAMMA) out = fp_add(lv, c);
         else if (OP == H2_OP_SUM) out = fp_add(lv, rv);
@@ -41,7 +65,7 @@ __global__ void __launch_bounds__(256) k_eval_op(Fr* res, const Fr* l, const Fr*
         else if (OP == H2_OP_LCTHETA) out = fp_add(fp_mul(lv, c), rv);
         else if (OP == H2_OP_LCBETA) out = fp_mul(fp_add(lv, c), rv);
         else out = c;
-        fp_store(res + i, out);
+        fr_store_stream(res + i, out, NT);
     }
 }
 
@@ -82,8 +106,14 @@ int eval_op_launch(int op, Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int
     r_rot = (int32_t)(((long long)r_rot % sz));
     Fr cv = c ? fr_host(c) : Fr{};
     dim3 g(grid_for(size)), b(256);
-#define H2_CASE(OPC) \
-    case OPC: hipLaunchKernelGGL(k_eval_op<OPC>, g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv); break;
+    static const bool nt = getenv("H2_ELEMENTWISE_NT") != nullptr;   // experiment knob
+#define H2_CASE(OPC)                                                                                                   \
+    case OPC:                                                                                                          \
+        if (nt)                                                                                                        \
+            hipLaunchKernelGGL((k_eval_op<OPC, true>), g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv);            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_eval_op<OPC, false>), g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv);           \
+        break;
     switch (op) {
         H2_CASE(H2_OP_MUL_C)
         H2_CASE(H2_OP_SUM_C)
@@ -526,6 +556,38 @@ int lincomb_launch(Fr* res, const Fr* const* polys, const uint64_t* coeffs, size
         a.accumulate = j0 != 0;
         hipLaunchKernelGGL(k_lincomb, dim3(grid_for(size)), dim3(256), 0, stream, a);
     }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a[i] *= g^i (the generalisation of distribute_powers_zeta, poly/domain.rs:382-398, to an arbitrary generator): with
+// g = zeta * extended_omega^j it turns a coefficient vector into the input of the n-point NTT that evaluates it on coset
+// j of the extended domain -- the unit of the coset-sharded multi-GPU proof.  Every lane raises g
+// to its first index once and then steps by g^256 over 8 strided (coalesced) elements: ~5.5 products per element.
+__global__ void __launch_bounds__(256) k_distribute_powers(Fr* a, size_t n, Fr g, Fr g_step) {
+    const size_t base = (size_t)blockIdx.x * (256 * 8) + threadIdx.x;
+    if (base >= n) return;
+    Fr w = fp_pow_u32(g, (uint32_t)base);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const size_t i = base + (size_t)k * 256;
+        if (i < n) {
+            fp_store(a + i, fp_mul(fp_load(a + i), w));
+            w = fp_mul(w, g_step);
+        }
+    }
+}
+
+int distribute_powers_launch(Fr* a, size_t n, const uint64_t g[4], hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    if (n > ((size_t)1 << 28)) {
+        set_last_error("h2_dev_distribute_powers: n exceeds 2^28");
+        return H2_ERR_INVALID;
+    }
+    const Fr gv = fr_host(g);
+    hipLaunchKernelGGL(k_distribute_powers, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, stream, a, n, gv,
+                       fp_pow_u32(gv, 256));
     H2_HIP(hipGetLastError());
     return H2_OK;
 }

@@ -22,5 +22,6 @@ int perm_sigma_launch(Fr* out, const uint32_t* map_col, const uint32_t* map_row,
 int perm_terms_launch(Fr* num, Fr* den, const Fr* value, const Fr* sigma, size_t n, const uint64_t beta[4],
                       const uint64_t gamma[4], const uint64_t delta_pow[4], const uint64_t omega[4], int first,
                       hipStream_t stream);
+int distribute_powers_launch(Fr* a, size_t n, const uint64_t g[4], hipStream_t stream);
 int random_fr_launch(const uint8_t key[32], size_t n, uint64_t* d_out, hipStream_t stream);
 }  // namespace h2

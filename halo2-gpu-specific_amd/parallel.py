@@ -1,19 +1,26 @@
 """Multi-GPU sharding of the hot path: one process per GPU (torch.distributed; backend "nccl" = RCCL
 over xGMI on the GPU box, "gloo" in the CPU tests).
 
-The path shards over independent units:
-  * per-column NTTs / MSMs / MSM+iNTTs are dealt round-robin to ranks -- no data-path collective
-    (reference: one rayon task per column, plonk/prover.rs:293-299,477-487,643-646);
-  * one MSM may also be split into contiguous ceil(n / P) chunks (gpu_multiexp_bound,
-    arithmetic.rs:425-435); each rank then holds one partial G1 point (96 B).  EC addition is not an
-    RCCL reduction operator, so the exchange is an all-gather of P x 96 B followed by a local fold
-    (h2_g1_sum) -- latency-bound, link bandwidth is irrelevant at this size.
+The path shards over independent units; DESIGN.md section 6 has the accounting:
+  * every MSM of a proof is split into contiguous ceil(n / P) chunks (gpu_multiexp_bound,
+    arithmetic.rs:425-435); each rank holds one partial G1 point (96 B) per MSM.  EC addition is not an
+    RCCL reduction operator, so the exchange is an all-gather of P x count x 96 B followed by a fold -- on the
+    device (h2_dev_g1_fold) under RCCL, on the host under gloo -- latency-bound, link bandwidth is irrelevant;
+  * the extended-domain phase of a proof (coset NTTs, evaluate_h, division by the vanishing polynomial, inverse
+    transform) is split by COSET of the n-th roots of unity: rank r evaluates the quotient on the cosets
+    j = r mod shards of the extended domain from replicated coefficient vectors -- no exchange until the c = 2^(extended_k - k)
+    per-coset polynomials P_j = sum_m gamma_j^m h_m are broadcast (one n-vector each) and un-mixed into the pieces
+    h_m by the inverse Vandermonde matrix (`coset_unmix_matrix`);
+  * whole columns can also be dealt round-robin (`shard_columns`) when a caller has independent polynomials
+    (bench.py's NTT leg: one polynomial per GPU, no collective).
 """
 import ctypes
 
 import numpy as np
 
 from ._lib import check, lib
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
 
 def shard_columns(num_columns, world, rank):
@@ -38,34 +45,89 @@ def g1_sum(points):
     return out
 
 
-def allgather_fold(partial_xyz, group=None, device=None):
-    """All-gather every rank's partial point and fold locally; every rank returns the full sum."""
-    import torch
+def _backend(group):
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    mine = torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64).copy())
-    if device is not None:
-        mine = mine.to(device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    pts = np.stack([t.cpu().numpy().view(np.uint64) for t in gathered])
-    return g1_sum(pts)
+    return dist.get_backend(group)
 
 
-def allgather_fold_many(partials_xyz, group=None, device=None):
+def allgather_fold(partial_xyz, group=None, device=None):
+    """All-gather every rank's partial point and fold; every rank returns the full sum."""
+    return allgather_fold_many(np.asarray(partial_xyz, dtype=np.uint64).reshape(1, 12), group, device)[0]
+
+
+def allgather_fold_many(partials_xyz, group=None, device=None, stream=None):
     """`partials_xyz`: (count, 12) -- this rank's partial point of each of `count` range-split MSMs.  One
-    all-gather of world x count x 96 B, then `count` local folds in rank order (so every rank derives the same
-    Jacobian representation, hence the same transcript).  Returns (count, 12)."""
+    all-gather of world x count x 96 B, then `count` folds in rank order (so every rank derives the same
+    Jacobian representation, hence the same transcript).  Returns (count, 12).
+
+    Under RCCL ("nccl") with a device the gathered points stay on the GPU: one upload of this rank's partials (the MSM's
+    window Horner finishes on the host), all-gather over xGMI, h2_dev_g1_fold, one read-back of count x 96 B.  Under
+    gloo (CPU tests, or two test processes sharing one GPU) the same exchange runs on host tensors."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     mine_np = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 12)
+    count = mine_np.shape[0]
     mine = torch.from_numpy(mine_np.view(np.int64).copy())
-    if device is not None:
-        mine = mine.to(device)
+    if device is not None and _backend(group) == "nccl":
+        mine = mine.to(device, non_blocking=True)
+        gathered = torch.empty((world, count, 12), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+        out = torch.empty((count, 12), dtype=torch.int64, device=device)
+        check(lib().h2_dev_g1_fold(gathered.data_ptr(), world, count, out.data_ptr(), stream), "h2_dev_g1_fold")
+        return out.cpu().numpy().view(np.uint64)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
-    pts = np.stack([t.cpu().numpy().view(np.uint64) for t in gathered])      # (world, count, 12)
-    return np.stack([g1_sum(pts[:, j, :]) for j in range(mine_np.shape[0])])
+    pts = np.stack([t.numpy().view(np.uint64) for t in gathered])      # (world, count, 12)
+    return np.stack([g1_sum(pts[:, j, :]) for j in range(count)])
+
+
+# ---- coset sharding of the extended-domain phase ---------------------------------------------------------------------
+def coset_plan(c, world, rank):
+    """c = 2^(extended_k - k) cosets over `world` ranks: shards = min(c, world) groups; rank r works on the cosets
+    j = r mod shards (ranks beyond c replicate a shard).  Returns (shards, owned cosets)."""
+    shards = min(c, world)
+    return shards, [j for j in range(c) if j % shards == rank % shards]
+
+
+def coset_unmix_matrix(gammas, rows):
+    """The per-coset polynomials are P_j = sum_m gamma_j^m h_m (gamma_j = (zeta extended_omega^j)^n, m < c): returns the
+    first `rows` rows of the inverse of the Vandermonde matrix V[j][m] = gamma_j^m modulo r, so that
+    h_m = sum_j M[m][j] P_j.  Host integers; c <= 8."""
+    c = len(gammas)
+    a = [[pow(g, m, R_MOD) for m in range(c)] + [1 if i == j else 0 for i in range(c)] for j, g in enumerate(gammas)]
+    for col in range(c):                       # Gauss-Jordan modulo r
+        piv = next(r for r in range(col, c) if a[r][col] % R_MOD)
+        a[col], a[piv] = a[piv], a[col]
+        inv = pow(a[col][col], -1, R_MOD)
+        a[col] = [v * inv % R_MOD for v in a[col]]
+        for r in range(c):
+            if r != col and a[r][col]:
+                f = a[r][col]
+                a[r] = [(v - f * w) % R_MOD for v, w in zip(a[r], a[col])]
+    return [row[c:] for row in a[:rows]]
+
+
+def exchange_cosets(mine, c, shards, group=None):
+    """`mine`: {coset j: (n, 4) int64 device tensor} for the cosets this rank evaluated.  Every coset polynomial is
+    broadcast from the first rank of its shard (rank j mod shards); returns the list of all c tensors.  One n-vector per
+    coset crosses the links (k = 24: 512 MiB each) -- the only bulk exchange of a proof."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    staged = _backend(group) != "nccl"          # gloo: through host memory
+    template = next(iter(mine.values()))
+    out = []
+    for j in range(c):
+        src = j % shards
+        t = mine[j] if (j in mine and rank == src) else torch.empty_like(template)
+        if j in mine and rank != src:
+            out.append(mine[j])                 # a replica of the shard already holds it; still take part in the broadcast
+        buf = t.cpu() if staged else t
+        dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        if not (j in mine and rank != src):
+            out.append(buf.to(template.device) if staged else buf)
+    return out

@@ -69,9 +69,11 @@ class Domain:
 class Device:
     """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
 
-    def __init__(self, device=0, group=None, force_collective=False):
+    def __init__(self, device=0, group=None, force_collective=False, force_cosets=False):
         """`group`: a torch.distributed process group (None = the default group when one is initialised) over which
-        every MSM of a proof is range-split; all ranks must then run the same proof on the same inputs."""
+        one proof is spread: every MSM is range-split over the ranks and the extended-domain phase is split by coset
+        (DESIGN.md section 6); all ranks must then run the same proof on the same inputs.  `force_cosets` runs the
+        coset path on a single device (all cosets locally): the same proof bytes by another route, for tests."""
         import torch  # plumbing only: device memory and the stream
 
         if not torch.cuda.is_available():
@@ -86,6 +88,7 @@ class Device:
         self._scratch = None
         self._pinned = {}
         self.group, self.group_size, self.group_rank, self.force_collective = group, 1, 0, force_collective
+        self.force_cosets = force_cosets
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized():
@@ -199,6 +202,38 @@ class Device:
                 self._scratch = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.dev)
         return self._scratch
 
+    # -- coset sharding of the extended domain (one proof over several ranks) --------------------------
+    def coset_plan(self, dom):
+        """None on the single-device path; else (c, shards, owned): the extended domain is the union of c =
+        2^(extended_k - k) cosets g_j H (g_j = zeta extended_omega^j, H = the n-th roots of unity; extended index c i + j
+        is point i of coset j); this rank evaluates the quotient on the cosets in `owned`."""
+        if self.group_size <= 1 and not self.force_cosets:
+            return None
+        from .parallel import coset_plan
+
+        c = 1 << (dom.extended_k - dom.k)
+        shards, owned = coset_plan(c, self.group_size, self.group_rank)
+        return c, shards, owned
+
+    def coeff_to_coset(self, poly, dom, j):
+        """values of a coefficient vector (n entries) on coset j: a[t] *= g_j^t, then the n-point NTT -- coeff_to_extended
+        (poly/domain.rs:270-287) restricted to the extended indices c i + j"""
+        out = self.clone(poly[:dom.n])
+        g = dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD
+        check(self.L.h2_dev_distribute_powers(out.data_ptr(), dom.n, _fr(g), self.stream), "h2_dev_distribute_powers")
+        tmp = self.empty(dom.n)
+        check(self.L.h2_dev_ntt(out.data_ptr(), tmp.data_ptr(), _fr(dom.omega), dom.k, self.stream), "h2_dev_ntt")
+        return out
+
+    def coset_to_coeff(self, vals, dom, j):
+        """in place: the polynomial of degree < n that takes the values `vals` on coset j"""
+        tmp = self.empty(dom.n)
+        check(self.L.h2_dev_intt(vals.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                 self.stream), "h2_dev_intt")
+        g_inv = _inv(dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD)
+        check(self.L.h2_dev_distribute_powers(vals.data_ptr(), dom.n, _fr(g_inv), self.stream), "h2_dev_distribute_powers")
+        return vals
+
     # -- transforms -------------------------------------------------------------------------------------
     def intt(self, t, dom):
         """lagrange_to_coeff in place (poly/domain.rs:233-266)"""
@@ -242,6 +277,7 @@ class Device:
             lo, hi = msm_split_range(n, self.group_size, self.group_rank)
         out = self.msm_partial(columns, bases, lo, hi, max_bits, also)
         if collective:
+            self.sync()
             out = allgather_fold_many(out, group=self.group, device=self.dev)
         return [jacobian_to_affine(r) for r in out]
 
@@ -323,8 +359,10 @@ def sharding_description(device):
     """how one proof is spread over the ranks of `device`'s process group (bench.py reports it)"""
     if device.group_size <= 1 and not device.force_collective:
         return "one proof on one device"
-    return ("one proof over %d rank(s): every MSM range-split over the ranks, partial points exchanged by one device-side "
-            "all-gather per batch and folded; transforms and elementwise passes replicated" % device.group_size)
+    return ("one proof over %d rank(s): every MSM range-split over the ranks (partial points: one all-gather per batch, folded "
+            "on the device); extended-domain phase (coset NTTs, evaluate_h, vanishing division, inverse transform) split by "
+            "coset of the n-th roots of unity, one n-vector per coset broadcast; the n-sized scans / elementwise passes "
+            "replicated" % device.group_size)
 
 
 class Params:
@@ -481,7 +519,8 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         pk.fixed_values.append(t)
     pk.fixed_commitments = D.msm_batch(pk.fixed_values, params.g_lagrange, n, 254)
     pk.fixed_polys = [D.intt(D.clone(t), dom) for t in pk.fixed_values]
-    pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys]
+    plan = D.coset_plan(dom)
+    pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys] if plan is None else None
     # permutation: sigma columns (Lagrange), polys, cosets
     ncols = len(cs.perm_columns)
     map_col, map_row = mapping if mapping is not None else permutation_mapping(ncols, n, copies)
@@ -499,19 +538,37 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         pk.sigma_values.append(out)
     pk.perm_commitments = D.msm_batch(pk.sigma_values, params.g_lagrange, n, 254)
     pk.sigma_polys = [D.intt(D.clone(t), dom) for t in pk.sigma_values]
-    pk.sigma_cosets = [D.coeff_to_extended(t, dom) for t in pk.sigma_polys]
+    pk.sigma_cosets = [D.coeff_to_extended(t, dom) for t in pk.sigma_polys] if plan is None else None
     # l0, l_last, l_active_row = 1 - (l_last + l_blind) on the extended coset (keygen.rs:395-425)
-    def lagrange_coset(rows):
+    def lagrange_poly(rows):
         t = D.zeros(n)
         D.set_rows(t, rows[0], [1] * len(rows))
-        return D.coeff_to_extended(D.intt(t, dom), dom)
+        return D.intt(t, dom)
 
-    pk.l0 = lagrange_coset([0])
-    pk.l_last = lagrange_coset([n - bf - 1])
-    l_blind = lagrange_coset(list(range(n - bf, n)))
-    tmp = D.eval_op(2, D.empty(dom.extended_n), pk.l_last, l_blind)            # H2_OP_SUM
-    one = D.eval_op(8, D.empty(dom.extended_n), c=1)                           # H2_OP_CONSTANT
-    pk.l_active_row = D.eval_op(4, one, one, tmp)                              # H2_OP_SUB
+    l0_poly, l_last_poly = lagrange_poly([0]), lagrange_poly([n - bf - 1])
+    l_blind_poly = lagrange_poly(list(range(n - bf, n)))
+
+    def active_row(l_last, l_blind, size):
+        tmp = D.eval_op(2, D.empty(size), l_last, l_blind)                     # H2_OP_SUM
+        one = D.eval_op(8, D.empty(size), c=1)                                 # H2_OP_CONSTANT
+        return D.eval_op(4, one, one, tmp)                                     # H2_OP_SUB
+
+    if plan is None:
+        pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
+        pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)
+        pk.coset = None
+    else:
+        # one proof over several ranks: only the cosets this rank evaluates, each an n-point table
+        pk.l0 = pk.l_last = pk.l_active_row = None
+        pk.coset = {}
+        for j in plan[2]:
+            l_last_j = D.coeff_to_coset(l_last_poly, dom, j)
+            pk.coset[j] = {
+                "fixed": [D.coeff_to_coset(t, dom, j) for t in pk.fixed_polys],
+                "sigma": [D.coeff_to_coset(t, dom, j) for t in pk.sigma_polys],
+                "l0": D.coeff_to_coset(l0_poly, dom, j), "l_last": l_last_j,
+                "l_active_row": active_row(l_last_j, D.coeff_to_coset(l_blind_poly, dom, j), n),
+            }
     pk.t_evaluations = D.upload(np.array([fr_to_mont_limbs(v) for v in dom.t_evaluations], dtype=np.uint64))
     # Evaluator::new: the gate program with the lookup / shuffle result calculations, and the compression programs
     # (evaluate_with_theta) of every lookup / shuffle expression list
@@ -847,39 +904,72 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
     advice_polys = [D.intt(t, dom) for t in advice_dev]          # in place: the Lagrange values are not needed again
-    ext = lambda t: D.coeff_to_extended(t, dom)  # noqa: E731
-    advice_cosets = [ext(t) for t in advice_polys]
-    instance_cosets = [ext(t) for t in instance_polys]
-    z_cosets = [ext(t) for t in z_polys]
-    lookup_z_cosets = [ext(t) for st in lookups for t in st["z_polys"]]
-    lookup_m_cosets = [ext(st["m_poly"]) for st in lookups]
-    shuffle_cosets = [ext(t) for t in shuffle_polys]
-    mark("cosets")
     g = pk.graph
-    b = ev.Builder().build(
-        k=dom.k, extended_k=ek, blinding_factors=bf, chunk_len=chunk,
-        constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
-        calculations=g.calculations, value_parts=pk.value_parts, lookups=pk.lookup_calcs, shuffles=pk.shuffle_calcs,
-        fixed=[t.data_ptr() for t in pk.fixed_cosets], advice=[t.data_ptr() for t in advice_cosets],
-        instance=[t.data_ptr() for t in instance_cosets],
-        l0=pk.l0.data_ptr(), l_last=pk.l_last.data_ptr(), l_active_row=pk.l_active_row.data_ptr(),
-        perm_z=[t.data_ptr() for t in z_cosets], perm_columns=[(_ANY[kd], i) for kd, i in cols],
-        perm_sigma=[t.data_ptr() for t in pk.sigma_cosets],
-        lookup_z=[t.data_ptr() for t in lookup_z_cosets], lookup_m=[t.data_ptr() for t in lookup_m_cosets],
-        shuffle_z=[t.data_ptr() for t in shuffle_cosets],
-        y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
-        delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.extended_omega),
-        jit_function=_jit_function(pk))
-    h = D.empty(en)
-    check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), h.data_ptr(), D.stream), "h2_dev_evaluate_h")
-    del advice_cosets, instance_cosets, z_cosets, lookup_z_cosets, lookup_m_cosets, shuffle_cosets
-    mark("evaluate_h")
+    plan = D.coset_plan(dom)
 
-    # ---- vanishing construct: divide, back to coefficients, commit the pieces (vanishing/prover.rs:69-112) -
-    check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
-                                            D.stream), "h2_dev_divide_by_vanishing_poly")
-    D.extended_to_coeff(h, dom)
-    pieces = [h[i * n:(i + 1) * n] for i in range(dom.quotient_poly_degree)]
+    def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size):
+        """the fused evaluator over one evaluation domain: `points_of` maps a coefficient vector to its values there"""
+        advice_cosets = [points_of(t) for t in advice_polys]
+        instance_cosets = [points_of(t) for t in instance_polys]
+        z_cosets = [points_of(t) for t in z_polys]
+        lookup_z_cosets = [points_of(t) for st in lookups for t in st["z_polys"]]
+        lookup_m_cosets = [points_of(st["m_poly"]) for st in lookups]
+        shuffle_cosets = [points_of(t) for t in shuffle_polys]
+        mark("cosets")
+        b = ev.Builder().build(
+            k=dom.k, extended_k=k_domain, blinding_factors=bf, chunk_len=chunk,
+            constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
+            calculations=g.calculations, value_parts=pk.value_parts, lookups=pk.lookup_calcs, shuffles=pk.shuffle_calcs,
+            fixed=[t.data_ptr() for t in tables["fixed"]], advice=[t.data_ptr() for t in advice_cosets],
+            instance=[t.data_ptr() for t in instance_cosets],
+            l0=tables["l0"].data_ptr(), l_last=tables["l_last"].data_ptr(), l_active_row=tables["l_active_row"].data_ptr(),
+            perm_z=[t.data_ptr() for t in z_cosets], perm_columns=[(_ANY[kd], i) for kd, i in cols],
+            perm_sigma=[t.data_ptr() for t in tables["sigma"]],
+            lookup_z=[t.data_ptr() for t in lookup_z_cosets], lookup_m=[t.data_ptr() for t in lookup_m_cosets],
+            shuffle_z=[t.data_ptr() for t in shuffle_cosets],
+            y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
+            delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
+            jit_function=_jit_function(pk))
+        out = D.empty(size)
+        check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")
+        mark("evaluate_h")
+        return out
+
+    if plan is None:
+        # ---- one device: the whole extended domain at once ------------------------------------------------------
+        tables = {"fixed": pk.fixed_cosets, "sigma": pk.sigma_cosets, "l0": pk.l0, "l_last": pk.l_last,
+                  "l_active_row": pk.l_active_row}
+        h = evaluate_quotient(lambda t: D.coeff_to_extended(t, dom), tables, ek, ZETA, dom.extended_omega, en)
+        # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
+        check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
+                                                D.stream), "h2_dev_divide_by_vanishing_poly")
+        D.extended_to_coeff(h, dom)
+        pieces = [h[i * n:(i + 1) * n] for i in range(dom.quotient_poly_degree)]
+    else:
+        # ---- one proof over several ranks: the extended domain by coset (DESIGN.md section 6).  On coset j (points
+        # g_j w^i, extended indices c i + j) every rotation stays inside the coset, the vanishing polynomial is the
+        # constant gamma_j - 1 (gamma_j = g_j^n) and h(X) = sum_m X^(n m) h_m(X) reads P_j(X) = sum_m gamma_j^m h_m(X): the
+        # evaluator runs on n points per coset with zeta := g_j, extended_omega := omega, extended_k := k; the inverse
+        # coset transform gives P_j; one n-vector per coset is exchanged; the pieces are h_m = sum_j Vinv[m][j] P_j.
+        from .parallel import coset_unmix_matrix, exchange_cosets
+
+        c, shards, owned = plan
+        mine = {}
+        for j in owned:
+            g_j = ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD
+            h_j = evaluate_quotient(lambda t, j=j: D.coeff_to_coset(t, dom, j), pk.coset[j], dom.k, g_j, dom.omega, n)
+            D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
+            mine[j] = D.coset_to_coeff(h_j, dom, j)
+        if D.group_size > 1:
+            D.sync()
+            polys_j = exchange_cosets(mine, c, shards, group=D.group)
+        else:
+            polys_j = [mine[j] for j in range(c)]
+        gammas = [pow(ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD, n, R_MOD) for j in range(c)]
+        unmix = coset_unmix_matrix(gammas, dom.quotient_poly_degree)
+        pieces = [D.lincomb(D.empty(n), polys_j, row, n) for row in unmix]
+        del polys_j, mine
+    mark("vanishing transforms")
     for P in D.msm_batch(pieces, params.g, n, 254):
         transcript.write_point(P)
     x = transcript.squeeze_challenge_scalar()

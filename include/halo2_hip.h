@@ -81,6 +81,10 @@ int h2_bases_unregister(const uint64_t *bases);
  * `.reduce(|acc, x| acc + x)` of arithmetic.rs:433-435; also used after an all-gather of per-rank
  * partial points when one MSM is split across processes (one process per GPU). */
 int h2_g1_sum(const uint64_t *points_xyz, size_t count, uint64_t out_xyz[12]);
+/* The same fold on the device, for the partial points of `count` range-split MSMs gathered from `world` ranks
+ * (d_points_xyz[(r * count + j) * 12 ..] = rank r's Jacobian partial of MSM j): d_out_xyz[j] = sum over r in rank order.
+ * Keeps the multi-GPU exchange on the device: all-gather (RCCL) -> this kernel -> one read-back of count x 96 B. */
+int h2_dev_g1_fold(const void *d_points_xyz, uint32_t world, uint32_t count, void *d_out_xyz, void *stream);
 /* gpu_multiexp_bound_and_fft: arithmetic.rs:375-410 (Params::commit_lagrange_and_ifft,
  * poly/commitment.rs:148-170): MSM over `bases` and, sharing the one upload, scalars <-
  * NTT(scalars, omega_inv) * divisor. */
@@ -162,6 +166,12 @@ int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, cons
  * (halo2-gpu-specific_amd/rng.py draws it from os.urandom; its seeded mode is for tests); rng.py also holds the host
  * twin the reference prover of the tests draws from. */
 int h2_dev_random_fr(const uint8_t key[32], size_t n, void *d_out, void *stream);
+
+/* a[i] *= g^i for i < n (n <= 2^28): distribute_powers_zeta (poly/domain.rs:382-398) for an arbitrary generator.  With
+ * g = zeta * extended_omega^j followed by an n-point h2_dev_ntt it evaluates a coefficient vector on coset j of the
+ * extended domain (extended index c i + j, c = 2^(extended_k - k)); with g^-1 after an n-point h2_dev_intt it inverts
+ * that.  The multi-GPU proof shards the extended domain by such cosets (one proof over several ranks). */
+int h2_dev_distribute_powers(void *d_a, size_t n, const uint64_t g[4], void *stream);
 
 /* Grand-sum column: z[0] = init, z[i] = z[i-1] + f[i-1] for i < n -- the `scan` of plonk/logup/prover.rs:353-367. */
 int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d_z, void *stream);

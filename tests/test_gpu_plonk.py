@@ -215,6 +215,69 @@ def test_proof_bytes_match_committed_hashes(oracle, device):
         assert hashlib.sha256(proof).hexdigest() == case["sha256"], (case["circuit"], k, case["scheme"])
 
 
+@pytest.mark.parametrize("which,k", [("mini", 7), ("rot", 6), ("lookup", 6)])
+def test_coset_path_reproduces_the_proof(oracle, device, which, k):
+    """the multi-GPU decomposition on one device: with force_cosets the quotient is evaluated coset by coset (n-point
+    transforms with zeta := zeta w_ext^j, the inverse coset transform, the inverse-Vandermonde un-mixing of the pieces)
+    instead of on the whole extended domain -- c = 2 (degree 3), 4 (degree 4) and 8 (degree 6) cosets; the proof bytes
+    must not change, and equal the reference prover's"""
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    ref_cs, make = {"mini": (rp.MiniPlonk, circuits.mini_plonk), "rot": (rp.RotGate, rot_gate_cs),
+                    "lookup": (rp.LookupShuffle, lookup_shuffle_cs)}[which]
+    syn = ref_cs.synthesize(k)
+    adv, fixed, copies = cols_to_arr(syn[0]), cols_to_arr(syn[1]), [(l[0], l[1], r[0], r[1]) for l, r in syn[2]]
+    inst = syn[3] if len(syn) > 3 else []
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, make(), fixed, copies)
+    want = prover.create_proof_ext(device, params, pk, adv, ProverRng(31), False, instances=inst)
+    D2 = prover.Device(force_cosets=True)
+    dom = pk.domain
+    assert D2.coset_plan(dom)[2] == list(range(1 << (dom.extended_k - dom.k)))
+    params2 = prover.Params(D2, k, params.g, params.g_lagrange)
+    pk2 = prover.keygen(D2, params2, make(), fixed, copies)
+    assert pk2.fixed_cosets is None and sorted(pk2.coset) == D2.coset_plan(dom)[2]
+    # the per-coset tables are the stride-c subsets of the extended tables
+    c = 1 << (dom.extended_k - dom.k)
+    for j in (0, c - 1):
+        assert device.torch.equal(pk2.coset[j]["l_active_row"], pk.l_active_row[j::c])
+        assert device.torch.equal(pk2.coset[j]["fixed"][0], pk.fixed_cosets[0][j::c])
+    for use_gwc in (False, True):
+        got = prover.create_proof_ext(D2, params2, pk2, adv, ProverRng(31), use_gwc, instances=inst)
+        if not use_gwc:
+            assert got == want
+        rpk = rp.keygen(ref_cs, k, S_TRAPDOOR, syn[1], syn[2])
+        assert got == rp.create_proof(rpk, syn[0], ProverRng(31), use_gwc=use_gwc, instances=inst)
+
+
+@pytest.mark.timeout(600)
+def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path):
+    """config 5's data flow with two ranks (here two processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
+    device): every MSM range-split + all-gather + fold, the extended domain split by coset + broadcast + un-mixing.  Both
+    ranks must emit the single-device proof."""
+    import subprocess
+    import sys
+
+    from h2util import ROOT
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 10
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    pk = prover.keygen(device, params, circuits.mini_plonk(), fixed, copies)
+    want = prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(9))
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % (ROOT, k, S_TRAPDOOR))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                         capture_output=True, text=True, timeout=500, env=dict(os.environ, H2_TEST_BACKEND="gloo"))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    proofs = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("PROOF ")]
+    assert len(proofs) == 2 and all(bytes.fromhex(h) == want for h in proofs)
+
+
 def _visible_devices():
     import torch
 
@@ -273,8 +336,13 @@ import os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
 rank = int(os.environ["RANK"]); local = int(os.environ.get("LOCAL_RANK", rank))
-torch.cuda.set_device(local)
-dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+if os.environ.get("H2_TEST_BACKEND") == "gloo":      # two ranks sharing cuda:0 (RCCL refuses two ranks on one device)
+    local = 0
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+else:
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 from halo2_gpu_specific_amd import circuits, prover
 from halo2_gpu_specific_amd.rng import ProverRng
 D = prover.Device(local)

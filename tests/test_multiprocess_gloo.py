@@ -43,6 +43,38 @@ assert t.tolist() == [1] * 7
 # bench-style timing reduction: max over ranks
 m = torch.tensor([float(rank + 1)], dtype=torch.float64); dist.all_reduce(m, op=dist.ReduceOp.MAX)
 assert m.item() == world
+# ---- coset sharding of the extended domain (parallel.coset_plan / exchange_cosets / coset_unmix_matrix): the quotient
+# h = h_0 + X^n h_1 (two pieces, degree-3 circuit: c = 2 cosets) is known here; every rank "evaluates" only its coset:
+# P_j = coset-iNTT of h on coset j = h_0 + gamma_j h_1.  After the broadcast and the un-mixing every rank holds h_0, h_1.
+from h2util import R_MOD, from_mont, to_mont, fr_mont
+k, j_deg = 6, 3
+d, _ = oracle.domain(j_deg, k)
+nn, c = 1 << k, 1 << (d.extended_k - k)
+shards, owned = parallel.coset_plan(c, world, rank)
+assert shards == 2 and owned == [rank]
+zeta, wext = from_mont(d.fr("g_coset").reshape(1, 4))[0], from_mont(d.fr("extended_omega").reshape(1, 4))[0]
+pieces = [from_mont(oracle.random_fr(70 + m, nn)) for m in range(c)]
+hcoef = to_mont([v for m in range(c) for v in pieces[m]])                   # h as one coefficient vector of length c n
+ext = from_mont(oracle.best_fft(to_mont([v * pow(zeta, t, R_MOD) %% R_MOD for t, v in enumerate(from_mont(hcoef))]),
+                                fr_mont(wext), d.extended_k))              # h on the whole extended coset
+mine = {}
+for j in owned:
+    g_j = zeta * pow(wext, j, R_MOD) %% R_MOD
+    vals = to_mont(ext[j::c])                                               # extended indices c i + j
+    w_inv = fr_mont(pow(pow(wext, c, R_MOD), -1, R_MOD))
+    coeffs = from_mont(oracle.ifft(vals, w_inv, k, fr_mont(pow(nn, -1, R_MOD))))
+    g_inv = pow(g_j, -1, R_MOD)
+    pj = [v * pow(g_inv, t, R_MOD) %% R_MOD for t, v in enumerate(coeffs)]
+    gamma = pow(g_j, nn, R_MOD)
+    assert pj == [(pieces[0][t] + gamma * pieces[1][t]) %% R_MOD for t in range(nn)], "P_j != sum gamma_j^m h_m"
+    mine[j] = torch.from_numpy(to_mont(pj).view(np.int64).copy())
+polys = parallel.exchange_cosets(mine, c, shards)
+gammas = [pow(zeta * pow(wext, j, R_MOD) %% R_MOD, nn, R_MOD) for j in range(c)]
+unmix = parallel.coset_unmix_matrix(gammas, c)
+for m in range(c):
+    got = [sum(unmix[m][j] * v for j, v in enumerate(col)) %% R_MOD
+           for col in zip(*[from_mont(t.numpy().view(np.uint64)) for t in polys])]
+    assert got == pieces[m], "rank %%d: piece %%d differs after the exchange" %% (rank, m)
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
 """

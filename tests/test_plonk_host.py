@@ -263,6 +263,28 @@ def test_domain_scalars(k, degree):
     assert d.rotate_omega(5, -3) * pow(d.omega, 3, rp.R) % rp.R == 5
 
 
+def test_coset_plan_and_unmix_matrix():
+    """parallel.coset_plan / coset_unmix_matrix: the multi-GPU split of the extended domain"""
+    from halo2_gpu_specific_amd import parallel
+
+    assert parallel.coset_plan(2, 8, 5) == (2, [1]) and parallel.coset_plan(8, 2, 1) == (2, [1, 3, 5, 7])
+    assert parallel.coset_plan(4, 4, 2) == (4, [2]) and parallel.coset_plan(4, 1, 0) == (1, [0, 1, 2, 3])
+    covered = sorted(j for r in range(4) for j in parallel.coset_plan(8, 4, r)[1])
+    assert covered == list(range(8))
+    rnd = random.Random(5)
+    for k, deg in ((4, 3), (5, 5), (3, 9)):
+        d = prover.Domain(k, deg)
+        c = 1 << (d.extended_k - d.k)
+        gammas = [pow(prover.ZETA * pow(d.extended_omega, j, rp.R) % rp.R, d.n, rp.R) for j in range(c)]
+        # the vanishing polynomial is the constant gamma_j - 1 on coset j: t_evaluations of the reference
+        assert [pow(g - 1, -1, rp.R) for g in gammas] == d.t_evaluations
+        h = [[rnd.randrange(rp.R) for _ in range(3)] for _ in range(c)]                 # c pieces of 3 coefficients
+        P = [[sum(pow(g, m, rp.R) * h[m][t] for m in range(c)) % rp.R for t in range(3)] for g in gammas]
+        M = parallel.coset_unmix_matrix(gammas, d.quotient_poly_degree)
+        for m in range(d.quotient_poly_degree):
+            assert [sum(M[m][j] * P[j][t] for j in range(c)) % rp.R for t in range(3)] == h[m]
+
+
 def test_rng_is_a_fixed_stream():
     a, b = ProverRng(9), ProverRng.deterministic(9)
     assert [a.next_u64() for _ in range(4)] == [b.next_u64() for _ in range(4)]
