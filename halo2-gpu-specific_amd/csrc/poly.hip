@@ -25,38 +25,15 @@ __device__ __forceinline__ size_t rot_index(size_t i, int32_t rot, size_t size) 
     return (size_t)v;
 }
 
-// streaming accesses: every operand is read once and the result written once, nothing is reused through the caches
-__device__ __forceinline__ Fr fr_load_stream(const Fr* p, bool nt) {
-    if (!nt) return fp_load(p);
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const v4* q = reinterpret_cast<const v4*>(p);
-    const v4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
-    Fr r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
-}
-__device__ __forceinline__ void fr_store_stream(Fr* p, const Fr& v, bool nt) {
-    if (!nt) {
-        fp_store(p, v);
-        return;
-    }
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    v4* q = reinterpret_cast<v4*>(p);
-    v4 a = {v.l[0], v.l[1], v.l[2], v.l[3]}, b = {v.l[4], v.l[5], v.l[6], v.l[7]};
-    __builtin_nontemporal_store(a, q);
-    __builtin_nontemporal_store(b, q + 1);
-}
-
-template <int OP, bool NT>
+template <int OP>
 __global__ void __launch_bounds__(256) k_eval_op(Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int32_t r_rot,
                                                  size_t size, Fr c) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) {
         Fr lv, rv, out;
-        if (OP != H2_OP_CONSTANT) lv = fr_load_stream(l + rot_index(i, l_rot, size), NT);
+        if (OP != H2_OP_CONSTANT) lv = fp_load(l + rot_index(i, l_rot, size));
         if (OP == H2_OP_SUM || OP == H2_OP_MUL || OP == H2_OP_SUB || OP == H2_OP_LCTHETA || OP == H2_OP_LCBETA)
-            rv = fr_load_stream(r + rot_index(i, r_rot, size), NT);
+            rv = fp_load(r + rot_index(i, r_rot, size));
         if (OP == H2_OP_MUL_C) out = fp_mul(lv, c);
         else if (OP == H2_OP_SUM_C || OP == H2_OP_ADDGAMMA) out = fp_add(lv, c);
         else if (OP == H2_OP_SUM) out = fp_add(lv, rv);
@@ -65,7 +42,7 @@ __global__ void __launch_bounds__(256) k_eval_op(Fr* res, const Fr* l, const Fr*
         else if (OP == H2_OP_LCTHETA) out = fp_add(fp_mul(lv, c), rv);
         else if (OP == H2_OP_LCBETA) out = fp_mul(fp_add(lv, c), rv);
         else out = c;
-        fr_store_stream(res + i, out, NT);
+        fp_store(res + i, out);
     }
 }
 
@@ -106,14 +83,8 @@ int eval_op_launch(int op, Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int
     r_rot = (int32_t)(((long long)r_rot % sz));
     Fr cv = c ? fr_host(c) : Fr{};
     dim3 g(grid_for(size)), b(256);
-    static const bool nt = getenv("H2_ELEMENTWISE_NT") != nullptr;   // experiment knob
-#define H2_CASE(OPC)                                                                                                   \
-    case OPC:                                                                                                          \
-        if (nt)                                                                                                        \
-            hipLaunchKernelGGL((k_eval_op<OPC, true>), g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv);            \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_eval_op<OPC, false>), g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv);           \
-        break;
+#define H2_CASE(OPC) \
+    case OPC: hipLaunchKernelGGL(k_eval_op<OPC>, g, b, 0, stream, res, l, r, l_rot, r_rot, size, cv); break;
     switch (op) {
         H2_CASE(H2_OP_MUL_C)
         H2_CASE(H2_OP_SUM_C)
