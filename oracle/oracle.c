@@ -444,10 +444,29 @@ EXPORT void oracle_best_fft(u256 *a, const u256 *omega, uint32_t log_n, int thre
             chunk_len *= 2;
             twiddle_chunk /= 2;
         }
-    } else { /* :643 */
-#pragma omp parallel num_threads(threads)
-#pragma omp single
-        recursive_butterfly_arithmetic(a, n, 1, twiddles, 0, log_threads + 1);
+    } else { /* :643 recursive_butterfly_arithmetic(a, n, 1, &twiddles) */
+        /* The reference hands the recursion to rayon::join (work stealing).  libgomp's single task queue does not scale
+         * that shape past ~32 threads (a 2^24 transform took 65 s on 256 threads), so the SAME butterflies are scheduled
+         * statically here: the sub-transforms of 2^15 elements (1 MiB: the depth at which the recursion fits a core's
+         * cache) run as independent loop items, each by the serial recursion; the levels above them are flat loops
+         * over their n / 2 butterflies.  Every butterfly has the operands and the twiddle the recursion gives it, so the
+         * output is bit-identical for any thread count. */
+        unsigned block_log = log_n < 15 ? log_n : 15;
+        size_t block = (size_t)1 << block_log, nblocks = n >> block_log;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (size_t b = 0; b < nblocks; b++)
+            recursive_butterfly_arithmetic(a + b * block, block, nblocks, twiddles, 4, 0); /* serial inside a block */
+        for (unsigned s = block_log + 1; s <= log_n; s++) {
+            size_t chunk = (size_t)1 << s, half_c = chunk >> 1, tw_chunk = n >> s;
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (size_t t = 0; t < n / 2; t++) {
+                size_t base = (t / half_c) * chunk, i = t % half_c;
+                if (i == 0)
+                    butterfly_one(&a[base], &a[base + half_c]);
+                else
+                    butterfly(&a[base + i], &a[base + half_c + i], &twiddles[i * tw_chunk]);
+            }
+        }
     }
     free(twiddles);
 }
