@@ -84,6 +84,38 @@ def allgather_fold_many(partials_xyz, group=None, device=None, stream=None):
     return np.stack([g1_sum(pts[:, j, :]) for j in range(count)])
 
 
+def allreduce_max(values, group=None, device=None):
+    """element-wise maximum of a short list of non-negative integers over the ranks (the per-column scalar bounds)"""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor(list(values), dtype=torch.int64)
+    if device is not None and _backend(group) == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def allgather_rows(t, lo, hi, group=None, stream=None):
+    """`t`: an (n, 4) int64 device tensor of which this rank holds the rows [lo, hi) (n / world rows, rank order); on
+    return every rank holds every row.  RCCL: one in-place all-gather over xGMI; gloo: through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    assert t.shape[0] % world == 0 and hi - lo == t.shape[0] // world
+    if stream is not None:
+        stream.synchronize()
+    if _backend(group) == "nccl":
+        dist.all_gather_into_tensor(t.view(-1), t[lo:hi].reshape(-1), group=group)
+        return t
+    mine = t[lo:hi].cpu()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    t.copy_(torch.cat(parts).to(t.device))
+    return t
+
+
 # ---- coset sharding of the extended-domain phase ---------------------------------------------------------------------
 def coset_plan(c, world, rank):
     """c = 2^(extended_k - k) cosets over `world` ranks: shards = min(c, world) groups; rank r works on the cosets

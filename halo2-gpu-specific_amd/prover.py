@@ -721,6 +721,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     transcript = Blake2bWrite()
     transcript.common_scalar(pk.transcript_repr)
+    if D.group_size > 1:
+        rng = rng.shared(D.group)            # every rank of one proof draws the same blinding values
 
     # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------
     if len(instances) != cs.num_instance:
@@ -740,7 +742,23 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # Every column is queued for upload on the copy stream first (DMA when it lives in pinned memory); the columns are
     # then blinded, measured (per-column max_bits, as the reference) and committed in small groups -- one pipelined
     # batch per group -- while the later groups are still in flight.
-    uploads = [D.upload_async(col) for col in advice]
+    # One proof over several ranks (n divisible by the group size): a rank uploads only ITS rows [lo, hi) of every
+    # column over PCIe -- exactly the range its share of the commitment needs -- and the ranks complete each other's
+    # columns over xGMI afterwards (parallel.allgather_rows): 1 / P of the witness per PCIe link instead of all of it.
+    sharded_upload = D.group_size > 1 and n % D.group_size == 0 and n // D.group_size > bf + 1
+    lo_r, hi_r = 0, n
+    if sharded_upload:
+        from .parallel import allgather_rows, allreduce_max, msm_split_range
+
+        lo_r, hi_r = msm_split_range(n, D.group_size, D.group_rank)
+        uploads = []
+        for col in advice:
+            t = D.empty(n)
+            with D.torch.cuda.stream(D.tstream):
+                t[lo_r:hi_r] = D.upload(np.ascontiguousarray(col[lo_r:hi_r]))
+            uploads.append((t, None))
+    else:
+        uploads = [D.upload_async(col) for col in advice]
     # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
     blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
     for ci in range(len(uploads)):
@@ -755,15 +773,22 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             if arrived is not None:
                 D.tstream.wait_event(arrived)
             if montgomery:                                       # find_max_scalar_bits needs the canonical values
-                check(L.h2_dev_batch_unmont(t.data_ptr(), n, D.stream), "h2_dev_batch_unmont")
-            with D.torch.cuda.stream(D.tstream):
-                t[usable:] = blind_dev[ci]
+                check(L.h2_dev_batch_unmont(t[lo_r:hi_r].data_ptr(), hi_r - lo_r, D.stream), "h2_dev_batch_unmont")
+            if hi_r > usable:                                    # the blinding rows live in the last rank's range
+                with D.torch.cuda.stream(D.tstream):
+                    t[usable:] = blind_dev[ci]
             cols_.append(t)
-        bits_ = [max(b, 1) for b in D.max_scalar_bits_many(cols_, n)]
+        bits_ = D.max_scalar_bits_many([t[lo_r:hi_r] for t in cols_], hi_r - lo_r)
+        if sharded_upload:
+            bits_ = allreduce_max(bits_, group=D.group, device=D.dev)       # find_max_scalar_bits over the whole column
+        bits_ = [max(b, 1) for b in bits_]
         for t in cols_:
-            check(L.h2_dev_batch_mont(t.data_ptr(), n, D.stream), "h2_dev_batch_mont")
+            check(L.h2_dev_batch_mont(t[lo_r:hi_r].data_ptr(), hi_r - lo_r, D.stream), "h2_dev_batch_mont")
         for P in D.msm_batch(cols_, params.g_lagrange, n, bits_):
             transcript.write_point(P)
+        if sharded_upload:
+            for t in cols_:
+                allgather_rows(t, lo_r, hi_r, group=D.group, stream=D.tstream)
         advice_dev += cols_
     del blind_dev
     del uploads

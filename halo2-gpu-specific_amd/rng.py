@@ -32,18 +32,19 @@ def _rotl32(x, k):
     return (x << np.uint32(k)) | (x >> np.uint32(32 - k))
 
 
-def chacha20_blocks(key, n):
-    """ChaCha20 blocks 0 .. n-1 under `key` (32 bytes), zero nonce, 64-bit block counter in words 12-13:
-    (n, 16) uint32, the keystream words in order (RFC 8439 block function)."""
+def chacha20_blocks(key, n, first=0, stream=0):
+    """ChaCha20 blocks first .. first + n - 1 under `key` (32 bytes), 64-bit block counter in words 12-13, nonce words
+    (stream, 0): (n, 16) uint32, the keystream words in order (RFC 8439 block function)."""
     k = np.frombuffer(bytes(key), dtype="<u4")
     assert k.shape == (8,)
     s = np.zeros((16, n), dtype=np.uint32)
     s[0], s[1], s[2], s[3] = 0x61707865, 0x3320646E, 0x79622D32, 0x6B206574
     for j in range(8):
         s[4 + j] = k[j]
-    ctr = np.arange(n, dtype=np.uint64)
+    ctr = np.arange(n, dtype=np.uint64) + np.uint64(first)
     s[12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     s[13] = (ctr >> np.uint64(32)).astype(np.uint32)
+    s[14] = stream
     x = s.copy()
 
     def qr(a, b, c, d):
@@ -64,8 +65,11 @@ class ProverRng:
     """seed=None (the default): OS entropy.  An integer seed: the deterministic test stream (xoshiro256** seeded
     through splitmix64)."""
 
-    def __init__(self, seed=None):
+    def __init__(self, seed=None, key=None):
+        """`key` (32 bytes of entropy): the same unpredictable stream on every holder of the key -- how the ranks of a
+        multi-GPU proof draw identical blinding values (`shared`)."""
         self.secure = seed is None
+        self.key, self._buf, self._block = (bytes(key) if key is not None else None), b"", 0
         if self.secure:
             self.s = None
             return
@@ -87,9 +91,30 @@ class ProverRng:
     def from_os_entropy(cls):
         return cls(None)
 
+    def shared(self, group=None):
+        """For one proof over several ranks: every rank must blind with the same values.  The OS-entropy mode becomes a
+        ChaCha20 stream under a key drawn by rank 0 and broadcast; the seeded test stream is already identical."""
+        if not self.secure or self.key is not None:
+            return self
+        import torch
+        import torch.distributed as dist
+
+        key = torch.frombuffer(bytearray(os.urandom(32)), dtype=torch.uint8).clone()
+        if dist.get_backend(group) == "nccl":
+            key = key.cuda()
+        dist.broadcast(key, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return ProverRng(key=bytes(key.cpu().tolist()))
+
+    def _keyed_bytes(self, count):
+        while len(self._buf) < count:
+            self._buf += chacha20_blocks(self.key, 4, first=self._block, stream=1).tobytes()
+            self._block += 4
+        out, self._buf = self._buf[:count], self._buf[count:]
+        return out
+
     def next_u64(self):
         if self.secure:
-            return int.from_bytes(os.urandom(8), "little")
+            return int.from_bytes(self._keyed_bytes(8) if self.key is not None else os.urandom(8), "little")
         s = self.s
         out = (_rotl((s[1] * 5) & _M64, 7) * 9) & _M64
         t = (s[1] << 17) & _M64
@@ -115,7 +140,7 @@ class ProverRng:
     def random_poly_key(self):
         """the 256-bit ChaCha20 key of the vanishing argument's blinding polynomial"""
         if self.secure:
-            return os.urandom(32)
+            return self._keyed_bytes(32) if self.key is not None else os.urandom(32)
         return b"".join(self.next_u64().to_bytes(8, "little") for _ in range(4))
 
     @staticmethod

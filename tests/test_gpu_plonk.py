@@ -276,6 +276,12 @@ def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device,
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     proofs = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("PROOF ")]
     assert len(proofs) == 2 and all(bytes.fromhex(h) == want for h in proofs)
+    secure = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("SECURE ")]
+    assert len(secure) == 2 and secure[0] == secure[1] != proofs[0]
+    vk = rp.Keys()
+    vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
+    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+    assert rp.verify_proof(vk, bytes.fromhex(secure[0]))
 
 
 def _visible_devices():
@@ -352,6 +358,9 @@ adv, fixed, copies = circuits.mini_plonk_synthesize(k)
 pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
 proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(9))
 sys.stdout.write("PROOF " + proof.hex() + "\n")
+# OS-entropy blinding: rank 0's key is broadcast (ProverRng.shared), so the ranks still agree on every byte
+secure = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng())
+sys.stdout.write("SECURE " + secure.hex() + "\n")
 sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()

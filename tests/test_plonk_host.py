@@ -303,6 +303,21 @@ def test_rng_defaults_to_os_entropy():
     assert a.fr() < rp.R and a.u16() < 65536
 
 
+def test_keyed_rng_is_shared_and_unpredictable_without_the_key():
+    """the multi-rank mode of the OS-entropy rng: the same key gives the same draws, another key different ones; the
+    blinding polynomial's key comes out of the same stream"""
+    import os as _os
+
+    k1, k2 = _os.urandom(32), _os.urandom(32)
+    a, b, c = ProverRng(key=k1), ProverRng(key=k1), ProverRng(key=k2)
+    assert a.secure and a.key == k1
+    da = [a.u16() for _ in range(5)] + [a.fr() for _ in range(3)] + [a.random_poly_key()]
+    db = [b.u16() for _ in range(5)] + [b.fr() for _ in range(3)] + [b.random_poly_key()]
+    dc = [c.u16() for _ in range(5)] + [c.fr() for _ in range(3)] + [c.random_poly_key()]
+    assert da == db != dc and all(v < rp.R for v in da[5:8]) and len(da[8]) == 32
+    assert ProverRng(3).shared() is not None and ProverRng(key=k1).shared().key == k1     # already shareable: unchanged
+
+
 def test_chacha20_keystream_known_answer():
     """the all-zero key / nonce / counter block of ChaCha20 (the classic test vector of the cipher, RFC 7539 A.1 #1)"""
     from halo2_gpu_specific_amd.rng import chacha20_blocks

@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/collect_profiles.sh <tag> -- the per-round evidence kept under profiles/ (run on the GPU box: `gpurun -- bash
+# tools/collect_profiles.sh r2`; writes gpurun_out/<tag>_profiles/, to be copied into profiles/<tag>_*).  Counter passes
+# (--pmc) are separate runs with --kernel-trace only, as the pool requires.
+set -u
+tag=${1:-rX}
+out=gpurun_out/${tag}_profiles
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+./tools/mulbench > "$out/mulbench.txt" 2>&1
+./tools/h2bench ntt 24 5 msm 14 254 10 msm 16 254 10 msm 18 254 10 msm 20 254 5 msm 22 254 3 msm 24 254 2 msm 20 16 5 msm 20 1 5 eval 25 3 > "$out/h2bench.txt" 2>&1
+python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats -d "$out/p_bench" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$out/bench_line_profiled.json" 2>/dev/null
+python3 tools/rocprof_summary.py "$(find "$out/p_bench" -name '*results.db' | head -1)" "$out/bench_kernel_stats.txt" > /dev/null
+CMD="./tools/h2bench ntt 24 2 msm 20 254 2 eval 25 2"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/p_f" -o f -- $CMD > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/p_w" -o w -- $CMD > /dev/null 2>&1
+python3 tools/hbm_traffic.py "$(find "$out/p_f" -name '*results.db' | head -1)" "$(find "$out/p_w" -name '*results.db' | head -1)" "$CMD" > "$out/hbm_traffic.json"
+rocprofv3 --kernel-trace --stats -d "$out/p_k22" -o k22 -- python3 tools/prove_bench.py 22 3 > "$out/create_proof_k22.txt" 2>/dev/null
+python3 tools/rocprof_summary.py "$(find "$out/p_k22" -name '*results.db' | head -1)" "$out/create_proof_k22_kernel_stats.txt" > /dev/null
+python3 tools/prove_bench.py 24 3 > "$out/create_proof_k24.txt" 2>&1
+python3 tools/lookup_bench.py 18 > "$out/lookup_k18.txt" 2>&1
+rm -rf "$out"/p_*
+ls -la "$out"
