@@ -88,7 +88,9 @@ class Device:
         self._scratch = None
         self._pinned = {}
         self.group, self.group_size, self.group_rank, self.force_collective = group, 1, 0, force_collective
-        self.force_cosets = force_cosets
+        import os
+
+        self.force_cosets = force_cosets or os.environ.get("H2_FORCE_COSETS") == "1"   # experiment knob
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized():
@@ -759,6 +761,12 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             uploads.append((t, None))
     else:
         uploads = [D.upload_async(col) for col in advice]
+    # The vanishing argument's random polynomial (vanishing/prover.rs:40-67) and its commitment depend on nothing the
+    # transcript has hashed: generated and committed NOW, while the witness columns cross PCIe on the copy stream (k = 24:
+    # a 25 ms MSM under a 29 ms transfer).  The commitment is written where the protocol puts it, after the z's.
+    random_poly = D.empty(n)
+    check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
+    random_commitment = D.msm(random_poly, params.g, n)
     # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
     blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
     for ci in range(len(uploads)):
@@ -906,14 +914,10 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
         shuffle_z.append(z)
     del num, inv, shuffle_inv
-    # vanishing argument: the random polynomial (vanishing/prover.rs:40-67), generated on the device
-    random_poly = D.empty(n)
-    check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
     # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z; the random polynomial's commitment does
     # not depend on anything hashed in between, so its MSM rides in the same pipelined batch (hashing order kept)
     all_z = z_dev + [z for st in lookups for z in st["z"]] + shuffle_z
-    z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254, also=(random_poly, params.g))
-    random_commitment = z_commitments.pop()
+    z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254)
     for P in z_commitments:
         transcript.write_point(P)
     z_polys = [D.intt(z, dom) for z in z_dev]

@@ -12,7 +12,10 @@ the seed: never use it outside tests and benchmarks.
 
 In both modes the vanishing argument's random polynomial comes from a ChaCha20 keystream under a 256-bit key
 (h2_dev_random_fr on the device, `random_poly_limbs` is its host twin): the key is 32 bytes of OS entropy, or four
-draws of the seeded stream.
+draws of a SECOND seeded stream.  The key does not come out of the main stream on purpose: the random polynomial and its
+commitment depend on nothing the transcript hashes, so the prover computes them while the witness is still crossing
+PCIe, long before the reference's draw order would reach them -- a key that is independent of the position in the
+main stream keeps the two provers' draws aligned whenever it is taken.
 """
 import os
 
@@ -73,6 +76,12 @@ class ProverRng:
         if self.secure:
             self.s = None
             return
+        self.s = self._expand(seed)
+        self._poly = None                      # the second stream (random-polynomial keys), made on first use
+        self._seed = seed & _M64
+
+    @staticmethod
+    def _expand(seed):
         s, st = seed & _M64, []
         for _ in range(4):
             s = (s + 0x9E3779B97F4A7C15) & _M64
@@ -80,7 +89,7 @@ class ProverRng:
             z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
             z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
             st.append(z ^ (z >> 31))
-        self.s = st
+        return st
 
     @classmethod
     def deterministic(cls, seed):
@@ -141,7 +150,9 @@ class ProverRng:
         """the 256-bit ChaCha20 key of the vanishing argument's blinding polynomial"""
         if self.secure:
             return self._keyed_bytes(32) if self.key is not None else os.urandom(32)
-        return b"".join(self.next_u64().to_bytes(8, "little") for _ in range(4))
+        if self._poly is None:
+            self._poly = ProverRng(self._seed ^ 0x706F6C795F6B6579)      # "poly_key": a stream of its own
+        return b"".join(self._poly.next_u64().to_bytes(8, "little") for _ in range(4))
 
     @staticmethod
     def random_poly_values(key, n):

@@ -11,6 +11,10 @@
  *   Fr            32 B = 4 x u64 little-endian limbs, Montgomery form (R = 2^256)
  *   G1Affine      64 B = {x: Fq, y: Fq} Montgomery, identity = (0, 0)
  *   G1 (result)   96 B = Jacobian {x, y, z: Fq} Montgomery, identity has z = 0
+ *   value range   every field element handed to the library is a valid residue image: below the modulus (the
+ *                 reference's own Fr / Fq invariant).  The multiplier relies on inputs below 2^254 (it skips the
+ *                 carry handling that such inputs cannot trigger); out-of-range limbs give unspecified residues, not
+ *                 an error.
  *   return value  0 = H2_OK, non-zero = error; h2_last_error() gives the text.  The
  *                 reference unwrap()s its GPU Results (arithmetic.rs:358,360,509), so the
  *                 Rust shim panics on non-zero.
