@@ -773,7 +773,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         blind[ci, :, 0] = [rng.u16() for _ in range(usable, n)]
     with D.torch.cuda.stream(D.tstream):
         blind_dev = D.torch.from_numpy(blind).to(D.dev)
-    group = max(1, min(4, len(uploads) // 3))
+    # columns are blinded, measured and committed in groups while later uploads are still in flight; small witnesses
+    # (<= 256 MiB: already on the device by the time the random polynomial is committed) go as one group -- one
+    # synchronisation and one pipelined / fused batch instead of several
+    group = len(uploads) if len(uploads) * n * 32 <= (256 << 20) else max(1, min(4, len(uploads) // 3))
+    group = max(group, 1)
     advice_dev = []
     for g0 in range(0, len(uploads), group):
         cols_ = []
