@@ -51,6 +51,35 @@ def _backend(group):
     return dist.get_backend(group)
 
 
+class _on_stream:
+    """Run the enclosed torch work -- copies, RCCL collectives (they make the CURRENT stream wait for the communicator's
+    stream) -- on the caller's compute stream, so that the kernels queued there before and after are ordered with it.
+    `stream` = None keeps torch's current stream and brackets the block with device synchronisations instead."""
+
+    def __init__(self, stream):
+        self.stream, self.ctx = stream, None
+
+    def __enter__(self):
+        import torch
+
+        if self.stream is None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return None
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    def __exit__(self, *exc):
+        import torch
+
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return False
+
+
 def allgather_fold(partial_xyz, group=None, device=None):
     """All-gather every rank's partial point and fold; every rank returns the full sum."""
     return allgather_fold_many(np.asarray(partial_xyz, dtype=np.uint64).reshape(1, 12), group, device)[0]
@@ -72,12 +101,17 @@ def allgather_fold_many(partials_xyz, group=None, device=None, stream=None):
     count = mine_np.shape[0]
     mine = torch.from_numpy(mine_np.view(np.int64).copy())
     if device is not None and _backend(group) == "nccl":
-        mine = mine.to(device, non_blocking=True)
-        gathered = torch.empty((world, count, 12), dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
-        out = torch.empty((count, 12), dtype=torch.int64, device=device)
-        check(lib().h2_dev_g1_fold(gathered.data_ptr(), world, count, out.data_ptr(), stream), "h2_dev_g1_fold")
-        return out.cpu().numpy().view(np.uint64)
+        with _on_stream(stream) as handle:
+            mine = mine.to(device)
+            gathered = torch.empty((world, count, 12), dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+            out = torch.empty((count, 12), dtype=torch.int64, device=device)
+            if handle is None:
+                torch.cuda.synchronize()       # the fold runs on the library's stream: the gather must have landed
+            check(lib().h2_dev_g1_fold(gathered.data_ptr(), world, count, out.data_ptr(), handle), "h2_dev_g1_fold")
+            if handle is None:
+                check(lib().h2_synchronize(), "h2_synchronize")
+            return out.cpu().numpy().view(np.uint64)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
     pts = np.stack([t.numpy().view(np.uint64) for t in gathered])      # (world, count, 12)
@@ -104,15 +138,14 @@ def allgather_rows(t, lo, hi, group=None, stream=None):
 
     world = dist.get_world_size(group)
     assert t.shape[0] % world == 0 and hi - lo == t.shape[0] // world
-    if stream is not None:
-        stream.synchronize()
-    if _backend(group) == "nccl":
-        dist.all_gather_into_tensor(t.view(-1), t[lo:hi].reshape(-1), group=group)
-        return t
-    mine = t[lo:hi].cpu()
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    t.copy_(torch.cat(parts).to(t.device))
+    with _on_stream(stream):
+        if _backend(group) == "nccl":
+            dist.all_gather_into_tensor(t.view(-1), t[lo:hi].reshape(-1), group=group)
+            return t
+        mine = t[lo:hi].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        t.copy_(torch.cat(parts).to(t.device))
     return t
 
 
@@ -142,7 +175,7 @@ def coset_unmix_matrix(gammas, rows):
     return [row[c:] for row in a[:rows]]
 
 
-def exchange_cosets(mine, c, shards, group=None):
+def exchange_cosets(mine, c, shards, group=None, stream=None):
     """`mine`: {coset j: (n, 4) int64 device tensor} for the cosets this rank evaluated.  Every coset polynomial is
     broadcast from the first rank of its shard (rank j mod shards); returns the list of all c tensors.  One n-vector per
     coset crosses the links (k = 24: 512 MiB each) -- the only bulk exchange of a proof."""
@@ -153,13 +186,14 @@ def exchange_cosets(mine, c, shards, group=None):
     staged = _backend(group) != "nccl"          # gloo: through host memory
     template = next(iter(mine.values()))
     out = []
-    for j in range(c):
-        src = j % shards
-        t = mine[j] if (j in mine and rank == src) else torch.empty_like(template)
-        if j in mine and rank != src:
-            out.append(mine[j])                 # a replica of the shard already holds it; still take part in the broadcast
-        buf = t.cpu() if staged else t
-        dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
-        if not (j in mine and rank != src):
-            out.append(buf.to(template.device) if staged else buf)
+    with _on_stream(stream):
+        for j in range(c):
+            src = j % shards
+            t = mine[j] if (j in mine and rank == src) else torch.empty_like(template)
+            if j in mine and rank != src:
+                out.append(mine[j])             # a replica of the shard already holds it; still take part in the broadcast
+            buf = t.cpu() if staged else t
+            dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+            if not (j in mine and rank != src):
+                out.append(buf.to(template.device) if staged else buf)
     return out

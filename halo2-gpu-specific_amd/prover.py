@@ -279,8 +279,7 @@ class Device:
             lo, hi = msm_split_range(n, self.group_size, self.group_rank)
         out = self.msm_partial(columns, bases, lo, hi, max_bits, also)
         if collective:
-            self.sync()
-            out = allgather_fold_many(out, group=self.group, device=self.dev)
+            out = allgather_fold_many(out, group=self.group, device=self.dev, stream=self.tstream)
         return [jacobian_to_affine(r) for r in out]
 
     def msm_partial(self, columns, bases, lo, hi, max_bits=254, also=None):
@@ -994,8 +993,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
             mine[j] = D.coset_to_coeff(h_j, dom, j)
         if D.group_size > 1:
-            D.sync()
-            polys_j = exchange_cosets(mine, c, shards, group=D.group)
+            polys_j = exchange_cosets(mine, c, shards, group=D.group, stream=D.tstream)
         else:
             polys_j = [mine[j] for j in range(c)]
         gammas = [pow(ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD, n, R_MOD) for j in range(c)]
