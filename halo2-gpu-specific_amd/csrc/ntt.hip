@@ -74,6 +74,7 @@ struct PassArgs {
     uint32_t prevT[4];    // their T_q logs
     uint32_t is_last, in_len, log_c;
     uint32_t zskip;  // first pass of a zero-padded transform: rows rho >= R >> zskip are zero (see the load loop)
+    uint32_t radix4;  // stage loop: two stages per LDS round trip (four elements per lane), launched with R / 4 * C threads
 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
@@ -188,9 +189,53 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
     }
     __syncthreads();
 
-    // ---- B radix-2 DIT stages in LDS
+    // ---- B radix-2 DIT stages in LDS.  With `radix4` two consecutive stages share one round trip: a lane takes the four
+    // rows p, p + h, p + 2h, p + 3h (h = 2^s, bits s and s + 1 of p clear), runs the two stage-s butterflies (one
+    // twiddle, index r = p mod h, for both) and the two stage-(s+1) butterflies (indices r and r + h) in registers and
+    // writes the four rows back: half the LDS instructions, address arithmetic and barriers of the stage-by-stage loop,
+    // the same products on the same operands.
+    uint32_t s0 = a.zskip;
+    if (a.radix4) {
+        const uint32_t nunits = total >> 2;
+        for (; s0 + 1 < B; s0 += 2) {
+            const uint32_t s = s0, h = 1u << s;
+            const uint32_t log_per = (B - 2 + log_c) - s;  // units that share one r: 2^log_per
+            const bool by_r = s != 0 && log_per >= 6 && (nthreads & 63) == 0;
+            for (uint32_t t = tid; t < nunits; t += nthreads) {
+                uint32_t c, r, p;
+                if (by_r) {
+                    r = t >> log_per;
+                    const uint32_t j = t & ((1u << log_per) - 1);
+                    c = j & (C - 1);
+                    p = ((j >> log_c) << (s + 2)) | r;
+                } else {
+                    c = t & (C - 1);
+                    const uint32_t b = t >> log_c;
+                    r = b & (h - 1);
+                    p = ((b >> s) << (s + 2)) | r;
+                }
+                const uint32_t i0 = (p << log_c) + c, step = h << log_c;
+                Fr x0 = lds_get(t_lo, t_hi, i0), x1 = lds_get(t_lo, t_hi, i0 + step);
+                Fr x2 = lds_get(t_lo, t_hi, i0 + 2 * step), x3 = lds_get(t_lo, t_hi, i0 + 3 * step);
+                const bool unit = s == 0 || (by_r && r == 0);  // the twiddles of index r are 1 (wave-uniform test)
+                if (!unit) {
+                    const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
+                    x1 = fp_mul(x1, wa);
+                    x3 = fp_mul(x3, wa);
+                }
+                Fr y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
+                if (!unit) y2 = fp_mul(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
+                y3 = fp_mul(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
+                lds_put(t_lo, t_hi, i0, fp_add(y0, y2));
+                lds_put(t_lo, t_hi, i0 + 2 * step, fp_sub(y0, y2));
+                lds_put(t_lo, t_hi, i0 + step, fp_add(y1, y3));
+                lds_put(t_lo, t_hi, i0 + 3 * step, fp_sub(y1, y3));
+            }
+            __syncthreads();
+        }
+    }
     const uint32_t nbf = total >> 1;
-    for (uint32_t s = a.zskip; s < B; s++) {
+    for (uint32_t s = s0; s < B; s++) {
         const uint32_t h = 1u << s;
         const uint32_t log_per = (B - 1 + log_c) - s;  // butterflies that share one twiddle index r: 2^log_per
         const bool by_r = s != 0 && log_per >= 6 && (nthreads & 63) == 0;
@@ -414,6 +459,11 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             a.log_c = log_c;
             uint32_t R = 1u << B, C = 1u << log_c;
             uint32_t threads = (R >> 1) * C;
+            // two stages per LDS round trip: four elements per lane, half the threads per tile (H2_NTT_RADIX4=0: one stage)
+            static const bool radix4 = !(getenv("H2_NTT_RADIX4") && atoi(getenv("H2_NTT_RADIX4")) == 0);
+            // (transforms below 2^18 are latency-bound chains of a few tiles: more lanes per tile finish them sooner)
+            a.radix4 = (radix4 && B >= 2 && threads >= 128 && L >= 18) ? 1u : 0u;
+            if (a.radix4) threads >>= 1;
             if (threads < 64) threads = 64;
             if (threads > 512) threads = 512;
             uint32_t ntiles = (1u << L) / (R * C);
