@@ -123,6 +123,7 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const 
     hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+template <bool RADIX4>
 __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
     const uint32_t B = a.B, R = 1u << B, log_c = a.log_c, C = 1u << log_c;
     uint4* t_lo = h2_smem;                  // R*C low halves
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
     // writes the four rows back: half the LDS instructions, address arithmetic and barriers of the stage-by-stage loop,
     // the same products on the same operands.
     uint32_t s0 = a.zskip;
-    if (a.radix4) {
+    if constexpr (RADIX4) {
         const uint32_t nunits = total >> 2;
         for (; s0 + 1 < B; s0 += 2) {
             const uint32_t s = s0, h = 1u << s;
@@ -387,7 +388,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         a.in = src; a.out = dst; a.tw_bfly = pl->tables; a.tw_lo = pl->tw_lo; a.tw_hi = pl->tw_hi;
         set_scale3(a, pre3, post3); a.log_n = 0; a.B = 0; a.s_log = 0; a.t_log = 0; a.nprev = 0;
         a.is_last = 1; a.in_len = in_len; a.log_c = 0;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
+        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
         H2_HIP(hipGetLastError());
         return;
     }
@@ -468,7 +469,10 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             if (threads > 512) threads = 512;
             uint32_t ntiles = (1u << L) / (R * C);
             size_t lds = ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
-            hipLaunchKernelGGL(k_ntt_pass, dim3(ntiles), dim3(threads), lds, stream, a);
+            if (a.radix4)
+                hipLaunchKernelGGL(k_ntt_pass<true>, dim3(ntiles), dim3(threads), lds, stream, a);
+            else
+                hipLaunchKernelGGL(k_ntt_pass<false>, dim3(ntiles), dim3(threads), lds, stream, a);
         }
         consumed += B;
     }
