@@ -62,6 +62,9 @@ SYMBOLS = {
     "h2_dev_batch_unmont": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_max_scalar_bits": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "h2_dev_random_points": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
+    "h2_dev_bases_precompute": (ctypes.c_int, [_vp, _sz, ctypes.c_uint32, _vp]),
+    "h2_dev_bases_forget": (ctypes.c_int, [_vp]),
+    "h2_dev_bases_precompute_bytes": (_sz, [_sz, ctypes.c_uint32]),
     "h2_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_eval_polynomial": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
     "h2_dev_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),

@@ -373,6 +373,18 @@ int h2_dev_msm_batch(const void* const* d_scalars, size_t count, const void* d_b
     });
 }
 
+int h2_dev_bases_precompute(const void* d_bases, size_t n, uint32_t digits, void* stream) {
+    if (n && !d_bases) return bad("h2_dev_bases_precompute: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return bases_precompute((const uint64_t*)d_bases, n, digits, pick_stream(ctx, stream));
+    });
+}
+int h2_dev_bases_forget(const void* d_bases) {
+    return guarded([&] { return bases_forget((const uint64_t*)d_bases); });
+}
+size_t h2_dev_bases_precompute_bytes(size_t n, uint32_t digits) { return bases_precompute_bytes(n, digits); }
+
 int h2_dev_random_points(uint64_t seed, size_t n, void* d_out, void* stream) {
     if (!d_out && n) return bad("h2_dev_random_points: null argument");
     return guarded([&] {

@@ -60,6 +60,8 @@ struct MsmShape {
     uint32_t wfull;             // windows 0 .. wfull - 1 are c bits wide, the rest c - 1 (see msm_shape)
     uint32_t R, range_shift;    // row ranges: rows i >> range_shift = r use windows r * W .. r * W + W - 1 (see msm_shape)
     uint32_t cols, Wc;          // fused multi-column shape: `cols` columns x Wc = W + 1 windows each (cols = 0: one MSM)
+    uint32_t tab;               // 1: shifted-base table (see ShiftTable): the W digits of a scalar share ONE window of nb buckets
+    size_t tab_stride;          // points per level of the table: digit w of row i adds table[w * tab_stride + i]
     size_t off_coltab;          // fused: per-column scalar pointers (8 B) and dominant values (32 B)
     uint32_t log_s;             // slice length S = 2^log_s entries
     uint32_t lo_bits, hi_bits;  // bucket id = hi (partition inside the window) : lo (bin inside the partition)
@@ -195,9 +197,131 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     return s;
 }
 
-// sized for the larger of the two shapes (with the extra window of a dominant scalar)
+// ---------------------------------------------------------------- shifted-base tables
+// A base table that is committed against again and again (the SRS: `params.g`, `params.g_lagrange`,
+// poly/commitment.rs:148-170) can be expanded ONCE into T[j][i] = [2^(o_j)] P_i, o_j = the bit offset of digit j
+// (h2_dev_bases_precompute; D x n x 64 B -- 12 GiB for 2^24 points, which is what 288 GB of HBM are for).  Digit j of
+// scalar i then adds T[j][i] into bucket |d| - 1 of a bucket set SHARED by all digits:
+//     sum_i s_i P_i = sum_i sum_j d_ij [2^(o_j)] P_i = sum_b (b + 1) * (sum of the +-T[j][i] with |d_ij| = b + 1),
+// so the number of buckets no longer grows with the number of windows and the windows can be much wider than 17 bits:
+// 12 digits of 22 / 21 bits instead of 15 of 17 at 2^24 (a fifth of the additions gone), one k_reduce window instead
+// of 15-20 (the latency-bound tail of small MSMs), no Horner on the host.  Semantics unchanged (arithmetic.rs:20-108).
+struct ShiftTable {
+    const Affine* table;  // level 0 = a copy of the bases
+    size_t n;             // points per level
+    uint32_t D, c, wfull; // digits; digit j is c bits wide for j < wfull, c - 1 after (balanced cut of 255 bits)
+};
+
+// digits a scalar below 2^max_bits needs: the signed top digit must not carry out, i.e. o_(j+1) >= max_bits + 1
+static uint32_t table_digits_used(const ShiftTable& t, uint32_t max_bits) {
+    uint32_t off = 0;
+    for (uint32_t j = 0; j < t.D; j++) {
+        off += t.c - (j >= t.wfull ? 1u : 0u);
+        if (off >= max_bits + 1) return j + 1;
+    }
+    return t.D;
+}
+
+static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const ShiftTable& t) {
+    MsmShape s{};
+    if (max_bits > 254) max_bits = 254;
+    if (max_bits == 0) max_bits = 1;
+    s.n = n;
+    s.tab = 1;
+    s.tab_stride = t.n;
+    s.c = t.c;
+    s.wfull = t.wfull;
+    s.W = table_digits_used(t, max_bits);
+    s.Wk = s.W + (hot ? 1u : 0u);
+    s.Wt = 1 + (hot ? 1u : 0u);
+    s.R = 1;
+    s.range_shift = 31;
+    s.Wc = s.W + 1;
+    s.nb = 1u << (s.c - 1);
+    s.nbt = s.Wt * s.nb;
+    // k_reduce: every quad pays a ~(c + c / 2)-step scalar multiplication to lift its chunk, so the chunks are as long
+    // as still leaves a workgroup per CU (<= 64 buckets: a chain of 128 additions)
+    s.qm = 4;
+    while (s.qm < 64 && (s.nb + REDUCE_T / 4 * s.qm - 1) / (REDUCE_T / 4 * s.qm) > 256) s.qm *= 2;
+    if (const char* env = getenv("H2_MSM_REDUCE_QM")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) s.qm = (uint32_t)v;
+    }
+    const uint32_t per_group = REDUCE_T / 4 * s.qm;
+    s.RG = (s.nb + per_group - 1) / per_group;
+    s.G = 1;
+    s.entries = n * s.Wk;
+    s.log_s = 6;
+    while (s.log_s > 3 && (s.entries >> s.log_s) < (1u << 18)) s.log_s--;
+    while (s.log_s < 10 && (s.entries >> (s.log_s + 1)) >= (1u << 20) && ((s.entries / s.nb) >> s.log_s) > 2) s.log_s++;
+    if (const char* env = getenv("H2_MSM_SLICE_LOG")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 10) s.log_s = (uint32_t)v;
+    }
+    // sort: 2^8 bins per k_bucket_sort workgroup -- with more, the lines its scattered stores keep open (bins x resident
+    // workgroups x 128 B) outgrow the L2 (measured at 2^24, 21-bit bucket ids: 2^8 bins 1.6 ms, 2^10 3.5 ms, 2^12 5.1 ms;
+    // k_partition over the remaining 2^13 partitions 3.0 / 2.5 / 2.0 ms) -- up to 2^13 partitions for k_partition
+    s.lo_bits = (s.c - 1 < 8) ? (s.c - 1) : 8;
+    while (s.c - 1 - s.lo_bits > 13 && s.lo_bits < 12) s.lo_bits++;
+    if (const char* env = getenv("H2_MSM_TABLE_LO")) {
+        int v = atoi(env);
+        if (v >= 4 && v <= 12 && (uint32_t)v <= s.c - 1 && s.c - 1 - (uint32_t)v <= 13) s.lo_bits = (uint32_t)v;
+    }
+    s.hi_bits = s.c - 1 - s.lo_bits;
+    s.np = s.Wt << s.hi_bits;
+    s.max_items = (s.entries >> s.log_s) + s.nbt + 2;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes, 256);
+        return r;
+    };
+    s.off_keys = take(s.entries * 4);
+    s.off_sorted = take(s.entries * 4);
+    s.off_tmp = take(s.entries * 8);
+    s.off_pcount = take(((size_t)s.np + 2) * 4);
+    s.off_pbase = take(((size_t)s.np + 2) * 4);
+    s.off_pcursor = take(((size_t)s.np + 2) * 4);
+    s.off_starts = take(((size_t)s.nbt + 2) * 4);
+    s.off_heavy = take(((size_t)s.nbt + 2) * 4);
+    s.off_partials = take(s.max_items * sizeof(XYZZ));
+    s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
+    s.off_winpart = take((size_t)s.Wt * (1 + s.RG) * sizeof(XYZZ));
+    s.off_rcount = take((size_t)s.Wt * 4);
+    s.off_coltab = take(64);
+    s.total = o;
+    return s;
+}
+
+namespace {
+std::mutex g_tab_mu;
+std::map<const uint64_t*, ShiftTable> g_tables;  // device base pointer -> its table
+}  // namespace
+
+// table whose bases contain [d_bases, d_bases + n): a view that starts at d_bases's row.  Used when it saves additions.
+static bool table_lookup(const uint64_t* d_bases, size_t n, uint32_t max_bits, ShiftTable* out) {
+    if (const char* env = getenv("H2_MSM_NO_TABLE"))
+        if (env[0] == '1') return false;
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    auto it = g_tables.upper_bound(d_bases);
+    if (it == g_tables.begin()) return false;
+    --it;
+    if (d_bases + 8 * n > it->first + 8 * it->second.n) return false;
+    ShiftTable t = it->second;
+    t.table += (d_bases - it->first) / 8;
+    // narrow columns: the plain pipeline's row ranges and fused groups are built for them, and a table saves nothing
+    if (table_digits_used(t, max_bits) >= msm_shape(n, max_bits, false).W) return false;
+    *out = t;
+    return true;
+}
+
+// sized for the larger of the two shapes (with the extra window of a dominant scalar), table forms included
 size_t msm_scratch_bytes(size_t n, uint32_t max_bits) {
-    return std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
+    size_t need = std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    for (const auto& kv : g_tables)
+        if (kv.second.n >= n) need = std::max(need, msm_shape_table(n, max_bits, true, kv.second).total);
+    return need;
 }
 // scratch that lets h2_dev_msm_batch(_ex) fuse `count` columns of bound `max_bits` over one base table
 size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
@@ -228,7 +352,8 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
                                                 uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
                                                 const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
-                                                uint32_t range_shift, uint32_t R, uint32_t wfull) {
+                                                uint32_t range_shift, uint32_t R, uint32_t wfull, uint32_t tabmode) {
+    // tabmode (shifted-base table): every digit's bucket belongs to window 0, the dominant-scalar window is window 1
     if (col_scalars != nullptr) {
         const uint32_t col = blockIdx.y;
         scalars = col_scalars[col];
@@ -246,7 +371,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             const bool is_hot = hot_on && fp_eq(raw, hot);
             const uint64_t m = __ballot(is_hot);
             if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
-                atomicAdd(&hist[(R * W) << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
+                atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
             keys[(size_t)W * n + i] = is_hot ? 0u : KEY_INVALID;
             if (is_hot) {
                 for (uint32_t w = 0; w < W; w++) keys[(size_t)w * n + i] = KEY_INVALID;
@@ -267,6 +392,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
         int nbits = 0;
         uint32_t w = 0, carry = 0;
         const uint32_t vw0 = (uint32_t)(i >> range_shift) * W;  // first window of this row's range
+        const uint32_t wstep = tabmode ? 0u : 1u;
         auto emit = [&](uint32_t raw, uint32_t cw) {  // cw: width of window w
             raw += carry;
             uint32_t neg = 0, mag = raw;
@@ -281,7 +407,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             if (mag != 0) {
                 uint32_t bucket = mag - 1;
                 out = bucket | neg;
-                atomicAdd(&hist[((vw0 + w) << hi_bits) + (bucket >> lo_bits)], 1u);
+                atomicAdd(&hist[((vw0 + w * wstep) << hi_bits) + (bucket >> lo_bits)], 1u);
             }
             keys[(size_t)w * n + i] = out;
             w++;
@@ -330,6 +456,29 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + x - v;
 }
 
+// the same over the SORT_T = 1024 threads (16 waves) of k_bucket_sort
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sh, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= (uint32_t)off) x += y;
+    }
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t t = sh[w];
+        if (w < wave) base += t;
+        all += t;
+    }
+    *total = all;
+    __syncthreads();
+    return base + x - v;
+}
+
 // pbase[p] = sum_{p' < p} pcount[p'] (p <= np), pcursor = pbase, starts[nbt] = total entries
 __global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint32_t np, uint32_t* pbase,
                                                     uint32_t* pcursor, uint32_t* starts, uint32_t nbt) {
@@ -359,12 +508,18 @@ __global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint
 // partition land in a contiguous run, so the 8-byte stores of a workgroup merge into full lines.
 __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t hi_bits,
                                                    uint32_t* pcursor, uint2* tmp, uint32_t range_shift, uint32_t W,
-                                                   uint32_t R) {
+                                                   uint32_t R, uint32_t tab_stride) {
     uint32_t* cnt = h2_msm_smem;               // 2^hi_bits local counters, then the reserved bases
     const uint32_t nparts = 1u << hi_bits, w = blockIdx.y;
     // window of these PART_T rows: ranges are multiples of PART_T rows; key array W (if present) is the dominant-scalar
-    // window, which is not cut into ranges
-    const uint32_t vw = (R > 1) ? (w == W ? R * W : (uint32_t)(((size_t)blockIdx.x * PART_T) >> range_shift) * W + w) : w;
+    // window, which is not cut into ranges.  Shifted-base table (tab_stride != 0): digit array w feeds window 0 with the
+    // points of table level w; the dominant-scalar array feeds window 1 with the bases themselves (level 0)
+    uint32_t vw = (R > 1) ? (w == W ? R * W : (uint32_t)(((size_t)blockIdx.x * PART_T) >> range_shift) * W + w) : w;
+    uint32_t level_base = 0;
+    if (tab_stride) {
+        vw = (w == W) ? 1u : 0u;
+        level_base = (w == W) ? 0u : w * tab_stride;
+    }
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
     const uint32_t ITEMS = PART_T / 256;
@@ -387,7 +542,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
     for (uint32_t k = 0; k < ITEMS; k++) {
         if (key[k] == KEY_INVALID) continue;
         uint32_t bucket = key[k] & ~SIGN_BIT;
-        uint32_t i = (uint32_t)(i0 + k * 256 + threadIdx.x);
+        uint32_t i = level_base + (uint32_t)(i0 + k * 256 + threadIdx.x);
         tmp[cnt[bucket >> lo_bits] + rank[k]] = make_uint2(i | (key[k] & SIGN_BIT), bucket & ((1u << lo_bits) - 1));
     }
 }
@@ -424,7 +579,7 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
                                                         uint32_t hot_partition, uint32_t hot_wc, uint64_t hot_mask,
                                                         uint32_t* starts, uint32_t* sorted) {
     uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
-    __shared__ uint32_t sh[4];
+    __shared__ uint32_t sh[16];
     const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
     const uint32_t e0 = pbase[p], e1 = pbase[p + 1];
     bool is_hot_partition = p == hot_partition;
@@ -454,11 +609,12 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
         }
     }
     __syncthreads();
-    // exclusive scan of nbins (<= 512) counters by the first 256 threads: (nbins / 256) consecutive bins each
-    const uint32_t per = (nbins + 255) / 256;
-    uint32_t local[2] = {0, 0}, sum = 0;
-    if (threadIdx.x < 256) {
-        for (uint32_t k = 0; k < per; k++) {
+    // exclusive scan of the nbins (<= 4096) counters: (nbins / SORT_T) consecutive bins per thread
+    const uint32_t per = (nbins + SORT_T - 1) / SORT_T;
+    uint32_t local[4] = {0, 0, 0, 0}, sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < per) {
             uint32_t b = threadIdx.x * per + k;
             uint32_t v = b < nbins ? bins[b] : 0;
             local[k] = sum;
@@ -468,20 +624,20 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
     __syncthreads();
     // bucket index of bin b of partition p: window w = p >> hi_bits, bucket = ((p & (2^hi_bits - 1)) << lo_bits) | b
     const uint32_t w = p >> hi_bits, hi = p & ((1u << hi_bits) - 1);
-    if (threadIdx.x < 256) {  // the first four waves, whole: the scan's barriers are matched below
+    {
         uint32_t total;
-        uint32_t ex = block_exclusive_scan_256(sum, sh, &total);
-        for (uint32_t k = 0; k < per; k++) {
-            uint32_t b = threadIdx.x * per + k;
-            if (b < nbins) {
-                uint32_t st = e0 + ex + local[k];
-                bins[b] = st;
-                starts[(size_t)w * nb + ((hi << lo_bits) | b)] = st;
+        uint32_t ex = block_exclusive_scan_1024(sum, sh, &total);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (k < per) {
+                uint32_t b = threadIdx.x * per + k;
+                if (b < nbins) {
+                    uint32_t st = e0 + ex + local[k];
+                    bins[b] = st;
+                    starts[(size_t)w * nb + ((hi << lo_bits) | b)] = st;
+                }
             }
         }
-    } else {
-        __syncthreads();  // block_exclusive_scan_256 holds two barriers
-        __syncthreads();
     }
     __syncthreads();
     if (!skewed) {
@@ -735,7 +891,8 @@ __global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32
     __syncthreads();
     if (!last_flag) return;
     __threadfence();
-    res = qd < RG ? xyzz_load_coherent(groups + (size_t)w * RG + qd) : xyzz_identity();
+    res = xyzz_identity();
+    for (uint32_t g2 = qd; g2 < RG; g2 += REDUCE_T / 4) res = xyzz_add_q(res, xyzz_load_coherent(groups + (size_t)w * RG + g2), q);
     res = quad_tree_sum<REDUCE_T / 4>(res, sh, qd, q);
     if (qd == 0) xyzz_store_q(winsum + w, res, q);
 }
@@ -942,6 +1099,133 @@ int fixed_base_mul_launch(const Fr* d_scalars, const uint64_t* d_table, size_t n
     return H2_OK;
 }
 
+// ---------------------------------------------------------------- shifted-base table build (h2_dev_bases_precompute)
+// One lane per base point: level j = [2^(width of digit j - 1)] level j - 1 by Jacobian doublings (a = 0, 2M + 5S
+// [dbl-2009-l]; BN254 G1 has prime order, so a doubling never meets the identity), X and Y parked in the table slot and
+// Z kept per level; then ONE inversion for all levels of the point (Montgomery's trick) and x = X / Z^2, y = Y / Z^3.
+// ~2300 field products per point: 0.3 s for 2^24 points, paid once per SRS.
+static constexpr uint32_t TABLE_MAX_D = 32;
+
+__global__ void __launch_bounds__(256) k_table_build(const Affine* bases, size_t n, size_t stride, uint32_t D, uint32_t c,
+                                                     uint32_t wfull, Affine* table) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine p = affine_load(bases + i);
+    fp_store(&table[i].x, p.x);
+    fp_store(&table[i].y, p.y);
+    if (affine_is_identity(p)) {
+        const Fq zero = fp_zero<FqParams>();
+        for (uint32_t j = 1; j < D; j++) {
+            fp_store(&table[j * stride + i].x, zero);
+            fp_store(&table[j * stride + i].y, zero);
+        }
+        return;
+    }
+    Fq z[TABLE_MAX_D], pre[TABLE_MAX_D];
+    Fq X = p.x, Y = p.y, Z = fp_one<FqParams>();
+#pragma unroll 1
+    for (uint32_t j = 1; j < D; j++) {
+        const uint32_t cw = c - ((j - 1) >= wfull ? 1u : 0u);
+#pragma unroll 1
+        for (uint32_t k = 0; k < cw; k++) {
+            const Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B);
+            Fq Dd = fp_sub(fp_sub(fp_sqr(fp_add(X, B)), A), C);
+            Dd = fp_dbl(Dd);
+            const Fq E = fp_add(fp_dbl(A), A);
+            const Fq F = fp_sqr(E);
+            const Fq Z3 = fp_dbl(fp_mul(Y, Z));
+            X = fp_sub(F, fp_dbl(Dd));
+            const Fq C8 = fp_dbl(fp_dbl(fp_dbl(C)));
+            Y = fp_sub(fp_mul(E, fp_sub(Dd, X)), C8);
+            Z = Z3;
+        }
+        fp_store(&table[j * stride + i].x, X);
+        fp_store(&table[j * stride + i].y, Y);
+        z[j] = Z;
+        pre[j] = j == 1 ? Z : fp_mul(pre[j - 1], Z);
+    }
+    if (D < 2) return;
+    Fq inv = fq_inv_device(pre[D - 1]);
+#pragma unroll 1
+    for (uint32_t j = D - 1; j >= 1; j--) {
+        const Fq zinv = j == 1 ? inv : fp_mul(inv, pre[j - 1]);
+        inv = fp_mul(inv, z[j]);
+        const Fq zi2 = fp_sqr(zinv);
+        Affine* slot = table + (j * stride + i);
+        fp_store(&slot->x, fp_mul(fp_load(&slot->x), zi2));
+        fp_store(&slot->y, fp_mul(fp_load(&slot->y), fp_mul(zi2, zinv)));
+    }
+}
+
+// digits for a table over n points: fewest additions D * n plus the bucket-proportional tail (k_finish, k_reduce: ~8
+// additions' worth per bucket), buckets 2^(c - 1) with c = ceil(255 / D) <= 23
+static uint32_t table_default_digits(size_t n) {
+    if (const char* env = getenv("H2_MSM_TABLE_DIGITS")) {
+        int v = atoi(env);
+        if (v >= 8 && v <= (int)TABLE_MAX_D) return (uint32_t)v;
+    }
+    double best = 1e300;
+    uint32_t best_d = 16;
+    for (uint32_t D = 12; D <= TABLE_MAX_D; D++) {
+        const uint32_t c = (255 + D - 1) / D;
+        const double cost = (double)D * (double)n + 8.0 * (double)(1u << (c - 1));
+        if (cost < best) {
+            best = cost;
+            best_d = D;
+        }
+    }
+    return best_d;
+}
+
+size_t bases_precompute_bytes(size_t n, uint32_t digits) {
+    if (digits == 0) digits = table_default_digits(n);
+    return (size_t)digits * n * sizeof(Affine);
+}
+
+int bases_forget(const uint64_t* d_bases) {
+    Affine* old = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        auto it = g_tables.find(d_bases);
+        if (it == g_tables.end()) return H2_OK;
+        old = const_cast<Affine*>(it->second.table);
+        g_tables.erase(it);
+    }
+    H2_HIP(hipDeviceSynchronize());  // nothing in flight reads the table
+    H2_HIP(hipFree(old));
+    return H2_OK;
+}
+
+int bases_precompute(const uint64_t* d_bases, size_t n, uint32_t digits, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    if (digits == 0) digits = table_default_digits(n);
+    if (digits < 8 || digits > TABLE_MAX_D || (size_t)digits * n >= ((size_t)1 << 31)) {
+        set_last_error("h2 bases_precompute: digits must be 8..32 and digits * n < 2^31 (table rows are indexed with 31 bits)");
+        return H2_ERR_INVALID;
+    }
+    bases_forget(d_bases);
+    ShiftTable t{};
+    t.n = n;
+    t.D = digits;
+    const uint32_t T = 255, base = T / digits, rem = T % digits;  // the balanced cut of msm_shape
+    t.c = rem ? base + 1 : base;
+    t.wfull = rem ? rem : digits;
+    Affine* table = nullptr;
+    H2_HIP(hipMalloc(&table, (size_t)digits * n * sizeof(Affine)));
+    hipLaunchKernelGGL(k_table_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const Affine*)d_bases, n, n,
+                       t.D, t.c, t.wfull, table);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        hipFree(table);
+        H2_HIP(e);
+    }
+    t.table = table;
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    g_tables[d_bases] = t;
+    return H2_OK;
+}
+
 // The window sums (one point per window, a few KB) go back to the host through a store kernel into mapped pinned
 // memory rather than hipMemcpyAsync: a DMA-engine copy queues behind whatever bulk transfer is in flight (the prover
 // uploads the next witness column while it commits the current one) and would stall the MSM for the whole transfer.
@@ -1024,19 +1308,20 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
         const uint32_t np_col = s.Wc << s.hi_bits;
         hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
                            s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
-                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull);
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull, 0u);
     } else {
         hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
                            max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
                            hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R,
-                           s.wfull);
+                           s.wfull, s.tab);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     hipLaunchKernelGGL(k_partition, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
-                       (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W, s.R);
+                       (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W, s.R,
+                       (uint32_t)s.tab_stride);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
-    const uint32_t hot_partition = (!fused && hot.on) ? ((s.R * s.W) << s.hi_bits) : 0xffffffffu;
+    const uint32_t hot_partition = (!fused && hot.on) ? ((s.tab ? 1u : s.R * s.W) << s.hi_bits) : 0xffffffffu;
     hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
                        s.hi_bits, s.nb, skew_threshold, hot_partition, fused ? s.Wc : 0u, fused ? fused->hot_mask : 0ull,
                        starts, sorted);
@@ -1057,8 +1342,17 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(4 * HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
     if (s.RG > 1) H2_HIP(hipMemsetAsync(scratch + s.off_rcount, 0, (size_t)s.Wt * 4, stream));
-    hipLaunchKernelGGL(k_reduce, dim3(s.RG, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, s.qm, winpart + s.Wt, winpart,
-                       (uint32_t*)(scratch + s.off_rcount));
+    if (s.tab) {
+        // one window of nb buckets; the dominant-scalar window only ever fills its bucket 0
+        hipLaunchKernelGGL(k_reduce, dim3(s.RG, 1), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, s.qm, winpart + s.Wt,
+                           winpart, (uint32_t*)(scratch + s.off_rcount));
+        if (s.Wt > 1)
+            hipLaunchKernelGGL(k_reduce, dim3(1, 1), dim3(REDUCE_T), 0, stream, buckets + s.nb, 1u, 1u, s.qm,
+                               winpart + s.Wt, winpart + 1, (uint32_t*)(scratch + s.off_rcount));
+    } else {
+        hipLaunchKernelGGL(k_reduce, dim3(s.RG, s.Wt), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, s.qm, winpart + s.Wt,
+                           winpart, (uint32_t*)(scratch + s.off_rcount));
+    }
     H2_HIP(hipGetLastError());
 }
 
@@ -1066,7 +1360,8 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
 static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12],
                           size_t w0 = 0) {  // w0: first window of the column inside a fused shape
     XYZZ acc = xyzz_identity();
-    for (int w = (int)s.W - 1; w >= 0; w--) {
+    if (s.tab) acc = winpart[w0];  // the digits' weights are in the table's points: one window, no Horner
+    for (int w = (int)(s.tab ? 0 : s.W) - 1; w >= 0; w--) {
         const uint32_t cw = s.c - ((uint32_t)w >= s.wfull ? 1u : 0u);  // the windows above w sit 2^cw higher
         for (uint32_t k = 0; k < cw; k++) acc = xyzz_double(acc);
         XYZZ ws = xyzz_identity();
@@ -1075,7 +1370,7 @@ static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<X
     }
     if (hot.on) {  // + v * E, E = the extra window's sum (bucket 0 carries weight 1)
         XYZZ e = xyzz_identity();
-        e = winpart[w0 + (size_t)s.R * s.W];
+        e = winpart[w0 + (s.tab ? 1u : (size_t)s.R * s.W)];
         const Fr v = fp_from_mont(hot.value);
         XYZZ r = xyzz_identity();
         for (int bit = 253; bit >= 0; bit--) {
@@ -1098,6 +1393,8 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         set_last_error("h2 msm: n * windows must be < 2^32 (sorted entries are indexed with 32 bits): split the MSM");
         return H2_ERR_INVALID;
     }
+    ShiftTable tab{};
+    const bool use_tab = table_lookup(d_bases, n, max_bits, &tab);
     if (!d_scratch || scratch_bytes < msm_scratch_bytes(n, max_bits)) {
         set_last_error("h2 msm: scratch too small (see h2_msm_scratch_bytes)");
         return H2_ERR_INVALID;
@@ -1111,8 +1408,8 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     // the extra window trades W additions per dominant row for one: with one or two windows there is nothing to gain,
     // only a giant bucket to fold and a 254-bit multiplication on the host
     if (hot.on && msm_shape(n, max_bits, false).W <= 2) hot.on = false;
-    MsmShape s = msm_shape(n, max_bits, hot.on);
-    msm_launch(s, hot, d_scalars, (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
+    MsmShape s = use_tab ? msm_shape_table(n, max_bits, hot.on, tab) : msm_shape(n, max_bits, hot.on);
+    msm_launch(s, hot, d_scalars, use_tab ? tab.table : (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
     const size_t wp = (size_t)s.Wt * s.G;
     XYZZ* h_win = (XYZZ*)staging.get(wp * sizeof(XYZZ));
     export_to_host((const XYZZ*)((char*)d_scratch + s.off_winpart), h_win, wp, stream);
@@ -1214,10 +1511,18 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     // columns that share their base table and their bound are committed as fused groups when the caller's scratch
     // allows it (h2_msm_batch_scratch_bytes); the rest goes through the two-stream pipeline below
     std::vector<char> done_fused(count, 0);
+    // columns whose bases have a shifted-base table go through the pipeline in table form
+    std::vector<ShiftTable> tabs(count);
+    std::vector<char> use_tab(count, 0);
+    for (size_t i = 0; i < count; i++) {
+        const uint32_t bits = bits_each ? bits_each[i] : max_bits;
+        const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
+        if (bits && bases) use_tab[i] = table_lookup(bases, n, bits, &tabs[i]) ? 1 : 0;
+    }
     if (getenv("H2_MSM_NO_FUSE") == nullptr) {
         H2_HIP(hipStreamSynchronize(stream));
         for (size_t i = 0; i < count; i++) {
-            if (done_fused[i]) continue;
+            if (done_fused[i] || use_tab[i]) continue;
             const uint32_t bits = bits_each ? bits_each[i] : max_bits;
             if (bits == 0) continue;
             const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
@@ -1225,7 +1530,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
             for (size_t j = i + 1; j < count; j++) {
                 const uint32_t bj = bits_each ? bits_each[j] : max_bits;
                 const uint64_t* basej = bases_each && bases_each[j] ? bases_each[j] : d_bases;
-                if (!done_fused[j] && bj == bits && basej == bases) members.push_back(j);
+                if (!done_fused[j] && !use_tab[j] && bj == bits && basej == bases) members.push_back(j);
             }
             const uint32_t limit = fused_group_limit(n, bits);
             for (size_t m0 = 0; m0 < members.size(); m0 += limit) {
@@ -1249,8 +1554,8 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     for (size_t i = 0; i < count; i++) {
         const uint32_t bits = bits_each ? bits_each[i] : max_bits;
         if (done_fused[i]) continue;
-        shapes[2 * i] = msm_shape(n, bits ? bits : 1, false);
-        shapes[2 * i + 1] = msm_shape(n, bits ? bits : 1, true);
+        shapes[2 * i] = use_tab[i] ? msm_shape_table(n, bits, false, tabs[i]) : msm_shape(n, bits ? bits : 1, false);
+        shapes[2 * i + 1] = use_tab[i] ? msm_shape_table(n, bits, true, tabs[i]) : msm_shape(n, bits ? bits : 1, true);
         per = std::max(per, align_up(std::max(shapes[2 * i].total, shapes[2 * i + 1].total), 256));
         wp_max = std::max(wp_max, (size_t)shapes[2 * i + 1].Wt * shapes[2 * i + 1].G);
     }
@@ -1288,7 +1593,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         char* scratch = (char*)d_scratch + (lane_of % lanes) * per;
         hipStream_t q = st[lane_of % lanes];
         lane_of++;
-        msm_launch(s, hots[i], d_scalars[i], (const Affine*)bases, bits, scratch, q);
+        msm_launch(s, hots[i], d_scalars[i], use_tab[i] ? tabs[i].table : (const Affine*)bases, bits, scratch, q);
         export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         H2_HIP(hipEventRecord(done[i], q));

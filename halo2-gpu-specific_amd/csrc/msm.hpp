@@ -28,6 +28,11 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
                         void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
 int fixed_base_mul_launch(const Fr* d_scalars, const uint64_t* d_table, size_t n, uint64_t* d_out, hipStream_t stream);
 size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
+// shifted-base table of a device-resident base set (msm.hip "shifted-base tables"): built once, used by every
+// msm_device* call whose bases lie inside [d_bases, d_bases + n)
+int bases_precompute(const uint64_t* d_bases, size_t n, uint32_t digits, hipStream_t stream);
+int bases_forget(const uint64_t* d_bases);
+size_t bases_precompute_bytes(size_t n, uint32_t digits);
 int g1_fold_launch(const uint64_t* d_points, uint32_t world, uint32_t count, uint64_t* d_out, hipStream_t stream);
 
 }  // namespace h2

@@ -322,6 +322,19 @@ int h2_dev_msm_batch(const void *const *d_scalars, size_t count, const void *d_b
 size_t h2_msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
 int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases_each, const uint32_t *max_bits_each,
                         size_t count, size_t n, void *d_scratch, size_t scratch_bytes, uint64_t *out_xyz, void *stream);
+/* Shifted-base table for a device-resident base set that is committed against repeatedly -- the SRS (`params.g`,
+ * `params.g_lagrange`: poly/commitment.rs:148-170 `commit` / `commit_lagrange`; the reference re-uploads them per call,
+ * arithmetic.rs:354-360).  Builds T[j][i] = [2^(o_j)] bases[i] for the `digits` digit offsets o_j (0 = chosen from n:
+ * 12 at 2^24, 15 at 2^20) in library-owned device memory (h2_dev_bases_precompute_bytes: digits x n x 64 B) and
+ * remembers it under `d_bases`.  From then on every h2_dev_msm / _batch / _batch_ex whose bases lie inside
+ * [d_bases, d_bases + n) and whose bound needs more windows than digits adds all digits of a scalar into ONE shared
+ * bucket set: ~20 % fewer point additions at 2^24, one reduction instead of one per window, no host Horner.  Same group
+ * element (multiexp_serial, arithmetic.rs:20-108).  Call it before sizing scratch with h2_msm_scratch_bytes.  The
+ * bases must not change while the table exists; h2_dev_bases_forget(d_bases) frees it (synchronises the device).
+ * H2_MSM_NO_TABLE=1 in the environment ignores all tables.  Synchronous (~0.3 s at 2^24). */
+int h2_dev_bases_precompute(const void *d_bases, size_t n, uint32_t digits, void *stream);
+int h2_dev_bases_forget(const void *d_bases);
+size_t h2_dev_bases_precompute_bytes(size_t n, uint32_t digits);
 int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_t l_rot, int32_t r_rot, size_t size,
                    const uint64_t c[4], void *stream);
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);

