@@ -143,6 +143,10 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
             fr_mul(&h[4 * i], v, RR);
         }
     }
+    if (const char* hot = getenv("H2BENCH_HOT")) {  // a column that is constant over all rows but the first n / HOT
+        const size_t keep = n / (size_t)std::max(1, atoi(hot));
+        for (size_t i = keep; i < n; i++) memcpy(&h[4 * i], &h[4 * 5], 32);
+    }
     void *d_s, *d_b, *d_scr;
     CK(hipMalloc(&d_s, n * 32));
     CK(hipMalloc(&d_b, n * 64));

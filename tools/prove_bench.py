@@ -25,7 +25,7 @@ def main():
     t2 = time.perf_counter()
     pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
     t3 = time.perf_counter()
-    print("k=%d  srs %.3fs  synthesize %.3fs  keygen %.3fs" % (k, t1 - t0, t2 - t1, t3 - t2))
+    print("k=%d  srs %.3fs (tables %.1f GiB)  synthesize %.3fs  keygen %.3fs" % (k, t1 - t0, params.table_bytes / 2**30, t2 - t1, t3 - t2))
     for rep in range(reps):
         timings = {}
         ta = time.perf_counter()
