@@ -1697,7 +1697,8 @@ int bases_unregister(const uint64_t* bases) {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->resident.find((const void*)bases);
         if (it != ctx->resident.end()) {
-            hipFree(it->second.ptr);
+            bases_forget((const uint64_t*)it->second.ptr);
+            (void)hipFree(it->second.ptr);
             ctx->resident.erase(it);
         }
     }
@@ -1716,7 +1717,8 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         for (auto it = ctx->resident.begin(); it != ctx->resident.end();) {
             auto r = g_registered.find((const uint64_t*)it->first);
             if (r == g_registered.end() || r->second.gen != it->second.gen || r->second.len != it->second.len) {
-                hipFree(it->second.ptr);
+                bases_forget((const uint64_t*)it->second.ptr);
+                (void)hipFree(it->second.ptr);
                 it = ctx->resident.erase(it);
             } else {
                 ++it;
@@ -1737,6 +1739,13 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         H2_HIP(hipMalloc(&c.ptr, reg.len * sizeof(Affine)));
         H2_HIP(hipMemcpyAsync(c.ptr, key, reg.len * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
         rit = ctx->resident.emplace((const void*)key, c).first;
+        // a registered SRS is committed against for the life of the process: give its device copy a shifted-base table
+        // when that takes less than half of the free memory (H2_MSM_TABLES=0: never)
+        const char* env = getenv("H2_MSM_TABLES");
+        size_t free_b = 0, total_b = 0;
+        if (!(env && env[0] == '0') && reg.len >= ((size_t)1 << 15) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            bases_precompute_bytes(reg.len, 0) < free_b / 2)
+            bases_precompute((const uint64_t*)c.ptr, reg.len, 0, ctx->stream);
     }
     return (const Affine*)rit->second.ptr + (bases - key) / 8;
 }

@@ -78,7 +78,10 @@ int h2_msm_multi(const uint64_t *scalars, const uint64_t *bases, size_t n, uint3
 /* Resident SRS (an improvement the reference lacks: it re-uploads the bases on every call,
  * arithmetic.rs:354-360).  After h2_bases_register(g, n) every host-buffer MSM whose `bases` range lies
  * inside [g, g + n) uses a device copy uploaded once per device (Params::g / g_lagrange never change,
- * poly/commitment.rs:23-29).  The caller must not modify a registered range before unregistering it. */
+ * poly/commitment.rs:23-29).  The caller must not modify a registered range before unregistering it.
+ * From 2^15 points on the device copy also gets a shifted-base table (see h2_dev_bases_precompute: digits x n x 64 B
+ * more device memory, built on first use, freed with the copy) when that fits in half of the free device memory;
+ * H2_MSM_TABLES=0 in the environment keeps the copy only. */
 int h2_bases_register(const uint64_t *bases, size_t n);
 int h2_bases_unregister(const uint64_t *bases);
 /* Host-side fold of `count` partial results (12 x u64 Jacobian each): the

@@ -165,7 +165,9 @@ pub fn intt<G: Group>(a: &mut [G], omega_inv: &G::Scalar, divisor: &G::Scalar, l
 }
 
 /// Call once after `Params::new` / `Params::read` (poly/commitment.rs:56-124,256-294): later `commit*` calls whose
-/// bases lie inside a registered range skip the 64 B/point upload.  Unregister before the vectors are dropped.
+/// bases lie inside a registered range skip the 64 B/point upload and run over the device copy's shifted-base table
+/// (include/halo2_hip.h, h2_dev_bases_precompute; built by the library on the first MSM).  Unregister before the
+/// vectors are dropped.
 pub fn register_params<C: CurveAffine>(g: &[C], g_lagrange: &[C]) {
     assert_layout::<C>();
     unsafe {
