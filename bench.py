@@ -334,11 +334,17 @@ def main():
         return leg
 
     if not args.no_msm:
-        out["msm"] = dict(workload="BASELINE configs[1]: 2^%d BN254 G1 MSM, uniform 254-bit scalars, resident in HBM" % args.msm_log_n,
-                          **msm_leg(args.msm_log_n, args.msm_steps, 8))
-        if args.k24 and args.msm_log_n != 24:
-            out["msm_k24"] = dict(workload="the metric's k = 24 size: 2^24 BN254 G1 MSM, uniform 254-bit scalars, resident in HBM",
-                                  **msm_leg(24, 3, 0))
+        for key, mlog, msteps, mbatch, what in (
+                ("msm", args.msm_log_n, args.msm_steps, 8, "BASELINE configs[1]: 2^%d BN254 G1 MSM, uniform 254-bit scalars, resident in HBM" % args.msm_log_n),
+                ("msm_k24", 24 if (args.k24 and args.msm_log_n != 24) else 0, 3, 0,
+                 "the metric's k = 24 size: 2^24 BN254 G1 MSM, uniform 254-bit scalars, resident in HBM")):
+            if not mlog:
+                continue
+            try:
+                out[key] = dict(workload=what, **msm_leg(mlog, msteps, mbatch))
+            except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- create_proof legs (configs[3] k = 22; configs[4]'s k = 24)
     def prove_leg(pk_k, steps, verify):
@@ -393,6 +399,26 @@ def main():
             "srs": "Params::unsafe_setup on the device with a fixed trapdoor (g[i] = [s^i]G, g_lagrange[i] = [l_i(s)]G)",
         }
 
+    # N > 1: the proof legs are ONE proof over all ranks -- collectives on the data path.  A rank that fails or stalls
+    # there would leave the others waiting inside RCCL for good, and the line above would never be printed: a watchdog
+    # thread prints what has been measured and ends the process when a leg overruns its budget.
+    watchdog_done = None
+    if world > 1:
+        import threading
+
+        watchdog_done = threading.Event()
+        budget = float(os.environ.get("H2_BENCH_PROOF_BUDGET_S", "240"))
+
+        def watchdog():
+            if watchdog_done.wait(budget):
+                return
+            if rank == 0:
+                out.setdefault("create_proof", {"error": "the multi-rank proof legs did not finish within %.0f s" % budget})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+
     for key, kk, steps in (("create_proof", args.prove_k, args.prove_steps), ("create_proof_k24", 24 if args.k24 else 0, 2)):
         if not kk or (key == "create_proof_k24" and args.prove_k == 24):
             continue
@@ -404,63 +430,68 @@ def main():
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    if watchdog_done is not None:
+        watchdog_done.set()
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:
-        from h2util import Oracle  # the oracle is only the timed CPU baseline here, never the product path
+        try:
+            from h2util import Oracle  # the oracle is only the timed CPU baseline here, never the product path
 
-        oracle = Oracle.get()
-        cores = os.cpu_count() or 1
-        clog = log_n                       # the GPU's own size (2^24)
-        wc = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - clog), R_MOD))
-        # team size: probed on a 2^20 transform (a fraction of a second each), then the full size is timed with the best
-        plog = min(clog, 20)
-        xp = oracle.random_fr(8, 1 << plog)
-        wp = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - plog), R_MOD))
-        best_t, best_th = None, cores
-        for th in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), min(cores, 32), min(cores, 16)}, reverse=True):
-            oracle.best_fft(xp, wp, plog, threads=th)          # warm the team
-            c0 = time.perf_counter()
-            oracle.best_fft(xp, wp, plog, threads=th)
-            dt = time.perf_counter() - c0
-            if best_t is None or dt < best_t:
-                best_t, best_th = dt, th
-        del xp
-        x = oracle.random_fr(7, 1 << clog)
-        reps, c0 = 0, time.perf_counter()
-        while reps < 3 and (time.perf_counter() - c0) < 12.0:
-            oracle.best_fft(x, wc, clog, threads=best_th)
-            reps += 1
-        ct = (time.perf_counter() - c0) / max(reps, 1)
-        out["cpu_baseline"] = {
-            "value": 3 * ((1 << clog) // 2) * clog / ct,
-            "unit": "Fr-ops/s",
-            "cores": best_th,
-            "host_threads_available": cores,
-            "kind": "port",
-            "sample": "oracle best_fft (C restatement of arithmetic.rs:556-705: serial bit reversal as the reference, the "
-            "butterflies of its recursion scheduled statically over the team) on one forward 2^%d NTT (the GPU's size), "
-            "%d reps, %.3f s each (includes the oracle wrapper's input copy); team size probed on 2^%d" % (clog, reps, ct, plog),
-        }
-        del x
-
-        # the MSM leg's CPU twin: best_multiexp (arithmetic.rs:465-492, c = ceil(ln n) per thread chunk) at the GPU's 2^20
-        if "msm" in out:
-            mlog_c = min(args.msm_log_n, 20)
-            ms, mp = oracle.random_fr(11, 1 << mlog_c), oracle.random_g1(12, 1 << mlog_c)
-            best_m, best_mth = None, cores
-            for th in sorted({cores, min(cores, 128), min(cores, 64)}, reverse=True):
+            oracle = Oracle.get()
+            cores = os.cpu_count() or 1
+            clog = log_n                       # the GPU's own size (2^24)
+            wc = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - clog), R_MOD))
+            # team size: probed on a 2^20 transform (a fraction of a second each), then the full size is timed with the best
+            plog = min(clog, 20)
+            xp = oracle.random_fr(8, 1 << plog)
+            wp = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - plog), R_MOD))
+            best_t, best_th = None, cores
+            for th in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), min(cores, 32), min(cores, 16)}, reverse=True):
+                oracle.best_fft(xp, wp, plog, threads=th)          # warm the team
                 c0 = time.perf_counter()
-                oracle.best_multiexp(ms, mp, threads=th)
+                oracle.best_fft(xp, wp, plog, threads=th)
                 dt = time.perf_counter() - c0
-                if best_m is None or dt < best_m:
-                    best_m, best_mth = dt, th
-            out["msm"]["cpu_baseline"] = {
-                "pairs_per_s": (1 << mlog_c) / best_m,
-                "cores": best_mth,
+                if best_t is None or dt < best_t:
+                    best_t, best_th = dt, th
+            del xp
+            x = oracle.random_fr(7, 1 << clog)
+            reps, c0 = 0, time.perf_counter()
+            while reps < 3 and (time.perf_counter() - c0) < 12.0:
+                oracle.best_fft(x, wc, clog, threads=best_th)
+                reps += 1
+            ct = (time.perf_counter() - c0) / max(reps, 1)
+            out["cpu_baseline"] = {
+                "value": 3 * ((1 << clog) // 2) * clog / ct,
+                "unit": "Fr-ops/s",
+                "cores": best_th,
+                "host_threads_available": cores,
                 "kind": "port",
-                "sample": "oracle best_multiexp on 2^%d uniform pairs (the GPU's size), best of 3 team sizes, %.3f s" % (mlog_c, best_m),
+                "sample": "oracle best_fft (C restatement of arithmetic.rs:556-705: serial bit reversal as the reference, the "
+                "butterflies of its recursion scheduled statically over the team) on one forward 2^%d NTT (the GPU's size), "
+                "%d reps, %.3f s each (includes the oracle wrapper's input copy); team size probed on 2^%d" % (clog, reps, ct, plog),
             }
+            del x
+
+            # the MSM leg's CPU twin: best_multiexp (arithmetic.rs:465-492, c = ceil(ln n) per thread chunk) at the GPU's 2^20
+            if "msm" in out:
+                mlog_c = min(args.msm_log_n, 20)
+                ms, mp = oracle.random_fr(11, 1 << mlog_c), oracle.random_g1(12, 1 << mlog_c)
+                best_m, best_mth = None, cores
+                for th in sorted({cores, min(cores, 128), min(cores, 64)}, reverse=True):
+                    c0 = time.perf_counter()
+                    oracle.best_multiexp(ms, mp, threads=th)
+                    dt = time.perf_counter() - c0
+                    if best_m is None or dt < best_m:
+                        best_m, best_mth = dt, th
+                out["msm"]["cpu_baseline"] = {
+                    "pairs_per_s": (1 << mlog_c) / best_m,
+                    "cores": best_mth,
+                    "kind": "port",
+                    "sample": "oracle best_multiexp on 2^%d uniform pairs (the GPU's size), best of 3 team sizes, %.3f s" % (mlog_c, best_m),
+                }
+        except Exception as e:  # noqa: BLE001 - the line must still be printed
+            out.setdefault("cpu_baseline", {"error": "%s: %s" % (type(e).__name__, e)})
 
     if rank == 0:
         print(json.dumps(out))
