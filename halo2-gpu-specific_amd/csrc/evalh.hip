@@ -362,14 +362,15 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         ja.gamma = p.gamma;
         ja.theta = p.theta;
         void* kargs[] = {&ja};
-        const unsigned jblocks = (unsigned)std::min<size_t>((size + 255) / 256, 256 * 16);
+        // one grid over the whole domain (poly.hip grid_for: neighbouring DRAM pages instead of all of them at once)
+        const unsigned jblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
         H2_HIP(hipModuleLaunchKernel((hipFunction_t)d->jit_function, jblocks, 1, 1, 256, 1, 1, 0, stream, kargs, nullptr));
     } else {
         hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
     }
 
     const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
-    unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 256 * 16);
+    unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
     if (d->n_perm_sets) {
         NttPlan* pl;
         if (have_lock) {

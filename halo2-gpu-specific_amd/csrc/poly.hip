@@ -46,9 +46,14 @@ __global__ void __launch_bounds__(256) k_eval_op(Fr* res, const Fr* l, const Fr*
     }
 }
 
+// One element per lane, the whole range as ONE grid: workgroups are dispatched in index order, so the chip works on a
+// moving window of neighbouring DRAM pages.  A capped grid whose workgroups stride across the whole operand keeps every
+// page of it open at once: measured with plain 16-byte kernels (tools/membench.hip, 1 GiB operands) 2 reads + 1 write run
+// at 6.1 TB/s as one grid and at 4.8-5.6 TB/s as 4-32 grid-striding workgroups per CU (writes alone: 6.9 vs 4.4 TB/s).
+// The kernels keep their grid-stride loops for ranges beyond 2^31 workgroups.
 static unsigned grid_for(size_t n) {
     size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
 }
