@@ -321,6 +321,21 @@ static bool table_lookup(const uint64_t* d_bases, size_t n, uint32_t max_bits, S
     return true;
 }
 
+int bases_forget(const uint64_t* d_bases);
+// drops the table whose bases contain d_bases (its bases no longer hold the points it was built from)
+static void table_drop_containing(const uint64_t* d_bases) {
+    const uint64_t* key = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        auto it = g_tables.upper_bound(d_bases);
+        if (it == g_tables.begin()) return;
+        --it;
+        if (d_bases >= it->first + 8 * it->second.n) return;
+        key = it->first;
+    }
+    bases_forget(key);
+}
+
 // sized for the larger of the two shapes (with the extra window of a dominant scalar), table forms included
 size_t msm_scratch_bytes(size_t n, uint32_t max_bits) {
     size_t need = std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
@@ -1260,6 +1275,23 @@ __global__ void __launch_bounds__(HOT_SAMPLES) k_sample(const Fr* scalars, size_
     fp_store(out + threadIdx.x, fp_load(scalars + idx));
 }
 
+// A table is keyed by the ADDRESS of its bases: freed and re-allocated device memory can come back at the same address
+// with other points in it.  Every MSM that is about to use a table therefore compares 64 sampled base rows with level 0
+// of the table (a copy of the bases as they were) next to the scalar sampling -- same stream, same synchronisation -- and
+// a table that no longer matches is dropped instead of producing a wrong commitment.
+__global__ void __launch_bounds__(HOT_SAMPLES) k_table_check(const Affine* bases, const Affine* level0, size_t n, uint32_t* stale) {
+    const size_t idx = ((size_t)threadIdx.x * 0x9E3779B1ull + 0x7F4A7C15ull) % n;
+    const uint4* a = (const uint4*)(bases + idx);
+    const uint4* b = (const uint4*)(level0 + idx);
+    bool differ = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint4 x = a[k], y = b[k];
+        differ |= x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+    }
+    if (differ) *stale = 1u;
+}
+
 struct Hot {
     bool on = false;
     Fr value{};         // Montgomery form, as stored in the column
@@ -1432,9 +1464,17 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     }
     static thread_local PinnedBuf staging;  // per calling thread: this entry point takes no context lock
     // 64 sampled scalars decide whether a dominant value gets its own window
-    Fr* h_samples = (Fr*)staging.get(HOT_SAMPLES * sizeof(Fr));
+    Fr* h_samples = (Fr*)staging.get((HOT_SAMPLES + 1) * sizeof(Fr));
+    uint32_t* h_stale = (uint32_t*)(h_samples + HOT_SAMPLES);
+    *h_stale = 0;
     hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars, n, (Fr*)h_samples);
+    if (use_tab)
+        hipLaunchKernelGGL(k_table_check, dim3(1), dim3(HOT_SAMPLES), 0, stream, (const Affine*)d_bases, tab.table, n, h_stale);
     H2_HIP(hipStreamSynchronize(stream));
+    if (use_tab && *h_stale) {
+        table_drop_containing(d_bases);
+        use_tab = false;
+    }
     Hot hot = detect_hot(h_samples);
     // the extra window trades W additions per dominant row for one: with one or two windows there is nothing to gain,
     // only a giant bucket to fold and a 254-bit multiplication on the host
@@ -1601,9 +1641,11 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         return H2_ERR_INVALID;
     }
     // pinned staging: the sampled scalars of every column, then the per-MSM window partials (async read-back)
-    char* pinned = (char*)ctx->pinned.get(count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ)));
+    char* pinned = (char*)ctx->pinned.get(count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ) + 16));
     Fr* h_samples = (Fr*)pinned;
     XYZZ* h_win = (XYZZ*)(pinned + count * HOT_SAMPLES * sizeof(Fr));
+    uint32_t* h_stale = (uint32_t*)(pinned + count * (HOT_SAMPLES * sizeof(Fr) + wp_max * sizeof(XYZZ)));  // per column
+    for (size_t i = 0; i < count; i++) h_stale[i] = 0;
     // pipeline lanes: one stream + one scratch slice each.  Two: a third and fourth lane (H2_MSM_LANES, when the scratch
     // holds them) were measured and do not pay -- 2^18: 0.78 (2) / 0.76 (3) / 0.84 (4) ms per MSM, 2^20: 2.06 / 2.08 / 2.17
     hipStream_t st[4] = {ctx->stream, ctx->copy_stream, ctx->aux_stream[0], ctx->aux_stream[1]};
@@ -1612,9 +1654,18 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         int v = atoi(env);
         if (v >= 2 && v <= 4 && per && (size_t)v * per <= scratch_bytes) lanes = (size_t)v;
     }
-    for (size_t i = 0; i < count; i++)
+    for (size_t i = 0; i < count; i++) {
         hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[i], n, h_samples + i * HOT_SAMPLES);
+        if (use_tab[i] && !done_fused[i])
+            hipLaunchKernelGGL(k_table_check, dim3(1), dim3(HOT_SAMPLES), 0, stream,
+                               (const Affine*)(bases_each && bases_each[i] ? bases_each[i] : d_bases), tabs[i].table, n, h_stale + i);
+    }
     H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
+    for (size_t i = 0; i < count; i++)
+        if (use_tab[i] && h_stale[i]) {  // the bases changed under their table (see k_table_check): windowed form, table dropped
+            table_drop_containing(bases_each && bases_each[i] ? bases_each[i] : d_bases);
+            use_tab[i] = 0;
+        }
     std::vector<Hot> hots(count);
     for (size_t i = 0; i < count; i++) {
         hots[i] = detect_hot(h_samples + i * HOT_SAMPLES);

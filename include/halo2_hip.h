@@ -333,7 +333,9 @@ int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases
  * [d_bases, d_bases + n) and whose bound needs more windows than digits adds all digits of a scalar into ONE shared
  * bucket set: ~20 % fewer point additions at 2^24, one reduction instead of one per window, no host Horner.  Same group
  * element (multiexp_serial, arithmetic.rs:20-108).  Call it before sizing scratch with h2_msm_scratch_bytes.  The
- * bases must not change while the table exists; h2_dev_bases_forget(d_bases) frees it (synchronises the device).
+ * bases must not change while the table exists (as a guard, every MSM compares 64 sampled base rows with the table's
+ * own copy first and drops a table that no longer matches); h2_dev_bases_forget(d_bases) frees it (synchronises the
+ * device).
  * H2_MSM_NO_TABLE=1 in the environment ignores all tables.  Synchronous (~0.3 s at 2^24). */
 int h2_dev_bases_precompute(const void *d_bases, size_t n, uint32_t digits, void *stream);
 int h2_dev_bases_forget(const void *d_bases);

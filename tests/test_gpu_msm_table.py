@@ -178,3 +178,22 @@ def test_table_msm_2p20(oracle):
         assert _affine(oracle, dev.msm(z)) == _affine(oracle, oracle.best_multiexp(z, pts))
     finally:
         dev.forget()
+
+
+def test_table_is_dropped_when_the_bases_change(oracle, small_tables):
+    """a table is keyed by the address of its bases; memory that comes back from the allocator at the same address
+    with other points in it must not be committed against through the old table (sampled rows are compared with the
+    table's copy of the bases before every use)"""
+    n = 1 << 13
+    old, new = oracle.random_g1(1001, n), oracle.random_g1(1002, n)
+    scalars = oracle.random_fr(1003, n)
+    dev = DevMsm(old)
+    dev.precompute()
+    assert _affine(oracle, dev.msm(scalars)) == _affine(oracle, oracle.best_multiexp(scalars, old))
+    dev.d_pts.copy_(dev.torch.from_numpy(new.view(np.int64)).cuda())          # same address, other points
+    dev.torch.cuda.synchronize()
+    assert _affine(oracle, dev.msm(scalars)) == _affine(oracle, oracle.best_multiexp(scalars, new))
+    assert _affine(oracle, dev.msm(scalars[:n // 2], 254, 0, n // 2)) == _affine(oracle, oracle.best_multiexp(scalars[:n // 2], new[:n // 2]))
+    dev.precompute()                                                           # a fresh table serves the new points
+    assert _affine(oracle, dev.msm(scalars)) == _affine(oracle, oracle.best_multiexp(scalars, new))
+    dev.forget()
