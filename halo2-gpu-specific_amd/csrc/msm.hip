@@ -113,8 +113,10 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     s.R = 1;
     s.range_shift = 31;
     s.cols = cols;
-    s.Wc = s.W + 1;
-    if (cols) s.Wt = cols * s.Wc;  // every column keeps a slot for its dominant-scalar window
+    // every fused column keeps a slot for its dominant-scalar window -- except in shapes of one or two windows, where that
+    // window is never used (see msm_device) and would only double the finish / reduce work
+    s.Wc = s.W + ((cols && s.W <= 2) ? 0u : 1u);
+    if (cols) s.Wt = cols * s.Wc;
     s.Wk = s.Wt;
     s.nb = 1u << (s.c - 1);
     // Row ranges.  A narrow column (booleans, bytes, a 10-bit opcode) has ONE window of a few buckets: one or a handful
@@ -375,12 +377,14 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
                                                 const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
                                                 uint32_t range_shift, uint32_t R, uint32_t wfull, uint32_t tabmode) {
     // tabmode (shifted-base table): every digit's bucket belongs to window 0, the dominant-scalar window is window 1
+    bool hot_slot = hot_on != 0;  // does key array W exist?
     if (col_scalars != nullptr) {
-        const uint32_t col = blockIdx.y;
+        const uint32_t col = blockIdx.y, Wc = np >> hi_bits;  // windows (= key arrays) per column: W or W + 1
         scalars = col_scalars[col];
         hot_on = (int)((col_hot_mask >> col) & 1);
         if (hot_on) hot = fp_load(col_hot + col);
-        keys += (size_t)col * (W + 1) * n;
+        hot_slot = Wc > W;
+        keys += (size_t)col * Wc * n;
         pcount += (size_t)col * np;
     }
     uint32_t* hist = h2_msm_smem;
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const Fr raw = fp_load(scalars + i);
-        if (hot_on || col_scalars != nullptr) {  // wave-uniform branch; a fused column always owns the extra window
+        if (hot_slot) {  // wave-uniform branch; a fused column of more than two windows always owns the extra window
             const bool is_hot = hot_on && fp_eq(raw, hot);
             const uint64_t m = __ballot(is_hot);
             if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
@@ -1511,6 +1515,7 @@ static int msm_device_fused(DeviceCtx* ctx, const Fr* const* d_scalars, uint32_t
     FusedCols fc{};
     for (uint32_t j = 0; j < cols; j++) {
         hots[j] = detect_hot(h_samples + (size_t)j * HOT_SAMPLES);
+        if (s.Wc == s.W) hots[j].on = false;  // one or two windows: no dominant-scalar slot
         if (hots[j].on) fc.hot_mask |= 1ull << j;
         tab[j] = (uint64_t)(uintptr_t)d_scalars[j];
     }
@@ -1542,10 +1547,15 @@ static uint32_t fused_group_limit(size_t n, uint32_t bits) {
         int v = atoi(env);
         if (v >= 10 && v <= 28) fuse_log = (uint32_t)v;
     }
-    if ((size_t)one.Wt * n > ((size_t)1 << fuse_log) || one.W < 8) return 1;
+    // Short bounds (a few windows): fused only when a column still spreads over >= 16 sort partitions; a column of a few
+    // hundred buckets is one partition and nothing but heavy buckets -- the row ranges of the single-column shape are
+    // what it needs
+    const uint32_t wc = one.W + (one.W <= 2 ? 0u : 1u);
+    const uint32_t lo0 = (one.c - 1 < 8) ? (one.c - 1) : 8;
+    if ((size_t)(one.W + 1) * n > ((size_t)1 << fuse_log) || (one.W < 8 && (one.W << (one.c - 1 - lo0)) < 16)) return 1;
     uint32_t best = 1;
     for (uint32_t g = 2; g <= 64; g++) {
-        const size_t wt = (size_t)g * (one.W + 1);
+        const size_t wt = (size_t)g * wc;
         if (wt * n > ((size_t)1 << 28)) break;
         if ((wt << (one.c - 1 - 9)) > 16384 && one.c - 1 > 9) break;  // lo_bits would exceed 9 (512 bins per partition)
         best = g;

@@ -797,6 +797,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # The vanishing argument's random polynomial (vanishing/prover.rs:40-67) and its commitment depend on nothing the
     # transcript has hashed: generated and committed NOW, while the witness columns cross PCIe on the copy stream (k = 24:
     # a 25 ms MSM under a 29 ms transfer).  The commitment is written where the protocol puts it, after the z's.
+    # (Small witnesses too: folding it into the advice columns' batch instead was measured slower, k = 18 lookup circuit
+    # 28.6 -> 30.2 ms -- the early MSM runs under the host's preparation of the blinding rows.)
     random_poly = D.empty(n)
     check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
     random_commitment = D.msm(random_poly, params.g, n)
@@ -826,6 +828,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         bits_ = D.max_scalar_bits_many([t[lo_r:hi_r] for t in cols_], hi_r - lo_r)
         if sharded_upload:
             bits_ = allreduce_max(bits_, group=D.group, device=D.dev)       # find_max_scalar_bits over the whole column
+        # bounds rounded up to a few classes (a bound is only an upper limit): columns that share one are committed as a
+        # fused group by the library -- a witness of many small-valued columns pays the fixed latencies of an MSM per
+        # class instead of per column
         bits_ = [max(b, 1) for b in bits_]
         for t in cols_:
             check(L.h2_dev_batch_mont(t[lo_r:hi_r].data_ptr(), hi_r - lo_r, D.stream), "h2_dev_batch_mont")
