@@ -738,7 +738,12 @@ def create_proof_from_witness(device, params, pk, witness, rng, use_gwc=True, ti
 def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=(), montgomery=False):
     """plonk/prover.rs:206-850.  advice: list of (n, 4) u64 columns, canonical integers (or Montgomery residues with
     montgomery=True); rows past the usable range are overwritten with blinding values; instances: one list of
-    canonical integers per instance column; rng: a rng.ProverRng.  Returns the proof bytes."""
+    canonical integers per instance column; rng: a rng.ProverRng.  Returns the proof bytes.
+
+    Several circuit instances in one proof (`circuits: &[ConcreteCircuit]`, prover.rs:206-232): pass `advice` as a list
+    of such column lists and `instances` as the matching list of instance-column lists.  Every phase then runs circuit
+    by circuit in the reference's order (instance commitments, advice commitments, theta, lookup multiplicities, beta /
+    gamma, permutation / lookup / shuffle products, y, ONE quotient over all circuits, x, evaluations, openings)."""
     import time
 
     D, L = device, device.L
@@ -759,19 +764,32 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if D.group_size > 1:
         rng = rng.shared(D.group)            # every rank of one proof draws the same blinding values
 
-    # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------
-    if len(instances) != cs.num_instance:
+    multi = len(advice) > 0 and isinstance(advice[0], (list, tuple))
+    advice_sets = [list(a) for a in advice] if multi else [list(advice)]
+    instance_sets = [list(i) for i in instances] if multi else [list(instances)]
+    if len(instance_sets) != len(advice_sets):
         raise ValueError("InvalidInstances")
-    instance_dev = []
-    for vals in instances:
-        if len(vals) > usable:
-            raise ValueError("InstanceTooLarge")
-        t = D.zeros(n)
-        D.set_rows(t, 0, list(vals))
-        instance_dev.append(t)
-    for P in D.msm_batch(instance_dev, params.g_lagrange, n, 254):
+    ncirc, nadv = len(advice_sets), len(advice_sets[0])
+    if any(len(a) != nadv for a in advice_sets):
+        raise ValueError("every circuit instance needs the same advice columns")
+    advice = [col for a in advice_sets for col in a]          # circuit-major: the order every phase walks them in
+
+    # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------
+    instance_dev_sets = []
+    for inst in instance_sets:
+        if len(inst) != cs.num_instance:
+            raise ValueError("InvalidInstances")
+        cols_i = []
+        for vals in inst:
+            if len(vals) > usable:
+                raise ValueError("InstanceTooLarge")
+            t = D.zeros(n)
+            D.set_rows(t, 0, list(vals))
+            cols_i.append(t)
+        instance_dev_sets.append(cols_i)
+    for P in D.msm_batch([t for cols_i in instance_dev_sets for t in cols_i], params.g_lagrange, n, 254):
         transcript.common_point(P)
-    instance_polys = [D.intt(D.clone(t), dom) for t in instance_dev]
+    instance_polys_sets = [[D.intt(D.clone(t), dom) for t in cols_i] for cols_i in instance_dev_sets]
 
     # ---- advice columns: blinding rows, bounded commitments (prover.rs:255-312) ----------------------------
     # Every column is queued for upload on the copy stream first (DMA when it lives in pinned memory); the columns are
@@ -844,28 +862,33 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     del uploads
     mark("advice commit")
     theta = transcript.squeeze_challenge_scalar()
+    # per-circuit state: every later phase walks `circuits` in order
+    circuits = [{"advice": advice_dev[ci * nadv:(ci + 1) * nadv], "instance": instance_dev_sets[ci],
+                 "instance_polys": instance_polys_sets[ci]} for ci in range(ncirc)]
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
-    def compress(program):
-        return _compress(D, dom, program, theta, pk.fixed_values, advice_dev, instance_dev)
+    for C in circuits:
+        def compress(program, C=C):
+            return _compress(D, dom, program, theta, pk.fixed_values, C["advice"], C["instance"])
 
-    lookups = []
-    for table_prog, set_progs in pk.lookup_programs:
-        st = {"table": compress(table_prog), "inputs": [[compress(pr) for pr in progs] for progs in set_progs]}
-        flat = [c for cols_ in st["inputs"] for c in cols_]
-        m = D.empty(n)
-        nbytes = L.h2_logup_scratch_bytes(n)
-        ptrs = (_vp * len(flat))(*[c.data_ptr() for c in flat])
-        check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
-                                          D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
-        D.set_rows(m, usable, [rng.u16() for _ in range(usable, n)])
-        st["m"], st["m_bits"] = m, max(16, (usable * len(flat)).bit_length())
-        lookups.append(st)
-    if lookups:
-        for P in D.msm_batch([st["m"] for st in lookups], params.g_lagrange, n, max(st["m_bits"] for st in lookups)):
+        C["lookups"] = []
+        for table_prog, set_progs in pk.lookup_programs:
+            st = {"table": compress(table_prog), "inputs": [[compress(pr) for pr in progs] for progs in set_progs]}
+            flat = [c for cols_ in st["inputs"] for c in cols_]
+            m = D.empty(n)
+            nbytes = L.h2_logup_scratch_bytes(n)
+            ptrs = (_vp * len(flat))(*[c.data_ptr() for c in flat])
+            check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
+                                              D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
+            D.set_rows(m, usable, [rng.u16() for _ in range(usable, n)])
+            st["m"], st["m_bits"] = m, max(16, (usable * len(flat)).bit_length())
+            C["lookups"].append(st)
+        # ---- shuffles: compressed expressions (shuffle/prover.rs:40-80) ------------------------------------------
+        C["shuffles"] = [[(compress(ip), compress(sp)) for ip, sp in group] for group in pk.shuffle_programs]
+    all_lookups = [st for C in circuits for st in C["lookups"]]
+    if all_lookups:
+        for P in D.msm_batch([st["m"] for st in all_lookups], params.g_lagrange, n, max(st["m_bits"] for st in all_lookups)):
             transcript.write_point(P)
-    # ---- shuffles: compressed expressions (shuffle/prover.rs:40-80) ----------------------------------------------
-    shuffles = [[(compress(ip), compress(sp)) for ip, sp in group] for group in pk.shuffle_programs]
     mark("lookups compress")
     beta = transcript.squeeze_challenge_scalar()
     gamma = transcript.squeeze_challenge_scalar()
@@ -873,119 +896,143 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # ---- permutation grand products (permutation/prover.rs:47-165) -----------------------------------
     chunk = cs.degree() - 2
     cols = cs.perm_columns
-    colvals = {"advice": advice_dev, "fixed": pk.fixed_values, "instance": instance_dev}
-    z_dev, last_z = [], 1
+    nsets = (len(cols) + chunk - 1) // chunk
     # Everything that has to be inverted before the grand products / sums can run -- the permutation denominators of
     # every set, (beta + f) of every lookup input and table, the shuffle products -- depends only on beta and gamma: it
-    # is laid out in ONE buffer and inverted by ONE batch inversion, so the inversion's serial a^(r-2) chain (~0.3 ms
-    # of pure latency per call) is paid once per proof instead of once per column.
-    nsets = (len(cols) + chunk - 1) // chunk
-    slots = nsets + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
-    nums = D.empty(max(nsets, 1) * n)
-    inv = D.empty(max(slots, 1) * n)
-    slot = lambda i: inv[i * n:(i + 1) * n]  # noqa: E731
-    for k_, si in enumerate(range(0, len(cols), chunk)):
-        for ci in range(si, min(si + chunk, len(cols))):
-            values = colvals[cols[ci][0]][cols[ci][1]]
-            check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), slot(k_).data_ptr(), values.data_ptr(),
-                                             pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
-                                             _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
-                                             D.stream), "h2_dev_permutation_terms")
-    at = nsets
-    for st in lookups:
-        st["inv_inputs"] = []
-        for cols_in in st["inputs"]:
-            st["inv_inputs"].append([])
-            for col in cols_in:                                     # beta + f_i
-                st["inv_inputs"][-1].append(D.eval_op(1, slot(at), col, c=beta))          # H2_OP_SUM_C
-                at += 1
-        st["inv_table"] = D.eval_op(1, slot(at), st["table"], c=beta)  # beta + t
-        at += 1
-    shuffle_inv = []
-    for group in shuffles:                                          # prod_i (beta^(i+1) + shuffle_i)
-        dst = slot(at)
-        for i, (_, shf) in enumerate(group):
-            if i == 0:
-                D.eval_op(1, dst, shf, c=beta)
-            else:
-                D.eval_op(6, dst, shf, dst, c=pow(beta, i + 1, R_MOD))       # H2_OP_LCBETA: (l + c) * r
-        shuffle_inv.append(dst)
-        at += 1
-    assert at == slots
-    if slots:
-        check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * n).data_ptr(), slots * n, D.stream), "h2_dev_batch_invert")
-    # ---- permutation grand products (permutation/prover.rs:89-165) ------------------------------------------
-    if nsets:
-        D.eval_op(3, nums, nums, inv[:nsets * n])                                     # H2_OP_MUL over all sets
-    for k_ in range(nsets):
-        z = D.empty(n)
-        check(L.h2_dev_prefix_product(nums[k_ * n:].data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
-        D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
-        last_z = D.get_rows(z, usable, 1)[0]
-        z_dev.append(z)
-    del nums
+    # is laid out in ONE buffer (per circuit instance) and inverted by ONE batch inversion, so the inversion's serial
+    # a^(r-2) chain (~0.3 ms of pure latency per call) is paid once per proof instead of once per column.
+    for C in circuits:
+        lookups, shuffles = C["lookups"], C["shuffles"]
+        colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
+        slots = nsets + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
+        nums = D.empty(max(nsets, 1) * n)
+        inv = D.empty(max(slots, 1) * n)
+        slot = lambda i, inv=inv: inv[i * n:(i + 1) * n]  # noqa: E731
+        for k_, si in enumerate(range(0, len(cols), chunk)):
+            for ci in range(si, min(si + chunk, len(cols))):
+                values = colvals[cols[ci][0]][cols[ci][1]]
+                check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), slot(k_).data_ptr(), values.data_ptr(),
+                                                 pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
+                                                 _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
+                                                 D.stream), "h2_dev_permutation_terms")
+        at = nsets
+        for st in lookups:
+            st["inv_inputs"] = []
+            for cols_in in st["inputs"]:
+                st["inv_inputs"].append([])
+                for col in cols_in:                                     # beta + f_i
+                    st["inv_inputs"][-1].append(D.eval_op(1, slot(at), col, c=beta))          # H2_OP_SUM_C
+                    at += 1
+            st["inv_table"] = D.eval_op(1, slot(at), st["table"], c=beta)  # beta + t
+            at += 1
+        C["shuffle_inv"] = []
+        for group in shuffles:                                          # prod_i (beta^(i+1) + shuffle_i)
+            dst = slot(at)
+            for i, (_, shf) in enumerate(group):
+                if i == 0:
+                    D.eval_op(1, dst, shf, c=beta)
+                else:
+                    D.eval_op(6, dst, shf, dst, c=pow(beta, i + 1, R_MOD))       # H2_OP_LCBETA: (l + c) * r
+            C["shuffle_inv"].append(dst)
+            at += 1
+        assert at == slots
+        if slots:
+            check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * n).data_ptr(), slots * n, D.stream), "h2_dev_batch_invert")
+        if nsets:
+            D.eval_op(3, nums, nums, inv[:nsets * n])                                     # H2_OP_MUL over all sets
+        C["nums"], C["inv"] = nums, inv
+    # ---- permutation grand products (permutation/prover.rs:89-165), circuit by circuit -------------------------
+    for C in circuits:
+        C["z"], last_z = [], 1
+        for k_ in range(nsets):
+            z = D.empty(n)
+            check(L.h2_dev_prefix_product(C["nums"][k_ * n:].data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+            last_z = D.get_rows(z, usable, 1)[0]
+            C["z"].append(z)
+        del C["nums"]
     num = D.empty(n)
     # ---- lookup grand sums (logup/prover.rs:243-415; blinding prover.rs:446-465) -------------------------------
-    for st in lookups:
-        st["z"] = []
-        last = 0
-        for si, inverted in enumerate(st["inv_inputs"]):
-            src = inverted[0]                                       # sum_i 1 / (beta + f_i)
-            for other in inverted[1:]:
-                src = D.eval_op(2, num, src, other)                 # H2_OP_SUM
-            if si == 0:                                             # - m / (beta + t)
-                D.eval_op(3, st["inv_table"], st["inv_table"], st["m"])
-                src = D.eval_op(4, num, src, st["inv_table"])       # H2_OP_SUB
-            z = D.empty(n)
-            check(L.h2_dev_prefix_sum(src.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
-            last = D.get_rows(z, usable, 1)[0]
-            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
-            st["z"].append(z)
-        if last != 0:
-            raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
-        del st["inv_inputs"], st["inv_table"]
+    for C in circuits:
+        for st in C["lookups"]:
+            st["z"] = []
+            last = 0
+            for si, inverted in enumerate(st["inv_inputs"]):
+                src = inverted[0]                                       # sum_i 1 / (beta + f_i)
+                for other in inverted[1:]:
+                    src = D.eval_op(2, num, src, other)                 # H2_OP_SUM
+                if si == 0:                                             # - m / (beta + t)
+                    D.eval_op(3, st["inv_table"], st["inv_table"], st["m"])
+                    src = D.eval_op(4, num, src, st["inv_table"])       # H2_OP_SUB
+                z = D.empty(n)
+                check(L.h2_dev_prefix_sum(src.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
+                last = D.get_rows(z, usable, 1)[0]
+                D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+                st["z"].append(z)
+            if last != 0:
+                raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
+            del st["inv_inputs"], st["inv_table"]
     # ---- shuffle products (shuffle/prover.rs:82-150; blinding prover.rs:512-530) -------------------------------
-    shuffle_z = []
-    for group, inverted in zip(shuffles, shuffle_inv):
-        for i, (inp, _) in enumerate(group):
-            D.eval_op(6, inverted, inp, inverted, c=pow(beta, i + 1, R_MOD))
-        z = D.empty(n)
-        check(L.h2_dev_prefix_product(inverted.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
-        if D.get_rows(z, usable, 1)[0] != 1:
-            raise ValueError("shuffle product does not return to one")
-        D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
-        shuffle_z.append(z)
-    del num, inv, shuffle_inv
-    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z; the random polynomial's commitment does
-    # not depend on anything hashed in between, so its MSM rides in the same pipelined batch (hashing order kept)
-    all_z = z_dev + [z for st in lookups for z in st["z"]] + shuffle_z
+    for C in circuits:
+        C["shuffle_z"] = []
+        for group, inverted in zip(C["shuffles"], C["shuffle_inv"]):
+            for i, (inp, _) in enumerate(group):
+                D.eval_op(6, inverted, inp, inverted, c=pow(beta, i + 1, R_MOD))
+            z = D.empty(n)
+            check(L.h2_dev_prefix_product(inverted.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+            if D.get_rows(z, usable, 1)[0] != 1:
+                raise ValueError("shuffle product does not return to one")
+            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+            C["shuffle_z"].append(z)
+        del C["inv"], C["shuffle_inv"]
+    del num
+    # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z, in the transcript's order: the permutation
+    # products of every circuit, then the lookup sums of every circuit, then the shuffle products (prover.rs:595-625)
+    all_z = ([z for C in circuits for z in C["z"]] + [z for C in circuits for st in C["lookups"] for z in st["z"]] +
+             [z for C in circuits for z in C["shuffle_z"]])
     z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254)
     for P in z_commitments:
         transcript.write_point(P)
-    z_polys = [D.intt(z, dom) for z in z_dev]
-    for st in lookups:
-        st["z_polys"] = [D.intt(z, dom) for z in st["z"]]
-        st["m_poly"] = D.intt(st["m"], dom)
-        del st["table"], st["inputs"]
-    shuffle_polys = [D.intt(z, dom) for z in shuffle_z]
-    del shuffles
+    for C in circuits:
+        C["z_polys"] = [D.intt(z, dom) for z in C["z"]]
+        for st in C["lookups"]:
+            st["z_polys"] = [D.intt(z, dom) for z in st["z"]]
+            st["m_poly"] = D.intt(st["m"], dom)
+            del st["table"], st["inputs"]
+        C["shuffle_polys"] = [D.intt(z, dom) for z in C["shuffle_z"]]
+        del C["shuffles"]
     mark("permutation")
     transcript.write_point(random_commitment)
     y = transcript.squeeze_challenge_scalar()
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
-    advice_polys = [D.intt(t, dom) for t in advice_dev]          # in place: the Lagrange values are not needed again
+    for C in circuits:
+        C["advice_polys"] = [D.intt(t, dom) for t in C["advice"]]    # in place: the Lagrange values are not needed again
     g = pk.graph
     plan = D.coset_plan(dom)
+    # Several circuits share one quotient: the reference keeps folding `value = value * y + term` from one circuit into
+    # the next (plonk/evaluation.rs:839-1100), i.e. h = sum_i y^(T (N - 1 - i)) h_i with T terms per circuit and h_i the
+    # fold of circuit i alone -- each circuit runs through the evaluator on its own and the results are combined.
+    terms_per_circuit = (len(pk.value_parts) + (2 * nsets + 1 if nsets else 0) +
+                         sum(2 * len(st["z_polys"]) + 1 for st in circuits[0]["lookups"]) + 3 * len(circuits[0]["shuffle_polys"]))
+    y_step = pow(y, terms_per_circuit, R_MOD)
 
     def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size):
+        total = None
+        for C in circuits:
+            h_c = evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size)
+            total = h_c if total is None else D.eval_op(5, total, total, h_c, c=y_step)     # H2_OP_LCTHETA: l * c + r
+        return total
+
+    def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size):
         """the fused evaluator over one evaluation domain: `points_of` maps a coefficient vector to its values there"""
-        advice_cosets = [points_of(t) for t in advice_polys]
-        instance_cosets = [points_of(t) for t in instance_polys]
-        z_cosets = [points_of(t) for t in z_polys]
+        lookups = C["lookups"]
+        advice_cosets = [points_of(t) for t in C["advice_polys"]]
+        instance_cosets = [points_of(t) for t in C["instance_polys"]]
+        z_cosets = [points_of(t) for t in C["z_polys"]]
         lookup_z_cosets = [points_of(t) for st in lookups for t in st["z_polys"]]
         lookup_m_cosets = [points_of(st["m_poly"]) for st in lookups]
-        shuffle_cosets = [points_of(t) for t in shuffle_polys]
+        shuffle_cosets = [points_of(t) for t in C["shuffle_polys"]]
         mark("cosets")
         b = ev.Builder().build(
             k=dom.k, extended_k=k_domain, blinding_factors=bf, chunk_len=chunk,
@@ -1064,22 +1111,29 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             if i + 1 < len(polys_):
                 want((name, i), p, last_rot)
 
-    for c, rot in cs.instance_queries:
-        want(("instance", c), instance_polys[c], rot)
-    for c, rot in cs.advice_queries:
-        want(("advice", c), advice_polys[c], rot)
+    # evaluations in the transcript's order (prover.rs:704-790): instance columns of every circuit, advice columns of
+    # every circuit, fixed, the random polynomial, sigma, then per circuit the permutation / lookup / shuffle products
+    for ci, C in enumerate(circuits):
+        for c, rot in cs.instance_queries:
+            want(("instance", ci, c), C["instance_polys"][c], rot)
+    for ci, C in enumerate(circuits):
+        for c, rot in cs.advice_queries:
+            want(("advice", ci, c), C["advice_polys"][c], rot)
     for c, rot in cs.fixed_queries:
         want(("fixed", c), pk.fixed_polys[c], rot)
     want(("random",), random_poly, 0)
     for i, p in enumerate(pk.sigma_polys):
         want(("sigma", i), p, 0)
-    want_set_evals("z", z_polys)
-    for li, st in enumerate(lookups):                                  # logup/prover.rs:419-446
-        want(("lookup_m", li), st["m_poly"], 0)
-        want_set_evals("lookup_z%d" % li, st["z_polys"])
-    for i, p in enumerate(shuffle_polys):                              # shuffle/prover.rs:196-212
-        want(("shuffle_z", i), p, 0)
-        want(("shuffle_z", i), p, 1)
+    for ci, C in enumerate(circuits):
+        want_set_evals("z%d" % ci, C["z_polys"])
+    for ci, C in enumerate(circuits):
+        for li, st in enumerate(C["lookups"]):                         # logup/prover.rs:419-446
+            want(("lookup_m", ci, li), st["m_poly"], 0)
+            want_set_evals("lookup_z%d_%d" % (ci, li), st["z_polys"])
+    for ci, C in enumerate(circuits):
+        for i, p in enumerate(C["shuffle_polys"]):                     # shuffle/prover.rs:196-212
+            want(("shuffle_z", ci, i), p, 0)
+            want(("shuffle_z", ci, i), p, 1)
     want(("h",), h_poly, 0, write=False)                               # opened, not written (vanishing/prover.rs:140-155)
     values = D.eval_polynomial_batch([p for _, p, _ in wanted], n, [dom.rotate_omega(x, r) for _, _, r in wanted])
     evals = {(key, rot): v for (key, _, rot), v in zip(wanted, values)}
@@ -1090,7 +1144,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     def evaluate(key, poly, rot):
         return evals[(key, rot)]
 
-    # ---- multiopen query list in the reference's order (prover.rs:792-840) -----------------------------------
+    # ---- multiopen query list in the reference's order (prover.rs:792-840): per circuit its instance, advice,
+    # permutation, lookup and shuffle openings; then fixed, sigma, h and the random polynomial -----------------------
     polys, queries = {}, []
 
     def query(key, poly, rot):
@@ -1104,17 +1159,18 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         for i in reversed(range(len(polys_) - 1)):
             query((name, i), polys_[i], last_rot)
 
-    for c, rot in cs.instance_queries:
-        query(("instance", c), instance_polys[c], rot)
-    for c, rot in cs.advice_queries:
-        query(("advice", c), advice_polys[c], rot)
-    open_sets("z", z_polys)
-    for li, st in enumerate(lookups):
-        query(("lookup_m", li), st["m_poly"], 0)
-        open_sets("lookup_z%d" % li, st["z_polys"])
-    for i, p in enumerate(shuffle_polys):
-        query(("shuffle_z", i), p, 0)
-        query(("shuffle_z", i), p, 1)
+    for ci, C in enumerate(circuits):
+        for c, rot in cs.instance_queries:
+            query(("instance", ci, c), C["instance_polys"][c], rot)
+        for c, rot in cs.advice_queries:
+            query(("advice", ci, c), C["advice_polys"][c], rot)
+        open_sets("z%d" % ci, C["z_polys"])
+        for li, st in enumerate(C["lookups"]):
+            query(("lookup_m", ci, li), st["m_poly"], 0)
+            open_sets("lookup_z%d_%d" % (ci, li), st["z_polys"])
+        for i, p in enumerate(C["shuffle_polys"]):
+            query(("shuffle_z", ci, i), p, 0)
+            query(("shuffle_z", ci, i), p, 1)
     for c, rot in cs.fixed_queries:
         query(("fixed", c), pk.fixed_polys[c], rot)
     for i, p in enumerate(pk.sigma_polys):

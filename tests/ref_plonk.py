@@ -582,168 +582,193 @@ def _argument_expressions(cs, adv, fix, inst, theta, beta, gamma, l0, ll, la, po
     return exprs
 
 
+def _is_multi(advice_in):
+    """several circuit instances: advice_in is a list of column lists (a column is a list of ints)"""
+    return len(advice_in) > 0 and len(advice_in[0]) > 0 and isinstance(advice_in[0][0], (list, tuple))
+
+
 def create_proof(pk, advice_in, rng, use_gwc=False, instances=()):
-    """plonk/prover.rs:206-850 (create_proof_ext); one circuit instance"""
+    """plonk/prover.rs:206-850 (create_proof_ext).  One circuit instance: advice_in = its columns, instances = its
+    instance columns; several (`circuits: &[ConcreteCircuit]`): lists of those, every phase circuit by circuit."""
     cs, dom = pk.cs, pk.dom
     n, bf = dom.n, cs.blinding_factors
     usable = n - (bf + 1)
+    multi = _is_multi(advice_in)
+    advice_sets = advice_in if multi else [advice_in]
+    instance_sets = instances if multi else [instances]
+    assert len(advice_sets) == len(instance_sets)
     t = Transcript()
     t.common_scalar(pk.transcript_repr)
+    circuits = []
     # instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written
-    assert len(instances) == _cs_get(cs, "num_instance", 0)
-    instance = []
-    for vals in instances:
-        assert len(vals) <= usable, "InstanceTooLarge"
-        instance.append(list(vals) + [0] * (n - len(vals)))
-    instance_polys = [dom.lagrange_to_coeff(col) for col in instance]
-    for p in instance_polys:
-        t.common_point(commit(pk, p))
+    for inst in instance_sets:
+        assert len(inst) == _cs_get(cs, "num_instance", 0)
+        C = {"instance": []}
+        for vals in inst:
+            assert len(vals) <= usable, "InstanceTooLarge"
+            C["instance"].append(list(vals) + [0] * (n - len(vals)))
+        C["instance_polys"] = [dom.lagrange_to_coeff(col) for col in C["instance"]]
+        for p in C["instance_polys"]:
+            t.common_point(commit(pk, p))
+        circuits.append(C)
     # advice: blinding rows (prover.rs:281-289), commitments
-    advice = [col[:] for col in advice_in]
-    for col in advice:
-        for r in range(usable, n):
-            col[r] = rng.u16()
-    advice_polys = [dom.lagrange_to_coeff(col) for col in advice]
-    for p in advice_polys:
-        t.write_point(commit(pk, p))
+    for C, adv_in in zip(circuits, advice_sets):
+        C["advice"] = [col[:] for col in adv_in]
+        for col in C["advice"]:
+            for r in range(usable, n):
+                col[r] = rng.u16()
+        C["advice_polys"] = [dom.lagrange_to_coeff(col) for col in C["advice"]]
+        for p in C["advice_polys"]:
+            t.write_point(commit(pk, p))
     theta = t.squeeze()
 
-    def row_access(i):
-        return (lambda c, r: advice[c][(i + r) % n], lambda c, r: pk.fixed_values[c][(i + r) % n],
-                lambda c, r: instance[c][(i + r) % n])
+    def row_access(C, i):
+        return (lambda c, r: C["advice"][c][(i + r) % n], lambda c, r: pk.fixed_values[c][(i + r) % n],
+                lambda c, r: C["instance"][c][(i + r) % n])
 
     # lookups: compressed inputs / table and the multiplicities (logup/prover.rs:63-240)
-    lk_state = []
-    for lk in _cs_get(cs, "lookups", []):
-        table = [_compress(lk["table"](*row_access(i)), theta) for i in range(n)]
-        inputs = [[[_compress(e(*row_access(i)), theta) for i in range(n)] for e in st] for st in lk["input_sets"]]
-        first = {}
-        for i in range(usable):
-            first.setdefault(table[i], i)          # a duplicated table value is credited to its first row
-        m = [0] * n
-        for st in inputs:
-            for col in st:
-                for i in range(usable):
-                    m[first[col[i]]] += 1          # KeyError = "logup binary_search_by_key should hit"
-        for i in range(usable, n):
-            m[i] = rng.u16()
-        m_poly = dom.lagrange_to_coeff(m)
-        t.write_point(commit(pk, m_poly))
-        lk_state.append({"table": table, "inputs": inputs, "m": m, "m_poly": m_poly})
-    # shuffles: compressed expressions (shuffle/prover.rs:40-80)
-    sh_state = []
-    for group in _cs_get(cs, "shuffles", []):
-        sh_state.append([([_compress(inp(*row_access(i)), theta) for i in range(n)],
-                          [_compress(shf(*row_access(i)), theta) for i in range(n)]) for inp, shf in group])
+    for C in circuits:
+        C["lk"] = []
+        for lk in _cs_get(cs, "lookups", []):
+            table = [_compress(lk["table"](*row_access(C, i)), theta) for i in range(n)]
+            inputs = [[[_compress(e(*row_access(C, i)), theta) for i in range(n)] for e in st] for st in lk["input_sets"]]
+            first = {}
+            for i in range(usable):
+                first.setdefault(table[i], i)          # a duplicated table value is credited to its first row
+            m = [0] * n
+            for st in inputs:
+                for col in st:
+                    for i in range(usable):
+                        m[first[col[i]]] += 1          # KeyError = "logup binary_search_by_key should hit"
+            for i in range(usable, n):
+                m[i] = rng.u16()
+            C["lk"].append({"table": table, "inputs": inputs, "m": m, "m_poly": dom.lagrange_to_coeff(m)})
+        # shuffles: compressed expressions (shuffle/prover.rs:40-80)
+        C["sh"] = []
+        for group in _cs_get(cs, "shuffles", []):
+            C["sh"].append([([_compress(inp(*row_access(C, i)), theta) for i in range(n)],
+                             [_compress(shf(*row_access(C, i)), theta) for i in range(n)]) for inp, shf in group])
+    for C in circuits:
+        for st in C["lk"]:
+            t.write_point(commit(pk, st["m_poly"]))
     beta = t.squeeze()
     gamma = t.squeeze()
-    # permutation grand products (permutation/prover.rs:47-165)
+    # permutation grand products (permutation/prover.rs:47-165), circuit by circuit
     chunk = cs.degree - 2
     cols = cs.perm_columns
-    colvals = {"advice": advice, "fixed": pk.fixed_values, "instance": instance}
-    zs, last_z = [], 1
-    for si in range(0, len(cols), chunk):
-        mv = [1] * n
-        for ci in range(si, min(si + chunk, len(cols))):
-            vals = colvals[cols[ci][0]][cols[ci][1]]
-            for i in range(n):
-                mv[i] = mv[i] * (beta * pk.sigma_values[ci][i] + gamma + vals[i]) % R
-        mv = [inv(v) for v in mv]
-        dw = pow(DELTA, si, R)
-        for ci in range(si, min(si + chunk, len(cols))):
-            vals = colvals[cols[ci][0]][cols[ci][1]]
-            for i in range(n):
-                mv[i] = mv[i] * (dw * beta + gamma + vals[i]) % R
-                dw = dw * dom.omega % R
-            dw = dw * DELTA % R
-        z = [last_z]
-        for i in range(n - 1):
-            z.append(z[i] * mv[i] % R)
-        for i in range(n - bf, n):
-            z[i] = rng.fr()
-        last_z = z[usable]
-        zs.append(z)
-    z_polys = [dom.lagrange_to_coeff(z) for z in zs]
+    for C in circuits:
+        colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
+        zs, last_z = [], 1
+        for si in range(0, len(cols), chunk):
+            mv = [1] * n
+            for ci in range(si, min(si + chunk, len(cols))):
+                vals = colvals[cols[ci][0]][cols[ci][1]]
+                for i in range(n):
+                    mv[i] = mv[i] * (beta * pk.sigma_values[ci][i] + gamma + vals[i]) % R
+            mv = [inv(v) for v in mv]
+            dw = pow(DELTA, si, R)
+            for ci in range(si, min(si + chunk, len(cols))):
+                vals = colvals[cols[ci][0]][cols[ci][1]]
+                for i in range(n):
+                    mv[i] = mv[i] * (dw * beta + gamma + vals[i]) % R
+                    dw = dw * dom.omega % R
+                dw = dw * DELTA % R
+            z = [last_z]
+            for i in range(n - 1):
+                z.append(z[i] * mv[i] % R)
+            for i in range(n - bf, n):
+                z[i] = rng.fr()
+            last_z = z[usable]
+            zs.append(z)
+        C["z_polys"] = [dom.lagrange_to_coeff(z) for z in zs]
     # lookup grand sums (logup/prover.rs:243-415, blinding prover.rs:446-465)
-    for st in lk_state:
-        st["z_polys"] = []
-        last = 0
-        for si, cols_in in enumerate(st["inputs"]):
-            g = [0] * n
-            for col in cols_in:
-                for i in range(n):
-                    g[i] = (g[i] + inv((beta + col[i]) % R)) % R
-            if si == 0:
-                for i in range(n):
-                    g[i] = (g[i] - inv((beta + st["table"][i]) % R) * st["m"][i]) % R
-            z = [last]
-            for i in range(usable):
-                z.append((z[i] + g[i]) % R)
-            last = z[usable]
-            z += [rng.fr() for _ in range(bf)]
-            assert len(z) == n
-            st["z_polys"].append(dom.lagrange_to_coeff(z))
-        assert last == 0, "the lookup does not hold"
+    for C in circuits:
+        for st in C["lk"]:
+            st["z_polys"] = []
+            last = 0
+            for si, cols_in in enumerate(st["inputs"]):
+                g = [0] * n
+                for col in cols_in:
+                    for i in range(n):
+                        g[i] = (g[i] + inv((beta + col[i]) % R)) % R
+                if si == 0:
+                    for i in range(n):
+                        g[i] = (g[i] - inv((beta + st["table"][i]) % R) * st["m"][i]) % R
+                z = [last]
+                for i in range(usable):
+                    z.append((z[i] + g[i]) % R)
+                last = z[usable]
+                z += [rng.fr() for _ in range(bf)]
+                assert len(z) == n
+                st["z_polys"].append(dom.lagrange_to_coeff(z))
+            assert last == 0, "the lookup does not hold"
     # shuffle products (shuffle/prover.rs:82-150, blinding prover.rs:512-530)
-    sh_polys = []
-    for group in sh_state:
-        prod = [1] * n
-        for i, (_, shf) in enumerate(group):
-            ch = pow(beta, i + 1, R)
-            for r in range(n):
-                prod[r] = prod[r] * (ch + shf[r]) % R
-        prod = [inv(v) for v in prod]
-        for i, (inp, _) in enumerate(group):
-            ch = pow(beta, i + 1, R)
-            for r in range(n):
-                prod[r] = prod[r] * (ch + inp[r]) % R
-        z = [1]
-        for i in range(usable):
-            z.append(z[i] * prod[i] % R)
-        assert z[usable] == 1, "the shuffle does not hold"
-        z += [rng.fr() for _ in range(bf)]
-        sh_polys.append(dom.lagrange_to_coeff(z))
-    for p in z_polys:
-        t.write_point(commit(pk, p))
-    for st in lk_state:
-        for p in st["z_polys"]:
+    for C in circuits:
+        C["sh_polys"] = []
+        for group in C["sh"]:
+            prod = [1] * n
+            for i, (_, shf) in enumerate(group):
+                ch = pow(beta, i + 1, R)
+                for r in range(n):
+                    prod[r] = prod[r] * (ch + shf[r]) % R
+            prod = [inv(v) for v in prod]
+            for i, (inp, _) in enumerate(group):
+                ch = pow(beta, i + 1, R)
+                for r in range(n):
+                    prod[r] = prod[r] * (ch + inp[r]) % R
+            z = [1]
+            for i in range(usable):
+                z.append(z[i] * prod[i] % R)
+            assert z[usable] == 1, "the shuffle does not hold"
+            z += [rng.fr() for _ in range(bf)]
+            C["sh_polys"].append(dom.lagrange_to_coeff(z))
+    for C in circuits:
+        for p in C["z_polys"]:
             t.write_point(commit(pk, p))
-    for p in sh_polys:
-        t.write_point(commit(pk, p))
+    for C in circuits:
+        for st in C["lk"]:
+            for p in st["z_polys"]:
+                t.write_point(commit(pk, p))
+    for C in circuits:
+        for p in C["sh_polys"]:
+            t.write_point(commit(pk, p))
     # vanishing argument: random polynomial (vanishing/prover.rs:40-67)
     random_poly = rng.random_poly(n)
     t.write_point(commit(pk, random_poly))
     y = t.squeeze()
-    # h(X) on the extended coset
+    # h(X) on the extended coset: ONE Horner fold in y over the expressions of every circuit (evaluation.rs:839-1100)
     ext = dom.coeff_to_extended
-    adv_c = [ext(p) for p in advice_polys]
     fix_c = [ext(p) for p in pk.fixed_polys]
-    ins_c = [ext(p) for p in instance_polys]
     sig_c = [ext(p) for p in pk.sigma_polys]
-    z_c = [ext(p) for p in z_polys]
-    lk_c = [(ext(st["m_poly"]), [ext(p) for p in st["z_polys"]]) for st in lk_state]
-    sh_c = [ext(p) for p in sh_polys]
+    for C in circuits:
+        C["adv_c"] = [ext(p) for p in C["advice_polys"]]
+        C["ins_c"] = [ext(p) for p in C["instance_polys"]]
+        C["z_c"] = [ext(p) for p in C["z_polys"]]
+        C["lk_c"] = [(ext(st["m_poly"]), [ext(p) for p in st["z_polys"]]) for st in C["lk"]]
+        C["sh_c"] = [ext(p) for p in C["sh_polys"]]
     en = dom.extended_n
     scale = en // n
     last_rot = -(bf + 1)
-    colc = {"advice": adv_c, "fixed": fix_c, "instance": ins_c}
     h = [0] * en
     point = ZETA
     for j in range(en):
-        adv = lambda c, r: adv_c[c][(j + r * scale) % en]  # noqa: E731
-        fix = lambda c, r: fix_c[c][(j + r * scale) % en]  # noqa: E731
-        ins = lambda c, r: ins_c[c][(j + r * scale) % en]  # noqa: E731
         jn, jl = (j + scale) % en, (j + last_rot * scale) % en
-        exprs = _gates(cs, adv, fix, ins)
-        exprs += _argument_expressions(
-            cs, adv, fix, ins, theta, beta, gamma, pk.l0[j], pk.l_last[j], pk.l_active_row[j], beta * point % R,
-            [(z_c[i][j], z_c[i][jn], z_c[i - 1][jl] if i else None) for i in range(len(z_c))],
-            [(mc[j], [(zc[i][j], zc[i][jn], zc[i - 1][jl] if i else None) for i in range(len(zc))]) for mc, zc in lk_c],
-            [(zc[j], zc[jn]) for zc in sh_c],
-            [c[j] for c in sig_c], [colc[kd][ix][j] for kd, ix in cs.perm_columns])
         acc = 0
-        for e in exprs:
-            acc = (acc * y + e) % R
+        for C in circuits:
+            adv_c, ins_c, z_c = C["adv_c"], C["ins_c"], C["z_c"]
+            colc = {"advice": adv_c, "fixed": fix_c, "instance": ins_c}
+            adv = lambda c, r: adv_c[c][(j + r * scale) % en]  # noqa: E731
+            fix = lambda c, r: fix_c[c][(j + r * scale) % en]  # noqa: E731
+            ins = lambda c, r: ins_c[c][(j + r * scale) % en]  # noqa: E731
+            exprs = _gates(cs, adv, fix, ins)
+            exprs += _argument_expressions(
+                cs, adv, fix, ins, theta, beta, gamma, pk.l0[j], pk.l_last[j], pk.l_active_row[j], beta * point % R,
+                [(z_c[i][j], z_c[i][jn], z_c[i - 1][jl] if i else None) for i in range(len(z_c))],
+                [(mc[j], [(zc[i][j], zc[i][jn], zc[i - 1][jl] if i else None) for i in range(len(zc))]) for mc, zc in C["lk_c"]],
+                [(zc[j], zc[jn]) for zc in C["sh_c"]],
+                [c[j] for c in sig_c], [colc[kd][ix][j] for kd, ix in cs.perm_columns])
+            for e in exprs:
+                acc = (acc * y + e) % R
         h[j] = acc * inv((pow(point, n, R) - 1) % R) % R
         point = point * dom.extended_omega % R
     h_coeffs = dom.extended_to_coeff(h)
@@ -753,10 +778,12 @@ def create_proof(pk, advice_in, rng, use_gwc=False, instances=()):
     x = t.squeeze()
     xn = pow(x, n, R)
     # evaluations (prover.rs:700-790)
-    for c, rot in _cs_get(cs, "instance_queries", []):
-        t.write_scalar(eval_poly(instance_polys[c], dom.rotate_omega(x, rot)))
-    for c, rot in cs.advice_queries:
-        t.write_scalar(eval_poly(advice_polys[c], dom.rotate_omega(x, rot)))
+    for C in circuits:
+        for c, rot in _cs_get(cs, "instance_queries", []):
+            t.write_scalar(eval_poly(C["instance_polys"][c], dom.rotate_omega(x, rot)))
+    for C in circuits:
+        for c, rot in cs.advice_queries:
+            t.write_scalar(eval_poly(C["advice_polys"][c], dom.rotate_omega(x, rot)))
     for c, rot in cs.fixed_queries:
         t.write_scalar(eval_poly(pk.fixed_polys[c], dom.rotate_omega(x, rot)))
     h_poly = fold(reversed(pieces), xn, n)
@@ -772,13 +799,16 @@ def create_proof(pk, advice_in, rng, use_gwc=False, instances=()):
             if i + 1 < len(polys_):
                 t.write_scalar(eval_poly(p, x_last))
 
-    write_set_evals(z_polys)
-    for st in lk_state:
-        t.write_scalar(eval_poly(st["m_poly"], x))
-        write_set_evals(st["z_polys"])
-    for p in sh_polys:
-        t.write_scalar(eval_poly(p, x))
-        t.write_scalar(eval_poly(p, x_next))
+    for C in circuits:
+        write_set_evals(C["z_polys"])
+    for C in circuits:
+        for st in C["lk"]:
+            t.write_scalar(eval_poly(st["m_poly"], x))
+            write_set_evals(st["z_polys"])
+    for C in circuits:
+        for p in C["sh_polys"]:
+            t.write_scalar(eval_poly(p, x))
+            t.write_scalar(eval_poly(p, x_next))
     # multiopen query list (prover.rs:792-840)
     polys = {}
     queries = []
@@ -795,17 +825,18 @@ def create_proof(pk, advice_in, rng, use_gwc=False, instances=()):
         for i in reversed(range(len(polys_) - 1)):
             q((name, i), polys_[i], last_rot)
 
-    for c, rot in _cs_get(cs, "instance_queries", []):
-        q(("instance", c), instance_polys[c], rot)
-    for c, rot in cs.advice_queries:
-        q(("advice", c), advice_polys[c], rot)
-    open_sets("z", z_polys)
-    for li, st in enumerate(lk_state):
-        q(("lookup_m", li), st["m_poly"], 0)
-        open_sets("lookup_z%d" % li, st["z_polys"])
-    for i, p in enumerate(sh_polys):
-        q(("shuffle_z", i), p, 0)
-        q(("shuffle_z", i), p, 1)
+    for ci, C in enumerate(circuits):
+        for c, rot in _cs_get(cs, "instance_queries", []):
+            q(("instance", ci, c), C["instance_polys"][c], rot)
+        for c, rot in cs.advice_queries:
+            q(("advice", ci, c), C["advice_polys"][c], rot)
+        open_sets("z%d" % ci, C["z_polys"])
+        for li, st in enumerate(C["lk"]):
+            q(("lookup_m", ci, li), st["m_poly"], 0)
+            open_sets("lookup_z%d_%d" % (ci, li), st["z_polys"])
+        for i, p in enumerate(C["sh_polys"]):
+            q(("shuffle_z", ci, i), p, 0)
+            q(("shuffle_z", ci, i), p, 1)
     for c, rot in cs.fixed_queries:
         q(("fixed", c), pk.fixed_polys[c], rot)
     for i, p in enumerate(pk.sigma_polys):
@@ -883,36 +914,43 @@ def opening_check(pk, left, right, pairing):
     return bp.pairing_check([(left, pk.s_g2), (g1_neg(right), bp.G2)])
 
 
-def verify_proof(pk, proof, use_gwc=False, pairing=False, instances=()):
-    """True iff the proof is accepted (plonk/verifier.rs:128-507)."""
+def verify_proof(pk, proof, use_gwc=False, pairing=False, instances=(), circuits=None):
+    """True iff the proof is accepted (plonk/verifier.rs:128-507).  `circuits` = number of circuit instances in the proof
+    (then `instances` is a list with one list of instance columns per circuit); None = one circuit, `instances` its columns."""
     cs, dom = pk.cs, pk.dom
     n, bf = dom.n, cs.blinding_factors
+    instance_sets = [instances] if circuits is None else list(instances)
+    ncirc = len(instance_sets)
+    assert circuits is None or circuits == ncirc
     t = Transcript(proof)
     t.common_scalar(pk.transcript_repr)
-    assert len(instances) == _cs_get(cs, "num_instance", 0)
     instance_commitments = []
-    for vals in instances:
-        assert len(vals) <= n - (bf + 1)
-        instance_commitments.append(commit(pk, dom.lagrange_to_coeff(list(vals) + [0] * (n - len(vals)))))
-        t.common_point(instance_commitments[-1])
-    advice_commitments = [t.read_point() for _ in range(cs.num_advice)]
+    for inst in instance_sets:
+        assert len(inst) == _cs_get(cs, "num_instance", 0)
+        coms = []
+        for vals in inst:
+            assert len(vals) <= n - (bf + 1)
+            coms.append(commit(pk, dom.lagrange_to_coeff(list(vals) + [0] * (n - len(vals)))))
+            t.common_point(coms[-1])
+        instance_commitments.append(coms)
+    advice_commitments = [[t.read_point() for _ in range(cs.num_advice)] for _ in range(ncirc)]
     theta = t.squeeze()
     lookups_cs, shuffles_cs = _cs_get(cs, "lookups", []), _cs_get(cs, "shuffles", [])
-    m_commitments = [t.read_point() for _ in lookups_cs]
+    m_commitments = [[t.read_point() for _ in lookups_cs] for _ in range(ncirc)]
     beta = t.squeeze()
     gamma = t.squeeze()
     chunk = cs.degree - 2
     nsets = (len(cs.perm_columns) + chunk - 1) // chunk
-    z_commitments = [t.read_point() for _ in range(nsets)]
-    lk_z_commitments = [[t.read_point() for _ in lk["input_sets"]] for lk in lookups_cs]
-    sh_commitments = [t.read_point() for _ in shuffles_cs]
+    z_commitments = [[t.read_point() for _ in range(nsets)] for _ in range(ncirc)]
+    lk_z_commitments = [[[t.read_point() for _ in lk["input_sets"]] for lk in lookups_cs] for _ in range(ncirc)]
+    sh_commitments = [[t.read_point() for _ in shuffles_cs] for _ in range(ncirc)]
     random_commitment = t.read_point()
     y = t.squeeze()
     h_commitments = [t.read_point() for _ in range(dom.quotient_poly_degree)]
     x = t.squeeze()
     instance_queries = _cs_get(cs, "instance_queries", [])
-    instance_evals = [t.read_scalar() for _ in instance_queries]
-    advice_evals = [t.read_scalar() for _ in cs.advice_queries]
+    instance_evals = [[t.read_scalar() for _ in instance_queries] for _ in range(ncirc)]
+    advice_evals = [[t.read_scalar() for _ in cs.advice_queries] for _ in range(ncirc)]
     fixed_evals = [t.read_scalar() for _ in cs.fixed_queries]
     random_eval = t.read_scalar()
     sigma_evals = [t.read_scalar() for _ in cs.perm_columns]
@@ -926,32 +964,36 @@ def verify_proof(pk, proof, use_gwc=False, pairing=False, instances=()):
             out.append(e)
         return out
 
-    z_evals = read_set_evals(nsets)
+    z_evals = [read_set_evals(nsets) for _ in range(ncirc)]
     lk_evals = []
-    for lk in lookups_cs:
-        m_eval = t.read_scalar()
-        lk_evals.append((m_eval, read_set_evals(len(lk["input_sets"]))))
-    sh_evals = [(t.read_scalar(), t.read_scalar()) for _ in shuffles_cs]
+    for _ in range(ncirc):
+        per = []
+        for lk in lookups_cs:
+            m_eval = t.read_scalar()
+            per.append((m_eval, read_set_evals(len(lk["input_sets"]))))
+        lk_evals.append(per)
+    sh_evals = [[(t.read_scalar(), t.read_scalar()) for _ in shuffles_cs] for _ in range(ncirc)]
     xn = pow(x, n, R)
     last_rot = -(bf + 1)
     l_evals = dom.l_i_range(x, xn, range(last_rot, 1))
     l_last, l_blind, l_0 = l_evals[0], sum(l_evals[1:1 + bf]) % R, l_evals[1 + bf]
-    adv = lambda c, r: advice_evals[cs.advice_queries.index((c, r))]  # noqa: E731
     fix = lambda c, r: fixed_evals[cs.fixed_queries.index((c, r))]  # noqa: E731
-    ins = lambda c, r: instance_evals[instance_queries.index((c, r))]  # noqa: E731
-    getters = {"advice": adv, "fixed": fix, "instance": ins}
 
     def triples(evs):
         return [(evs[i]["cur"], evs[i]["next"], evs[i - 1]["last"] if i else None) for i in range(len(evs))]
 
-    exprs = _gates(cs, adv, fix, ins)
-    exprs += _argument_expressions(
-        cs, adv, fix, ins, theta, beta, gamma, l_0, l_last, (1 - (l_last + l_blind)) % R, beta * x % R,
-        triples(z_evals), [(m_eval, triples(evs)) for m_eval, evs in lk_evals], sh_evals,
-        sigma_evals, [getters[kd](ix, 0) for kd, ix in cs.perm_columns])
     expected_h = 0
-    for e in exprs:
-        expected_h = (expected_h * y + e) % R
+    for ci in range(ncirc):
+        adv = lambda c, r, ci=ci: advice_evals[ci][cs.advice_queries.index((c, r))]  # noqa: E731
+        ins = lambda c, r, ci=ci: instance_evals[ci][instance_queries.index((c, r))]  # noqa: E731
+        getters = {"advice": adv, "fixed": fix, "instance": ins}
+        exprs = _gates(cs, adv, fix, ins)
+        exprs += _argument_expressions(
+            cs, adv, fix, ins, theta, beta, gamma, l_0, l_last, (1 - (l_last + l_blind)) % R, beta * x % R,
+            triples(z_evals[ci]), [(m_eval, triples(evs)) for m_eval, evs in lk_evals[ci]], sh_evals[ci],
+            sigma_evals, [getters[kd](ix, 0) for kd, ix in cs.perm_columns])
+        for e in exprs:
+            expected_h = (expected_h * y + e) % R
     expected_h = expected_h * inv((xn - 1) % R) % R
     h_commitment = None
     for c in reversed(h_commitments):
@@ -970,17 +1012,18 @@ def verify_proof(pk, proof, use_gwc=False, pairing=False, instances=()):
         for i in reversed(range(len(coms) - 1)):
             q((name, i), coms[i], last_rot, evs[i]["last"])
 
-    for (c, rot), ev in zip(instance_queries, instance_evals):
-        q(("instance", c), instance_commitments[c], rot, ev)
-    for (c, rot), ev in zip(cs.advice_queries, advice_evals):
-        q(("advice", c), advice_commitments[c], rot, ev)
-    open_sets("z", z_commitments, z_evals)
-    for li, (m_eval, evs) in enumerate(lk_evals):
-        q(("lookup_m", li), m_commitments[li], 0, m_eval)
-        open_sets("lookup_z%d" % li, lk_z_commitments[li], evs)
-    for i, (cur, nxt) in enumerate(sh_evals):
-        q(("shuffle_z", i), sh_commitments[i], 0, cur)
-        q(("shuffle_z", i), sh_commitments[i], 1, nxt)
+    for ci in range(ncirc):
+        for (c, rot), ev in zip(instance_queries, instance_evals[ci]):
+            q(("instance", ci, c), instance_commitments[ci][c], rot, ev)
+        for (c, rot), ev in zip(cs.advice_queries, advice_evals[ci]):
+            q(("advice", ci, c), advice_commitments[ci][c], rot, ev)
+        open_sets("z%d" % ci, z_commitments[ci], z_evals[ci])
+        for li, (m_eval, evs) in enumerate(lk_evals[ci]):
+            q(("lookup_m", ci, li), m_commitments[ci][li], 0, m_eval)
+            open_sets("lookup_z%d_%d" % (ci, li), lk_z_commitments[ci][li], evs)
+        for i, (cur, nxt) in enumerate(sh_evals[ci]):
+            q(("shuffle_z", ci, i), sh_commitments[ci][i], 0, cur)
+            q(("shuffle_z", ci, i), sh_commitments[ci][i], 1, nxt)
     for (c, rot), ev in zip(cs.fixed_queries, fixed_evals):
         q(("fixed", c), pk.fixed_commitments[c], rot, ev)
     for i, ev in enumerate(sigma_evals):

@@ -70,6 +70,47 @@ def test_proof_bytes_match_reference_prover(oracle, device, which, k):
         assert rp.verify_proof(rpk, proof, use_gwc=use_gwc)
 
 
+@pytest.mark.parametrize("which,k", [("mini", 5), ("lookup", 6)])
+def test_several_circuit_instances_match_reference_prover(oracle, device, which, k):
+    """`circuits: &[ConcreteCircuit]` (plonk/prover.rs:206-232): two (three) circuit instances in one proof -- the device
+    prover runs every phase circuit by circuit and combines the per-circuit quotients by powers of y; bytes equal to the
+    reference prover's single Horner fold over all circuits, accepted by its verifier"""
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+    from test_plonk_host import _second_lookup_shuffle_witness
+
+    if which == "mini":
+        ref_cs, cs = rp.MiniPlonk, circuits.mini_plonk()
+        adv_a, fixed, copies = ref_cs.synthesize(k, a=5)
+        advs = [adv_a, ref_cs.synthesize(k, a=7)[0], ref_cs.synthesize(k, a=11)[0]]
+        insts = [(), (), ()]
+    else:
+        ref_cs, cs = rp.LookupShuffle, lookup_shuffle_cs()
+        adv_a, fixed, copies, inst_a = ref_cs.synthesize(k)
+        adv_b, inst_b = _second_lookup_shuffle_witness(k)
+        advs, insts = [adv_a, adv_b], [inst_a, inst_b]
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    rpk = rp.keygen(ref_cs, k, S_TRAPDOOR, fixed, copies)
+    for seed, use_gwc in ((1, False), (2, True)):
+        proof = prover.create_proof_ext(device, params, pk, [cols_to_arr(a) for a in advs], ProverRng(seed), use_gwc,
+                                        instances=insts)
+        want = rp.create_proof(rpk, advs, ProverRng(seed), use_gwc=use_gwc, instances=insts)
+        assert len(proof) == len(want)
+        first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
+        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+        assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=insts, circuits=len(advs))
+    # one circuit in the list form is the single-circuit proof
+    one = prover.create_proof_ext(device, params, pk, [cols_to_arr(advs[0])], ProverRng(5), False, instances=[insts[0]])
+    assert one == prover.create_proof_ext(device, params, pk, cols_to_arr(advs[0]), ProverRng(5), False, instances=insts[0])
+    # the coset decomposition of the multi-GPU path (one quotient per coset, every circuit folded into it)
+    D2 = prover.Device(force_cosets=True)
+    params2 = prover.Params(D2, k, params.g, params.g_lagrange)
+    pk2 = prover.keygen(D2, params2, cs, cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+    got = prover.create_proof_ext(D2, params2, pk2, [cols_to_arr(a) for a in advs], ProverRng(1), False, instances=insts)
+    assert got == rp.create_proof(rpk, advs, ProverRng(1), instances=insts)
+
+
 def test_bad_witness_is_rejected(oracle, device):
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng

@@ -113,6 +113,46 @@ def test_reference_prover_is_accepted(cs, k):
             pass
 
 
+def _second_lookup_shuffle_witness(k):
+    """the LookupShuffle witness with another public input (w[0] = instance[0][0] = 43)"""
+    adv, fixed, copies, inst = rp.LookupShuffle.synthesize(k)
+    adv = [c[:] for c in adv]
+    adv[11][0] = 43
+    return adv, [[43, 7]]
+
+
+def test_reference_prover_with_several_circuit_instances():
+    """`circuits: &[ConcreteCircuit]` (plonk/prover.rs:206-232): every phase circuit by circuit, one quotient.  One
+    circuit given in the list form is the single-circuit proof; two circuits verify with their own public inputs only."""
+    cs, k = rp.MiniPlonk, 4
+    adv5, fixed, copies = cs.synthesize(k, a=5)
+    adv7, _, _ = cs.synthesize(k, a=7)
+    pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
+    assert rp.create_proof(pk, [adv5], ProverRng(3), instances=[()]) == rp.create_proof(pk, adv5, ProverRng(3))
+    for use_gwc in (False, True):
+        proof = rp.create_proof(pk, [adv5, adv7], ProverRng(3), use_gwc=use_gwc, instances=[(), ()])
+        assert rp.verify_proof(pk, proof, use_gwc=use_gwc, instances=[(), ()], circuits=2)
+        assert len(proof) > len(rp.create_proof(pk, adv5, ProverRng(3), use_gwc=use_gwc))
+        bad = bytearray(proof)
+        bad[32 * 4 + 3] ^= 1                                    # an advice commitment of the second circuit
+        try:
+            assert not rp.verify_proof(pk, bytes(bad), use_gwc=use_gwc, instances=[(), ()], circuits=2)
+        except AssertionError:
+            pass
+    bad7 = [c[:] for c in adv7]
+    bad7[2][0] += 1                                             # the second circuit's witness breaks its gate
+    assert not rp.verify_proof(pk, rp.create_proof(pk, [adv5, bad7], ProverRng(3), instances=[(), ()]), instances=[(), ()], circuits=2)
+    # lookups, shuffles and instance columns in both circuits
+    cs, k = rp.LookupShuffle, 5
+    adv, fixed, copies, inst = cs.synthesize(k)
+    adv2, inst2 = _second_lookup_shuffle_witness(k)
+    pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
+    proof = rp.create_proof(pk, [adv, adv2], ProverRng(8), instances=[inst, inst2])
+    assert rp.verify_proof(pk, proof, instances=[inst, inst2], circuits=2)
+    assert not rp.verify_proof(pk, proof, instances=[inst2, inst], circuits=2)
+    assert not rp.verify_proof(pk, proof, instances=[inst, inst], circuits=2)
+
+
 def test_pairing_self_checks():
     import bn254_pairing as bp
 
