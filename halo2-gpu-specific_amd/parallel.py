@@ -8,9 +8,10 @@ The path shards over independent units; DESIGN.md section 6 has
     device (h2_dev_g1_fold) under RCCL, on the host under gloo -- latency-bound, link bandwidth is irrelevant;
   * the extended-domain phase of a proof (coset NTTs, evaluate_h, division by the vanishing polynomial, inverse
     transform) is split by COSET of the n-th roots of unity: rank r evaluates the quotient on the cosets
-    j = r mod shards of the extended domain from replicated coefficient vectors -- no exchange until the c = 2^(extended_k - k)
-    per-coset polynomials P_j = sum_m gamma_j^m h_m are broadcast (one n-vector each) and un-mixed into the pieces
-    h_m by the inverse Vandermonde matrix (`coset_unmix_matrix`);
+    j = r mod shards from replicated coefficient vectors -- only the c = degree - 1 cosets that determine the quotient's
+    c pieces, not all 2^(extended_k - k) of the extended domain -- no exchange until the per-coset polynomials
+    P_j = sum_m gamma_j^m h_m are broadcast (one n-vector each) and un-mixed into the pieces h_m by the inverse
+    Vandermonde matrix (`coset_unmix_matrix`);
   * whole columns can also be dealt round-robin (`shard_columns`) when a caller has independent polynomials
     (bench.py's NTT leg: one polynomial per GPU, no collective).
 """
@@ -151,16 +152,17 @@ def allgather_rows(t, lo, hi, group=None, stream=None):
 
 # ---- coset sharding of the extended-domain phase ---------------------------------------------------------------------
 def coset_plan(c, world, rank):
-    """c = 2^(extended_k - k) cosets over `world` ranks: shards = min(c, world) groups; rank r works on the cosets
-    j = r mod shards (ranks beyond c replicate a shard).  Returns (shards, owned cosets)."""
+    """c cosets (the quotient_poly_degree = degree - 1 cosets that determine the quotient, prover.Device.coset_plan) over
+    `world` ranks: shards = min(c, world) groups; rank r works on the cosets j = r mod shards (ranks beyond c replicate
+    a shard).  Returns (shards, owned cosets)."""
     shards = min(c, world)
     return shards, [j for j in range(c) if j % shards == rank % shards]
 
 
 def coset_unmix_matrix(gammas, rows):
-    """The per-coset polynomials are P_j = sum_m gamma_j^m h_m (gamma_j = (zeta extended_omega^j)^n, m < c): returns the
-    first `rows` rows of the inverse of the Vandermonde matrix V[j][m] = gamma_j^m modulo r, so that
-    h_m = sum_j M[m][j] P_j.  Host integers; c <= 8."""
+    """The per-coset polynomials are P_j = sum_m gamma_j^m h_m (gamma_j = (zeta extended_omega^j)^n, m < c = len(gammas)):
+    returns the first `rows` rows of the inverse of the Vandermonde matrix V[j][m] = gamma_j^m modulo r, so that
+    h_m = sum_j M[m][j] P_j.  With c = rows = quotient_poly_degree cosets the system is square.  Host integers; c <= 8."""
     c = len(gammas)
     a = [[pow(g, m, R_MOD) for m in range(c)] + [1 if i == j else 0 for i in range(c)] for j, g in enumerate(gammas)]
     for col in range(c):                       # Gauss-Jordan modulo r

@@ -207,14 +207,22 @@ class Device:
 
     # -- coset sharding of the extended domain (one proof over several ranks) --------------------------
     def coset_plan(self, dom):
-        """None on the single-device path; else (c, shards, owned): the extended domain is the union of c =
-        2^(extended_k - k) cosets g_j H (g_j = zeta extended_omega^j, H = the n-th roots of unity; extended index c i + j
-        is point i of coset j); this rank evaluates the quotient on the cosets in `owned`."""
-        if self.group_size <= 1 and not self.force_cosets:
-            return None
+        """None = the quotient is evaluated on the whole extended domain; else (c, shards, owned): it is evaluated coset
+        by coset.  The extended domain is the union of 2^(extended_k - k) cosets g_j H (g_j = zeta extended_omega^j, H =
+        the n-th roots of unity; extended index 2^(extended_k - k) i + j is point i of coset j), but the quotient has
+        only quotient_poly_degree = degree - 1 pieces h_t of n coefficients, and on coset j it reads
+        P_j(X) = sum_t gamma_j^t h_t(X) (gamma_j = g_j^n): its values on the FIRST c = quotient_poly_degree cosets
+        determine it (a c x c Vandermonde system per coefficient).  This rank evaluates the cosets in `owned`.
+
+        Used when one proof is spread over several ranks.  On a single device the fused extended-domain transforms win
+        (2^(extended_k - k) is the next power of two above degree - 1, so at best 5 of 8 cosets are saved, and the
+        per-coset launches cost more than that below k = 22: profiles/r2_coset_path_vs_extended.txt); `force_cosets` /
+        H2_COSETS=1 runs the coset route there -- the same proof bytes -- for tests."""
         from .parallel import coset_plan
 
-        c = 1 << (dom.extended_k - dom.k)
+        c = dom.quotient_poly_degree
+        if self.group_size <= 1 and not self.force_cosets and os.environ.get("H2_COSETS") != "1":
+            return None
         shards, owned = coset_plan(c, self.group_size, self.group_rank)
         return c, shards, owned
 
@@ -1010,6 +1018,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         C["advice_polys"] = [D.intt(t, dom) for t in C["advice"]]    # in place: the Lagrange values are not needed again
     g = pk.graph
     plan = D.coset_plan(dom)
+    if D.group_size <= 1:                      # on one device the proving key decides which tables exist
+        if pk.coset is None:
+            plan = None
+        elif plan is None:
+            plan = (dom.quotient_poly_degree, 1, sorted(pk.coset))
     # Several circuits share one quotient: the reference keeps folding `value = value * y + term` from one circuit into
     # the next (plonk/evaluation.rs:839-1100), i.e. h = sum_i y^(T (N - 1 - i)) h_i with T terms per circuit and h_i the
     # fold of circuit i alone -- each circuit runs through the evaluator on its own and the results are combined.

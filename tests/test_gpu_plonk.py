@@ -275,13 +275,13 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
     want = prover.create_proof_ext(device, params, pk, adv, ProverRng(31), False, instances=inst)
     D2 = prover.Device(force_cosets=True)
     dom = pk.domain
-    assert D2.coset_plan(dom)[2] == list(range(1 << (dom.extended_k - dom.k)))
+    assert D2.coset_plan(dom)[2] == list(range(dom.quotient_poly_degree))     # the cosets that determine the quotient
     params2 = prover.Params(D2, k, params.g, params.g_lagrange)
     pk2 = prover.keygen(D2, params2, make(), fixed, copies)
     assert pk2.fixed_cosets is None and sorted(pk2.coset) == D2.coset_plan(dom)[2]
     # the per-coset tables are the stride-c subsets of the extended tables
     c = 1 << (dom.extended_k - dom.k)
-    for j in (0, c - 1):
+    for j in (0, dom.quotient_poly_degree - 1):
         assert device.torch.equal(pk2.coset[j]["l_active_row"], pk.l_active_row[j::c])
         assert device.torch.equal(pk2.coset[j]["fixed"][0], pk.fixed_cosets[0][j::c])
     for use_gwc in (False, True):
