@@ -580,14 +580,16 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
 // offset of every bucket of the partition (written to `starts`), then the entries are placed.
 // A partition far above the average size means a skewed column (a witness column that is mostly one value:
 // every such scalar lands in one bucket): its entries would serialise on one LDS counter, so the counter updates
-// are aggregated per wave -- lanes holding the key of the first active lane are served by one atomic, twice,
-// and only what is left falls back to per-lane atomics.
+// are aggregated per wave -- lanes holding the key of the first active lane are served by one atomic, four times over
+// (a witness column of three or four distinct values is then served completely), and only what is left falls back to
+// per-lane atomics.
+static constexpr int SKEW_ROUNDS = 4;  // distinct keys of a wave served by one atomic each (a column of 3-4 values: all of them)
 __device__ __forceinline__ uint32_t lds_count_aggregated(uint32_t* bins, uint32_t key, bool valid) {
     const uint32_t lane = threadIdx.x & 63;
     uint64_t active = __ballot(valid);
     uint32_t result = 0;
 #pragma unroll
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < SKEW_ROUNDS; round++) {
         if (active == 0) break;
         const int leader = __ffsll((unsigned long long)active) - 1;
         const uint32_t k = __shfl(key, leader, 64);
