@@ -403,16 +403,24 @@ class Params:
         import weakref
 
         L = device.L
-        if self.n < (1 << 15) or self.table_bytes:
+        # one proof over several ranks: this rank only ever commits its own contiguous range of the bases (the range
+        # split of every MSM), so the tables cover that range only -- and their digit count is chosen for its length
+        lo, hi = 0, self.n
+        if device.group_size > 1:
+            from .parallel import msm_split_range
+
+            lo, hi = msm_split_range(self.n, device.group_size, device.group_rank)
+        rows = hi - lo
+        if rows < (1 << 15) or self.table_bytes:
             return False
-        need = 2 * L.h2_dev_bases_precompute_bytes(self.n, digits)
+        need = 2 * L.h2_dev_bases_precompute_bytes(rows, digits)
         free, _ = device.torch.cuda.mem_get_info(device.dev)
         if need > free // 2:
             return False
         device.sync()
-        ptrs = [self.g.data_ptr(), self.g_lagrange.data_ptr()]
+        ptrs = [self.g.data_ptr() + 64 * lo, self.g_lagrange.data_ptr() + 64 * lo]
         for ptr in ptrs:
-            check(L.h2_dev_bases_precompute(ptr, self.n, digits, device.stream), "h2_dev_bases_precompute")
+            check(L.h2_dev_bases_precompute(ptr, rows, digits, device.stream), "h2_dev_bases_precompute")
         self.table_bytes = need
         weakref.finalize(self, _forget_tables, L, ptrs)
         return True

@@ -293,7 +293,8 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
 
 
 @pytest.mark.timeout(600)
-def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path):
+@pytest.mark.parametrize("k", [10, 17])
+def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, k):
     """config 5's data flow with two ranks (here two processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold, the extended domain split by coset + broadcast + un-mixing.  Both
     ranks must emit the single-device proof."""
@@ -304,7 +305,6 @@ def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device,
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
-    k = 10
     adv, fixed, copies = circuits.mini_plonk_synthesize(k)
     params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
     pk = prover.keygen(device, params, circuits.mini_plonk(), fixed, copies)
