@@ -129,6 +129,22 @@ class Builder:
         return self
 
 
+def _rebind(self, *, fixed, advice, instance, y, theta):
+    """the same program over other columns / another challenge: only the pointer tables and the two scalars change
+    (what a cached theta-compression descriptor needs from one proof to the next)"""
+    d = self.desc
+    assert (d.n_fixed, d.n_advice, d.n_instance) == (len(fixed), len(advice), len(instance))
+    self.bound = [self._ptrs(fixed), self._ptrs(advice), self._ptrs(instance)]
+    del self.keep[-3:]                       # _ptrs parked them in `keep`; `bound` owns them (replaced on the next rebind)
+    d.fixed, d.advice, d.instance = self.bound
+    d.y = _fr(*[int(x) for x in y])
+    d.theta = _fr(*[int(x) for x in theta])
+    return self
+
+
+Builder.rebind = _rebind
+
+
 def evaluate_h(builder):
     """host buffers in, numpy (2^extended_k, 4) out"""
     out = np.zeros((1 << builder.desc.extended_k, 4), dtype=np.uint64)
