@@ -396,6 +396,7 @@ def main():
             "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
             "steps": steps,
             "peak_device_memory_gib": round(peak_gib, 1),
+            "srs_shifted_base_tables_gib": round(params.table_bytes / 2**30, 1),   # library memory, not in the peak above
             "srs": "Params::unsafe_setup on the device with a fixed trapdoor (g[i] = [s^i]G, g_lagrange[i] = [l_i(s)]G)",
         }
 
