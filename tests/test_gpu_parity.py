@@ -607,13 +607,13 @@ def test_msm_narrow_columns_row_ranges(oracle, n):
 
 @pytest.mark.timeout(300)
 def test_msm_randomised_shapes():
-    """tools/msm_fuzz.py for a short budget: random sizes, bounds and value distributions against the oracle (the long
-    runs -- thousands of cases -- are recorded in DESIGN.md)"""
+    """tools/msm_fuzz.py for a short budget: random sizes, bounds and value distributions against the oracle, windowed and
+    over shifted-base tables with random digit counts (the long runs -- thousands of cases -- are recorded in DESIGN.md)"""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "20", "11"], capture_output=True, text=True,
-                         timeout=280)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "20", "11", "tables"], capture_output=True,
+                         text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "all equal to the oracle" in out.stdout
+    assert "all equal to the oracle" in out.stdout and "over tables" in out.stdout

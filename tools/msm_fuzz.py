@@ -1,6 +1,8 @@
 """Randomised MSM parity: random sizes (1 .. 2^19, ragged), scalar bounds (1 .. 254 bits) and value distributions
 (uniform under the bound, a few distinct values, one dominant value, sparse, booleans, P / -P pairs in the bases) through
-the C ABI against the CPU oracle, for a time budget.   usage: python tools/msm_fuzz.py [seconds] [seed]"""
+the C ABI against the CPU oracle, for a time budget.   usage: python tools/msm_fuzz.py [seconds] [seed] [tables]
+With `tables` every case also runs over a shifted-base table of its bases (h2_dev_bases_precompute with a random digit
+count, tables allowed from one row on), through the device entry point."""
 import os
 import sys
 import time
@@ -18,6 +20,9 @@ from halo2_gpu_specific_amd import arithmetic as ar  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+tables = len(sys.argv) > 3 and sys.argv[3] == "tables"
+if tables:
+    os.environ["H2_MSM_TABLE_MIN_N"] = "1"
 rng = np.random.default_rng(seed)
 oracle = Oracle.get()
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
@@ -36,6 +41,22 @@ def rand_ints(count, bits):
         for w in row:
             v = (v << 62) | int(w)
         out.append((v & ((1 << bits) - 1)) % R_MOD)
+    return out
+
+
+def over_table(scalars, pts, bits, digits):
+    import halo2_gpu_specific_amd as h2
+
+    L = h2.lib()
+    d_p = torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).cuda()
+    d_s = torch.from_numpy(np.ascontiguousarray(scalars).view(np.int64)).cuda()
+    assert L.h2_dev_bases_precompute(d_p.data_ptr(), len(pts), digits, None) == 0, L.h2_last_error()
+    nbytes = L.h2_msm_scratch_bytes(len(pts), bits)
+    scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device="cuda")
+    out = np.zeros(12, dtype=np.uint64)
+    rc = L.h2_dev_msm(d_s.data_ptr(), d_p.data_ptr(), len(pts), bits, scratch.data_ptr(), nbytes, out.ctypes.data, None)
+    assert rc == 0, L.h2_last_error()
+    assert L.h2_dev_bases_forget(d_p.data_ptr()) == 0
     return out
 
 
@@ -78,4 +99,9 @@ while time.time() < t_end:
     if got != want:
         print("MISMATCH n=%d bits=%d use_bits=%d kind=%d seed=%d case=%d" % (n, bits, use_bits, kind, seed, cases))
         sys.exit(1)
-print("msm_fuzz: %d cases in %.0f s, all equal to the oracle (seed %d)" % (cases, budget, seed))
+    if tables:
+        digits = int(rng.choice([0, 11, 12, 13, 15, 16, 20, 27, 32]))
+        if aff(over_table(scalars, pts, use_bits, digits)) != want:
+            print("MISMATCH over a table: n=%d bits=%d use_bits=%d kind=%d digits=%d seed=%d case=%d" % (n, bits, use_bits, kind, digits, seed, cases))
+            sys.exit(1)
+print("msm_fuzz: %d cases in %.0f s, all equal to the oracle (seed %d)%s" % (cases, budget, seed, ", windowed and over tables" if tables else ""))
