@@ -260,9 +260,9 @@ static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const Shi
         int v = atoi(env);
         if (v >= 1 && v <= 10) s.log_s = (uint32_t)v;
     }
-    // sort: 2^8 bins per k_bucket_sort workgroup -- with more, the lines its scattered stores keep open (bins x resident
-    // workgroups x 128 B) outgrow the L2 (measured at 2^24, 21-bit bucket ids: 2^8 bins 1.6 ms, 2^10 3.5 ms, 2^12 5.1 ms;
-    // k_partition over the remaining 2^13 partitions 3.0 / 2.5 / 2.0 ms) -- up to 2^13 partitions for k_partition
+    // sort: 2^8 bins per k_bucket_sort workgroup -- measured at 2^24 with 21-bit bucket ids: 2^8 bins 1.6 ms, 2^10 3.5 ms,
+    // 2^12 5.1 ms (placing the bins in sweeps of 256 does not change that: profiles/r2_msm_experiments.txt), k_partition
+    // over the remaining 2^13 / 2^11 / 2^9 partitions 3.0 / 2.5 / 2.0 ms -- so up to 2^13 partitions for k_partition
     s.lo_bits = (s.c - 1 < 8) ? (s.c - 1) : 8;
     while (s.c - 1 - s.lo_bits > 13 && s.lo_bits < 12) s.lo_bits++;
     if (const char* env = getenv("H2_MSM_TABLE_LO")) {
