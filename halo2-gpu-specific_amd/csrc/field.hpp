@@ -252,6 +252,8 @@ H2_DEV void mad_acc(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 // drops the add-with-carry after every multiply-add whose column sum provably still fits 64 bits.
 template <class P>
 __device__ __forceinline__ Fp<P> fp_mul_dev(const Fp<P>& a, const Fp<P>& b);
+template <class P>
+__device__ __forceinline__ Fp<P> fp_sqr_dev(const Fp<P>& a);  // a * a with 36 operand products instead of 64
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
 #define H2_MAD_FREE_V(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y))
 #define H2_MAD_FREE_S(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y))
@@ -369,7 +371,11 @@ H2_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
 
 template <class P>
 H2_DEV Fp<P> fp_sqr(const Fp<P>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL) && !defined(H2_NO_SQR)
+    return fp_sqr_dev(a);
+#else
     return fp_mul(a, a);
+#endif
 }
 
 // canonical integer <-> Montgomery (`batch_mont` / `batch_unmont`, arithmetic.rs:235-241,280-286)

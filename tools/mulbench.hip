@@ -36,6 +36,26 @@ __global__ void k_check(F* out, const F* a, const F* b, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fp_store(out + i, fp_mul(fp_load(a + i), fp_load(b + i)));
 }
+template <class F>
+__global__ void k_check_sqr(F* out, const F* a, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fp_store(out + i, fp_sqr(fp_load(a + i)));
+}
+template <class F, int CHAINS>
+__global__ void __launch_bounds__(256) k_sq(F* out, const F* in) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    F x[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; c++) x[c] = fp_load(in + ((i + 7 * c) & 1023));
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) x[c] = fp_sqr(x[c]);
+    }
+    F acc = x[0];
+#pragma unroll
+    for (int c = 1; c < CHAINS; c++) acc = fp_add(acc, x[c]);
+    fp_store(out + i, acc);
+}
 
 // bare multiply-add stream: 8 independent 64-bit accumulators per lane, no carries consumed
 __global__ void __launch_bounds__(256) k_mad(uint32_t* out, uint32_t seed) {
@@ -107,6 +127,16 @@ int check_field(const char* name) {
     }
     printf("%-3s fp_mul device vs host (4 x u64 CIOS) on %d pairs incl. edge values: %d mismatches, %d non-canonical results\n",
            name, n, bad, noncanon);
+    // the dedicated square (36 operand products) against the host product a * a, same inputs
+    hipLaunchKernelGGL(k_check_sqr<F>, dim3(n / 256), dim3(256), 0, 0, dg, da, n);
+    CK(hipMemcpy(got.data(), dg, n * sizeof(F), hipMemcpyDeviceToHost));
+    int sbad = 0;
+    for (int i = 0; i < n; i++) {
+        F x = lt_mod(a[i]) ? a[i] : fp_reduce_once(a[i]);
+        if (!fp_eq(fp_mul(x, x), got[i]) || !lt_mod(got[i])) sbad++;
+    }
+    printf("%-3s fp_sqr device vs host a * a on %d values incl. edge values: %d mismatches\n", name, n, sbad);
+    bad += sbad;
     hipFree(da); hipFree(db); hipFree(dg);
     return bad + noncanon;
 }
@@ -158,5 +188,16 @@ int main() {
     }
     run<Fq, 1>("Fq", ldss[0], (Fq*)d_out, (Fq*)d_in, mad_rate);
     run<Fq, 2>("Fq", ldss[1], (Fq*)d_out, (Fq*)d_in, mad_rate);
+    {   // the dedicated square: 100 multiply-adds per product instead of 136
+        int blocks = 256 * 32;
+        hipEvent_t s0, s1; CK(hipEventCreate(&s0)); CK(hipEventCreate(&s1));
+        hipLaunchKernelGGL((k_sq<Fq, 2>), dim3(blocks), dim3(256), 0, 0, (Fq*)d_out, (Fq*)d_in);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(s0));
+        hipLaunchKernelGGL((k_sq<Fq, 2>), dim3(blocks), dim3(256), 0, 0, (Fq*)d_out, (Fq*)d_in);
+        CK(hipEventRecord(s1)); CK(hipEventSynchronize(s1));
+        float ms; CK(hipEventElapsedTime(&ms, s0, s1));
+        printf("Fq sqr   chains=2  %8.3f ms  %.3e squarings/s\n", ms, (double)blocks * 256 * ITERS * 2 / (ms * 1e-3));
+    }
     return bad ? 2 : 0;
 }
