@@ -422,7 +422,7 @@ class Params:
         for ptr in ptrs:
             check(L.h2_dev_bases_precompute(ptr, rows, digits, device.stream), "h2_dev_bases_precompute")
         self.table_bytes = need
-        weakref.finalize(self, _forget_tables, L, ptrs)
+        weakref.finalize(self, _forget_tables, L, ptrs).atexit = False   # at interpreter exit the process frees them
         return True
 
     @staticmethod
