@@ -393,6 +393,109 @@ H2_DEV Fp<P> fp_from_mont(const Fp<P>& a) {
     return fp_mul(a, one);
 }
 
+// 1 / a in Montgomery form (a R -> a^-1 R; 0 -> 0) by Kaliski's almost-Montgomery inverse: a binary extended GCD on
+// (u, v) = (p, a R) with cofactors (r, s) -- u s + v r = p throughout -- that ends after n <= k <= 2 n halvings (n = 254)
+// with a R's inverse times 2^k, followed by 512 - k modular doublings (a^-1 R^-1 2^k * 2^(512 - k) = a^-1 R).  ~360
+// rounds of 8-limb shifts / adds / subtractions instead of the 254 squarings + 127 products of a^(p-2).  The four cases
+// of a round are branches: for a wave whose lanes hold the SAME value (k_batch_invert's shared inversion) that is 105 us
+// against 230 us; lanes with different values serialise the cases (287 us) -- per-lane inversions keep a^(p-2).
+template <class P>
+H2_DEV Fp<P> fp_inv(const Fp<P>& a) {
+    uint32_t u[8], v[8], r[8], s[8];
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u[i] = P::MOD[i];
+        v[i] = a.l[i];
+        r[i] = 0;
+        s[i] = i == 0 ? 1u : 0u;
+        nz |= a.l[i];
+    }
+    if (nz == 0) return a;
+    uint32_t k = 0;
+    auto halve = [](uint32_t* x) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = (x[i] >> 1) | (i < 7 ? x[i + 1] << 31 : 0u);
+    };
+    auto dbl = [](uint32_t* x) {
+#pragma unroll
+        for (int i = 7; i >= 0; i--) x[i] = (x[i] << 1) | (i ? x[i - 1] >> 31 : 0u);
+    };
+    auto sub = [](uint32_t* x, const uint32_t* y) {  // x -= y
+        uint32_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t d = x[i] - y[i], b1 = x[i] < y[i] ? 1u : 0u, e = d - bw, b2 = d < bw ? 1u : 0u;
+            x[i] = e;
+            bw = b1 | b2;
+        }
+    };
+    auto add = [](uint32_t* x, const uint32_t* y) {  // x += y
+        uint32_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t t = x[i] + y[i], c1 = t < y[i] ? 1u : 0u, e = t + cy, c2 = e < cy ? 1u : 0u;
+            x[i] = e;
+            cy = c1 | c2;
+        }
+    };
+    auto greater = [](const uint32_t* x, const uint32_t* y) {  // x > y
+#pragma unroll
+        for (int i = 7; i >= 0; i--)
+            if (x[i] != y[i]) return x[i] > y[i];
+        return false;
+    };
+    for (;;) {
+        uint32_t vnz = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) vnz |= v[i];
+        if (vnz == 0) break;
+        // the four cases as branches: a wave whose lanes hold the same value (the shared inversion of k_batch_invert)
+        // runs one of them per round; lanes with different values serialise them
+        if ((u[0] & 1) == 0) {
+            halve(u);
+            dbl(s);
+        } else if ((v[0] & 1) == 0) {
+            halve(v);
+            dbl(r);
+        } else if (greater(u, v)) {
+            sub(u, v);
+            halve(u);
+            add(r, s);
+            dbl(s);
+        } else {
+            sub(v, u);
+            halve(v);
+            add(s, r);
+            dbl(r);
+        }
+        k++;
+    }
+    // r in [0, 2p): x = p - (r mod p) = (a R)^-1 2^k mod p
+    Fp<P> x;
+    {
+        uint32_t d[8];
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t e = (uint64_t)r[i] - P::MOD[i] - bw;
+            d[i] = (uint32_t)e;
+            bw = (e >> 32) & 1;
+        }
+        uint64_t bw2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t rr = bw ? r[i] : d[i];  // r mod p
+            uint64_t e = (uint64_t)P::MOD[i] - rr - bw2;
+            x.l[i] = (uint32_t)e;
+            bw2 = (e >> 32) & 1;
+        }
+    }
+    x = fp_reduce_once(x);  // r mod p = 0 cannot happen for a != 0, but p - 0 = p must not escape
+    for (uint32_t i = k; i < 512; i++) x = fp_dbl(x);
+    return x;
+}
+
 // a^e for a 32-bit exponent (square-and-multiply, MSB first)
 template <class P>
 H2_DEV Fp<P> fp_pow_u32(const Fp<P>& a, uint32_t e) {
