@@ -302,10 +302,20 @@ Fr fr_from_u64x4(const uint64_t v[4]) {
 void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits) {
     bits.clear();
     if (log_n == 0) return;
-    // as many 8-bit passes as possible, the remainder first (it needs no inter-pass twiddle)
-    uint32_t rem = log_n % 8;
+    // as many 8-bit passes as possible, the remainder first (it needs no inter-pass twiddle).  A remainder of ONE bit would
+    // be a whole sweep over memory for a single stage (2^25, the extended domain of a k = 24 proof: 1 + 8 + 8 + 8): it is
+    // folded into a 9-bit pass at the END instead (8 + 8 + 9: the middle pass keeps its 2^16-entry twiddle table; 512-row
+    // tiles of 4 columns, 74 KB of LDS): 2^25 4.61 -> 4.33 ms, 2^17 47 -> 41 us.  Two 9-bit passes pay up to 2^18 (9 + 9:
+    // 69 -> 62 us) but not at 2^26 (8 + 9 + 9: 8.98 -> 9.04 ms), three never.
+    const uint32_t rem = log_n % 8, q = log_n / 8;
+    static const bool nine = !(getenv("H2_NTT_NINE") && atoi(getenv("H2_NTT_NINE")) == 0);
+    if (nine && q >= rem && (rem == 1 || (rem == 2 && log_n <= 18))) {
+        for (uint32_t p = 0; p < q - rem; p++) bits.push_back(8);
+        for (uint32_t p = 0; p < rem; p++) bits.push_back(9);
+        return;
+    }
     if (rem) bits.push_back(rem);
-    for (uint32_t p = 0; p < log_n / 8; p++) bits.push_back(8);
+    for (uint32_t p = 0; p < q; p++) bits.push_back(8);
 }
 
 NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream) {
@@ -469,6 +479,14 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             if (threads > 512) threads = 512;
             uint32_t ntiles = (1u << L) / (R * C);
             size_t lds = ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
+            if (lds > 64 * 1024) {  // beyond the default dynamic LDS limit: raise it once
+                static bool raised = false;
+                if (!raised) {
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    raised = true;
+                }
+            }
             if (a.radix4)
                 hipLaunchKernelGGL(k_ntt_pass<true>, dim3(ntiles), dim3(threads), lds, stream, a);
             else

@@ -144,6 +144,23 @@ def test_ntt_full_size(oracle, log_n):
     assert np.array_equal(back, x)
 
 
+def test_ntt_2p25_nine_bit_pass(oracle):
+    """2^25 -- the extended domain of a k = 24 proof -- runs as passes of 8 + 8 + 9 bits: sampled outputs against
+    the oracle's Horner evaluation X[k] = sum_j x_j w^(jk) (arithmetic.rs:714-735 restated), and the round trip"""
+    log_n = 25
+    n = 1 << log_n
+    x = oracle.random_fr(0x2525, n)
+    omega = omega_for(log_n)
+    got = ar.best_fft(x.copy(), fr_mont(omega), log_n)
+    for k in (0, 1, 255, 256, 65535, 65536 + 257, (1 << 24) + 12345, n - 1):
+        point = fr_mont(pow(omega, k, R_MOD))
+        want = np.zeros(4, dtype=np.uint64)
+        oracle.lib.oracle_eval_polynomial(x.ctypes.data, n, point.ctypes.data, want.ctypes.data)
+        assert np.array_equal(got[k], want), k
+    back = ar.gpu_ifft(got, fr_mont(pow(omega, -1, R_MOD)), log_n, fr_mont(pow(n, -1, R_MOD)))
+    assert np.array_equal(back, x)
+
+
 def test_coset_golden(oracle):
     for case in load_golden("coset_kat.json"):
         d, _ = oracle.domain(case["j"], case["k"])
