@@ -213,7 +213,12 @@ struct ShiftTable {
     const Affine* table;  // level 0 = a copy of the bases
     size_t n;             // points per level
     uint32_t D, c, wfull; // digits; digit j is c bits wide for j < wfull, c - 1 after (balanced cut of 255 bits)
+    const Affine* blocks; // sums of BLOCK_ROWS consecutive bases (see "dominant value over whole blocks"); null in a view
+                          // that does not start on a block boundary
 };
+static constexpr uint32_t BLOCK_ROWS = 256;           // = the rows a k_digits workgroup takes per step
+static constexpr uint32_t BLOCK_INDEX0 = 0x40000000u; // point index of block sum 0 in the sorted entries
+static constexpr uint32_t BLOCK_KEY = 0x40000000u;    // key of a row that stands for its whole block (bucket 0)
 
 // digits a scalar below 2^max_bits needs: the signed top digit must not carry out, i.e. o_(j+1) >= max_bits + 1
 static uint32_t table_digits_used(const ShiftTable& t, uint32_t max_bits) {
@@ -302,21 +307,31 @@ std::mutex g_tab_mu;
 std::map<const uint64_t*, ShiftTable> g_tables;  // device base pointer -> its table
 }  // namespace
 
-// table whose bases contain [d_bases, d_bases + n): a view that starts at d_bases's row.  Used when it saves additions.
-static bool table_lookup(const uint64_t* d_bases, size_t n, uint32_t max_bits, ShiftTable* out) {
+// table whose bases contain [d_bases, d_bases + n): a view that starts at d_bases's row
+static bool table_find(const uint64_t* d_bases, size_t n, ShiftTable* out) {
     if (const char* env = getenv("H2_MSM_NO_TABLE"))
         if (env[0] == '1') return false;
-    // below 2^15 scalars the windowed pipeline (and its fused groups) is as fast: 2^14 0.41 vs 0.44 ms
-    size_t min_n = (size_t)1 << 15;
-    if (const char* env = getenv("H2_MSM_TABLE_MIN_N")) min_n = (size_t)atoll(env);
-    if (n < min_n) return false;
     std::lock_guard<std::mutex> g(g_tab_mu);
     auto it = g_tables.upper_bound(d_bases);
     if (it == g_tables.begin()) return false;
     --it;
     if (d_bases + 8 * n > it->first + 8 * it->second.n) return false;
     ShiftTable t = it->second;
-    t.table += (d_bases - it->first) / 8;
+    const size_t off = (size_t)(d_bases - it->first) / 8;
+    t.table += off;
+    t.blocks = (t.blocks && off % BLOCK_ROWS == 0) ? t.blocks + off / BLOCK_ROWS : nullptr;
+    *out = t;
+    return true;
+}
+
+// ... and is it worth using for this bound?
+static bool table_lookup(const uint64_t* d_bases, size_t n, uint32_t max_bits, ShiftTable* out) {
+    // below 2^15 scalars the windowed pipeline (and its fused groups) is as fast: 2^14 0.41 vs 0.44 ms
+    size_t min_n = (size_t)1 << 15;
+    if (const char* env = getenv("H2_MSM_TABLE_MIN_N")) min_n = (size_t)atoll(env);
+    if (n < min_n) return false;
+    ShiftTable t;
+    if (!table_find(d_bases, n, &t)) return false;
     // narrow columns: the plain pipeline's row ranges and fused groups are built for them, and a table saves nothing
     if (table_digits_used(t, max_bits) >= msm_shape(n, max_bits, false).W) return false;
     *out = t;
@@ -375,8 +390,13 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
                                                 uint32_t max_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t np,
                                                 uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
                                                 const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
-                                                uint32_t range_shift, uint32_t R, uint32_t wfull, uint32_t tabmode) {
+                                                uint32_t range_shift, uint32_t R, uint32_t wfull, uint32_t tabmode,
+                                                size_t block_rows_end) {
     // tabmode (shifted-base table): every digit's bucket belongs to window 0, the dominant-scalar window is window 1
+    // block_rows_end (dominant value over whole blocks): rows below it lie in complete blocks of BLOCK_ROWS bases whose
+    // SUMS are tabulated next to the bases -- the padding rows of a circuit make a grand-product column one value over
+    // millions of consecutive rows: a block of 256 rows all holding the dominant value enters its bucket as ONE point
+    // (row 0 of the block carries BLOCK_KEY, the other 255 nothing) instead of 256.
     bool hot_slot = hot_on != 0;  // does key array W exist?
     if (col_scalars != nullptr) {
         const uint32_t col = blockIdx.y, Wc = np >> hi_bits;  // windows (= key arrays) per column: W or W + 1
@@ -390,19 +410,29 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
     uint32_t* hist = h2_msm_smem;
     for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) hist[k] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const Fr raw = fp_load(scalars + i);
-        if (hot_slot) {  // wave-uniform branch; a fused column of more than two windows always owns the extra window
-            const bool is_hot = hot_on && fp_eq(raw, hot);
-            const uint64_t m = __ballot(is_hot);
-            if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
-                atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
-            keys[(size_t)W * n + i] = is_hot ? 0u : KEY_INVALID;
+    for (size_t base = (size_t)blockIdx.x * blockDim.x; base < n; base += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const Fr raw = valid ? fp_load(scalars + i) : fp_zero<FrParams>();
+        if (hot_slot) {  // uniform branch; a fused column of more than two windows always owns the extra window
+            const bool is_hot = valid && hot_on && fp_eq(raw, hot);
+            bool whole_block = false;
+            if (block_rows_end) whole_block = __syncthreads_and(is_hot ? 1 : 0) != 0 && base + BLOCK_ROWS <= block_rows_end;
+            if (whole_block) {
+                if (threadIdx.x == 0) atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], 1u);
+                keys[(size_t)W * n + i] = threadIdx.x == 0 ? BLOCK_KEY : KEY_INVALID;
+            } else {
+                const uint64_t m = __ballot(is_hot);
+                if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
+                    atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], (uint32_t)__popcll(m));  // partition 0 of the extra window
+                if (valid) keys[(size_t)W * n + i] = is_hot ? 0u : KEY_INVALID;
+            }
             if (is_hot) {
                 for (uint32_t w = 0; w < W; w++) keys[(size_t)w * n + i] = KEY_INVALID;
                 continue;
             }
         }
+        if (!valid) continue;
         Fr s = fp_from_mont(raw);  // canonical little-endian integer (to_repr, arithmetic.rs:21)
         // keep only the low max_bits bits (multiexp_bound contract)
 #pragma unroll
@@ -558,7 +588,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
         size_t i = i0 + k * 256 + threadIdx.x;
         key[k] = (i < n) ? keys[(size_t)w * n + i] : KEY_INVALID;
         rank[k] = 0;
-        if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&cnt[(key[k] & ~SIGN_BIT) >> lo_bits], 1u);
+        if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&cnt[(key[k] & ~(SIGN_BIT | BLOCK_KEY)) >> lo_bits], 1u);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) {
@@ -569,8 +599,10 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
 #pragma unroll
     for (uint32_t k = 0; k < ITEMS; k++) {
         if (key[k] == KEY_INVALID) continue;
-        uint32_t bucket = key[k] & ~SIGN_BIT;
-        uint32_t i = level_base + (uint32_t)(i0 + k * 256 + threadIdx.x);
+        uint32_t bucket = key[k] & ~(SIGN_BIT | BLOCK_KEY);
+        const uint32_t row = (uint32_t)(i0 + k * 256 + threadIdx.x);
+        // a row that stands for its whole block of BLOCK_ROWS bases (k_digits) refers to the block's tabulated sum
+        const uint32_t i = (key[k] & BLOCK_KEY) ? BLOCK_INDEX0 + row / BLOCK_ROWS : level_base + row;
         tmp[cnt[bucket >> lo_bits] + rank[k]] = make_uint2(i | (key[k] & SIGN_BIT), bucket & ((1u << lo_bits) - 1));
     }
 }
@@ -697,8 +729,8 @@ __global__ void __launch_bounds__(256) k_copy_hot(const uint2* tmp, const uint32
 }
 
 // ---------------------------------------------------------------- k_acc_slice (hot loop)
-__global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const uint32_t* sorted, const uint32_t* starts,
-                                                   uint32_t nbt, uint32_t log_s, XYZZ* partials) {
+__global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const Affine* block_sums, const uint32_t* sorted,
+                                                   const uint32_t* starts, uint32_t nbt, uint32_t log_s, XYZZ* partials) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // slice index
     const uint32_t total = starts[nbt];                        // number of (non-zero digit) entries
     uint32_t e = s << log_s;
@@ -739,7 +771,8 @@ __global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const ui
             }
         }
         uint32_t ref = sorted[e];
-        Affine p = affine_load(bases + (ref & ~SIGN_BIT));
+        const uint32_t idx = ref & ~SIGN_BIT;
+        Affine p = affine_load(idx >= BLOCK_INDEX0 ? block_sums + (idx - BLOCK_INDEX0) : bases + idx);
         acc = xyzz_madd(acc, p, (ref & SIGN_BIT) != 0);
     }
     xyzz_store(partials + (b + s), acc);
@@ -1188,6 +1221,25 @@ __global__ void __launch_bounds__(256) k_table_build(const Affine* bases, size_t
     }
 }
 
+// sums of BLOCK_ROWS consecutive bases (blocks of a registered base set; see k_digits "dominant value over whole blocks")
+__global__ void __launch_bounds__(64) k_block_sums(const Affine* bases, size_t nblocks, Affine* out) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    XYZZ acc = xyzz_identity();
+#pragma unroll 1
+    for (uint32_t k = 0; k < BLOCK_ROWS; k++) acc = xyzz_madd(acc, affine_load(bases + b * BLOCK_ROWS + k), false);
+    const Fq zero = fp_zero<FqParams>();
+    if (fp_is_zero(acc.zz)) {  // the identity (the bases of a block cancel): (0, 0)
+        fp_store(&out[b].x, zero);
+        fp_store(&out[b].y, zero);
+        return;
+    }
+    const Fq t = fq_inv_device(acc.zzz);
+    const Fq u = fp_mul(acc.zz, t);
+    fp_store(&out[b].x, fp_mul(acc.x, fp_sqr(u)));
+    fp_store(&out[b].y, fp_mul(acc.y, t));
+}
+
 // digits for a table over n points: fewest additions D * n plus the bucket-proportional tail (k_finish, k_reduce: ~8
 // additions' worth per bucket), buckets 2^(c - 1) with c = ceil(255 / D) <= 23
 static uint32_t table_default_digits(size_t n) {
@@ -1216,16 +1268,18 @@ size_t bases_precompute_bytes(size_t n, uint32_t digits) {
 }
 
 int bases_forget(const uint64_t* d_bases) {
-    Affine* old = nullptr;
+    Affine *old = nullptr, *old_blocks = nullptr;
     {
         std::lock_guard<std::mutex> g(g_tab_mu);
         auto it = g_tables.find(d_bases);
         if (it == g_tables.end()) return H2_OK;
         old = const_cast<Affine*>(it->second.table);
+        old_blocks = const_cast<Affine*>(it->second.blocks);
         g_tables.erase(it);
     }
     H2_HIP(hipDeviceSynchronize());  // nothing in flight reads the table
     H2_HIP(hipFree(old));
+    if (old_blocks) H2_HIP(hipFree(old_blocks));
     return H2_OK;
 }
 
@@ -1243,17 +1297,24 @@ int bases_precompute(const uint64_t* d_bases, size_t n, uint32_t digits, hipStre
     const uint32_t T = 255, base = T / digits, rem = T % digits;  // the balanced cut of msm_shape
     t.c = rem ? base + 1 : base;
     t.wfull = rem ? rem : digits;
-    Affine* table = nullptr;
+    Affine *table = nullptr, *blocks = nullptr;
+    const size_t nblocks = n / BLOCK_ROWS;
     H2_HIP(hipMalloc(&table, (size_t)digits * n * sizeof(Affine)));
+    if (nblocks && hipMalloc(&blocks, nblocks * sizeof(Affine)) != hipSuccess) blocks = nullptr;  // optional
     hipLaunchKernelGGL(k_table_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const Affine*)d_bases, n, n,
                        t.D, t.c, t.wfull, table);
+    if (blocks)
+        hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, stream, (const Affine*)d_bases,
+                           nblocks, blocks);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
-        hipFree(table);
+        (void)hipFree(table);
+        if (blocks) (void)hipFree(blocks);
         H2_HIP(e);
     }
     t.table = table;
+    t.blocks = blocks;
     std::lock_guard<std::mutex> g(g_tab_mu);
     g_tables[d_bases] = t;
     return H2_OK;
@@ -1304,6 +1365,7 @@ struct Hot {
     bool on = false;
     Fr value{};         // Montgomery form, as stored in the column
     uint32_t live = HOT_SAMPLES;  // sampled rows that will cost digits: neither zero nor (when `on`) the dominant value
+    const Affine* block_sums = nullptr;  // sums of the BLOCK_ROWS-row blocks of this MSM's bases, when they are tabulated
 };
 
 static Hot detect_hot(const Fr* samples) {
@@ -1374,12 +1436,12 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
         const uint32_t np_col = s.Wc << s.hi_bits;
         hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
                            s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
-                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull, 0u);
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull, 0u, (size_t)0);
     } else {
         hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
                            max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
                            hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R,
-                           s.wfull, s.tab);
+                           s.wfull, s.tab, (hot.on && hot.block_sums) ? s.n / BLOCK_ROWS * BLOCK_ROWS : (size_t)0);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     if (s.tab && s.hi_bits > 10)
@@ -1403,8 +1465,8 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
                 hipLaunchKernelGGL(k_copy_hot, dim3(1024), dim3(256), 0, stream, tmp, pbase,
                                    (col * s.Wc + s.W) << s.hi_bits, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
-    hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases, sorted, starts, s.nbt,
-                       s.log_s, partials);
+    hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
+                       (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
     hipLaunchKernelGGL(k_finish, dim3((s.nbt + 63) / 64), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
                        buckets, heavy + 1, heavy);
     hipLaunchKernelGGL(k_finish_mid, dim3(512), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1, heavy, buckets);
@@ -1464,8 +1526,13 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         set_last_error("h2 msm: n * windows must be < 2^32 (sorted entries are indexed with 32 bits): split the MSM");
         return H2_ERR_INVALID;
     }
-    ShiftTable tab{};
+    ShiftTable tab{}, found{};
     bool use_tab = table_lookup(d_bases, n, max_bits, &tab);
+    bool have_tab = use_tab;  // a table of these bases exists (its block sums serve the windowed form too)
+    if (use_tab)
+        found = tab;
+    else
+        have_tab = table_find(d_bases, n, &found);
     if (!d_scratch || scratch_bytes < msm_scratch_bytes(n, max_bits)) {
         set_last_error("h2 msm: scratch too small (see h2_msm_scratch_bytes)");
         return H2_ERR_INVALID;
@@ -1476,18 +1543,19 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     uint32_t* h_stale = (uint32_t*)(h_samples + HOT_SAMPLES);
     *h_stale = 0;
     hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars, n, (Fr*)h_samples);
-    if (use_tab)
-        hipLaunchKernelGGL(k_table_check, dim3(1), dim3(HOT_SAMPLES), 0, stream, (const Affine*)d_bases, tab.table, n, h_stale);
+    if (have_tab)
+        hipLaunchKernelGGL(k_table_check, dim3(1), dim3(HOT_SAMPLES), 0, stream, (const Affine*)d_bases, found.table, n, h_stale);
     H2_HIP(hipStreamSynchronize(stream));
-    if (use_tab && *h_stale) {
+    if (have_tab && *h_stale) {
         table_drop_containing(d_bases);
-        use_tab = false;
+        use_tab = have_tab = false;
     }
     Hot hot = detect_hot(h_samples);
     // the extra window trades W additions per dominant row for one: with one or two windows there is nothing to gain,
     // only a giant bucket to fold and a 254-bit multiplication on the host
     if (hot.on && msm_shape(n, max_bits, false).W <= 2) hot.on = false;
     use_tab = use_tab && table_pays(tab, n, max_bits, hot);
+    if (hot.on && have_tab && found.blocks && (use_tab ? (size_t)tab.D * tab.n : n) < BLOCK_INDEX0) hot.block_sums = found.blocks;
     MsmShape s = use_tab ? msm_shape_table(n, max_bits, hot.on, tab) : msm_shape(n, max_bits, hot.on);
     msm_launch(s, hot, d_scalars, use_tab ? tab.table : (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
     const size_t wp = (size_t)s.Wt * s.G;
@@ -1598,12 +1666,19 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     // allows it (h2_msm_batch_scratch_bytes); the rest goes through the two-stream pipeline below
     std::vector<char> done_fused(count, 0);
     // columns whose bases have a shifted-base table go through the pipeline in table form
-    std::vector<ShiftTable> tabs(count);
-    std::vector<char> use_tab(count, 0);
+    std::vector<ShiftTable> tabs(count), founds(count);
+    std::vector<char> use_tab(count, 0), have_tab(count, 0);
     for (size_t i = 0; i < count; i++) {
         const uint32_t bits = bits_each ? bits_each[i] : max_bits;
         const uint64_t* bases = bases_each && bases_each[i] ? bases_each[i] : d_bases;
-        if (bits && bases) use_tab[i] = table_lookup(bases, n, bits, &tabs[i]) ? 1 : 0;
+        if (!bits || !bases) continue;
+        use_tab[i] = table_lookup(bases, n, bits, &tabs[i]) ? 1 : 0;
+        if (use_tab[i]) {
+            founds[i] = tabs[i];
+            have_tab[i] = 1;
+        } else {
+            have_tab[i] = table_find(bases, n, &founds[i]) ? 1 : 0;  // its block sums serve the windowed form too
+        }
     }
     if (getenv("H2_MSM_NO_FUSE") == nullptr) {
         H2_HIP(hipStreamSynchronize(stream));
@@ -1670,15 +1745,15 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
     }
     for (size_t i = 0; i < count; i++) {
         hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[i], n, h_samples + i * HOT_SAMPLES);
-        if (use_tab[i] && !done_fused[i])
+        if (have_tab[i] && !done_fused[i])
             hipLaunchKernelGGL(k_table_check, dim3(1), dim3(HOT_SAMPLES), 0, stream,
-                               (const Affine*)(bases_each && bases_each[i] ? bases_each[i] : d_bases), tabs[i].table, n, h_stale + i);
+                               (const Affine*)(bases_each && bases_each[i] ? bases_each[i] : d_bases), founds[i].table, n, h_stale + i);
     }
     H2_HIP(hipStreamSynchronize(stream));  // inputs produced on the caller's stream are complete; samples are in
     for (size_t i = 0; i < count; i++)
-        if (use_tab[i] && h_stale[i]) {  // the bases changed under their table (see k_table_check): windowed form, table dropped
+        if (have_tab[i] && h_stale[i]) {  // the bases changed under their table (see k_table_check): windowed form, table dropped
             table_drop_containing(bases_each && bases_each[i] ? bases_each[i] : d_bases);
-            use_tab[i] = 0;
+            use_tab[i] = have_tab[i] = 0;
         }
     std::vector<Hot> hots(count);
     for (size_t i = 0; i < count; i++) {
@@ -1693,6 +1768,9 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
                 use_tab[i] = 0;
             }
         }
+        if (hots[i].on && have_tab[i] && !done_fused[i] && founds[i].blocks &&
+            (use_tab[i] ? (size_t)tabs[i].D * tabs[i].n : n) < BLOCK_INDEX0)
+            hots[i].block_sums = founds[i].blocks;
     }
     std::vector<hipEvent_t> done(count, nullptr);
     size_t lane_of = 0;

@@ -331,7 +331,9 @@ int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases
  * 12 at 2^24, 15 at 2^20) in library-owned device memory (h2_dev_bases_precompute_bytes: digits x n x 64 B) and
  * remembers it under `d_bases`.  From then on every h2_dev_msm / _batch / _batch_ex whose bases lie inside
  * [d_bases, d_bases + n) and whose bound needs more windows than digits adds all digits of a scalar into ONE shared
- * bucket set: ~20 % fewer point additions at 2^24, one reduction instead of one per window, no host Horner.  Same group
+ * bucket set: ~20 % fewer point additions at 2^24, one reduction instead of one per window, no host Horner.  The sums
+ * of every 256 consecutive bases are tabulated too (n / 256 points): a column whose dominant value fills whole blocks
+ * of rows (a grand product over padding rows) adds one point per block instead of 256, in either form.  Same group
  * element (multiexp_serial, arithmetic.rs:20-108).  Call it before sizing scratch with h2_msm_scratch_bytes.  The
  * bases must not change while the table exists (as a guard, every MSM compares 64 sampled base rows with the table's
  * own copy first and drops a table that no longer matches); h2_dev_bases_forget(d_bases) frees it (synchronises the

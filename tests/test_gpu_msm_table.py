@@ -95,10 +95,12 @@ def test_table_sub_ranges_and_forget(oracle, small_tables):
     n = 1 << 14
     pts = oracle.random_g1(801, n)
     scalars = oracle.random_fr(802, n)
+    scalars[n // 4:n // 2] = scalars[3]     # a dominant value over whole 256-row blocks (their tabulated sums are used when the
+    scalars[n // 2 + 77:] = scalars[3]      # view starts on a block boundary) and over ragged runs
     dev = DevMsm(pts)
     dev.precompute()
     got = {}
-    for lo, m in ((0, n), (0, n // 2), (n // 2, n // 2), (1000, 3000), (n - 1, 1), (7, n - 7)):
+    for lo, m in ((0, n), (0, n // 2), (n // 2, n // 2), (1000, 3000), (n - 1, 1), (7, n - 7), (4096, 8192), (4097, 8000), (n // 4, n // 4)):
         want = _affine(oracle, oracle.best_multiexp(scalars[lo:lo + m], pts[lo:lo + m]))
         got[(lo, m)] = dev.msm(scalars[lo:lo + m], 254, lo, m)
         assert _affine(oracle, got[(lo, m)]) == want, (lo, m)
