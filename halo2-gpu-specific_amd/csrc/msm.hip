@@ -70,7 +70,7 @@ struct MsmShape {
     size_t n, entries, max_items;
     // scratch offsets (bytes)
     size_t off_keys, off_sorted, off_tmp, off_pcount, off_pbase, off_pcursor, off_starts, off_heavy, off_partials,
-        off_buckets, off_winpart, off_rcount, total;
+        off_buckets, off_winpart, off_rcount, off_bflags, total;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -195,6 +195,7 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
     s.off_winpart = take((size_t)s.Wt * (1 + s.RG) * sizeof(XYZZ));  // window sums, then the RG group partials of each
     s.off_rcount = take((size_t)s.Wt * 4);
+    s.off_bflags = take(n / 256 + 4);  // one byte per 256-row block: the block is one entry of the dominant-value bucket
     s.off_coltab = take((size_t)(cols ? cols : 1) * 64);
     s.total = o;
     return s;
@@ -297,6 +298,7 @@ static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const Shi
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
     s.off_winpart = take((size_t)s.Wt * (1 + s.RG) * sizeof(XYZZ));
     s.off_rcount = take((size_t)s.Wt * 4);
+    s.off_bflags = take(n / 256 + 4);  // one byte per 256-row block: the block is one entry of the dominant-value bucket
     s.off_coltab = take(64);
     s.total = o;
     return s;
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
                                                 uint32_t* keys, uint32_t* pcount, int hot_on, Fr hot,
                                                 const Fr* const* col_scalars, const Fr* col_hot, uint64_t col_hot_mask,
                                                 uint32_t range_shift, uint32_t R, uint32_t wfull, uint32_t tabmode,
-                                                size_t block_rows_end) {
+                                                size_t block_rows_end, uint8_t* block_flags) {
     // tabmode (shifted-base table): every digit's bucket belongs to window 0, the dominant-scalar window is window 1
     // block_rows_end (dominant value over whole blocks): rows below it lie in complete blocks of BLOCK_ROWS bases whose
     // SUMS are tabulated next to the bases -- the padding rows of a circuit make a grand-product column one value over
@@ -419,8 +421,13 @@ __global__ void __launch_bounds__(256) k_digits(const Fr* scalars, size_t n, uin
             bool whole_block = false;
             if (block_rows_end) whole_block = __syncthreads_and(is_hot ? 1 : 0) != 0 && base + BLOCK_ROWS <= block_rows_end;
             if (whole_block) {
-                if (threadIdx.x == 0) atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], 1u);
+                // the W digit keys of these rows are neither written nor read: k_partition skips flagged blocks
+                if (threadIdx.x == 0) {
+                    atomicAdd(&hist[(tabmode ? 1u : R * W) << hi_bits], 1u);
+                    block_flags[base / BLOCK_ROWS] = 1;
+                }
                 keys[(size_t)W * n + i] = threadIdx.x == 0 ? BLOCK_KEY : KEY_INVALID;
+                continue;
             } else {
                 const uint64_t m = __ballot(is_hot);
                 if (m && (int)(threadIdx.x & 63) == __ffsll((unsigned long long)m) - 1)
@@ -566,7 +573,7 @@ __global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint
 template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t hi_bits,
                                                    uint32_t* pcursor, uint2* tmp, uint32_t range_shift, uint32_t W,
-                                                   uint32_t R, uint32_t tab_stride) {
+                                                   uint32_t R, uint32_t tab_stride, const uint8_t* block_flags) {
     uint32_t* cnt = h2_msm_smem;               // 2^hi_bits local counters, then the reserved bases
     const uint32_t nparts = 1u << hi_bits, w = blockIdx.y;
     // window of these PART_T rows: ranges are multiples of PART_T rows; key array W (if present) is the dominant-scalar
@@ -586,7 +593,9 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
 #pragma unroll
     for (uint32_t k = 0; k < ITEMS; k++) {
         size_t i = i0 + k * 256 + threadIdx.x;
-        key[k] = (i < n) ? keys[(size_t)w * n + i] : KEY_INVALID;
+        // rows of a block that entered the dominant-value bucket as one point have no digit keys (k_digits)
+        const bool skip = block_flags != nullptr && w != W && i < n && block_flags[(i0 + k * 256) / BLOCK_ROWS] != 0;
+        key[k] = (i < n && !skip) ? keys[(size_t)w * n + i] : KEY_INVALID;
         rank[k] = 0;
         if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&cnt[(key[k] & ~(SIGN_BIT | BLOCK_KEY)) >> lo_bits], 1u);
     }
@@ -1430,28 +1439,34 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
 
     H2_HIP(hipMemsetAsync(pcount, 0, ((size_t)s.np + 2) * 4, stream));
     H2_HIP(hipMemsetAsync(heavy, 0, 4, stream));
+    uint8_t* bflags = nullptr;  // per 256-row block: entered the dominant-value bucket as one point (block sums tabulated)
+    if (!fused && hot.on && hot.block_sums) {
+        bflags = (uint8_t*)(scratch + s.off_bflags);
+        H2_HIP(hipMemsetAsync(bflags, 0, s.n / 256 + 4, stream));
+    }
     unsigned nblk = (unsigned)((s.n + 255) / 256);
     unsigned dblk = nblk < 1024 ? nblk : 1024;  // grid-stride: one LDS histogram flush per workgroup
     if (fused) {
         const uint32_t np_col = s.Wc << s.hi_bits;
         hipLaunchKernelGGL(k_digits, dim3(dblk, s.cols), dim3(256), (size_t)np_col * 4, stream, (const Fr*)nullptr, s.n, s.c,
                            s.W, s.nb, max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, np_col, keys, pcount, 0,
-                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull, 0u, (size_t)0);
+                           hot.value, fused->scalars, fused->hot_values, fused->hot_mask, 31u, 1u, s.wfull, 0u, (size_t)0,
+                           (uint8_t*)nullptr);
     } else {
         hipLaunchKernelGGL(k_digits, dim3(dblk), dim3(256), (size_t)s.np * 4, stream, d_scalars, s.n, s.c, s.W, s.nb,
                            max_bits > 254 ? 254u : max_bits, s.lo_bits, s.hi_bits, s.np, keys, pcount, hot.on ? 1 : 0,
                            hot.value, (const Fr* const*)nullptr, (const Fr*)nullptr, (uint64_t)0, s.range_shift, s.R,
-                           s.wfull, s.tab, (hot.on && hot.block_sums) ? s.n / BLOCK_ROWS * BLOCK_ROWS : (size_t)0);
+                           s.wfull, s.tab, bflags ? s.n / BLOCK_ROWS * BLOCK_ROWS : (size_t)0, bflags);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     if (s.tab && s.hi_bits > 10)
         hipLaunchKernelGGL(k_partition<PART_T_TABLE>, dim3((unsigned)((s.n + PART_T_TABLE - 1) / PART_T_TABLE), s.Wk), dim3(256),
                            (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
-                           s.R, (uint32_t)s.tab_stride);
+                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
     else
         hipLaunchKernelGGL(k_partition<PART_T>, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
                            (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
-                           s.R, (uint32_t)s.tab_stride);
+                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
     const uint32_t hot_partition = (!fused && hot.on) ? ((s.tab ? 1u : s.R * s.W) << s.hi_bits) : 0xffffffffu;
