@@ -496,11 +496,12 @@ H2_DEV Fp<P> fp_inv(const Fp<P>& a) {
     return x;
 }
 
-// a^e for a 32-bit exponent (square-and-multiply, MSB first)
+// a^e for a 32-bit exponent (square-and-multiply from the top set bit)
 template <class P>
 H2_DEV Fp<P> fp_pow_u32(const Fp<P>& a, uint32_t e) {
-    Fp<P> acc = fp_one<P>();
-    for (int i = 31; i >= 0; i--) {
+    if (e == 0) return fp_one<P>();
+    Fp<P> acc = a;
+    for (int i = 30 - __builtin_clz(e); i >= 0; i--) {
         acc = fp_sqr(acc);
         if ((e >> i) & 1) acc = fp_mul(acc, a);
     }

@@ -563,9 +563,9 @@ int distribute_powers_launch(Fr* a, size_t n, const uint64_t g[4], hipStream_t s
 //   prover   permutation/prover.rs:89-128    per column of a set:
 //              den[i] *= beta * sigma[i] + gamma + value[i]
 //              num[i] *= DELTA^{col} * omega^{i} * beta + gamma + value[i]
-// omega^i: every lane raises omega to its first index once and then steps by omega^256 over PT_ITEMS strided
-// (coalesced) elements.
-static constexpr int PT_ITEMS = 8;
+// omega^i: every lane raises omega to its first index once (~35 products) and then steps by omega^256 over PT_ITEMS
+// strided (coalesced) elements: 32 of them, so that the power costs ~1 product per element next to the 2-4 of the terms.
+static constexpr int PT_ITEMS = 32;
 
 __global__ void __launch_bounds__(256) k_perm_sigma(Fr* out, const uint32_t* map_col, const uint32_t* map_row, size_t n,
                                                     Fr delta, Fr omega) {
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) k_perm_terms(PermTermsArgs a) {
     const size_t base = (size_t)blockIdx.x * (256 * PT_ITEMS) + threadIdx.x;
     if (base >= a.n) return;
     Fr w = fp_mul(fp_pow_u32(a.omega, (uint32_t)base), a.delta_beta);
-#pragma unroll
+#pragma unroll 2
     for (int k = 0; k < PT_ITEMS; k++) {
         size_t i = base + (size_t)k * 256;
         if (i >= a.n) break;
