@@ -834,6 +834,28 @@ __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint
     xyzz_store_q(buckets + b, acc, q);
 }
 
+// The same fold with ONE LANE per bucket, for bucket counts that fill the chip many times over (2^21 buckets of a
+// shifted-base table at 2^24): there the fold is bound by throughput, and a quad spends four lanes on the latency of
+// one chain (2^24 over a table, batch of 8: 21.3 -> 20.9 ms per MSM; at 2^19 buckets the two forms tie, below the quads win).
+__global__ void __launch_bounds__(256) k_finish_lane(const XYZZ* partials, const uint32_t* starts, uint32_t nbt,
+                                                     uint32_t log_s, XYZZ* buckets, uint32_t* heavy_list,
+                                                     uint32_t* heavy_count) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbt) return;
+    const uint32_t e0 = starts[b], e1 = starts[b + 1];
+    XYZZ acc = xyzz_identity();
+    if (e1 > e0) {
+        const uint32_t first = e0 >> log_s, last = (e1 - 1) >> log_s;
+        if (last - first + 1 > FINISH_SERIAL) {
+            heavy_list[atomicAdd(heavy_count, 1u)] = b;
+            return;
+        }
+        acc = xyzz_load(partials + (b + first));
+        for (uint32_t sl = first + 1; sl <= last; sl++) acc = xyzz_add(acc, xyzz_load(partials + (b + sl)));
+    }
+    xyzz_store(buckets + b, acc);
+}
+
 // Buckets on the heavy list with <= MID_MAX partials (a narrow column: thousands of buckets with a few hundred entries
 // each) take ONE WAVE each: its 16 quads fold the partials strided by 16, then a 4-level tree over the wave by lane
 // shuffles; a workgroup per such bucket (k_finish_heavy) would spend a 6-level tree on one partial per quad and walk the
@@ -1482,8 +1504,13 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
     hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
                        (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
-    hipLaunchKernelGGL(k_finish, dim3((s.nbt + 63) / 64), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
-                       buckets, heavy + 1, heavy);
+    static const uint32_t lane_from = getenv("H2_MSM_FINISH_LANE_LOG") ? 1u << atoi(getenv("H2_MSM_FINISH_LANE_LOG")) : 1u << 21;
+    if (s.nbt >= lane_from)
+        hipLaunchKernelGGL(k_finish_lane, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
+                           buckets, heavy + 1, heavy);
+    else
+        hipLaunchKernelGGL(k_finish, dim3((s.nbt + 63) / 64), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
+                           buckets, heavy + 1, heavy);
     hipLaunchKernelGGL(k_finish_mid, dim3(512), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1, heavy, buckets);
     hipLaunchKernelGGL(k_finish_heavy, dim3(64, HEAVY_SPLIT), dim3(256), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy);

@@ -634,3 +634,8 @@ def test_msm_randomised_shapes():
                          text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "all equal to the oracle" in out.stdout and "over tables" in out.stdout
+    # the one-lane-per-bucket fold (used from 2^21 buckets on) forced onto every shape
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "10", "12", "tables"], capture_output=True,
+                         text=True, timeout=280, env=dict(os.environ, H2_MSM_FINISH_LANE_LOG="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "all equal to the oracle" in out.stdout
