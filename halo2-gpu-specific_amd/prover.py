@@ -23,7 +23,7 @@ import numpy as np
 from . import evaluation as ev
 from ._lib import check, lib
 from .circuit import compile_compress, compile_evaluator
-from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, jacobian_to_affine,
+from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, g1_add_affine, jacobian_to_affine,
                          point_to_bytes)
 
 ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
@@ -900,16 +900,34 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 with D.torch.cuda.stream(D.tstream):
                     t[usable:] = blind_dev[ci]
             cols_.append(t)
-        bits_ = D.max_scalar_bits_many([t[lo_r:hi_r] for t in cols_], hi_r - lo_r)
+        # The blinding rows are 16-bit values whatever the column holds (prover.rs:281-289), so the bound the reference
+        # computes over the whole column is never below 16 bits -- a column of booleans or of a few tiny values then runs
+        # as ONE window of 2^16 buckets with everything in its first partition.  A commitment is a sum: the usable rows
+        # are committed under THEIR bound (the narrow-column shapes of the MSM) and the bf + 1 blinding rows as one more
+        # (fused, few-point) MSM per group; the two points are added.
+        split_tail = not sharded_upload and not (D.group_size > 1 or D.force_collective) and usable >= (1 << 12)
+        m_rows = usable if split_tail else hi_r - lo_r
+        bits_ = D.max_scalar_bits_many([t[lo_r:lo_r + m_rows] for t in cols_], m_rows)
         if sharded_upload:
             bits_ = allreduce_max(bits_, group=D.group, device=D.dev)       # find_max_scalar_bits over the whole column
-        # bounds rounded up to a few classes (a bound is only an upper limit): columns that share one are committed as a
-        # fused group by the library -- a witness of many small-valued columns pays the fixed latencies of an MSM per
-        # class instead of per column
         bits_ = [max(b, 1) for b in bits_]
         for t in cols_:
             check(L.h2_dev_batch_mont(t[lo_r:hi_r].data_ptr(), hi_r - lo_r, D.stream), "h2_dev_batch_mont")
-        for P in D.msm_batch(cols_, params.g_lagrange, n, bits_):
+        # ... for the columns whose usable rows are narrower than the blinding rows (and large enough for the narrow shapes
+        # to matter): the others are committed whole, under the bound of the whole column
+        narrow_ = [i for i, b in enumerate(bits_) if split_tail and b <= 12 and n >= (1 << 20)]
+        whole_ = [i for i in range(len(cols_)) if i not in narrow_]
+        points_ = [None] * len(cols_)
+        if whole_:
+            wb = [max(bits_[i], 16) if split_tail else bits_[i] for i in whole_]
+            for i, P in zip(whole_, D.msm_batch([cols_[i] for i in whole_], params.g_lagrange, n, wb)):
+                points_[i] = P
+        if narrow_:
+            main_ = D.msm_batch([cols_[i] for i in narrow_], params.g_lagrange, usable, [bits_[i] for i in narrow_])
+            tail_ = D.msm_batch([cols_[i][usable:] for i in narrow_], params.g_lagrange[usable:], n - usable, 16)
+            for i, a_, b_ in zip(narrow_, main_, tail_):
+                points_[i] = g1_add_affine(a_, b_)
+        for P in points_:
             transcript.write_point(P)
         if sharded_upload:
             for t in cols_:

@@ -42,6 +42,23 @@ def jacobian_to_affine(xyz):
     return (x * zi2 % Q_MOD, y * zi2 % Q_MOD * zi % Q_MOD)
 
 
+def g1_add_affine(P, Q):
+    """P + Q on BN254 G1 for affine points as returned by jacobian_to_affine (None = the identity)"""
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if (y1 + y2) % Q_MOD == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, Q_MOD) % Q_MOD
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, Q_MOD) % Q_MOD
+    x3 = (lam * lam - x1 - x2) % Q_MOD
+    return (x3, (lam * (x1 - x3) - y1) % Q_MOD)
+
+
 def point_to_bytes(P):
     if P is None:
         return bytes(32)
