@@ -253,6 +253,31 @@ class Device:
                                  self.stream), "h2_dev_intt")
         return t
 
+    def intt_on_side_stream(self, cols, dom):
+        """coefficient forms of `cols` (left untouched) computed on the side stream, behind what is queued on the compute
+        stream now; returns (copies, event): the compute stream must wait for the event before it reads the copies.
+        The transforms then fill the issue slots that the latency-bound tails of the commitments in between leave."""
+        if getattr(self, "_side", None) is None:
+            import concurrent.futures
+
+            self._side = (self.torch.cuda.Stream(device=self.dev), concurrent.futures.ThreadPoolExecutor(max_workers=1))
+        side = self._side[0]
+        ready = self.torch.cuda.Event()
+        ready.record(self.tstream)
+        side.wait_event(ready)
+        out = []
+        with self.torch.cuda.stream(side):
+            for t in cols:
+                c = t.clone()
+                tmp = self.torch.empty_like(c)
+                check(self.L.h2_dev_intt(c.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                         _vp(side.cuda_stream)), "h2_dev_intt")
+                c.record_stream(self.tstream)
+                out.append(c)
+            done = self.torch.cuda.Event()
+            done.record(side)
+        return out, done
+
     def coeff_to_extended(self, t, dom, out=None):
         out = out if out is not None else self.empty(dom.extended_n)
         tmp = self.empty(dom.extended_n)
@@ -940,6 +965,13 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # per-circuit state: every later phase walks `circuits` in order
     circuits = [{"advice": advice_dev[ci * nadv:(ci + 1) * nadv], "instance": instance_dev_sets[ci],
                  "instance_polys": instance_polys_sets[ci]} for ci in range(ncirc)]
+    # the advice columns are final: their coefficient forms (needed from the quotient on) are computed on the side stream
+    # while the lookup / permutation phases run on the compute stream -- up to k = 20, where those phases are chains of
+    # small latency-bound kernels (k = 18 lookup circuit 28.9 -> 27.6 ms); at k = 22 / 24 they fill the chip themselves and
+    # the transforms only take their time away (60.1 vs 60.2 ms, 210 vs 211)
+    side_intt = None
+    if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= 20 and D.group_size <= 1 and not D.force_collective):
+        side_intt = D.intt_on_side_stream(advice_dev, dom)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
     for C in circuits:
@@ -1081,8 +1113,16 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     y = transcript.squeeze_challenge_scalar()
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
-    for C in circuits:
-        C["advice_polys"] = [D.intt(t, dom) for t in C["advice"]]    # in place: the Lagrange values are not needed again
+    if side_intt is not None:
+        polys_, done_ = side_intt
+        D.tstream.wait_event(done_)
+        for ci, C in enumerate(circuits):
+            C["advice_polys"] = polys_[ci * nadv:(ci + 1) * nadv]
+            C["advice"] = None                                       # the Lagrange values are not needed again
+        del advice_dev
+    else:
+        for C in circuits:
+            C["advice_polys"] = [D.intt(t, dom) for t in C["advice"]]    # in place: the Lagrange values are not needed again
     g = pk.graph
     plan = D.coset_plan(dom)
     if D.group_size <= 1:                      # on one device the proving key decides which tables exist
