@@ -253,10 +253,11 @@ class Device:
                                  self.stream), "h2_dev_intt")
         return t
 
-    def intt_on_side_stream(self, cols, dom):
-        """coefficient forms of `cols` (left untouched) computed on the side stream, behind what is queued on the compute
-        stream now; returns (copies, event): the compute stream must wait for the event before it reads the copies.
-        The transforms then fill the issue slots that the latency-bound tails of the commitments in between leave."""
+    def intt_on_side_stream(self, cols, dom, extend=False):
+        """coefficient forms of `cols` (left untouched) -- and with `extend` their values on the extended domain --
+        computed on the side stream, behind what is queued on the compute stream now; returns (copies, extended or None,
+        event): the compute stream must wait for the event before it reads them.  The transforms then fill the issue
+        slots that the latency-bound tails of the commitments in between leave."""
         if getattr(self, "_side", None) is None:
             import concurrent.futures
 
@@ -274,9 +275,20 @@ class Device:
                                          _vp(side.cuda_stream)), "h2_dev_intt")
                 c.record_stream(self.tstream)
                 out.append(c)
+            ext = None
+            if extend:
+                ext = []
+                for c in out:
+                    e = self.torch.empty((dom.extended_n, 4), dtype=self.torch.int64, device=self.dev)
+                    tmp = self.torch.empty_like(e)
+                    check(self.L.h2_dev_coeff_to_extended(c.data_ptr(), e.data_ptr(), tmp.data_ptr(), dom.k, dom.extended_k,
+                                                          _fr(dom.g_coset), _fr(dom.g_coset_inv), _fr(dom.extended_omega),
+                                                          _vp(side.cuda_stream)), "h2_dev_coeff_to_extended")
+                    e.record_stream(self.tstream)
+                    ext.append(e)
             done = self.torch.cuda.Event()
             done.record(side)
-        return out, done
+        return out, ext, done
 
     def coeff_to_extended(self, t, dom, out=None):
         out = out if out is not None else self.empty(dom.extended_n)
@@ -971,7 +983,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # the transforms only take their time away (60.1 vs 60.2 ms, 210 vs 211)
     side_intt = None
     if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= 20 and D.group_size <= 1 and not D.force_collective):
-        side_intt = D.intt_on_side_stream(advice_dev, dom)
+        side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and pk.coset is None)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
     for C in circuits:
@@ -1114,10 +1126,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
     if side_intt is not None:
-        polys_, done_ = side_intt
+        polys_, ext_, done_ = side_intt
         D.tstream.wait_event(done_)
         for ci, C in enumerate(circuits):
             C["advice_polys"] = polys_[ci * nadv:(ci + 1) * nadv]
+            C["advice_extended"] = ext_[ci * nadv:(ci + 1) * nadv] if ext_ is not None else None
             C["advice"] = None                                       # the Lagrange values are not needed again
         del advice_dev
     else:
@@ -1147,7 +1160,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size):
         """the fused evaluator over one evaluation domain: `points_of` maps a coefficient vector to its values there"""
         lookups = C["lookups"]
-        advice_cosets = [points_of(t) for t in C["advice_polys"]]
+        pre = C.get("advice_extended") if size == en else None    # already extended on the side stream (small proofs)
+        advice_cosets = pre if pre is not None else [points_of(t) for t in C["advice_polys"]]
         instance_cosets = [points_of(t) for t in C["instance_polys"]]
         z_cosets = [points_of(t) for t in C["z_polys"]]
         lookup_z_cosets = [points_of(t) for st in lookups for t in st["z_polys"]]
