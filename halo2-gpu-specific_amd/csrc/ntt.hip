@@ -150,42 +150,94 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
         K_uniform = hi_to_K(hi, a);
     }
 
-    // ---- load (+ zero pad, coset pre-scale, inter-pass twiddle), bit-reversed rows into LDS
-    for (uint32_t e = tid; e < total; e += nthreads) {
-        uint32_t rho, c, idx, K;
-        if (!a.is_last) {
-            c = e & (C - 1);
-            rho = e >> log_c;
-            idx = base + (rho << a.s_log) + c;
-            K = K_uniform;
-        } else {
-            rho = e & (R - 1);
-            c = e >> B;
-            K = (tile_id << log_c) + c;
-            idx = (K_to_hi(K, a) << B) + rho;
+    // ---- load (+ zero pad, coset pre-scale, inter-pass twiddle), bit-reversed rows into LDS.
+    // A lane's NE elements are fetched as ONE batch -- every global load (the elements, then their twiddles) is issued
+    // before the first product needs one -- so a tile pays one memory latency, not one per element (the rows of an early
+    // pass are 2 MiB apart: each of those loads is a DRAM page of its own).
+    constexpr uint32_t NE = RADIX4 ? 4 : 2;
+    for (uint32_t e0 = tid; e0 < total; e0 += NE * nthreads) {
+        uint32_t rho[NE], col[NE], idx[NE], Kk[NE];
+        bool live[NE];
+        Fr x[NE];
+#pragma unroll
+        for (uint32_t q = 0; q < NE; q++) {
+            const uint32_t e = e0 + q * nthreads;
+            if (!a.is_last) {
+                col[q] = e & (C - 1);
+                rho[q] = (e >> log_c) & (R - 1);
+                idx[q] = base + (rho[q] << a.s_log) + col[q];
+                Kk[q] = K_uniform;
+            } else {
+                rho[q] = e & (R - 1);
+                col[q] = (e >> B) & (C - 1);
+                Kk[q] = (tile_id << log_c) + col[q];
+                idx[q] = (K_to_hi(Kk[q], a) << B) + rho[q];
+            }
+            // Zero padding by 2^z (coeff_to_extended): the rows rho >= R >> z of the first pass are zero, so its first z
+            // stages are butterflies (u, 0) -> (u, u) whatever the twiddle: each loaded element is written to the 2^z rows
+            // those stages would copy it to (the low z bits of the bit-reversed row index) and the stage loop starts at z.
+            live[q] = e < total && !(a.zskip && rho[q] >= (R >> a.zskip));
         }
-        // Zero padding by 2^z (coeff_to_extended): the rows rho >= R >> z of the first pass are zero, so its first z
-        // stages are butterflies (u, 0) -> (u, u) whatever the twiddle: each loaded element is written to the 2^z rows
-        // those stages would copy it to (the low z bits of the bit-reversed row index) and the stage loop starts at z.
-        if (a.zskip && rho >= (R >> a.zskip)) continue;
-        Fr x = (idx < a.in_len) ? fp_load(a.in + idx) : fp_zero<FrParams>();
+#pragma unroll
+        for (uint32_t q = 0; q < NE; q++) {
+            x[q] = fp_zero<FrParams>();
+            if (live[q] && idx[q] < a.in_len) x[q] = fp_load(a.in + idx[q]);
+        }
         if (a.has_pre3) {
-            uint32_t m = idx % 3;
-            if (m != 0) x = fp_mul(x, m == 1 ? a.pre3[1] : a.pre3[2]);
-        }
-        if (a.nprev != 0) {
-            // omega^(rho * S * K)
-            uint32_t ex = (uint32_t)(((uint64_t)rho * K) << a.s_log) & n_mask;
-            if (a.tw_direct != nullptr) {
-                if (ex != 0) x = fp_mul(x, fp_load(a.tw_direct + ((rho << a.t_log) | K)));
-            } else if (ex != 0 || a.hi_scaled) {
-                x = fp_mul(x, twiddle_pow(a, ex));
+#pragma unroll
+            for (uint32_t q = 0; q < NE; q++) {
+                const uint32_t m = idx[q] % 3;
+                Fr w;
+#pragma unroll
+                for (int l = 0; l < 8; l++) w.l[l] = m == 1 ? a.pre3[1].l[l] : a.pre3[2].l[l];
+                if (m != 0) x[q] = fp_mul(x[q], w);
             }
         }
-        if (a.zskip) {
-            for (uint32_t m = 0; m < (1u << a.zskip); m++) lds_put(t_lo, t_hi, ((bitrev(rho, B) | m) << log_c) + c, x);
-        } else {
-            lds_put(t_lo, t_hi, (bitrev(rho, B) << log_c) + c, x);
+        if (a.nprev != 0) {
+            // omega^(rho * S * K); a unit twiddle (rho = 0 or K = 0) multiplies like any other: the tables hold it
+            if (a.tw_direct != nullptr) {
+#pragma unroll
+                for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
+                    Fr w[2];
+#pragma unroll
+                    for (uint32_t q = 0; q < 2; q++) w[q] = fp_load(a.tw_direct + ((rho[q0 + q] << a.t_log) | Kk[q0 + q]));
+#pragma unroll
+                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = fp_mul(x[q0 + q], w[q]);
+                }
+            } else if (a.log_n <= LO_BITS) {
+#pragma unroll
+                for (uint32_t q = 0; q < NE; q++) {
+                    const uint32_t ex = (uint32_t)(((uint64_t)rho[q] * Kk[q]) << a.s_log) & n_mask;
+                    x[q] = fp_mul(x[q], fp_load(a.tw_lo + ex));
+                }
+            } else {
+                // two at a time: 16 twiddle halves in flight next to the elements keeps the kernel within 128 VGPRs
+#pragma unroll
+                for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
+                    Fr wl[2], wh[2];
+#pragma unroll
+                    for (uint32_t q = 0; q < 2; q++) {
+                        const uint32_t ex = (uint32_t)(((uint64_t)rho[q0 + q] * Kk[q0 + q]) << a.s_log) & n_mask;
+                        wl[q] = fp_load(a.tw_lo + (ex & ((1u << LO_BITS) - 1)));
+                        wh[q] = fp_load(a.tw_hi + (ex >> LO_BITS));
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = fp_mul(x[q0 + q], fp_mul(wl[q], wh[q]));
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NE; q++) {
+            // (row and column again from e: cheaper than keeping them in registers across the products)
+            const uint32_t e = e0 + q * nthreads;
+            const uint32_t r_q = a.is_last ? (e & (R - 1)) : ((e >> log_c) & (R - 1));
+            const uint32_t c_q = a.is_last ? ((e >> B) & (C - 1)) : (e & (C - 1));
+            if (e >= total || (a.zskip && r_q >= (R >> a.zskip))) continue;
+            if (a.zskip) {
+                for (uint32_t m = 0; m < (1u << a.zskip); m++) lds_put(t_lo, t_hi, ((bitrev(r_q, B) | m) << log_c) + c_q, x[q]);
+            } else {
+                lds_put(t_lo, t_hi, (bitrev(r_q, B) << log_c) + c_q, x[q]);
+            }
         }
     }
     __syncthreads();
@@ -264,20 +316,33 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
         __syncthreads();
     }
 
-    // ---- store (+ post-scale on the final pass)
-    for (uint32_t e = tid; e < total; e += nthreads) {
-        uint32_t c = e & (C - 1), k = e >> log_c;
-        uint32_t idx;
-        if (!a.is_last)
-            idx = base + (k << a.s_log) + c;
-        else
-            idx = ((tile_id << log_c) + c) + (k << a.t_log);
-        Fr y = lds_get(t_lo, t_hi, (k << log_c) + c);
-        if (a.is_last && a.has_post3 && !a.hi_scaled) {
-            uint32_t m = idx % 3;
-            y = fp_mul(y, m == 0 ? a.post3[0] : (m == 1 ? a.post3[1] : a.post3[2]));
+    // ---- store (+ post-scale on the final pass), batched like the loads
+    for (uint32_t e0 = tid; e0 < total; e0 += NE * nthreads) {
+        Fr y[NE];
+        uint32_t idx[NE];
+#pragma unroll
+        for (uint32_t q = 0; q < NE; q++) {
+            const uint32_t e = e0 + q * nthreads;
+            const uint32_t c = e & (C - 1), k = (e >> log_c) & (R - 1);
+            if (!a.is_last)
+                idx[q] = base + (k << a.s_log) + c;
+            else
+                idx[q] = ((tile_id << log_c) + c) + (k << a.t_log);
+            y[q] = lds_get(t_lo, t_hi, (k << log_c) + c);
         }
-        fp_store(a.out + idx, y);
+        if (a.is_last && a.has_post3 && !a.hi_scaled) {
+#pragma unroll
+            for (uint32_t q = 0; q < NE; q++) {
+                const uint32_t m = idx[q] % 3;
+                Fr w;
+#pragma unroll
+                for (int l = 0; l < 8; l++) w.l[l] = m == 0 ? a.post3[0].l[l] : (m == 1 ? a.post3[1].l[l] : a.post3[2].l[l]);
+                y[q] = fp_mul(y[q], w);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NE; q++)
+            if (e0 + q * nthreads < total) fp_store(a.out + idx[q], y[q]);
     }
 }
 
