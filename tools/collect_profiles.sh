@@ -8,7 +8,7 @@ out=gpurun_out/${tag}_profiles
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ./tools/mulbench > "$out/mulbench.txt" 2>&1
-./tools/h2bench ntt 24 5 msm 14 254 10 msm 16 254 10 msm 18 254 10 msm 20 254 5 msm 22 254 3 msm 24 254 2 msm 20 16 5 msm 20 1 5 eval 25 3 > "$out/h2bench.txt" 2>&1
+./tools/h2bench ntt 24 20 msm 14 254 10 msm 16 254 10 msm 18 254 10 msm 20 254 5 msm 22 254 3 msm 24 254 2 msm 20 16 5 msm 20 1 5 eval 25 3 > "$out/h2bench.txt" 2>&1
 ./tools/membench > "$out/membench.txt" 2>&1
 for L in 16 18 20 22 24; do ./tools/h2bench msmt $L 254 3; done > "$out/msm_table.txt" 2>&1
 for H in 8 2; do H2BENCH_HOT=$H ./tools/h2bench msmt 24 254 2; done >> "$out/msm_table.txt" 2>&1
