@@ -50,6 +50,16 @@ __global__ void __launch_bounds__(256) k_direct_table(Fr* out, Fr base, uint32_t
     fp_store(out + i, fp_pow_u32(base, e));
 }
 
+// out[(K << bits) | rho] = base^((rho * K) mod n) (* d when `scale`): the last pass's inter-pass twiddles in load order
+__global__ void __launch_bounds__(256) k_last_table(Fr* out, Fr base, uint32_t bits, uint32_t log_n, Fr d, uint32_t scale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers 2^log_n exactly (log_n >= 8)
+    const uint32_t rho = i & ((1u << bits) - 1), K = i >> bits;
+    const uint32_t e = (uint32_t)((uint64_t)rho * K) & ((1u << log_n) - 1);
+    Fr w = fp_pow_u32(base, e);
+    if (scale) w = fp_mul(w, d);
+    fp_store(out + i, w);
+}
+
 // out[i] = in[i] * d
 __global__ void __launch_bounds__(256) k_scale_table(Fr* out, const Fr* in, Fr d, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,6 +74,7 @@ struct PassArgs {
     const Fr* tw_lo;    // min(n, 4096) entries: w^i
     const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
     const Fr* tw_direct;  // non-null: inter-pass twiddle = tw_direct[(rho << consumed) | K] (no generation multiply)
+    uint32_t direct_kmajor;  // ... = tw_direct[(K << B) | rho] instead (the last pass's table: read in load order)
     uint32_t hi_scaled;  // tw_hi already carries the uniform post-scale (1/n): never skip, no post multiply
     Fr pre3[3];         // has_pre3: x *= pre3[idx % 3] on the first-pass load (idx % 3 == 0 skipped)
     Fr post3[3];        // has_post3: y *= post3[idx % 3] on the final store
@@ -200,7 +211,8 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                 for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
                     Fr w[2];
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; q++) w[q] = fp_load(a.tw_direct + ((rho[q0 + q] << a.t_log) | Kk[q0 + q]));
+                    for (uint32_t q = 0; q < 2; q++)
+                        w[q] = fp_load(a.tw_direct + (a.direct_kmajor ? ((Kk[q0 + q] << B) | rho[q0 + q]) : ((rho[q0 + q] << a.t_log) | Kk[q0 + q])));
 #pragma unroll
                     for (uint32_t q = 0; q < 2; q++) x[q0 + q] = fp_mul(x[q0 + q], w[q]);
                 }
@@ -392,6 +404,7 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
     pl->log_n = log_n;
     ntt_split(log_n, pl->bits);
     Fr w = fr_from_u64x4(omega);
+    pl->w = w;
     const uint32_t n = 1u << log_n;
     uint32_t lo_count = n < (1u << LO_BITS) ? n : (1u << LO_BITS);
     uint32_t hi_count = log_n > LO_BITS ? (n >> LO_BITS) : 0;
@@ -524,6 +537,44 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             }
             a.tw_hi = scaled;
             a.hi_scaled = 1;
+        }
+        // The last pass of a large transform reads its inter-pass twiddles from a complete table (32 B x n, streamed in the
+        // order of its loads) instead of composing each from two: one product per element instead of two, on a pass that
+        // is bound by VALU issue and has the HBM time to spare (2^24: 1.84 -> see DESIGN 3.2).  One table per divisor
+        // folded into it; H2_NTT_LAST_TABLE=0 or a failed allocation leave the lo x hi form.
+        static const bool last_table = !(getenv("H2_NTT_LAST_TABLE") && atoi(getenv("H2_NTT_LAST_TABLE")) == 0);
+        static const uint32_t last_table_max = getenv("H2_NTT_LAST_TABLE_MAX_LOG") ? (uint32_t)atoi(getenv("H2_NTT_LAST_TABLE_MAX_LOG")) : 26u;
+        if (last && p > 0 && last_table && L >= 18 && L <= last_table_max) {
+            const bool scaled = a.hi_scaled != 0;
+            std::string key;
+            if (scaled) {
+                char kb[80];
+                snprintf(kb, sizeof kb, "%08x%08x%08x%08x%08x%08x%08x%08x", post3[0].l[7], post3[0].l[6], post3[0].l[5],
+                         post3[0].l[4], post3[0].l[3], post3[0].l[2], post3[0].l[1], post3[0].l[0]);
+                key = kb;
+            }
+            Fr* tab = nullptr;
+            {
+                std::lock_guard<std::mutex> g(pl->mu);
+                auto it = pl->last_direct.find(key);
+                if (it == pl->last_direct.end()) {
+                    if (hipMalloc(&tab, sizeof(Fr) << L) != hipSuccess) {
+                        (void)hipGetLastError();  // no room: this plan keeps composing its twiddles
+                        tab = nullptr;
+                    } else {
+                        hipLaunchKernelGGL(k_last_table, dim3((1u << L) / 256), dim3(256), 0, stream, tab, pl->w, B, L,
+                                           scaled ? post3[0] : pl->w, scaled ? 1u : 0u);
+                        H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per divisor)
+                    }
+                    pl->last_direct[key] = tab;
+                } else {
+                    tab = it->second;
+                }
+            }
+            if (tab != nullptr) {
+                a.tw_direct = tab;
+                a.direct_kmajor = 1;
+            }
         }
         {
             // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
