@@ -149,7 +149,9 @@ def main():
 
     # roofline of the dominant kernel (k_ntt_pass): algorithmic bytes per SURVEY.md 8(d) =
     # 64 * n * ceil(log_n / 12) per transform, spread over the passes this build launches per transform
-    passes = (log_n + 7) // 8 if log_n else 1   # csrc/ntt.hip ntt_split: 8-bit passes, the remainder first
+    # csrc/ntt.hip ntt_split: 8-bit passes, the remainder first -- or folded into 9-bit passes at the end (one-bit remainders)
+    q8, rem8 = divmod(log_n, 8)
+    passes = (q8 if (q8 >= rem8 and (rem8 == 1 or (rem8 == 2 and log_n <= 18))) else q8 + (1 if rem8 else 0)) if log_n else 1
     alg_bytes_per_transform = 64 * n * ((log_n + 11) // 12)
     launches = args.steps * 2 * passes
     avg_launch_ms = ev_ms.value / launches
@@ -169,8 +171,9 @@ def main():
 
     # products per transform (csrc/ntt.hip k_ntt_pass): (n/2) log2 n butterflies minus the twiddle-1 ones the early stages
     # skip (stage 0 of every pass; the r = 0 waves of stages 1-3), one tabulated inter-pass twiddle per element in the
-    # middle passes and two (lo x hi, then the product) in the last
-    mults_per_transform = n * (passes * 3.2 + max(passes - 2, 0) + (2 if passes > 1 else 0)) if log_n >= 8 else (log_n / 2.0 + passes) * n
+    # middle passes and one in the last (a complete table for 2^18 .. 2^26 points; lo x hi and the product otherwise)
+    last_tw = 1 if 18 <= log_n <= 26 else 2   # the last pass reads its twiddle from a complete table at these sizes
+    mults_per_transform = n * (passes * 3.06 + max(passes - 2, 0) + (last_tw if passes > 1 else 0)) if log_n >= 8 else (log_n / 2.0 + passes) * n
     out = {
         "metric": "NTT Fr-ops/s @ k=24 (forward+inverse 2^24 BN254 Fr NTT; MSM G1-adds/s under 'msm')",
         "value": value,
@@ -209,8 +212,8 @@ def main():
                 "peak_mul_per_s": MUL_HW_BOUND,
                 "frac": mults_per_transform / (passes * avg_launch_ms * 1e-3) / MUL_HW_BOUND,
                 "multiplier_in_a_loop_per_s": MUL_MEASURED,
-                "note": "products per transform: ~3.2 per element per 8-bit pass (4 butterflies, the twiddle-1 ones of the early "
-                "stages skipped) + one inter-pass twiddle product per element in the middle passes and two in the last",
+                "note": "products per transform: 3.06 per element per 8-bit pass (4 butterflies, the twiddle-1 ones of the early "
+                "stages skipped) + one tabulated inter-pass twiddle product per element in the middle passes and in the last",
             },
         },
     }

@@ -285,7 +285,11 @@ int h2_jit_load(const char *code_object_path, const char *kernel_name, const voi
 
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for
- * log_n <= 8).  Results land in d_a (in place from the caller's view). */
+ * log_n <= 8).  Results land in d_a (in place from the caller's view).
+ * Device memory the library keeps per (device, log_n, omega) for the life of the process: the twiddle tables of the
+ * transform (a few MiB) and, for 2^18 .. 2^26 points, the last pass's complete twiddle set -- 32 B x 2^log_n, one per
+ * divisor it is used with (512 MiB at 2^24; built on first use; the environment variable H2_NTT_LAST_TABLE=0 or a failed
+ * allocation leave the smaller two-level tables in use, at one more multiplication per element). */
 int h2_dev_ntt(void *d_a, void *d_tmp, const uint64_t omega[4], uint32_t log_n, void *stream);
 int h2_dev_intt(void *d_a, void *d_tmp, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n,
                 void *stream);
