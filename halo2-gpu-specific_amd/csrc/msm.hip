@@ -586,23 +586,51 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
         level_base = (w == W) ? 0u : w * tab_stride;
     }
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) cnt[k] = 0;
-    __syncthreads();
     const uint32_t ITEMS = TILE / 256;
     uint32_t key[TILE / 256], rank[TILE / 256];
     const size_t i0 = (size_t)blockIdx.x * TILE;
+    // All of a lane's keys are requested before the first one is used (the loop used to wait for each key, and for the
+    // block flag in front of it, in turn: 2 x ITEMS memory latencies per tile).  Rows beyond n read the last row and are
+    // discarded; the flags of the tile's blocks (one per 256 rows, the same for every lane) go through LDS.
+    uint32_t* sflag = cnt + nparts;   // ITEMS words: block k of the tile is flagged
+    if (threadIdx.x < ITEMS) {
+        const size_t row0 = i0 + (size_t)threadIdx.x * 256;   // BLOCK_ROWS == 256 == the stride of k
+        sflag[threadIdx.x] = (block_flags != nullptr && w != W && row0 < n) ? block_flags[row0 / BLOCK_ROWS] : 0u;
+    }
 #pragma unroll
     for (uint32_t k = 0; k < ITEMS; k++) {
-        size_t i = i0 + k * 256 + threadIdx.x;
+        const size_t i = i0 + k * 256 + threadIdx.x;
+        key[k] = keys[(size_t)w * n + (i < n ? i : n - 1)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        const size_t i = i0 + k * 256 + threadIdx.x;
         // rows of a block that entered the dominant-value bucket as one point have no digit keys (k_digits)
-        const bool skip = block_flags != nullptr && w != W && i < n && block_flags[(i0 + k * 256) / BLOCK_ROWS] != 0;
-        key[k] = (i < n && !skip) ? keys[(size_t)w * n + i] : KEY_INVALID;
+        if (i >= n || sflag[k] != 0) key[k] = KEY_INVALID;
         rank[k] = 0;
         if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&cnt[(key[k] & ~(SIGN_BIT | BLOCK_KEY)) >> lo_bits], 1u);
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x) {
-        uint32_t v = cnt[k];
-        cnt[k] = v ? atomicAdd(&pcursor[(vw << hi_bits) + k], v) : 0;
+    // reserve the tile's run in every partition; a lane owns nparts / 256 of them and its reservations go out eight at a
+    // time (one returning atomic at a time was up to 32 round trips to memory per tile)
+    for (uint32_t k0 = threadIdx.x; k0 < nparts; k0 += 8 * blockDim.x) {
+        uint32_t v[8], b[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) v[j] = (k0 + j * blockDim.x < nparts) ? cnt[k0 + j * blockDim.x] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = k0 + j * blockDim.x;
+            b[j] = 0;
+            if (TILE >= 16384) {   // nearly every partition receives entries from a tile this large: no branch, no wait
+                if (k < nparts) b[j] = atomicAdd(&pcursor[(vw << hi_bits) + k], v[j]);
+            } else if (v[j]) {
+                b[j] = atomicAdd(&pcursor[(vw << hi_bits) + k], v[j]);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            if (k0 + j * blockDim.x < nparts) cnt[k0 + j * blockDim.x] = b[j];
     }
     __syncthreads();
 #pragma unroll
@@ -1483,11 +1511,11 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
     if (s.tab && s.hi_bits > 10)
         hipLaunchKernelGGL(k_partition<PART_T_TABLE>, dim3((unsigned)((s.n + PART_T_TABLE - 1) / PART_T_TABLE), s.Wk), dim3(256),
-                           (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
+                           ((size_t)4 << s.hi_bits) + 4 * (PART_T_TABLE / 256), stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
                            s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
     else
         hipLaunchKernelGGL(k_partition<PART_T>, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
-                           (size_t)4 << s.hi_bits, stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
+                           ((size_t)4 << s.hi_bits) + 4 * (PART_T / 256), stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
                            s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);

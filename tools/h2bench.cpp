@@ -73,6 +73,26 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 // The device takes ~30 ms of load to reach its steady clock (after an idle second the first 2^24 transforms run 25 % slow,
 // tools/experiments/ntt_ramp.py): every timed loop is preceded by SPIN_MS of the same call (H2BENCH_SPIN_MS, 0 = none).
+// H2BENCH_CUMASK=<hex words, low first, comma separated>: run the MSM modes on a stream restricted to those CUs
+// (hipExtStreamCreateWithCUMask) -- an experiment knob: what a kernel costs on one XCD tells what bounds it on eight.
+static void* g_stream = nullptr;
+static void init_stream() {
+    const char* m = getenv("H2BENCH_CUMASK");
+    if (!m) return;
+    std::vector<uint32_t> mask;
+    std::string t(m);
+    size_t pos = 0;
+    while (pos < t.size()) {
+        size_t e = t.find(',', pos);
+        if (e == std::string::npos) e = t.size();
+        mask.push_back((uint32_t)strtoul(t.substr(pos, e - pos).c_str(), nullptr, 16));
+        pos = e + 1;
+    }
+    hipStream_t st;
+    CK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    g_stream = (void*)st;
+}
+
 static double spin_ms() {
     static const double v = getenv("H2BENCH_SPIN_MS") ? atof(getenv("H2BENCH_SPIN_MS")) : 80.0;
     return v;
@@ -177,11 +197,11 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
     size_t sb = h2_msm_scratch_bytes(n, bits);
     CK(hipMalloc(&d_scr, sb));
     uint64_t out0[12], out[12];
-    H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out0, nullptr));
+    H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out0, g_stream));
     H2(h2_synchronize());
-    SPIN(H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, nullptr)));
+    SPIN(H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, g_stream)));
     double t0 = now();
-    for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, nullptr));
+    for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scr, sb, out, g_stream));
     double t1 = now();
     // batch of 8 MSMs over the same bases (pipelined on two internal streams)
     const int BATCH = 8;
@@ -192,10 +212,10 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
     const void* ptrs[BATCH];
     for (int b = 0; b < BATCH; b++) ptrs[b] = d_s;
     uint64_t outs[BATCH * 12];
-    H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, nullptr));
-    SPIN(H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, nullptr)));
+    H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, g_stream));
+    SPIN(H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, g_stream)));
     double b0 = now();
-    for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, nullptr));
+    for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scr2, sb2, outs, g_stream));
     double b1 = now();
     double bms = (b1 - b0) / reps / BATCH * 1e3;
     CK(hipFree(d_scr2));
@@ -216,18 +236,18 @@ static int bench_msm(int log_n, int bits, int reps, int mode) {
         void *d_scrt, *d_scrt2;
         CK(hipMalloc(&d_scrt, sbt));
         uint64_t outt[12];
-        H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, outt, nullptr));
+        H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, outt, g_stream));
         H2(h2_synchronize());
-        SPIN(H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, out, nullptr)));
+        SPIN(H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, out, g_stream)));
         double t2 = now();
-        for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, out, nullptr));
+        for (int r = 0; r < reps; r++) H2(h2_dev_msm(d_s, d_b, n, bits, d_scrt, sbt, out, g_stream));
         double t3 = now();
         size_t sbt2 = 2 * ((sbt + 255) / 256 * 256);
         CK(hipMalloc(&d_scrt2, sbt2));
-        H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, nullptr));
-        SPIN(H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, nullptr)));
+        H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, g_stream));
+        SPIN(H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, g_stream)));
         double b2 = now();
-        for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, nullptr));
+        for (int r = 0; r < reps; r++) H2(h2_dev_msm_batch(ptrs, BATCH, d_b, n, bits, d_scrt2, sbt2, outs, g_stream));
         double b3 = now();
         // same group element?  table result + (- plain result) must be the identity (z = 0)
         static const uint64_t Q[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
@@ -291,6 +311,7 @@ static int bench_eval(int log_n, int reps) {
 }
 
 int main(int argc, char** argv) {
+    init_stream();
     if (h2_device_count() < 1) {
         printf("no device\n");
         return 1;
