@@ -697,7 +697,15 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
     for (uint32_t k = threadIdx.x; k < nbins; k += SORT_T) bins[k] = 0;
     __syncthreads();
     if (!skewed) {
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_T) atomicAdd(&bins[tmp[e].y], 1u);
+        // (eight loads in flight per lane: one at a time, a partition of 24 000 entries was 24 memory latencies per pass)
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 8 * SORT_T) {
+            uint32_t key[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) key[j] = tmp[min(e + j * SORT_T, e1 - 1)].y;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+                if (e + j * SORT_T < e1) atomicAdd(&bins[key[j]], 1u);
+        }
     } else {
         for (uint32_t e = e0 + threadIdx.x; e < e1 + (SORT_T - 1); e += 4 * SORT_T) {  // whole waves stay in the loop
             uint32_t key[4];
@@ -740,9 +748,13 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
     }
     __syncthreads();
     if (!skewed) {
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += SORT_T) {
-            uint2 v = tmp[e];
-            sorted[atomicAdd(&bins[v.y], 1u)] = v.x;
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 8 * SORT_T) {
+            uint2 v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = tmp[min(e + j * SORT_T, e1 - 1)];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+                if (e + j * SORT_T < e1) sorted[atomicAdd(&bins[v[j].y], 1u)] = v[j].x;
         }
     } else {
         for (uint32_t e = e0 + threadIdx.x; e < e1 + (SORT_T - 1); e += 4 * SORT_T) {
