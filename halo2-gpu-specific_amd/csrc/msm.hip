@@ -50,6 +50,8 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t REDUCE_T = 512;    // threads per k_reduce workgroup = 128 quads (two waves per SIMD)
 static constexpr uint32_t REDUCE_QM = 32;    // consecutive buckets a quad walks (fewer when that still fits the chip)
 static constexpr uint32_t PART_T = 2048;      // entries per k_partition workgroup (256 threads x 8)
+static constexpr uint32_t PART_AB_T = 8192;       // entries per workgroup of the two-level partition passes (256 threads x 32)
+static constexpr uint32_t PARTA_GROUPS_MAX = 128; // level-A groups (2^a_bits <= 2^7)
 static constexpr uint32_t PART_T_TABLE = 16384;  // ... over a shifted-base table with many partitions (256 threads x 64)
 
 struct MsmShape {
@@ -70,7 +72,9 @@ struct MsmShape {
     size_t n, entries, max_items;
     // scratch offsets (bytes)
     size_t off_keys, off_sorted, off_tmp, off_pcount, off_pbase, off_pcursor, off_starts, off_heavy, off_partials,
-        off_buckets, off_winpart, off_rcount, off_bflags, total;
+        off_buckets, off_winpart, off_rcount, off_bflags, off_tmpa, total;
+    uint32_t two_level;         // table shape: partition in two coalesced passes (k_part_a / k_part_b), a_bits + b_bits = hi_bits
+    uint32_t a_bits;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -300,6 +304,12 @@ static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const Shi
     s.off_rcount = take((size_t)s.Wt * 4);
     s.off_bflags = take(n / 256 + 4);  // one byte per 256-row block: the block is one entry of the dominant-value bucket
     s.off_coltab = take(64);
+    // two-level partition (H2_MSM_TWO_LEVEL=0: the single pass): the entries pass through a second 8-byte-per-entry buffer
+    static const bool two_level = !(getenv("H2_MSM_TWO_LEVEL") && atoi(getenv("H2_MSM_TWO_LEVEL")) == 0);
+    static const uint32_t two_level_min_hi = getenv("H2_MSM_TWO_LEVEL_MIN_HI") ? (uint32_t)atoi(getenv("H2_MSM_TWO_LEVEL_MIN_HI")) : 8u;
+    s.two_level = (two_level && s.hi_bits >= two_level_min_hi && s.hi_bits >= 2 && s.hi_bits <= 14) ? 1u : 0u;
+    s.a_bits = s.hi_bits / 2;
+    s.off_tmpa = s.two_level ? take(s.entries * 8 + (PARTA_GROUPS_MAX * 3 + 4) * 4) : 0;
     s.total = o;
     return s;
 }
@@ -360,7 +370,8 @@ size_t msm_scratch_bytes(size_t n, uint32_t max_bits) {
     size_t need = std::max(msm_shape(n, max_bits, true).total, msm_shape(n, max_bits, false).total);
     std::lock_guard<std::mutex> g(g_tab_mu);
     for (const auto& kv : g_tables)
-        if (kv.second.n >= n) need = std::max(need, msm_shape_table(n, max_bits, true, kv.second).total);
+        if (kv.second.n >= n)   // (both forms: with the dominant-scalar array the slices can come out longer and the partials fewer)
+            need = std::max(need, std::max(msm_shape_table(n, max_bits, true, kv.second).total, msm_shape_table(n, max_bits, false, kv.second).total));
     return need;
 }
 // scratch that lets h2_dev_msm_batch(_ex) fuse `count` columns of bound `max_bits` over one base table
@@ -573,9 +584,9 @@ __global__ void __launch_bounds__(256) k_scan_parts(const uint32_t* pcount, uint
 template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t hi_bits,
                                                    uint32_t* pcursor, uint2* tmp, uint32_t range_shift, uint32_t W,
-                                                   uint32_t R, uint32_t tab_stride, const uint8_t* block_flags) {
+                                                   uint32_t R, uint32_t tab_stride, const uint8_t* block_flags, uint32_t w_first) {
     uint32_t* cnt = h2_msm_smem;               // 2^hi_bits local counters, then the reserved bases
-    const uint32_t nparts = 1u << hi_bits, w = blockIdx.y;
+    const uint32_t nparts = 1u << hi_bits, w = blockIdx.y + w_first;
     // window of these PART_T rows: ranges are multiples of PART_T rows; key array W (if present) is the dominant-scalar
     // window, which is not cut into ranges.  Shifted-base table (tab_stride != 0): digit array w feeds window 0 with the
     // points of table level w; the dominant-scalar array feeds window 1 with the bases themselves (level 0)
@@ -642,6 +653,150 @@ __global__ void __launch_bounds__(256) k_partition(const uint32_t* keys, size_t 
         const uint32_t i = (key[k] & BLOCK_KEY) ? BLOCK_INDEX0 + row / BLOCK_ROWS : level_base + row;
         tmp[cnt[bucket >> lo_bits] + rank[k]] = make_uint2(i | (key[k] & SIGN_BIT), bucket & ((1u << lo_bits) - 1));
     }
+}
+
+// ---------------------------------------------------------------- two-level partition over a table
+// k_partition leaves 2 x 10^8 separate 8-byte stores at 2^24 (a tile of 16384 keys has two entries per partition, written
+// by different lanes at different times).  Here the 2^hi_bits partitions are reached in two passes of 2^a_bits groups and
+// 2^b_bits partitions per group; each pass reorders its tile in LDS first, so a lane's neighbours write neighbouring
+// entries and a run leaves the CU as whole cache lines.  Entries between the passes: (reference | sign, bucket).
+// aux (after the entries of tmpa): cursor_a[G], tile_start[G + 1] (tiles of pass B per group, prefix sums).
+__global__ void __launch_bounds__(PARTA_GROUPS_MAX) k_part_init(const uint32_t* pbase, uint32_t a_bits, uint32_t b_bits,
+                                                                uint32_t* cursor_a, uint32_t* tile_start) {
+    __shared__ uint32_t tiles[PARTA_GROUPS_MAX];
+    const uint32_t G = 1u << a_bits, a = threadIdx.x;
+    if (a < G) {
+        const uint32_t gs = pbase[a << b_bits], ge = pbase[(a + 1) << b_bits];
+        cursor_a[a] = gs;
+        tiles[a] = (ge - gs + PART_AB_T - 1) / PART_AB_T;
+    }
+    __syncthreads();
+    if (a == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < G; k++) {
+            tile_start[k] = run;
+            run += tiles[k];
+        }
+        tile_start[G] = run;
+    }
+}
+
+// reorder the tile's `total` staged entries group by group and write them out: consecutive staged entries of one group go
+// to consecutive addresses
+__device__ __forceinline__ void part_ab_flush(const uint2* stage, uint32_t total, const uint32_t* loff, const uint32_t* gbase,
+                                              uint32_t shift, uint32_t mask, bool strip, uint32_t lo_mask, uint2* out) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+        uint2 e = stage[idx];
+        const uint32_t g = (e.y >> shift) & mask;
+        const uint32_t dst = gbase[g] + (idx - loff[g]);
+        if (strip) e.y &= lo_mask;
+        out[dst] = e;
+    }
+}
+
+// exclusive scan of hist[0..bins) (bins <= 128, two waves) -> loff, total; reserves the tile's run in every group (every
+// lane of the workgroup calls this: it contains a barrier)
+__device__ __forceinline__ void part_ab_reserve(const uint32_t* hist, uint32_t* loff, uint32_t* gbase, uint32_t bins,
+                                                uint32_t* cursors, uint32_t* total_out, uint32_t* wsum) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v = 0, x = 0;
+    if (t < 128) {
+        v = t < bins ? hist[t] : 0u;
+        x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= (uint32_t)off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+    }
+    __syncthreads();
+    if (t < 128) {
+        const uint32_t base = wave ? wsum[0] : 0u;
+        if (t < bins) {
+            loff[t] = base + x - v;
+            gbase[t] = v ? atomicAdd(&cursors[t], v) : 0u;
+        }
+        if (t == 127) *total_out = base + x;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_part_a(const uint32_t* keys, size_t n, uint32_t lo_bits, uint32_t b_bits,
+                                                uint32_t a_bits, uint32_t* cursor_a, uint2* tmpa, uint32_t tab_stride,
+                                                const uint8_t* block_flags) {
+    constexpr uint32_t ITEMS = PART_AB_T / 256;
+    __shared__ uint32_t hist[PARTA_GROUPS_MAX], loff[PARTA_GROUPS_MAX], gbase[PARTA_GROUPS_MAX], sflag[ITEMS], total_sh, wsum[2];
+    uint2* stage = (uint2*)h2_msm_smem;  // PART_AB_T entries
+    const uint32_t w = blockIdx.y, G = 1u << a_bits;
+    const size_t i0 = (size_t)blockIdx.x * PART_AB_T;
+    const uint32_t level_base = w * tab_stride;
+    if (threadIdx.x < G) hist[threadIdx.x] = 0;
+    if (threadIdx.x < ITEMS) {
+        const size_t row0 = i0 + (size_t)threadIdx.x * 256;
+        sflag[threadIdx.x] = (block_flags != nullptr && row0 < n) ? block_flags[row0 / BLOCK_ROWS] : 0u;
+    }
+    uint32_t key[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        const size_t i = i0 + k * 256 + threadIdx.x;
+        key[k] = keys[(size_t)w * n + (i < n ? i : n - 1)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        const size_t i = i0 + k * 256 + threadIdx.x;
+        if (i >= n || sflag[k] != 0) key[k] = KEY_INVALID;
+        rank[k] = 0;
+        if (key[k] != KEY_INVALID) rank[k] = atomicAdd(&hist[((key[k] & ~(SIGN_BIT | BLOCK_KEY)) >> lo_bits) >> b_bits], 1u);
+    }
+    __syncthreads();
+    part_ab_reserve(hist, loff, gbase, G, cursor_a, &total_sh, wsum);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        if (key[k] == KEY_INVALID) continue;
+        const uint32_t bucket = key[k] & ~(SIGN_BIT | BLOCK_KEY);
+        const uint32_t row = (uint32_t)(i0 + k * 256 + threadIdx.x);
+        const uint32_t ref = (key[k] & BLOCK_KEY) ? BLOCK_INDEX0 + row / BLOCK_ROWS : level_base + row;
+        stage[loff[(bucket >> lo_bits) >> b_bits] + rank[k]] = make_uint2(ref | (key[k] & SIGN_BIT), bucket);
+    }
+    __syncthreads();
+    part_ab_flush(stage, total_sh, loff, gbase, lo_bits + b_bits, G - 1, false, 0, tmpa);
+}
+
+__global__ void __launch_bounds__(256) k_part_b(const uint2* tmpa, const uint32_t* pbase, uint32_t lo_bits, uint32_t b_bits,
+                                                uint32_t a_bits, const uint32_t* tile_start, uint32_t* pcursor, uint2* tmp) {
+    constexpr uint32_t ITEMS = PART_AB_T / 256;
+    __shared__ uint32_t hist[PARTA_GROUPS_MAX], loff[PARTA_GROUPS_MAX], gbase[PARTA_GROUPS_MAX], total_sh, group_sh, wsum[2];
+    uint2* stage = (uint2*)h2_msm_smem;
+    const uint32_t G = 1u << a_bits, P = 1u << b_bits;
+    if (blockIdx.x >= tile_start[G]) return;
+    if (threadIdx.x < G && tile_start[threadIdx.x] <= blockIdx.x && blockIdx.x < tile_start[threadIdx.x + 1]) group_sh = threadIdx.x;
+    if (threadIdx.x < P) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t a = group_sh;
+    const uint32_t gs = pbase[a << b_bits], ge = pbase[(a + 1) << b_bits];
+    const uint32_t e0 = gs + (blockIdx.x - tile_start[a]) * PART_AB_T;
+    uint2 ent[ITEMS];
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        const uint32_t e = e0 + k * 256 + threadIdx.x;
+        ent[k] = tmpa[e < ge ? e : ge - 1];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++) {
+        const uint32_t e = e0 + k * 256 + threadIdx.x;
+        rank[k] = e < ge ? atomicAdd(&hist[(ent[k].y >> lo_bits) & (P - 1)], 1u) : 0xffffffffu;
+    }
+    __syncthreads();
+    part_ab_reserve(hist, loff, gbase, P, pcursor + (a << b_bits), &total_sh, wsum);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ITEMS; k++)
+        if (rank[k] != 0xffffffffu) stage[loff[(ent[k].y >> lo_bits) & (P - 1)] + rank[k]] = ent[k];
+    __syncthreads();
+    part_ab_flush(stage, total_sh, loff, gbase, lo_bits, P - 1, true, (1u << lo_bits) - 1, tmp);
 }
 
 // ---------------------------------------------------------------- k_bucket_sort (sort pass B)
@@ -1521,14 +1676,38 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
                            s.wfull, s.tab, bflags ? s.n / BLOCK_ROWS * BLOCK_ROWS : (size_t)0, bflags);
     }
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(256), 0, stream, pcount, s.np, pbase, pcursor, starts, s.nbt);
-    if (s.tab && s.hi_bits > 10)
+    if (s.tab && s.two_level) {
+        uint2* tmpa = (uint2*)(scratch + s.off_tmpa);
+        uint32_t* cursor_a = (uint32_t*)(scratch + s.off_tmpa + s.entries * 8);
+        uint32_t* tile_start = cursor_a + PARTA_GROUPS_MAX;
+        const uint32_t a_bits = s.a_bits, b_bits = s.hi_bits - s.a_bits;
+        static bool lds_raised[64] = {};   // per device: 64 KiB of staging + the static tables exceed the default dynamic limit
+        int dev = 0;
+        H2_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !lds_raised[dev]) {
+            H2_HIP(hipFuncSetAttribute((const void*)k_part_a, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            H2_HIP(hipFuncSetAttribute((const void*)k_part_b, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            if (dev >= 0 && dev < 64) lds_raised[dev] = true;
+        }
+        hipLaunchKernelGGL(k_part_init, dim3(1), dim3(PARTA_GROUPS_MAX), 0, stream, pbase, a_bits, b_bits, cursor_a, tile_start);
+        hipLaunchKernelGGL(k_part_a, dim3((unsigned)((s.n + PART_AB_T - 1) / PART_AB_T), s.W), dim3(256), (size_t)PART_AB_T * 8,
+                           stream, keys, s.n, s.lo_bits, b_bits, a_bits, cursor_a, tmpa, (uint32_t)s.tab_stride,
+                           (const uint8_t*)bflags);
+        if (s.Wk > s.W)  // the dominant-scalar array: one partition behind the 2^hi_bits of window 0, appended as before
+            hipLaunchKernelGGL(k_partition<PART_T_TABLE>, dim3((unsigned)((s.n + PART_T_TABLE - 1) / PART_T_TABLE), s.Wk - s.W),
+                               dim3(256), ((size_t)4 << s.hi_bits) + 4 * (PART_T_TABLE / 256), stream, keys, s.n, s.lo_bits,
+                               s.hi_bits, pcursor, tmp, s.range_shift, s.W, s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags,
+                               s.W);
+        hipLaunchKernelGGL(k_part_b, dim3((unsigned)(s.entries / PART_AB_T + (1u << a_bits) + 1)), dim3(256), (size_t)PART_AB_T * 8,
+                           stream, (const uint2*)tmpa, pbase, s.lo_bits, b_bits, a_bits, tile_start, pcursor, tmp);
+    } else if (s.tab && s.hi_bits > 10)
         hipLaunchKernelGGL(k_partition<PART_T_TABLE>, dim3((unsigned)((s.n + PART_T_TABLE - 1) / PART_T_TABLE), s.Wk), dim3(256),
                            ((size_t)4 << s.hi_bits) + 4 * (PART_T_TABLE / 256), stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
-                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
+                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags, 0u);
     else
         hipLaunchKernelGGL(k_partition<PART_T>, dim3((unsigned)((s.n + PART_T - 1) / PART_T), s.Wk), dim3(256),
                            ((size_t)4 << s.hi_bits) + 4 * (PART_T / 256), stream, keys, s.n, s.lo_bits, s.hi_bits, pcursor, tmp, s.range_shift, s.W,
-                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags);
+                           s.R, (uint32_t)s.tab_stride, (const uint8_t*)bflags, 0u);
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
     const uint32_t hot_partition = (!fused && hot.on) ? ((s.tab ? 1u : s.R * s.W) << s.hi_bits) : 0xffffffffu;
@@ -1639,6 +1818,10 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
     use_tab = use_tab && table_pays(tab, n, max_bits, hot);
     if (hot.on && have_tab && found.blocks && (use_tab ? (size_t)tab.D * tab.n : n) < BLOCK_INDEX0) hot.block_sums = found.blocks;
     MsmShape s = use_tab ? msm_shape_table(n, max_bits, hot.on, tab) : msm_shape(n, max_bits, hot.on);
+    if (s.total > scratch_bytes) {   // (cannot happen while h2_msm_scratch_bytes covers every shape; never run past the buffer)
+        set_last_error("h2 msm: internal: the chosen shape needs more scratch than h2_msm_scratch_bytes reported");
+        return H2_ERR_INVALID;
+    }
     msm_launch(s, hot, d_scalars, use_tab ? tab.table : (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
     const size_t wp = (size_t)s.Wt * s.G;
     XYZZ* h_win = (XYZZ*)staging.get(wp * sizeof(XYZZ));

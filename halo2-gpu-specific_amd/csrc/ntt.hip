@@ -596,11 +596,12 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             uint32_t ntiles = (1u << L) / (R * C);
             size_t lds = ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
             if (lds > 64 * 1024) {  // beyond the default dynamic LDS limit: raise it once
-                static bool raised = false;
-                if (!raised) {
+                static bool raised[64] = {};  // per device
+                const int dev = ctx->device;
+                if (dev < 0 || dev >= 64 || !raised[dev]) {
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    raised = true;
+                    if (dev >= 0 && dev < 64) raised[dev] = true;
                 }
             }
             if (a.radix4)
