@@ -10,7 +10,8 @@
 //   k_sample      64 scalars -> host: does one value dominate the column? (it then gets its own window, see k_digits)
 //   k_digits      scalar -> canonical (one Montgomery mul), signed digits of BALANCED width (c or c - 1 bits), keys, and
 //                 the histogram of (window, bucket >> lo_bits) partitions; narrow columns: rows cut into ranges = windows
-//   k_scan_parts / k_partition / k_bucket_sort   two-level counting sort of (point index, sign) by (window, bucket)
+//   k_scan_parts / k_partition / k_bucket_sort   two-level counting sort of (point index, sign) by (window, bucket); over a
+//                 shifted-base table k_partition is k_part_a + k_part_b: two passes that reorder their tile in LDS first
 //   k_acc_slice   one thread per fixed-size SLICE of the sorted list: exactly S mixed XYZZ
 //                 additions per lane whatever the bucket sizes are; a partial sum is emitted at
 //                 every bucket boundary inside the slice                              [hot loop]
