@@ -832,7 +832,7 @@ __device__ __forceinline__ uint32_t lds_count_aggregated(uint32_t* bins, uint32_
 __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const uint32_t* pbase, uint32_t lo_bits,
                                                         uint32_t hi_bits, uint32_t nb, uint32_t skew_threshold,
                                                         uint32_t hot_partition, uint32_t hot_wc, uint64_t hot_mask,
-                                                        uint32_t* starts, uint32_t* sorted) {
+                                                        uint32_t* starts, uint32_t* sorted, uint32_t stage_cap) {
     uint32_t* bins = h2_msm_smem;  // 2^lo_bits counters, reused as cursors
     __shared__ uint32_t sh[16];
     const uint32_t nbins = 1u << lo_bits, p = blockIdx.x;
@@ -904,13 +904,27 @@ __global__ void __launch_bounds__(SORT_T) k_bucket_sort(const uint2* tmp, const 
     }
     __syncthreads();
     if (!skewed) {
+        // a partition that fits the staging area is put in order in LDS and leaves as whole lines: placed directly, its
+        // entries are 4-byte stores at 2^lo_bits different frontiers (64 transactions per wave and store)
+        uint32_t* stage = bins + nbins;
+        const bool staged = (e1 - e0) <= stage_cap;   // uniform over the workgroup
         for (uint32_t e = e0 + threadIdx.x; e < e1; e += 8 * SORT_T) {
             uint2 v[8];
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) v[j] = tmp[min(e + j * SORT_T, e1 - 1)];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++)
-                if (e + j * SORT_T < e1) sorted[atomicAdd(&bins[v[j].y], 1u)] = v[j].x;
+            for (uint32_t j = 0; j < 8; j++) {
+                if (e + j * SORT_T >= e1) continue;
+                const uint32_t pos = atomicAdd(&bins[v[j].y], 1u);
+                if (staged)
+                    stage[pos - e0] = v[j].x;
+                else
+                    sorted[pos] = v[j].x;
+            }
+        }
+        if (staged) {
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < e1 - e0; i += SORT_T) sorted[e0 + i] = stage[i];
         }
     } else {
         for (uint32_t e = e0 + threadIdx.x; e < e1 + (SORT_T - 1); e += 4 * SORT_T) {
@@ -1712,9 +1726,23 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     // a partition holding more than 4x its fair share (and at least a few thousand entries) takes the skew path
     uint32_t skew_threshold = (uint32_t)std::max<size_t>(4 * (s.entries / s.np), 4096);
     const uint32_t hot_partition = (!fused && hot.on) ? ((s.tab ? 1u : s.R * s.W) << s.hi_bits) : 0xffffffffu;
-    hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), (size_t)4 << s.lo_bits, stream, tmp, pbase, s.lo_bits,
-                       s.hi_bits, s.nb, skew_threshold, hot_partition, fused ? s.Wc : 0u, fused ? fused->hot_mask : 0ull,
-                       starts, sorted);
+    // partitions of a large MSM over a table are all about the same size (24-29 000 entries at 2^21 .. 2^24): with room
+    // for one of them in LDS the sorted list is written as whole lines (H2_MSM_SORT_STAGE=0: placed directly)
+    static const bool sort_stage = !(getenv("H2_MSM_SORT_STAGE") && atoi(getenv("H2_MSM_SORT_STAGE")) == 0);
+    const size_t avg_part = s.entries / s.np;
+    const uint32_t stage_cap = (sort_stage && s.tab && avg_part >= 8192 && avg_part + avg_part / 10 <= 32768) ? 32768u : 0u;
+    if (stage_cap) {
+        static bool raised[64] = {};
+        int dev = 0;
+        H2_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            H2_HIP(hipFuncSetAttribute((const void*)k_bucket_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_bucket_sort, dim3(s.np), dim3(SORT_T), ((size_t)4 << s.lo_bits) + (size_t)stage_cap * 4, stream, tmp, pbase,
+                       s.lo_bits, s.hi_bits, s.nb, skew_threshold, hot_partition, fused ? s.Wc : 0u,
+                       fused ? fused->hot_mask : 0ull, starts, sorted, stage_cap);
     if (!fused && hot.on) hipLaunchKernelGGL(k_copy_hot, dim3(2048), dim3(256), 0, stream, tmp, pbase, hot_partition, sorted);
     if (fused)
         for (uint32_t col = 0; col < s.cols; col++)
