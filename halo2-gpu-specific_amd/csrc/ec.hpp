@@ -103,7 +103,7 @@ H2_DEV XYZZ xyzz_madd(const XYZZ& acc, const Affine& q, bool negate) {
     Fq qq = fp_mul(acc.x, pp);
     XYZZ r;
     r.x = fp_sub(fp_sub(fp_sqr(r_), ppp), fp_dbl(qq));
-    r.y = fp_sub(fp_mul(r_, fp_sub(qq, r.x)), fp_mul(acc.y, ppp));
+    r.y = fp_mul2(r_, fp_sub(qq, r.x), fp_neg(acc.y), ppp);  // R (Q - X3) - Y1 PPP under one reduction
     r.zz = fp_mul(acc.zz, pp);
     r.zzz = fp_mul(acc.zzz, ppp);
     return r;

@@ -254,6 +254,8 @@ template <class P>
 __device__ __forceinline__ Fp<P> fp_mul_dev(const Fp<P>& a, const Fp<P>& b);
 template <class P>
 __device__ __forceinline__ Fp<P> fp_sqr_dev(const Fp<P>& a);  // a * a with 36 operand products instead of 64
+template <class P>
+__device__ __forceinline__ Fp<P> fp_mul2_dev(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d);  // a b + c d, ONE reduction
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
 #define H2_MAD_FREE_V(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y))
 #define H2_MAD_FREE_S(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y))
@@ -379,6 +381,18 @@ H2_DEV Fp<P> fp_sqr(const Fp<P>& a) {
 }
 
 // canonical integer <-> Montgomery (`batch_mont` / `batch_unmont`, arithmetic.rs:235-241,280-286)
+// a * b + c * d (Montgomery form) with ONE reduction on the device: 128 operand products and 64 reduction products in a
+// single column scan instead of 2 x (64 + 64) -- the `R (Q - X3) - Y1 PPP` of a point addition, with -Y1 for c.  Inputs
+// below 2^254 as everywhere; the result is the canonical residue, identical to fp_add(fp_mul(a, b), fp_mul(c, d)).
+template <class P>
+H2_DEV Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL) && !defined(H2_NO_MUL2)
+    return fp_mul2_dev(a, b, c, d);
+#else
+    return fp_add(fp_mul(a, b), fp_mul(c, d));
+#endif
+}
+
 template <class P>
 H2_DEV Fp<P> fp_to_mont(const Fp<P>& canon) {
     Fp<P> rr;

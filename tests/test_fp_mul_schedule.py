@@ -1,0 +1,117 @@
+"""The generated multiplier schedules (tools/gen_fp_mul.py -> csrc/fp_mul_gen.hpp), executed line by line with Python
+integers: every schedule -- product, square, a * b + c * d under one reduction -- must give the Montgomery result for
+random and edge inputs below 2^254, and a multiply-add emitted as "cannot carry" must indeed never carry.  (The device
+runs the same lines as v_mad_u64_u32 / v_addc_co_u32; tools/mulbench checks the compiled code against the host product.)
+"""
+import importlib.util
+import os
+import random
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("gen_fp_mul", os.path.join(ROOT, "tools", "gen_fp_mul.py"))
+gen = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(gen)
+
+M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+MAD = re.compile(r"H2_MAD_(FREE|SET|ACC)_[VS]\(([^,]+), ([^)]+)\);")
+
+
+def limbs(v):
+    return [(v >> (32 * i)) & M32 for i in range(8)]
+
+
+def run(lines, p, ops):
+    """ops: {"a": int, "b": int, ...}; returns the schedule's result after the final conditional subtraction"""
+    mod = limbs(p)
+    inv = (-pow(p, -1, 1 << 32)) & M32
+    env = {k: limbs(v) for k, v in ops.items()}
+    if "a" in ops:  # operands of the squaring schedule
+        two_a = limbs(2 * ops["a"])
+        for k in range(2, 8):
+            env["d%d" % k] = two_a[k]
+        for j in range(7):
+            env["f%d" % j] = (limbs(ops["a"])[j + 1] << 1) & M32
+    m = {}
+    lo, hi, r = 0, 0, [0] * 8
+
+    def val(tok):
+        tok = tok.strip()
+        g = re.fullmatch(r"([abcd])\.l\[(\d)\]", tok)
+        if g:
+            return env[g.group(1)][int(g.group(2))]
+        g = re.fullmatch(r"P::MOD\[(\d)\]", tok)
+        if g:
+            return mod[int(g.group(1))]
+        if tok in m:
+            return m[tok]
+        return env[tok]
+
+    for ln in lines:
+        ln = ln.strip()
+        g = MAD.match(ln)
+        if g:
+            s = lo + val(g.group(2)) * val(g.group(3))
+            carry, lo = s >> 64, s & M64
+            assert carry <= 1
+            if g.group(1) == "FREE":
+                assert carry == 0, "a multiply-add emitted as carry-free carried: " + ln
+            elif g.group(1) == "SET":
+                hi = carry
+            else:
+                hi = (hi + carry) & M32
+            continue
+        g = re.match(r"const uint32_t (m\d) = \(uint32_t\)lo \* P::INV;", ln)
+        if g:
+            m[g.group(1)] = ((lo & M32) * inv) & M32
+            continue
+        g = re.match(r"r\.l\[(\d)\] = \(uint32_t\)lo;", ln)
+        if g:
+            r[int(g.group(1))] = lo & M32
+            continue
+        if ln.startswith("H2_SHIFT1"):
+            lo = (lo >> 32) | (hi << 32)
+            continue
+        if ln.startswith("H2_SHIFT0"):
+            lo >>= 32
+            continue
+        assert ln.startswith("//") or not ln, "unparsed schedule line: " + ln
+    out = sum(x << (32 * i) for i, x in enumerate(r))
+    assert out < 2 * p, "schedule result not below 2p"
+    return out - p if out >= p else out
+
+
+def operands(p, rng, count):
+    edge = [0, 1, p - 1, p, (1 << 254) - 1, (1 << 253), p - 2, (1 << 254) - (1 << 224)]
+    for x in edge:
+        for y in edge:
+            yield x, y
+    for _ in range(count):
+        yield rng.randrange(1 << 254), rng.randrange(1 << 254)
+
+
+@pytest.mark.parametrize("name", sorted(gen.FIELDS))
+def test_product_and_square_schedules(name):
+    p = gen.FIELDS[name]
+    rinv = pow(1 << 256, -1, p)
+    rng = random.Random(1)
+    mul, _ = gen.schedule(p)
+    sqr, _ = gen.schedule(p, square=True)
+    for a, b in operands(p, rng, 300):
+        assert run(mul, p, {"a": a, "b": b}) == a * b * rinv % p
+        assert run(sqr, p, {"a": a}) == a * a * rinv % p
+
+
+@pytest.mark.parametrize("name", sorted(gen.FIELDS))
+def test_two_products_one_reduction_schedule(name):
+    p = gen.FIELDS[name]
+    rinv = pow(1 << 256, -1, p)
+    rng = random.Random(2)
+    dual, stats = gen.schedule(p, dual=True)
+    assert stats["free"] + stats["set"] + stats["acc"] == 128 + 64 - 8 + 8  # 128 operand + 56 reduction + 8 m_i p_0 terms
+    pairs = list(operands(p, rng, 200))
+    for i, (a, b) in enumerate(pairs):
+        c, d = pairs[(7 * i + 3) % len(pairs)]
+        assert run(dual, p, {"a": a, "b": b, "c": c, "d": d}) == (a * b + c * d) * rinv % p
