@@ -436,7 +436,9 @@ def main():
             if rank == 0:
                 out.setdefault("create_proof", {"error": "the multi-rank proof legs did not finish within %.0f s" % budget})
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            # a stalled collective is a FAILED run: every rank ends non-zero so that torchrun / the harness see it
+            # (no restart or re-exec from a process that has initialised the GPU)
+            os._exit(2)
 
         threading.Thread(target=watchdog, daemon=True).start()
 

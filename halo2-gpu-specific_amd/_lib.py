@@ -32,6 +32,9 @@ SYMBOLS = {
     "h2_device_count": (ctypes.c_int, []),
     "h2_last_error": (ctypes.c_char_p, []),
     "h2_synchronize": (ctypes.c_int, []),
+    "h2_release_plans": (ctypes.c_int, []),
+    "h2_set_table_budget": (ctypes.c_int, [_sz]),
+    "h2_library_memory_bytes": (_sz, []),
     "h2_ntt": (ctypes.c_int, [_vp, _vp, _u32]),
     "h2_intt": (ctypes.c_int, [_vp, _vp, _vp, _u32]),
     "h2_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),

@@ -30,7 +30,7 @@ int bad(const char* msg) {
 }
 
 // plan lookup is the only shared mutable state touched by the h2_dev_* paths
-NttPlan* plan_locked(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, bool have_lock) {
+PlanRef plan_locked(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t s, bool have_lock) {
     if (have_lock) return ntt_get_plan(ctx, log_n, omega, s);
     std::lock_guard<std::mutex> g(ctx->mu);
     return ntt_get_plan(ctx, log_n, omega, s);
@@ -42,8 +42,8 @@ int dev_ntt_impl(DeviceCtx* ctx, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_le
     std::vector<uint32_t> bits;
     ntt_split(log_n, bits);
     if (bits.size() >= 2 && tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
-    NttPlan* pl = plan_locked(ctx, log_n, omega, s, have_lock);
-    ntt_run(ctx, pl, src, dst, tmp, in_len, pre3, post3, s);
+    PlanRef pl = plan_locked(ctx, log_n, omega, s, have_lock);  // pinned until the passes are launched
+    ntt_run(ctx, pl.get(), src, dst, tmp, in_len, pre3, post3, s);
     return H2_OK;
 }
 
@@ -79,6 +79,38 @@ int h2_synchronize(void) {
         }
         return (int)H2_OK;
     });
+}
+
+// ------------------------------------------------------------------ library-held device memory
+int h2_release_plans(void) {
+    return guarded([&] {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        for (DeviceCtx* ctx : existing_contexts()) {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            H2_HIP(hipSetDevice(ctx->device));
+            ntt_release_plans(ctx);
+        }
+        (void)hipSetDevice(prev);
+        return (int)H2_OK;
+    });
+}
+
+int h2_set_table_budget(size_t bytes) {
+    ntt_set_table_budget(bytes);
+    return H2_OK;
+}
+
+size_t h2_library_memory_bytes(void) {
+    size_t total = 0;
+    int rc = guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        std::lock_guard<std::mutex> g(ctx->mu);
+        total = ntt_plan_bytes(ctx) + msm_library_bytes(ctx) + ctx->buf_a.cap + ctx->buf_b.cap + ctx->buf_c.cap +
+                ctx->buf_d.cap + ctx->msm_scratch.cap + ctx->evalh_scratch.cap;
+        return (int)H2_OK;
+    });
+    return rc == H2_OK ? total : 0;
 }
 
 // ------------------------------------------------------------------ NTT, host buffers

@@ -74,6 +74,7 @@ struct DeviceCtx {
     PinnedBuf pinned;
     std::map<const void*, ResidentCopy> resident;  // registered host base ranges -> device copies (msm.hip)
     std::map<std::string, NttPlan*> plans;
+    size_t ntt_last_table_bytes = 0;   // of the optional last-pass tables (ntt.hip; guarded by ntt.hip's table mutex)
     hipDeviceProp_t prop;
 };
 

@@ -372,7 +372,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
     unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
     if (d->n_perm_sets) {
-        NttPlan* pl;
+        PlanRef pl;  // pinned until the kernels that read its power tables are launched
         if (have_lock) {
             pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
         } else {

@@ -9,7 +9,7 @@
 //
 // The multiplier is a product-scanning (Comba) Montgomery multiplication built on
 // v_mad_u64_u32 with its carry-out routed through an SGPR pair into one v_addc_co_u32,
-// i.e. 1 half-rate multiply-add + 1 full-rate add per 32x32 partial product (136 mads per
+// i.e. 1 multiply-add (half the issue rate of a 32-bit add: 12.4 vs 24.6 lanes/clk/SIMD, profiles/r1_ubench.txt) + at most 1 add-with-carry per 32x32 partial product (136 mads per
 // modular multiplication; measured chip ceiling 1.31e11 multiplications/s, profiles/r1_mulbench.txt).  No MFMA: there is no dense contraction here.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1508,6 +1508,19 @@ size_t bases_precompute_bytes(size_t n, uint32_t digits) {
     return (size_t)digits * n * sizeof(Affine);
 }
 
+// device memory this translation unit keeps for `ctx`'s device: shifted-base tables (all: they are keyed by device
+// address) and the device copies of registered host SRS ranges
+size_t msm_library_bytes(DeviceCtx* ctx) {
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        for (const auto& kv : g_tables)
+            bytes += (size_t)kv.second.D * kv.second.n * sizeof(Affine) + (kv.second.blocks ? kv.second.n / BLOCK_ROWS * sizeof(Affine) : 0);
+    }
+    for (const auto& kv : ctx->resident) bytes += kv.second.len * sizeof(Affine);
+    return bytes;
+}
+
 int bases_forget(const uint64_t* d_bases) {
     Affine *old = nullptr, *old_blocks = nullptr;
     {
@@ -2178,11 +2191,18 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         rit = ctx->resident.emplace((const void*)key, c).first;
         // a registered SRS is committed against for the life of the process: give its device copy a shifted-base table
         // when that takes less than half of the free memory (H2_MSM_TABLES=0: never)
+        // -- an OPTIONAL optimisation: a failed build (allocation, launch) must not fail the MSM that triggered it; the
+        // windowed pipeline answers with the same point
         const char* env = getenv("H2_MSM_TABLES");
         size_t free_b = 0, total_b = 0;
         if (!(env && env[0] == '0') && reg.len >= ((size_t)1 << 15) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-            bases_precompute_bytes(reg.len, 0) < free_b / 2)
-            bases_precompute((const uint64_t*)c.ptr, reg.len, 0, ctx->stream);
+            bases_precompute_bytes(reg.len, 0) < free_b / 2) {
+            try {
+                if (bases_precompute((const uint64_t*)c.ptr, reg.len, 0, ctx->stream) != H2_OK) (void)hipGetLastError();
+            } catch (const HipError&) {
+                (void)hipGetLastError();  // clear the sticky error; no table for this copy
+            }
+        }
     }
     return (const Affine*)rit->second.ptr + (bases - key) / 8;
 }

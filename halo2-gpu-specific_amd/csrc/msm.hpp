@@ -33,6 +33,7 @@ size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count);
 int bases_precompute(const uint64_t* d_bases, size_t n, uint32_t digits, hipStream_t stream);
 int bases_forget(const uint64_t* d_bases);
 size_t bases_precompute_bytes(size_t n, uint32_t digits);
+size_t msm_library_bytes(DeviceCtx* ctx);
 int g1_fold_launch(const uint64_t* d_points, uint32_t world, uint32_t count, uint64_t* d_out, hipStream_t stream);
 
 }  // namespace h2

@@ -395,10 +395,129 @@ void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits) {
     for (uint32_t p = 0; p < q; p++) bits.push_back(8);
 }
 
-NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream) {
+// ---- library memory: the optional last-pass tables are budgeted per device and evicted least-recently-used first
+static std::mutex g_tab_mu;                 // guards every plan's last_direct map and DeviceCtx::ntt_last_table_bytes
+static std::atomic<uint64_t> g_tick{0};
+static std::atomic<size_t> g_budget_override{(size_t)-1};
+
+static size_t parse_bytes(const char* s) {
+    char* end = nullptr;
+    double v = strtod(s, &end);
+    if (end && (*end == 'K' || *end == 'k')) v *= 1024.0;
+    if (end && (*end == 'M' || *end == 'm')) v *= 1024.0 * 1024.0;
+    if (end && (*end == 'G' || *end == 'g')) v *= 1024.0 * 1024.0 * 1024.0;
+    return v <= 0 ? 0 : (size_t)v;
+}
+
+void ntt_set_table_budget(size_t bytes) { g_budget_override.store(bytes); }
+
+size_t ntt_table_budget(DeviceCtx* ctx) {
+    const size_t o = g_budget_override.load();
+    if (o != (size_t)-1) return o;
+    static const char* env = getenv("H2_NTT_TABLE_BUDGET");
+    if (env) return parse_bytes(env);
+    return (size_t)ctx->prop.totalGlobalMem / 32;
+}
+
+static void free_plan(NttPlan* pl) {
+    if (pl->tables) (void)hipFree(pl->tables);
+    for (const Fr* t : pl->tw_direct)
+        if (t) (void)hipFree(const_cast<Fr*>(t));
+    for (auto& kv : pl->scaled_hi)
+        if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : pl->last_direct)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    delete pl;
+}
+
+size_t ntt_release_plans(DeviceCtx* ctx) {
+    std::vector<NttPlan*> gone;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        for (auto it = ctx->plans.begin(); it != ctx->plans.end();) {
+            NttPlan* pl = it->second;
+            bool busy = pl->users.load() != 0;
+            for (auto& kv : pl->last_direct) busy = busy || kv.second.users != 0;
+            if (busy) {
+                ++it;
+                continue;
+            }
+            bytes += pl->table_bytes;
+            for (auto& kv : pl->last_direct) {
+                bytes += kv.second.bytes;
+                ctx->ntt_last_table_bytes -= kv.second.bytes;
+            }
+            for (auto& kv : pl->scaled_hi) bytes += (sizeof(Fr) << pl->log_n) >> LO_BITS;
+            gone.push_back(pl);
+            it = ctx->plans.erase(it);
+        }
+    }
+    if (!gone.empty()) {
+        // nobody can reach these plans any more; passes already launched against their tables finish first
+        H2_HIP(hipDeviceSynchronize());
+        for (NttPlan* pl : gone) free_plan(pl);
+    }
+    return bytes;
+}
+
+size_t ntt_plan_bytes(DeviceCtx* ctx) {
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    size_t bytes = 0;
+    for (auto& kv : ctx->plans) {
+        NttPlan* pl = kv.second;
+        bytes += pl->table_bytes;
+        for (auto& t : pl->last_direct) bytes += t.second.bytes;
+        bytes += pl->scaled_hi.size() * ((sizeof(Fr) << pl->log_n) >> LO_BITS);
+    }
+    return bytes;
+}
+
+// Makes room for `need` more bytes of last-pass tables on `ctx`: idle tables leave in least-recently-used order.
+// Returns false when the budget cannot hold `need` even then.  Call WITHOUT g_tab_mu.
+static bool last_table_make_room(DeviceCtx* ctx, size_t need) {
+    const size_t budget = ntt_table_budget(ctx);
+    if (need > budget) return false;
+    std::vector<Fr*> gone;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        while (ctx->ntt_last_table_bytes + need > budget) {
+            NttPlan::LastTable* victim = nullptr;
+            NttPlan* owner = nullptr;
+            std::string vkey;
+            for (auto& pk : ctx->plans)
+                for (auto& kv : pk.second->last_direct)
+                    if (kv.second.ptr && kv.second.users == 0 && (!victim || kv.second.last_use < victim->last_use)) {
+                        victim = &kv.second;
+                        owner = pk.second;
+                        vkey = kv.first;
+                    }
+            if (!victim) break;
+            gone.push_back(victim->ptr);
+            ctx->ntt_last_table_bytes -= victim->bytes;
+            owner->last_direct.erase(vkey);
+        }
+        if (ctx->ntt_last_table_bytes + need > budget && gone.empty()) return false;
+    }
+    if (!gone.empty()) {
+        H2_HIP(hipDeviceSynchronize());  // passes launched against an evicted table have finished before it is freed
+        for (Fr* t : gone) (void)hipFree(t);
+    }
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    return ctx->ntt_last_table_bytes + need <= budget;
+}
+
+PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream) {
     std::string key = plan_key(log_n, omega);
-    auto it = ctx->plans.find(key);
-    if (it != ctx->plans.end()) return it->second;
+    {
+        std::lock_guard<std::mutex> g(g_tab_mu);
+        auto it = ctx->plans.find(key);
+        if (it != ctx->plans.end()) {
+            it->second->users.fetch_add(1);
+            it->second->last_use = ++g_tick;
+            return PlanRef(it->second);
+        }
+    }
 
     NttPlan* pl = new NttPlan();
     pl->log_n = log_n;
@@ -415,6 +534,7 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
         total += (1u << b) >> 1 ? (1u << b) >> 1 : 1;
     }
     H2_HIP(hipMalloc(&pl->tables, total * sizeof(Fr)));
+    pl->table_bytes = total * sizeof(Fr);
     pl->tw_lo = pl->tables;
     pl->tw_hi = pl->tables + lo_count;
     hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, pl->tables, w, 1u, lo_count);
@@ -439,6 +559,7 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
             if (p > 0 && !last && B + consumed <= 16) {
                 uint32_t cnt = 1u << (B + consumed);
                 H2_HIP(hipMalloc(&tab, (size_t)cnt * sizeof(Fr)));
+                pl->table_bytes += (size_t)cnt * sizeof(Fr);
                 hipLaunchKernelGGL(k_direct_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, tab, w, consumed,
                                    log_n - consumed - B, log_n, cnt);
             }
@@ -451,8 +572,11 @@ NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], h
     // torch stream, or the host API after a device-API first use) must not launch passes against tables still being
     // written.  Once per (log_n, omega) for the life of the process.
     H2_HIP(hipStreamSynchronize(stream));
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    pl->users.fetch_add(1);
+    pl->last_use = ++g_tick;
     ctx->plans[key] = pl;
-    return pl;
+    return PlanRef(pl);
 }
 
 // Runs the transform.  `src` (in_len valid elements, zero-extended to n) -> result in `dst`.
@@ -541,9 +665,11 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         // The last pass of a large transform reads its inter-pass twiddles from a complete table (32 B x n, streamed in the
         // order of its loads) instead of composing each from two: one product per element instead of two, on a pass that
         // is bound by VALU issue and has the HBM time to spare (2^24: 1.84 -> see DESIGN 3.2).  One table per divisor
-        // folded into it; H2_NTT_LAST_TABLE=0 or a failed allocation leave the lo x hi form.
+        // folded into it, inside the per-device budget (ntt_table_budget: the least recently used idle table leaves
+        // first); H2_NTT_LAST_TABLE=0, no room in the budget or a failed allocation leave the lo x hi form.
         static const bool last_table = !(getenv("H2_NTT_LAST_TABLE") && atoi(getenv("H2_NTT_LAST_TABLE")) == 0);
         static const uint32_t last_table_max = getenv("H2_NTT_LAST_TABLE_MAX_LOG") ? (uint32_t)atoi(getenv("H2_NTT_LAST_TABLE_MAX_LOG")) : 26u;
+        NttPlan::LastTable* used_table = nullptr;
         if (last && p > 0 && last_table && L >= 18 && L <= last_table_max) {
             const bool scaled = a.hi_scaled != 0;
             std::string key;
@@ -553,26 +679,47 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                          post3[0].l[4], post3[0].l[3], post3[0].l[2], post3[0].l[1], post3[0].l[0]);
                 key = kb;
             }
-            Fr* tab = nullptr;
-            {
-                std::lock_guard<std::mutex> g(pl->mu);
+            const size_t bytes = sizeof(Fr) << L;
+            auto pin = [&]() -> NttPlan::LastTable* {  // with g_tab_mu held
                 auto it = pl->last_direct.find(key);
-                if (it == pl->last_direct.end()) {
-                    if (hipMalloc(&tab, sizeof(Fr) << L) != hipSuccess) {
-                        (void)hipGetLastError();  // no room: this plan keeps composing its twiddles
-                        tab = nullptr;
-                    } else {
-                        hipLaunchKernelGGL(k_last_table, dim3((1u << L) / 256), dim3(256), 0, stream, tab, pl->w, B, L,
-                                           scaled ? post3[0] : pl->w, scaled ? 1u : 0u);
-                        H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per divisor)
-                    }
-                    pl->last_direct[key] = tab;
-                } else {
-                    tab = it->second;
-                }
+                if (it == pl->last_direct.end() || it->second.ptr == nullptr) return nullptr;
+                it->second.users++;
+                it->second.last_use = ++g_tick;
+                return &it->second;
+            };
+            {
+                std::lock_guard<std::mutex> g(g_tab_mu);
+                used_table = pin();
             }
-            if (tab != nullptr) {
-                a.tw_direct = tab;
+            if (!used_table && last_table_make_room(ctx, bytes)) {
+                // built outside the lock (a table is 0.5 .. 2 GiB of powers); a second builder of the same table loses
+                Fr* tab = nullptr;
+                if (hipMalloc(&tab, bytes) != hipSuccess) {
+                    (void)hipGetLastError();  // no room on the device: this transform composes its twiddles
+                    tab = nullptr;
+                } else {
+                    hipLaunchKernelGGL(k_last_table, dim3((1u << L) / 256), dim3(256), 0, stream, tab, pl->w, B, L,
+                                       scaled ? post3[0] : pl->w, scaled ? 1u : 0u);
+                    H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it
+                }
+                Fr* loser = nullptr;
+                {
+                    std::lock_guard<std::mutex> g(g_tab_mu);
+                    used_table = pin();
+                    if (used_table) {
+                        loser = tab;
+                    } else if (tab) {
+                        NttPlan::LastTable& e = pl->last_direct[key];
+                        e.ptr = tab;
+                        e.bytes = bytes;
+                        ctx->ntt_last_table_bytes += bytes;
+                        used_table = pin();
+                    }
+                }
+                if (loser) (void)hipFree(loser);
+            }
+            if (used_table != nullptr) {
+                a.tw_direct = used_table->ptr;
                 a.direct_kmajor = 1;
             }
         }
@@ -608,6 +755,10 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                 hipLaunchKernelGGL(k_ntt_pass<true>, dim3(ntiles), dim3(threads), lds, stream, a);
             else
                 hipLaunchKernelGGL(k_ntt_pass<false>, dim3(ntiles), dim3(threads), lds, stream, a);
+        }
+        if (used_table) {  // launched: an eviction from here on synchronises the device before it frees
+            std::lock_guard<std::mutex> g(g_tab_mu);
+            used_table->users--;
         }
         consumed += B;
     }

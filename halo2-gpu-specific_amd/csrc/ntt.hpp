@@ -1,5 +1,6 @@
 // ntt.hpp -- NTT plan (cached twiddle tables per (log_n, omega)) and the pass driver.
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -15,15 +16,60 @@ struct NttPlan {
     const Fr* tw_hi = nullptr;         // w^(i<<12),  i < n >> 12
     std::vector<const Fr*> tw_bfly;    // per pass: (w^(n/R))^e, e < R/2
     std::vector<const Fr*> tw_direct;  // per pass: full inter-pass twiddle table or nullptr
+    size_t table_bytes = 0;            // of `tables` and the per-pass direct tables
     std::mutex mu;                     // guards scaled_hi, last_direct
     std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)
     // the last pass's complete inter-pass twiddle set, w^(rho * K) at [(K << B_last) | rho] (2^log_n entries, streamed in
-    // the order the pass loads its elements), keyed by the divisor folded into it ("" = none); nullptr = allocation failed
-    std::map<std::string, Fr*> last_direct;
+    // the order the pass loads its elements), keyed by the divisor folded into it ("" = none).  These are the large
+    // optional tables (32 B x n each): they count against the per-device budget (ntt_table_budget) and the least
+    // recently used idle one is evicted when a new one would exceed it; a transform that finds none composes its
+    // twiddles from the two-level tables (one more product per element, same values).
+    struct LastTable {
+        Fr* ptr = nullptr;
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+        int users = 0;  // transforms between looking the table up and having launched the pass that reads it
+    };
+    std::map<std::string, LastTable> last_direct;
+    std::atomic<int> users{0};         // callers holding the plan (PlanRef): a plan in use is not released
+    uint64_t last_use = 0;
+};
+
+// a plan handed out by ntt_get_plan stays alive until its PlanRef goes (h2_release_plans skips plans in use)
+struct PlanRef {
+    NttPlan* pl = nullptr;
+    PlanRef() = default;
+    explicit PlanRef(NttPlan* p) : pl(p) {}
+    PlanRef(PlanRef&& o) noexcept : pl(o.pl) { o.pl = nullptr; }
+    PlanRef& operator=(PlanRef&& o) noexcept {
+        if (this != &o) {
+            if (pl) pl->users.fetch_sub(1);
+            pl = o.pl;
+            o.pl = nullptr;
+        }
+        return *this;
+    }
+    PlanRef(const PlanRef&) = delete;
+    PlanRef& operator=(const PlanRef&) = delete;
+    ~PlanRef() {
+        if (pl) pl->users.fetch_sub(1);
+    }
+    NttPlan* operator->() const { return pl; }
+    NttPlan* get() const { return pl; }
 };
 
 void ntt_split(uint32_t log_n, std::vector<uint32_t>& bits);
-NttPlan* ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream);
+// call with ctx->mu held (the plan map is per device); the returned reference pins the plan
+PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hipStream_t stream);
+// frees every plan of `ctx` that no caller holds, with all its tables (synchronises the device first); call with
+// ctx->mu held.  Returns the bytes released.
+size_t ntt_release_plans(DeviceCtx* ctx);
+// bytes of device memory the plans of `ctx` hold (twiddle tables + last-pass tables); call with ctx->mu held
+size_t ntt_plan_bytes(DeviceCtx* ctx);
+// per-device budget of the optional last-pass tables: H2_NTT_TABLE_BUDGET (bytes; K / M / G suffixes) or
+// h2_set_table_budget; default 1/32 of the device's memory (9 GiB on an MI355X: a k = 24 proof's four tables take 3)
+size_t ntt_table_budget(DeviceCtx* ctx);
+void ntt_set_table_budget(size_t bytes);
 // src (in_len valid elements, zero-extended to 2^log_n) -> dst; tmp = 2^log_n scratch (needed when
 // the plan has >= 2 passes).  pre3 / post3: nullable HOST pointers to 3 Fr each (passed by value
 // in the kernel arguments): x[i] *= pre3[i % 3] (i % 3 != 0) on load, y[i] *= post3[i % 3] on store.

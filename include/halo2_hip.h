@@ -50,6 +50,22 @@ const char *h2_last_error(void);
 /* blocks until all work queued by this library on every pooled device has finished */
 int h2_synchronize(void);
 
+/* ---- device memory the library keeps between calls ---------------------------------------------
+ * The reference bounds its device memory by keeping coefficient forms and re-deriving extended cosets through a small
+ * cache (plonk/evaluation_gpu.rs:335-468, HALO2_PROOF_GPU_EVAL_CACHE).  Here the caller owns every polynomial; what the
+ * LIBRARY holds per device is: NTT plans (twiddle tables, a few MiB per (log_n, omega)), the optional complete last-pass
+ * twiddle tables (32 B x n per (plan, divisor): 512 MiB at 2^24), shifted-base tables (h2_dev_bases_precompute), device
+ * copies of registered SRS ranges and the host-API staging arenas.
+ *  - The last-pass tables live inside a per-device budget: H2_NTT_TABLE_BUDGET in the environment (bytes, K / M / G
+ *    suffixes) or h2_set_table_budget; default 1/32 of the device's memory.  When a new table would exceed it, idle
+ *    tables leave in least-recently-used order; a transform without a table composes its twiddles (same values).
+ *  - h2_release_plans frees every plan (and its tables) that no call is using, on every device: for callers that
+ *    cycle through domains or coset generators.  Synchronises the devices.
+ *  - h2_library_memory_bytes: what the library holds on the current device right now. */
+int h2_release_plans(void);
+int h2_set_table_budget(size_t bytes);
+size_t h2_library_memory_bytes(void);
+
 /* ---- NTT (host buffers) ---------------------------------------------------------------- */
 /* best_fft -> gpu_fft: arithmetic.rs:546-554, :495-512.  a: 2^log_n Fr, in place. */
 int h2_ntt(uint64_t *a, const uint64_t omega[4], uint32_t log_n);

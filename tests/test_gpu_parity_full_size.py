@@ -1,0 +1,105 @@
+"""GPU parity AT THE METRIC'S SIZES (BASELINE.json: k = 24), every output against the CPU oracle -- not against another
+form of the HIP path and not on sampled outputs:
+
+* 2^24-point MSM vs `oracle.best_multiexp` (arithmetic.rs:20-108, :465-492 restated): uniform 254-bit scalars through the
+  windowed pipeline (host-buffer entry point `h2_msm`) and over a shifted-base table (`h2_dev_msm` after
+  `h2_dev_bases_precompute`), and a column that is 7/8 one value (the shape of a grand-product column);
+* the full 2^25-point NTT (the extended domain of a k = 24 proof, 8 + 8 + 9-bit passes) vs `oracle.best_fft`
+  (arithmetic.rs:556-705), all 2^25 elements;
+* `coeff_to_extended` -> `divide_by_vanishing_poly` -> `extended_to_coeff` at k = 24 / extended 2^25
+  (poly/domain.rs:270-287, :354-373, :328-350), all elements.
+
+The oracle side costs ~10 s of host time per MSM / transform on the GPU box's cores."""
+import os
+
+import numpy as np
+import pytest
+
+from halo2_gpu_specific_amd import arithmetic as ar
+from h2util import R_MOD, arr_to_points, fr_mont
+from test_gpu_msm_table import DevMsm
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+S = 28
+ROOT = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+LOG_N = 24
+# libgomp does not scale the oracle's rayon-shaped FFT recursion past ~32 threads (65 s per 2^24 transform on the GPU box's
+# 256 hardware threads against 1.6 s on 32: DESIGN.md section 5); bench.py probes the team size the same way
+FFT_THREADS = min(32, os.cpu_count() or 1)
+
+
+def _affine(oracle, jac):
+    return arr_to_points(oracle.to_affine(np.asarray(jac, dtype=np.uint64)))[0]
+
+
+@pytest.fixture(scope="module")
+def bases24(oracle):
+    return oracle.random_g1(0x48414C4F32 + 24, 1 << LOG_N)
+
+
+@pytest.fixture(scope="module")
+def columns24(oracle):
+    n = 1 << LOG_N
+    uniform = oracle.random_fr(0x48414C4F32 + 2424, n)
+    dominant = oracle.random_fr(0x48414C4F32 + 2425, n)
+    dominant[n // 8:] = dominant[7]                     # 7/8 of the rows hold one 254-bit value (whole 256-row blocks of it)
+    return {"uniform": uniform, "7/8 dominant": dominant}
+
+
+@pytest.fixture(scope="module")
+def want24(oracle, bases24, columns24):
+    return {name: _affine(oracle, oracle.best_multiexp(col, bases24)) for name, col in columns24.items()}
+
+
+def test_msm_2p24_windowed_vs_oracle(oracle, bases24, columns24, want24):
+    """BASELINE's k = 24 MSM through `h2_msm` (scalars and bases uploaded by the call: no table exists for an
+    unregistered host buffer, so this is the windowed pipeline: c = 17, 15 windows)"""
+    for name, col in columns24.items():
+        got = _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(col, bases24, 254))
+        assert got == want24[name], name
+
+
+def test_msm_2p24_over_table_vs_oracle(oracle, bases24, columns24, want24):
+    """the same columns over the 12 GiB shifted-base table (12 digits of 21 / 22 bits, one shared bucket set, two-level
+    partition): the form `bench.py`'s `msm_k24.over_shifted_base_table` and the k = 24 proof use"""
+    dev = DevMsm(bases24)
+    dev.precompute()
+    try:
+        for name, col in columns24.items():
+            assert _affine(oracle, dev.msm(col, 254)) == want24[name], name
+    finally:
+        dev.forget()
+
+
+def test_ntt_2p25_every_element_vs_oracle(oracle):
+    log_n = 25
+    n = 1 << log_n
+    omega = pow(ROOT, 1 << (S - log_n), R_MOD)
+    x = oracle.random_fr(0x25250000, n)
+    got = ar.best_fft(x.copy(), fr_mont(omega), log_n)
+    want = oracle.best_fft(x, fr_mont(omega), log_n, threads=FFT_THREADS)
+    assert np.array_equal(got, want)
+    del want
+    back = ar.gpu_ifft(got, fr_mont(pow(omega, -1, R_MOD)), log_n, fr_mont(pow(n, -1, R_MOD)))
+    assert np.array_equal(back, x)
+
+
+def test_coset_divide_inverse_k24_vs_oracle(oracle):
+    """the extended-domain leg of a k = 24 degree-3 proof (BASELINE configs[4]): 2^24 coefficients -> the 2^25-point coset,
+    divided by the vanishing polynomial, back to 2 * 2^24 coefficients"""
+    d, t = oracle.domain(3, LOG_N)
+    assert d.extended_k == 25
+    coeffs = oracle.random_fr(0x2424C0, 1 << LOG_N)
+    ext = ar.coeff_to_extended(coeffs, d.k, d.extended_k, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega"))
+    want = oracle.coeff_to_extended(coeffs, d, threads=FFT_THREADS)
+    assert np.array_equal(ext, want)
+    del want
+    div = ar.divide_by_vanishing_poly(ext.copy(), t)
+    oracle.lib.oracle_divide_by_vanishing_poly(ext.ctypes.data, len(ext), t.ctypes.data, len(t), 64)
+    assert np.array_equal(div, ext)
+    got_c = ar.extended_to_coeff(
+        div, d.k, d.extended_k, d.quotient_poly_degree, d.fr("g_coset"), d.fr("g_coset_inv"), d.fr("extended_omega_inv"),
+        d.fr("extended_ifft_divisor"),
+    )
+    assert np.array_equal(got_c, oracle.extended_to_coeff(ext, d, threads=FFT_THREADS))
