@@ -91,6 +91,8 @@ SYMBOLS = {
     "h2_dev_points_compress": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_jit_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _vp]),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
+    "h2_evaluate_h_coeff": (ctypes.c_int, [_vp, _vp]),
+    "h2_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz]),
     "h2_dev_evaluate_h": (ctypes.c_int, [_vp, _vp, _vp]),
     "h2_timer_start": (ctypes.c_int, [_vp]),
     "h2_timer_stop": (ctypes.c_int, [_vp, _fp]),

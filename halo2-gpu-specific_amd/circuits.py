@@ -41,3 +41,55 @@ def mini_plonk_synthesize(k, a=5, alloc=None):
     z, o, t = np.zeros(pairs, dtype=np.int64), np.ones(pairs, dtype=np.int64), np.full(pairs, 2, dtype=np.int64)
     copies = np.concatenate([np.stack([z, r0, z, r1], axis=1), np.stack([o, r1, t, r0], axis=1)])
     return adv, fixed, copies
+
+
+def wide(quads=16):
+    """A wide, lookup-bearing circuit in the shape of the zkWasm circuits this fork exists for (many advice columns,
+    degree 5, range lookups; examples/range-check.rs:104-137 and examples/lookup_api.rs are its small relatives):
+    4 * quads advice columns (a, b, c, d per quad), fixed q (row selector) and t (range table); one gate with a
+    polynomial q * (a * b * c - d) per quad (degree 4); quads / 2 logup lookups into t, each with one input set of
+    two columns (the a's of two neighbouring quads: degree 2 + 1 + 1 + 1 = 5); equality on the first two columns."""
+    cs = ConstraintSystem("wide-%d" % quads)
+    adv = [cs.advice_column() for _ in range(4 * quads)]
+    q, t = cs.fixed_column(), cs.fixed_column()
+    cs.enable_equality(adv[0])
+    cs.enable_equality(adv[1])
+    qq = cs.query_fixed(q)
+    cells = [cs.query_advice(col) for col in adv]
+    cs.create_gate("mul3", [qq * (cells[4 * i] * cells[4 * i + 1] * cells[4 * i + 2] + cells[4 * i + 3] * (-1))
+                            for i in range(quads)])
+    tt = cs.query_fixed(t)
+    for l in range(quads // 2):
+        cs.lookup_any("range%d" % l, [tt], [[[cells[8 * l]], [cells[8 * l + 4]]]])
+    cs.set_minimum_degree(5)            # as benches/plonk.rs:181; what two inputs per lookup set need
+    return cs
+
+
+def wide_synthesize(k, quads=16, alloc=None):
+    """Witness of `wide`: t[i] = i for i < T = min(usable rows, 2^16); a, b, c < T from multiplicative hashes of (row,
+    column), d = a b c on the usable rows; b of quad 0 is a of quad 0 one row up, tied by copy constraints on the first
+    min(usable - 1, 2^16) rows.  Returns (advice[4 * quads], fixed[2], copies) in the layout of mini_plonk_synthesize."""
+    n = 1 << k
+    usable = n - 6
+    T = min(usable, 1 << 16)
+    ncols = 4 * quads
+    adv = alloc(ncols, n) if alloc else [np.zeros((n, 4), dtype=np.uint64) for _ in range(ncols)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
+    fixed[0][:usable, 0] = 1
+    fixed[1][:T, 0] = np.arange(T, dtype=np.uint64)
+    rows = np.arange(usable, dtype=np.uint64)
+    for qd in range(quads):
+        vals = []
+        for j in range(3):
+            col = 4 * qd + j
+            v = ((rows * np.uint64(2654435761) + np.uint64(40503 * col + 7)) >> np.uint64(5)) % np.uint64(T)
+            vals.append(v)
+        if qd == 0:
+            vals[1] = np.concatenate([np.array([3 % T], dtype=np.uint64), vals[0][:-1]])
+        for j in range(3):
+            adv[4 * qd + j][:usable, 0] = vals[j]
+        adv[4 * qd + 3][:usable, 0] = vals[0] * vals[1] * vals[2]          # < 2^48
+    m = min(usable - 1, 1 << 16)
+    r = np.arange(m, dtype=np.int64)
+    copies = np.stack([np.zeros(m, dtype=np.int64), r, np.ones(m, dtype=np.int64), r + 1], axis=1)
+    return adv, fixed, copies

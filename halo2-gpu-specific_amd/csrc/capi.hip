@@ -637,6 +637,34 @@ int h2_dev_lincomb(void* d_res, const void* const* d_polys, const uint64_t* coef
     });
 }
 
+// host buffers: every operand crosses PCIe once (count x size x 32 B in, size x 32 B out)
+int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coeffs, size_t count, size_t size) {
+    if (!res || (count && (!polys || !coeffs))) return bad("h2_lincomb: null argument");
+    for (size_t i = 0; i < count; i++)
+        if (!polys[i]) return bad("h2_lincomb: null operand");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        const size_t bytes = size * sizeof(Fr);
+        if (count == 0 || size == 0) {
+            memset(res, 0, bytes);
+            return (int)H2_OK;
+        }
+        Fr* d_all = (Fr*)ctx->buf_a.get(bytes * count);
+        Fr* d_res = (Fr*)ctx->buf_b.get(bytes);
+        std::vector<const Fr*> ptrs(count);
+        for (size_t i = 0; i < count; i++) {
+            ptrs[i] = d_all + i * size;
+            H2_HIP(hipMemcpyAsync(d_all + i * size, polys[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        int rc = lincomb_launch(d_res, ptrs.data(), coeffs, count, size, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
 int h2_dev_permutation_sigma(void* d_out, const void* d_map_col, const void* d_map_row, size_t n,
                              const uint64_t delta[4], const uint64_t omega[4], void* stream) {
     if (n && (!d_out || !d_map_col || !d_map_row || !delta || !omega)) return bad("h2_dev_permutation_sigma: null argument");
@@ -709,6 +737,14 @@ int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
     return guarded([&] {
         DeviceLease lease;
         return evalh_host(lease.ctx, desc, values);
+    });
+}
+
+int h2_evaluate_h_coeff(const h2_evalh_desc* desc, uint64_t* values) {
+    if (!desc || !values) return bad("h2_evaluate_h_coeff: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        return evalh_host_coeffs(lease.ctx, desc, values);
     });
 }
 

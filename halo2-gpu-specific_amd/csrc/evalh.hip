@@ -22,6 +22,7 @@
 #include "evalh.hpp"
 #include "evalh_jit.hpp"
 #include "ntt.hpp"
+#include "poly.hpp"
 
 namespace h2 {
 
@@ -494,6 +495,150 @@ int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
         }
         cleanup();
         return rc;
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+}
+
+// ---------------------------------------------------------------- coefficient forms in, extended values out
+// out[i] = in[c * i + j]  /  out[c * i + j] = in[i]: one coset of the n-th roots of unity inside the extended domain
+__global__ void __launch_bounds__(256) k_coset_gather(const Fr* in, Fr* out, size_t n, uint32_t log_c, uint32_t j) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fp_store(out + i, fp_load(in + ((i << log_c) | j)));
+}
+__global__ void __launch_bounds__(256) k_coset_scatter(const Fr* in, Fr* out, size_t n, uint32_t log_c, uint32_t j) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fp_store(out + ((i << log_c) | j), fp_load(in + i));
+}
+
+// The shape of the reference's cuda `Evaluator::evaluate_h` (plonk/evaluation.rs:1229-1985): every column arrives as a
+// COEFFICIENT vector of 2^k elements in host memory (the `cuda` proving key keeps no extended cosets, plonk.rs:226-240),
+// `l_active_row` as extended values (2^extended_k, host), and the numerator comes back as 2^extended_k host values.
+// The reference re-derives extended cosets through a 5-entry cache while it walks its expression trees; here the
+// extended domain is visited one coset g_j H of the n-th roots of unity at a time (g_j = zeta * extended_omega^j,
+// extended index c i + j = point i of coset j, c = 2^(extended_k - k)): every distinct column is uploaded ONCE, taken to
+// coset j by a[t] *= g_j^t and an n-point NTT, and the fused evaluator runs with extended_k := k, zeta := g_j,
+// extended_omega := omega -- on one coset a rotation is an index shift and nothing else changes.  Device memory is
+// (distinct columns) x 2 x 2^k x 32 B + two extended vectors: bounded by the circuit's width, not by width x 2^extended_k.
+int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
+    if (!d || !values) {
+        set_last_error("h2_evaluate_h_coeff: null argument");
+        return H2_ERR_INVALID;
+    }
+    if (d->extended_k < d->k || d->extended_k > 28) {
+        set_last_error("h2_evaluate_h_coeff: bad k / extended_k");
+        return H2_ERR_INVALID;
+    }
+    const uint32_t log_c = d->extended_k - d->k, c = 1u << log_c;
+    const size_t n = (size_t)1 << d->k, size = (size_t)1 << d->extended_k;
+    const size_t nbytes = n * sizeof(Fr), ebytes = size * sizeof(Fr);
+    hipStream_t stream = ctx->stream;
+    std::vector<void*> owned;
+    auto cleanup = [&] {
+        for (void* q : owned) (void)hipFree(q);
+    };
+    auto dmalloc = [&](size_t bytes) {
+        void* q = nullptr;
+        H2_HIP(hipMalloc(&q, bytes));
+        owned.push_back(q);
+        return q;
+    };
+    try {
+        // every distinct coefficient vector once: (device coefficients, device values on the current coset)
+        std::map<const uint64_t*, std::pair<Fr*, Fr*>> cols;
+        auto add = [&](const uint64_t* h) {
+            if (!h || cols.count(h)) return;
+            Fr* dc = (Fr*)dmalloc(nbytes);
+            Fr* dv = (Fr*)dmalloc(nbytes);
+            H2_HIP(hipMemcpyAsync(dc, h, nbytes, hipMemcpyHostToDevice, stream));
+            cols[h] = {dc, dv};
+        };
+        size_t n_lookup_z = 0;
+        for (uint32_t t = 0; t < d->n_lookups; t++) n_lookup_z += d->lookup_sets[t];
+        auto add_table = [&](const uint64_t* const* tab, size_t cnt) {
+            for (size_t i = 0; i < cnt; i++) add(tab[i]);
+        };
+        add_table(d->fixed, d->n_fixed);
+        add_table(d->advice, d->n_advice);
+        add_table(d->instance, d->n_instance);
+        add_table(d->perm_z, d->n_perm_sets);
+        add_table(d->perm_sigma, d->n_perm_columns);
+        add_table(d->lookup_z, n_lookup_z);
+        add_table(d->lookup_m, d->n_lookups);
+        add_table(d->shuffle_z, d->n_shuffles);
+        add(d->l0);
+        add(d->l_last);
+        Fr* d_active = nullptr;
+        Fr* d_active_j = nullptr;
+        if (d->l_active_row) {
+            d_active = (Fr*)dmalloc(ebytes);
+            d_active_j = (Fr*)dmalloc(nbytes);
+            H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+        }
+        Fr* d_values = (Fr*)dmalloc(ebytes);
+        Fr* d_values_j = (Fr*)dmalloc(nbytes);
+        Fr* d_tmp = (Fr*)dmalloc(nbytes);
+        // omega = extended_omega^c generates the n-th roots of unity
+        const Fr w_ext = fr_from_u64x4(d->extended_omega), zeta = fr_from_u64x4(d->zeta);
+        Fr omega = w_ext;
+        for (uint32_t t = 0; t < log_c; t++) omega = fp_sqr(omega);
+        uint64_t omega_u[4], g_u[4];
+        for (int i = 0; i < 4; i++) omega_u[i] = (uint64_t)omega.l[2 * i] | ((uint64_t)omega.l[2 * i + 1] << 32);
+        PlanRef pl = ntt_get_plan(ctx, d->k, omega_u, stream);  // the caller holds ctx->mu (DeviceLease)
+        const unsigned nblocks = (unsigned)((n + 255) / 256);
+        Fr g = zeta;  // g_0
+        for (uint32_t j = 0; j < c; j++) {
+            for (int i = 0; i < 4; i++) g_u[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
+            for (auto& kv : cols) {
+                Fr* dc = kv.second.first;
+                Fr* dv = kv.second.second;
+                H2_HIP(hipMemcpyAsync(dv, dc, nbytes, hipMemcpyDeviceToDevice, stream));
+                int rc = distribute_powers_launch(dv, n, g_u, stream);
+                if (rc != H2_OK) {
+                    cleanup();
+                    return rc;
+                }
+                ntt_run(ctx, pl.get(), dv, dv, d_tmp, (uint32_t)n, nullptr, nullptr, stream);
+            }
+            if (d_active) hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);
+            h2_evalh_desc dd = *d;
+            dd.extended_k = d->k;
+            for (int i = 0; i < 4; i++) {
+                dd.zeta[i] = g_u[i];
+                dd.extended_omega[i] = omega_u[i];
+            }
+            auto on_coset = [&](const uint64_t* h) -> const uint64_t* { return h ? (const uint64_t*)cols[h].second : nullptr; };
+            auto map_table = [&](const uint64_t* const* tab, size_t cnt, std::vector<const uint64_t*>& out) {
+                out.resize(cnt);
+                for (size_t i = 0; i < cnt; i++) out[i] = on_coset(tab[i]);
+                return out.data();
+            };
+            std::vector<const uint64_t*> t_fixed, t_adv, t_inst, t_pz, t_ps, t_lz, t_lm, t_sz;
+            dd.fixed = map_table(d->fixed, d->n_fixed, t_fixed);
+            dd.advice = map_table(d->advice, d->n_advice, t_adv);
+            dd.instance = map_table(d->instance, d->n_instance, t_inst);
+            dd.perm_z = map_table(d->perm_z, d->n_perm_sets, t_pz);
+            dd.perm_sigma = map_table(d->perm_sigma, d->n_perm_columns, t_ps);
+            dd.lookup_z = map_table(d->lookup_z, n_lookup_z, t_lz);
+            dd.lookup_m = map_table(d->lookup_m, d->n_lookups, t_lm);
+            dd.shuffle_z = map_table(d->shuffle_z, d->n_shuffles, t_sz);
+            dd.l0 = on_coset(d->l0);
+            dd.l_last = on_coset(d->l_last);
+            dd.l_active_row = (const uint64_t*)d_active_j;
+            int rc = evalh_device(ctx, &dd, d_values_j, stream, true);
+            if (rc != H2_OK) {
+                cleanup();
+                return rc;
+            }
+            hipLaunchKernelGGL(k_coset_scatter, dim3(nblocks), dim3(256), 0, stream, d_values_j, d_values, n, log_c, j);
+            g = fp_mul(g, w_ext);
+        }
+        H2_HIP(hipGetLastError());
+        H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
+        H2_HIP(hipStreamSynchronize(stream));
+        cleanup();
+        return H2_OK;
     } catch (...) {
         cleanup();
         throw;

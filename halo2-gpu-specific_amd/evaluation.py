@@ -150,3 +150,11 @@ def evaluate_h(builder):
     out = np.zeros((1 << builder.desc.extended_k, 4), dtype=np.uint64)
     check(lib().h2_evaluate_h(ctypes.byref(builder.desc), out.ctypes.data_as(_vp)), "h2_evaluate_h")
     return out
+
+
+def evaluate_h_coeff(builder):
+    """h2_evaluate_h_coeff: the descriptor's column pointers are host COEFFICIENT vectors of 2^k elements (l_active_row
+    extended values); numpy (2^extended_k, 4) out -- the shape of the reference's cuda evaluate_h (evaluation.rs:1229-1241)"""
+    out = np.zeros((1 << builder.desc.extended_k, 4), dtype=np.uint64)
+    check(lib().h2_evaluate_h_coeff(ctypes.byref(builder.desc), out.ctypes.data_as(_vp)), "h2_evaluate_h_coeff")
+    return out

@@ -67,11 +67,79 @@ class Domain:
         return x * pow(self.omega if rot >= 0 else self.omega_inv, abs(rot), R_MOD) % R_MOD
 
 
+def parse_bytes(text):
+    """'12G', '512M', '4096' -> bytes; None / '' -> None"""
+    if text is None or str(text).strip() == "":
+        return None
+    t = str(text).strip()
+    mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30, "T": 1 << 40}.get(t[-1].upper())
+    return int(float(t[:-1]) * mult) if mult else int(float(t))
+
+
+def footprint(cs, dom, cached_cosets=None):
+    """Device bytes of polynomial data a proof of this circuit holds at its peak, by residency mode:
+    'extended' = every extended coset resident (the proving key's fixed / sigma / l tables for the life of the key, the
+    witness-dependent ones during the quotient phase); 'cosets' = coefficient forms only, the extended domain visited
+    one coset of the n-th roots of unity at a time with `cached_cosets` sets of proving-key tables retained.
+    A planning estimate (it decides the mode against H2_DEVICE_MEM_BUDGET), not an allocator."""
+    n, en = dom.n, dom.extended_n
+    chunk = max(cs.degree() - 2, 1)
+    nsets = (len(cs.perm_columns) + chunk - 1) // chunk
+    F, A, I, P = cs.num_fixed, cs.num_advice, cs.num_instance, len(cs.perm_columns)
+    lk_sets = sum(len(sets) for _, _, sets in cs.lookups)
+    witness_polys = A + I + nsets + lk_sets + len(cs.lookups) + len(cs.shuffles)
+    key_polys = 2 * (F + P)                                   # Lagrange values and coefficient forms
+    c = dom.quotient_poly_degree
+    cached = c if cached_cosets is None else max(1, min(c, cached_cosets))
+    base = 32 * n * (key_polys + 2 * witness_polys + 4 + c)   # + random / h / scratch vectors, the c per-coset quotients
+    return {"extended": base + 32 * en * ((F + P + 3) + witness_polys + 2),
+            "cosets": base + 32 * n * ((F + P + 3) * cached + witness_polys + 3)}
+
+
+class CosetTables:
+    """The proving key's tables on single cosets of the extended domain (fixed / sigma columns, l0, l_last,
+    l_active_row: n values each), built on demand from the coefficient forms and retained least-recently-used up to
+    `keep` cosets -- this build's counterpart of the reference's extended-FFT cache (plonk/evaluation_gpu.rs:335-468,
+    HALO2_PROOF_GPU_EVAL_CACHE): a miss costs (fixed + sigma + 3) n-point coset transforms (1.8 ms each at 2^24)."""
+
+    def __init__(self, build, cosets, keep=None):
+        self.build, self.cosets, self.keep = build, list(cosets), keep
+        self.tabs, self.tick, self.hits, self.misses = {}, 0, 0, 0
+
+    def __iter__(self):
+        return iter(self.cosets)
+
+    def __getitem__(self, j):
+        hit = self.tabs.get(j)
+        if hit is None:
+            self.misses += 1
+            if self.keep is not None:
+                while self.tabs and len(self.tabs) >= max(self.keep, 1):
+                    del self.tabs[min(self.tabs, key=lambda i: self.tabs[i][1])]
+            hit = self.tabs[j] = [self.build(j), 0]
+        else:
+            self.hits += 1
+        self.tick += 1
+        hit[1] = self.tick
+        return hit[0]
+
+    def trim(self):
+        """after a proof: keep = 0 retains nothing between proofs"""
+        if self.keep is not None:
+            while len(self.tabs) > self.keep:
+                del self.tabs[min(self.tabs, key=lambda i: self.tabs[i][1])]
+
+
 class Device:
     """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
 
-    def __init__(self, device=0, group=None, force_collective=False, force_cosets=False):
-        """`group`: a torch.distributed process group (None = the default group when one is initialised) over which
+    def __init__(self, device=0, group=None, force_collective=False, force_cosets=False, mem_budget=None, eval_cache=None):
+        """`mem_budget` (bytes; default H2_DEVICE_MEM_BUDGET, K / M / G suffixes; None = the device's memory): what the
+        polynomial data of keygen + one proof may occupy.  A circuit whose extended cosets do not fit runs the
+        extended-domain phase coset by coset from coefficient forms (`footprint`, `CosetTables`) -- the same proof bytes;
+        `eval_cache` (default HALO2_PROOF_GPU_EVAL_CACHE, the reference's name) = how many cosets' worth of proving-key
+        tables stay resident in that mode (setting it selects the mode; unset = as many as the budget holds).
+        `group`: a torch.distributed process group (None = the default group when one is initialised) over which
         one proof is spread: every MSM is range-split over the ranks and the extended-domain phase is split by coset
         (DESIGN.md section 6); all ranks must then run the same proof on the same inputs.  `force_cosets` runs the
         coset path on a single device (all cosets locally): the same proof bytes by another route, for tests."""
@@ -92,6 +160,13 @@ class Device:
         import os
 
         self.force_cosets = force_cosets or os.environ.get("H2_FORCE_COSETS") == "1"   # experiment knob
+        self.mem_budget = mem_budget if mem_budget is not None else parse_bytes(os.environ.get("H2_DEVICE_MEM_BUDGET"))
+        if mem_budget is None and self.mem_budget is not None and not os.environ.get("H2_NTT_TABLE_BUDGET"):
+            # a process-wide budget from the environment also bounds what the library keeps for itself (the optional
+            # last-pass twiddle tables of the transforms): a sixteenth of it
+            self.L.h2_set_table_budget(self.mem_budget // 16)
+        env_cache = os.environ.get("HALO2_PROOF_GPU_EVAL_CACHE")
+        self.eval_cache = eval_cache if eval_cache is not None else (int(env_cache) if env_cache not in (None, "") else None)
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized():
@@ -225,6 +300,27 @@ class Device:
             return None
         shards, owned = coset_plan(c, self.group_size, self.group_rank)
         return c, shards, owned
+
+    def residency(self, cs, dom):
+        """('extended', None) or ('cosets', keep): how the extended-domain phase of this circuit runs on ONE device under
+        the memory budget.  `keep` = cosets' worth of proving-key tables retained between uses."""
+        c = dom.quotient_poly_degree
+        if self.eval_cache is not None:
+            return "cosets", max(0, min(c, self.eval_cache))
+        budget = self.mem_budget
+        if budget is None:
+            budget = self.torch.cuda.get_device_properties(self.dev).total_memory
+            if footprint(cs, dom)["extended"] <= budget * 0.8:      # the rest: MSM scratch, library tables, allocator slack
+                return "extended", None
+        elif footprint(cs, dom)["extended"] <= budget:
+            return "extended", None
+        for keep in range(c, 0, -1):
+            if footprint(cs, dom, keep)["cosets"] <= budget:
+                return "cosets", keep
+        if footprint(cs, dom, 1)["cosets"] > budget * 1.5:
+            raise MemoryError("this circuit needs ~%.1f GiB of device memory even coset by coset; the budget is %.1f GiB"
+                              % (footprint(cs, dom, 1)["cosets"] / 2**30, budget / 2**30))
+        return "cosets", 0
 
     def coeff_to_coset(self, poly, dom, j):
         """values of a coefficient vector (n entries) on coset j: a[t] *= g_j^t, then the n-point NTT -- coeff_to_extended
@@ -481,15 +577,20 @@ class Params:
         rows = hi - lo
         if rows < (1 << 15) or self.table_bytes:
             return False
-        need = 2 * L.h2_dev_bases_precompute_bytes(rows, digits)
+        one = L.h2_dev_bases_precompute_bytes(rows, digits)
         free, _ = device.torch.cuda.mem_get_info(device.dev)
-        if need > free // 2:
+        # what the tables may take: half of the free memory, and under a memory budget (H2_DEVICE_MEM_BUDGET) a third of
+        # it.  Each base set is optional on its own: g_lagrange first (the advice / product / multiplicity columns of a
+        # wide circuit are committed against it; g only takes the h pieces, the random polynomial and the openings).
+        room = free // 2 if device.mem_budget is None else min(free // 2, device.mem_budget // 3)
+        which = [self.g_lagrange, self.g][:max(0, min(2, room // one))] if one else []
+        if not which:
             return False
         device.sync()
-        ptrs = [self.g.data_ptr() + 64 * lo, self.g_lagrange.data_ptr() + 64 * lo]
+        ptrs = [t.data_ptr() + 64 * lo for t in which]
         for ptr in ptrs:
             check(L.h2_dev_bases_precompute(ptr, rows, digits, device.stream), "h2_dev_bases_precompute")
-        self.table_bytes = need
+        self.table_bytes = one * len(ptrs)
         weakref.finalize(self, _forget_tables, L, ptrs).atexit = False   # at interpreter exit the process frees them
         return True
 
@@ -639,6 +740,11 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     pk.fixed_commitments = D.msm_batch(pk.fixed_values, params.g_lagrange, n, 254)
     pk.fixed_polys = [D.intt(D.clone(t), dom) for t in pk.fixed_values]
     plan = D.coset_plan(dom)
+    # one device under a memory budget: when the extended cosets do not fit, the proving key keeps coefficient forms only
+    # and the extended-domain phase runs coset by coset (all quotient_poly_degree of them, tables built on demand)
+    pk.residency, keep = ("cosets", None) if plan is not None else D.residency(cs, dom)
+    if plan is None and pk.residency == "cosets":
+        plan = (dom.quotient_poly_degree, 1, list(range(dom.quotient_poly_degree)))
     pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys] if plan is None else None
     # permutation: sigma columns (Lagrange), polys, cosets
     ncols = len(cs.perm_columns)
@@ -678,16 +784,22 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         pk.coset = None
     else:
         # one proof over several ranks: only the cosets this rank evaluates, each an n-point table
+        # (under a memory budget on one device: every coset, built on demand and retained up to `keep` of them)
         pk.l0 = pk.l_last = pk.l_active_row = None
-        pk.coset = {}
-        for j in plan[2]:
+
+        def coset_tables(j):
             l_last_j = D.coeff_to_coset(l_last_poly, dom, j)
-            pk.coset[j] = {
+            return {
                 "fixed": [D.coeff_to_coset(t, dom, j) for t in pk.fixed_polys],
                 "sigma": [D.coeff_to_coset(t, dom, j) for t in pk.sigma_polys],
                 "l0": D.coeff_to_coset(l0_poly, dom, j), "l_last": l_last_j,
                 "l_active_row": active_row(l_last_j, D.coeff_to_coset(l_blind_poly, dom, j), n),
             }
+
+        pk.coset = CosetTables(coset_tables, plan[2], keep)
+        if keep is None:                       # one proof over several ranks: this rank's cosets stay resident
+            for j in plan[2]:
+                pk.coset[j]
     pk.t_evaluations = D.upload(np.array([fr_to_mont_limbs(v) for v in dom.t_evaluations], dtype=np.uint64))
     # Evaluator::new: the gate program with the lookup / shuffle result calculations, and the compression programs
     # (evaluate_with_theta) of every lookup / shuffle expression list
@@ -1141,7 +1253,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if D.group_size <= 1:                      # on one device the proving key decides which tables exist
         if pk.coset is None:
             plan = None
-        elif plan is None:
+        else:
             plan = (dom.quotient_poly_degree, 1, sorted(pk.coset))
     # Several circuits share one quotient: the reference keeps folding `value = value * y + term` from one circuit into
     # the next (plonk/evaluation.rs:839-1100), i.e. h = sum_i y^(T (N - 1 - i)) h_i with T terms per circuit and h_i the
@@ -1220,6 +1332,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         unmix = coset_unmix_matrix(gammas, dom.quotient_poly_degree)
         pieces = [D.lincomb(D.empty(n), polys_j, row, n) for row in unmix]
         del polys_j, mine
+        pk.coset.trim()
     mark("vanishing transforms")
     for P in D.msm_batch(pieces, params.g, n, 254):
         transcript.write_point(P)

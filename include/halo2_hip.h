@@ -168,6 +168,9 @@ int h2_dev_prefix_product(const void *d_f, size_t n, const uint64_t init[4], voi
  * count x 4 u64 on the host.  d_res may alias d_polys[0] only. */
 int h2_dev_lincomb(void *d_res, const void *const *d_polys, const uint64_t *coeffs, size_t count, size_t size,
                    void *stream);
+/* the same on host buffers (the GWC cuda branch's shape, gwc/prover.rs:57-151: every p_i is uploaded for its
+ * eval_mul_c / eval_sum pair): polys = host array of `count` host pointers; one upload per operand, one fused pass. */
+int h2_lincomb(uint64_t *res, const uint64_t *const *polys, const uint64_t *coeffs, size_t count, size_t size);
 
 /* Permutation argument, the elementwise work on either side of the grand-product scan.
  * keygen (plonk/permutation/keygen.rs:197-238): out[j] = DELTA^{map_col[j]} * omega^{map_row[j]} -- one sigma column
@@ -288,6 +291,14 @@ typedef struct {
 
 /* Host buffers everywhere (descriptor and every pointer in it); values: 2^extended_k Fr out. */
 int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);
+/* The cuda `Evaluator::evaluate_h`'s own shape (plonk/evaluation.rs:1229-1241: advice / instance as coefficient forms,
+ * a proving key without extended cosets, plonk.rs:226-240): every column pointer of the descriptor -- fixed, advice,
+ * instance, l0, l_last, perm_z, perm_sigma, lookup_z, lookup_m, shuffle_z -- is a HOST coefficient vector of 2^k Fr;
+ * l_active_row is HOST extended values (2^extended_k, as the reference keeps it); values: 2^extended_k Fr out (host).
+ * Each distinct vector is uploaded once; the extended domain is visited one coset of the n-th roots of unity at a
+ * time, so device memory is (distinct columns) x 2 x 2^k x 32 B + two extended vectors whatever extended_k is -- the
+ * memory-bounded route (the reference bounds it with a 5-entry cache of extended FFTs, evaluation_gpu.rs:335-468). */
+int h2_evaluate_h_coeff(const h2_evalh_desc *desc, uint64_t *values);
 /* Column / table pointers inside `desc` are DEVICE pointers (the descriptor itself and its program
  * arrays -- constants, rotations, calculations, ... and the pointer tables -- stay in host memory).
  * d_values: 2^extended_k Fr on the device.  Work space is taken from the library's arena. */

@@ -1,17 +1,182 @@
 //! halo2_proofs/src/hip.rs -- the Rust side of the MI355X drop-in: `extern "C"` declarations of
-//! `include/halo2_hip.h` (libhalo2_hip.so) and the thin wrappers the `#[cfg(feature = "hip")]` bodies in
-//! `arithmetic.rs` call (integration/halo2_proofs_hip.patch adds those bodies and this file).
+//! `include/halo2_hip.h` (libhalo2_hip.so), the `#[repr(C)]` mirror of `h2_evalh_desc`, and the thin wrappers the
+//! `#[cfg(feature = "hip")]` bodies call (integration/halo2_proofs_hip.patch adds those bodies, this file and
+//! plonk/evaluation_hip.rs).
 //!
 //! UNCOMPILED in the build image (no Rust toolchain there): kept as source so that a maintainer with `cargo` can
 //! apply the patch, point HALO2_HIP_LIB_DIR at the directory holding libhalo2_hip.so and build with
 //! `--features hip`.  The wrappers keep the reference's conventions: the same `transmute`s from the generic
 //! `C::Scalar` / `C` / `C::Curve` to bn256 memory images (arithmetic.rs:351-352,364-365,391-394,507-508), and a
 //! panic on any GPU failure (the reference `unwrap()`s its kernel results, arithmetic.rs:358,360,509).
+//!
+//! Call sites re-targeted by the patch:
+//!   arithmetic.rs   gpu_multiexp*, gpu_multiexp_bound_and_fft, gpu_fft, gpu_ifft          -> msm, msm_intt, ntt, intt
+//!   poly/domain.rs  coeff_to_extended :270-287, extended_to_coeff :328-350,
+//!                   divide_by_vanishing_poly :354-373                                     -> the functions of the same name
+//!   poly/commitment.rs  Params::unsafe_setup :56-124, Params::read :256-294               -> register_params (+ Drop)
+//!   poly/multiopen/gwc/prover.rs :57-151  (poly_batch = sum v^i p_i)                      -> lincomb
+//!   plonk/evaluation.rs  Evaluator::evaluate_h (cuda) :1229-1241,
+//!                        evaluate / evaluate_with_theta (cuda) :2315-2326, :2393-2396     -> plonk/evaluation_hip.rs over
+//!                                                                                            H2EvalhDesc + evaluate_h*
 #![cfg(feature = "hip")]
 #![allow(missing_docs)]
 
 use crate::arithmetic::{CurveAffine, Group};
 use std::os::raw::{c_char, c_int, c_void};
+
+// ---------------------------------------------------------------------------------------------------------------
+// the plain-C flattening of `Evaluator` (include/halo2_hip.h, "evaluate_h"): field for field, same order, same types.
+// tests/test_integration_patch.py compiles a C program that prints offsetof() of every h2_evalh_desc field and
+// compares with H2_EVALH_DESC_OFFSETS below.
+// ---------------------------------------------------------------------------------------------------------------
+pub const H2_VS_CONSTANT: u32 = 0;
+pub const H2_VS_INTERMEDIATE: u32 = 1;
+pub const H2_VS_FIXED: u32 = 2;
+pub const H2_VS_ADVICE: u32 = 3;
+pub const H2_VS_INSTANCE: u32 = 4;
+
+pub const H2_CALC_ADD: u32 = 0;
+pub const H2_CALC_SUB: u32 = 1;
+pub const H2_CALC_MUL: u32 = 2;
+pub const H2_CALC_NEGATE: u32 = 3;
+pub const H2_CALC_LC_CHALLENGE: u32 = 4;
+pub const H2_CALC_LC_THETA: u32 = 5;
+pub const H2_CALC_ADD_CHALLENGE: u32 = 6;
+pub const H2_CALC_STORE: u32 = 7;
+
+pub const H2_CHALLENGE_BETA: u32 = 0;
+pub const H2_CHALLENGE_GAMMA: u32 = 1;
+
+pub const H2_ANY_ADVICE: u32 = 0;
+pub const H2_ANY_FIXED: u32 = 1;
+pub const H2_ANY_INSTANCE: u32 = 2;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct H2ValueSource {
+    pub kind: u32,
+    pub index: u32,
+    pub rot: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct H2Calculation {
+    pub op: u32,
+    pub a: H2ValueSource,
+    pub b: H2ValueSource,
+    pub challenge: u32,
+    pub power: u32,
+}
+
+#[repr(C)]
+pub struct H2EvalhDesc {
+    pub k: u32,
+    pub extended_k: u32,
+    pub blinding_factors: u32,
+    pub chunk_len: u32,
+    pub constants: *const u64,
+    pub n_constants: u32,
+    pub rotations: *const i32,
+    pub n_rotations: u32,
+    pub calculations: *const H2Calculation,
+    pub n_calculations: u32,
+    pub value_parts: *const H2ValueSource,
+    pub n_value_parts: u32,
+    pub n_lookups: u32,
+    pub lookup_sets: *const u32,
+    pub lookup_calcs: *const H2Calculation,
+    pub n_shuffles: u32,
+    pub shuffle_calcs: *const H2Calculation,
+    pub fixed: *const *const u64,
+    pub n_fixed: u32,
+    pub advice: *const *const u64,
+    pub n_advice: u32,
+    pub instance: *const *const u64,
+    pub n_instance: u32,
+    pub l0: *const u64,
+    pub l_last: *const u64,
+    pub l_active_row: *const u64,
+    pub n_perm_sets: u32,
+    pub perm_z: *const *const u64,
+    pub n_perm_columns: u32,
+    pub perm_col_type: *const u32,
+    pub perm_col_index: *const u32,
+    pub perm_sigma: *const *const u64,
+    pub lookup_z: *const *const u64,
+    pub lookup_m: *const *const u64,
+    pub shuffle_z: *const *const u64,
+    pub y: [u64; 4],
+    pub beta: [u64; 4],
+    pub gamma: [u64; 4],
+    pub theta: [u64; 4],
+    pub delta: [u64; 4],
+    pub zeta: [u64; 4],
+    pub extended_omega: [u64; 4],
+    pub jit_function: *const c_void,
+}
+
+/// (field, byte offset) of `h2_evalh_desc` on the LP64 ABI both sides are built for; checked against the C header by
+/// tests/test_integration_patch.py (and, once compiled, by `desc_layout_matches_header` below).
+pub const H2_EVALH_DESC_OFFSETS: &[(&str, usize)] = &[
+    ("k", 0),
+    ("extended_k", 4),
+    ("blinding_factors", 8),
+    ("chunk_len", 12),
+    ("constants", 16),
+    ("n_constants", 24),
+    ("rotations", 32),
+    ("n_rotations", 40),
+    ("calculations", 48),
+    ("n_calculations", 56),
+    ("value_parts", 64),
+    ("n_value_parts", 72),
+    ("n_lookups", 76),
+    ("lookup_sets", 80),
+    ("lookup_calcs", 88),
+    ("n_shuffles", 96),
+    ("shuffle_calcs", 104),
+    ("fixed", 112),
+    ("n_fixed", 120),
+    ("advice", 128),
+    ("n_advice", 136),
+    ("instance", 144),
+    ("n_instance", 152),
+    ("l0", 160),
+    ("l_last", 168),
+    ("l_active_row", 176),
+    ("n_perm_sets", 184),
+    ("perm_z", 192),
+    ("n_perm_columns", 200),
+    ("perm_col_type", 208),
+    ("perm_col_index", 216),
+    ("perm_sigma", 224),
+    ("lookup_z", 232),
+    ("lookup_m", 240),
+    ("shuffle_z", 248),
+    ("y", 256),
+    ("beta", 288),
+    ("gamma", 320),
+    ("theta", 352),
+    ("delta", 384),
+    ("zeta", 416),
+    ("extended_omega", 448),
+    ("jit_function", 480),
+];
+pub const H2_EVALH_DESC_SIZE: usize = 488;
+pub const H2_VALUE_SOURCE_SIZE: usize = 12;
+pub const H2_CALCULATION_SIZE: usize = 36;
+
+#[cfg(test)]
+mod layout {
+    use super::*;
+    #[test]
+    fn desc_layout_matches_header() {
+        assert_eq!(std::mem::size_of::<H2ValueSource>(), H2_VALUE_SOURCE_SIZE);
+        assert_eq!(std::mem::size_of::<H2Calculation>(), H2_CALCULATION_SIZE);
+        assert_eq!(std::mem::size_of::<H2EvalhDesc>(), H2_EVALH_DESC_SIZE);
+    }
+}
 
 extern "C" {
     pub fn h2_version() -> c_int;
@@ -64,14 +229,24 @@ extern "C" {
         size: usize,
         c: *const u64,
     ) -> c_int;
+    // gwc/prover.rs:57-151: res = sum_j coeffs[j] * polys[j]
+    pub fn h2_lincomb(res: *mut u64, polys: *const *const u64, coeffs: *const u64, count: usize, size: usize) -> c_int;
     pub fn h2_eval_polynomial(poly: *const u64, n: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
     pub fn h2_batch_mont(a: *mut u64, n: usize) -> c_int;
     pub fn h2_batch_unmont(a: *mut u64, n: usize) -> c_int;
+    // Evaluator::evaluate_h: extended cosets in (the CPU twin's shape, evaluation.rs:778-1226) / coefficient forms in
+    // (the cuda shape, :1229-1241); evaluate_with_theta is h2_evaluate_h with y := theta, extended_k := k
+    pub fn h2_evaluate_h(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
+    pub fn h2_evaluate_h_coeff(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
     // resident SRS: Params::g / g_lagrange are uploaded once per device instead of once per MSM
     pub fn h2_bases_register(bases: *const u64, n: usize) -> c_int;
     pub fn h2_bases_unregister(bases: *const u64) -> c_int;
     pub fn h2_g1_sum(points: *const c_void, count: usize, out_xyz: *mut c_void) -> c_int;
+    // device memory the library keeps between calls (plans, last-pass twiddle tables): budget / release / report
+    pub fn h2_release_plans() -> c_int;
+    pub fn h2_set_table_budget(bytes: usize) -> c_int;
+    pub fn h2_library_memory_bytes() -> usize;
 }
 
 /// The reference unwrap()s its GPU results: keep that behaviour.
@@ -90,6 +265,13 @@ fn assert_layout<C: CurveAffine>() {
     assert_eq!(std::mem::size_of::<C::Scalar>(), 32, "Fr is not a 32-byte memory image");
     assert_eq!(std::mem::size_of::<C>(), 64, "G1Affine is not a 64-byte {{x, y}} memory image");
     assert_eq!(std::mem::size_of::<C::Curve>(), 96, "G1 is not a 96-byte {{x, y, z}} memory image");
+}
+
+/// The 4 x u64 Montgomery image of a scalar (what the descriptor's challenge fields hold).
+#[inline]
+pub fn limbs<F>(v: &F) -> [u64; 4] {
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    unsafe { std::mem::transmute_copy::<F, [u64; 4]>(v) }
 }
 
 /// `gpu_multiexp_single_gpu_with_bound` (multi = false) / `gpu_multiexp_bound` (multi = true: the library cuts the
@@ -164,10 +346,123 @@ pub fn intt<G: Group>(a: &mut [G], omega_inv: &G::Scalar, divisor: &G::Scalar, l
     check(rc, "ifft");
 }
 
-/// Call once after `Params::new` / `Params::read` (poly/commitment.rs:56-124,256-294): later `commit*` calls whose
+/// `EvaluationDomain::coeff_to_extended` (poly/domain.rs:270-287): the zeta-power pre-scale (distribute_powers_zeta,
+/// :382-398), the zero padding and the extended NTT are one fused device pass over the 2^k inputs.
+pub fn coeff_to_extended<G: Group>(
+    coeffs: &[G],
+    k: u32,
+    extended_k: u32,
+    g_coset: &G::Scalar,
+    g_coset_inv: &G::Scalar,
+    extended_omega: &G::Scalar,
+) -> Vec<G> {
+    assert_eq!(std::mem::size_of::<G>(), 32, "coeff_to_extended over a non-scalar group is not accelerated");
+    assert_eq!(coeffs.len(), 1usize << k);
+    let mut out = vec![G::group_zero(); 1usize << extended_k];
+    let rc = unsafe {
+        h2_coeff_to_extended(
+            coeffs.as_ptr() as *const u64,
+            out.as_mut_ptr() as *mut u64,
+            k,
+            extended_k,
+            g_coset as *const G::Scalar as *const u64,
+            g_coset_inv as *const G::Scalar as *const u64,
+            extended_omega as *const G::Scalar as *const u64,
+        )
+    };
+    check(rc, "coeff_to_extended");
+    out
+}
+
+/// `EvaluationDomain::extended_to_coeff` (poly/domain.rs:328-350): inverse extended NTT, 1 / n_ext and the zeta^-1
+/// powers fused into its last pass, truncated to `out_len = n * quotient_poly_degree` coefficients.
+pub fn extended_to_coeff<G: Group>(
+    a: &[G],
+    out_len: usize,
+    extended_k: u32,
+    g_coset: &G::Scalar,
+    g_coset_inv: &G::Scalar,
+    extended_omega_inv: &G::Scalar,
+    extended_ifft_divisor: &G::Scalar,
+) -> Vec<G> {
+    assert_eq!(std::mem::size_of::<G>(), 32, "extended_to_coeff over a non-scalar group is not accelerated");
+    assert_eq!(a.len(), 1usize << extended_k);
+    let mut out = vec![G::group_zero(); out_len];
+    let rc = unsafe {
+        h2_extended_to_coeff(
+            a.as_ptr() as *const u64,
+            out.as_mut_ptr() as *mut u64,
+            out_len,
+            extended_k,
+            g_coset as *const G::Scalar as *const u64,
+            g_coset_inv as *const G::Scalar as *const u64,
+            extended_omega_inv as *const G::Scalar as *const u64,
+            extended_ifft_divisor as *const G::Scalar as *const u64,
+        )
+    };
+    check(rc, "extended_to_coeff");
+    out
+}
+
+/// `EvaluationDomain::divide_by_vanishing_poly` (poly/domain.rs:354-373): a[i] *= t_evaluations[i % t_len], in place.
+pub fn divide_by_vanishing_poly<G: Group>(a: &mut [G], t_evaluations: &[G::Scalar]) {
+    assert_eq!(std::mem::size_of::<G>(), 32, "divide_by_vanishing_poly over a non-scalar group is not accelerated");
+    let rc = unsafe {
+        h2_divide_by_vanishing_poly(
+            a.as_mut_ptr() as *mut u64,
+            a.len(),
+            t_evaluations.as_ptr() as *const u64,
+            t_evaluations.len(),
+        )
+    };
+    check(rc, "divide_by_vanishing_poly");
+}
+
+/// The GWC batching loop `poly_batch = poly_batch * v + poly` (poly/multiopen/gwc/prover.rs:45-151) in closed form:
+/// `sum_i v^(m-1-i) polys[i]`, one upload per operand and one fused device pass.
+pub fn lincomb<F>(polys: &[&[F]], coeffs: &[F]) -> Vec<F>
+where
+    F: Copy + Default,
+{
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    assert_eq!(polys.len(), coeffs.len());
+    let size = polys.first().map(|p| p.len()).unwrap_or(0);
+    assert!(polys.iter().all(|p| p.len() == size));
+    let mut out = vec![F::default(); size];
+    let ptrs: Vec<*const u64> = polys.iter().map(|p| p.as_ptr() as *const u64).collect();
+    let rc = unsafe {
+        h2_lincomb(
+            out.as_mut_ptr() as *mut u64,
+            ptrs.as_ptr(),
+            coeffs.as_ptr() as *const u64,
+            polys.len(),
+            size,
+        )
+    };
+    check(rc, "lincomb");
+    out
+}
+
+/// `h2_evaluate_h_coeff` / `h2_evaluate_h`: `values` receives 2^extended_k scalars.  The descriptor's pointers must
+/// outlive the call (plonk/evaluation_hip.rs builds it from borrowed slices on its own stack frame).
+pub fn evaluate_h<F: Copy + Default>(desc: &H2EvalhDesc, from_coefficient_forms: bool) -> Vec<F> {
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    let mut values = vec![F::default(); 1usize << desc.extended_k];
+    let rc = unsafe {
+        if from_coefficient_forms {
+            h2_evaluate_h_coeff(desc as *const H2EvalhDesc, values.as_mut_ptr() as *mut u64)
+        } else {
+            h2_evaluate_h(desc as *const H2EvalhDesc, values.as_mut_ptr() as *mut u64)
+        }
+    };
+    check(rc, "evaluate_h");
+    values
+}
+
+/// Called by `Params::unsafe_setup` / `Params::read` (poly/commitment.rs:56-124,256-294): later `commit*` calls whose
 /// bases lie inside a registered range skip the 64 B/point upload and run over the device copy's shifted-base table
-/// (include/halo2_hip.h, h2_dev_bases_precompute; built by the library on the first MSM).  Unregister before the
-/// vectors are dropped.
+/// (include/halo2_hip.h, h2_dev_bases_precompute; built by the library on the first MSM).  `Params`'s `Drop`
+/// (added by the patch) unregisters before the vectors go.
 pub fn register_params<C: CurveAffine>(g: &[C], g_lagrange: &[C]) {
     assert_layout::<C>();
     unsafe {
@@ -181,4 +476,11 @@ pub fn unregister_params<C: CurveAffine>(g: &[C], g_lagrange: &[C]) {
         check(h2_bases_unregister(g.as_ptr() as *const u64), "bases_unregister");
         check(h2_bases_unregister(g_lagrange.as_ptr() as *const u64), "bases_unregister");
     }
+}
+
+/// `N_GPU`'s default (plonk/prover.rs:56-74: `Device::all().len()` under cuda): the devices the library's pool sees.
+pub fn device_count() -> usize {
+    let n = unsafe { h2_device_count() };
+    assert!(n > 0, "no HIP device visible");
+    n as usize
 }

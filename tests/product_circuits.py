@@ -8,6 +8,10 @@ def mini_plonk_cs():
     return circuits.mini_plonk()
 
 
+def wide_cs(quads):
+    return circuits.wide(quads)
+
+
 def rot_gate_cs():
     """the product-side description of ref_plonk.RotGate"""
     cs = hc.ConstraintSystem("rot-gate")

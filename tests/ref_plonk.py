@@ -253,6 +253,8 @@ class MiniPlonk:
         from halo2_gpu_specific_amd.formats import cs_store
 
         make = {"mini-plonk": pc.mini_plonk_cs, "rot-gate": pc.rot_gate_cs, "lookup-shuffle": pc.lookup_shuffle_cs}
+        if cls.name.startswith("wide-"):
+            return cs_store(pc.wide_cs(int(cls.name[5:])))
         return cs_store(make[cls.name]())
 
     @staticmethod
@@ -379,6 +381,57 @@ class LookupShuffle:
         copies = [((0, 0), (1, 0))]
         instances = [[42, 7]]
         return adv, fixed, copies, instances
+
+
+def wide_class(quads):
+    """the big-integer twin of halo2-gpu-specific_amd.circuits.wide: 4 * quads advice columns (a, b, c, d per quad),
+    fixed q and t; q * (a b c - d) per quad; quads / 2 logup lookups of two columns each into t; equality on columns 0, 1"""
+
+    class Wide:
+        num_advice, num_fixed = 4 * quads, 2
+        advice_queries = [(c, 0) for c in range(4 * quads)]
+        fixed_queries = [(0, 0), (1, 0)]
+        perm_columns = [("advice", 0), ("advice", 1)]
+        degree = 5
+        blinding_factors = 5
+        name = "wide-%d" % quads
+        cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
+
+        @staticmethod
+        def gates(adv, fix):
+            q = fix(0, 0)
+            return [q * (adv(4 * i, 0) * adv(4 * i + 1, 0) % R * adv(4 * i + 2, 0) - adv(4 * i + 3, 0)) % R for i in range(quads)]
+
+        lookups = [{"table": lambda adv, fix, inst: [fix(1, 0)],
+                    "input_sets": [[lambda adv, fix, inst, l=l: [adv(8 * l, 0)], lambda adv, fix, inst, l=l: [adv(8 * l + 4, 0)]]]}
+                   for l in range(quads // 2)]
+
+        @staticmethod
+        def synthesize(k):
+            """same witness as circuits.wide_synthesize, as Python integers"""
+            n = 1 << k
+            usable = n - 6
+            T = min(usable, 1 << 16)
+            adv = [[0] * n for _ in range(4 * quads)]
+            fixed = [[0] * n for _ in range(2)]
+            for r in range(usable):
+                fixed[0][r] = 1
+            for i in range(T):
+                fixed[1][i] = i
+            mask = (1 << 64) - 1
+            for qd in range(quads):
+                for r in range(usable):
+                    v = [(((r * 2654435761 + 40503 * (4 * qd + j) + 7) & mask) >> 5) % T for j in range(3)]
+                    if qd == 0:
+                        v[1] = 3 % T if r == 0 else (((((r - 1) * 2654435761 + 7) & mask) >> 5) % T)
+                    for j in range(3):
+                        adv[4 * qd + j][r] = v[j]
+                    adv[4 * qd + 3][r] = v[0] * v[1] * v[2]
+            m = min(usable - 1, 1 << 16)
+            copies = [((0, r), (1, r + 1)) for r in range(m)]
+            return adv, fixed, copies
+
+    return Wide
 
 
 def permutation_mapping(ncols, n, copies):

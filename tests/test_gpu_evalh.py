@@ -54,3 +54,51 @@ def test_generated_kernel_matches_interpreter_and_oracle(oracle, seed, k, ek, kw
     assert path is not None, "hipcc could not build the generated kernel"
     b.desc.jit_function = jit.load(path)
     assert np.array_equal(ev.evaluate_h(b), want)
+
+
+@pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),
+                                             (35, 5, 7, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=5)),
+                                             (36, 4, 14, dict(lookup_sets=(2,), n_shuffles=1))])
+def test_evaluate_h_from_coefficient_forms(oracle, seed, j, k, kwargs):
+    """h2_evaluate_h_coeff -- coefficient forms in, the numerator on the extended domain out, computed coset by coset
+    (the cuda evaluate_h's shape, plonk/evaluation.rs:1229-1241) -- against the oracle's evaluate_h on the oracle's own
+    extended cosets (coeff_to_extended, poly/domain.rs:270-287): 2, 4, 4, 1 (extended_k = k), 4 and 4 cosets"""
+    import copy
+
+    d, _ = oracle.domain(j, k)
+    ek = d.extended_k
+    kw = random_case(seed, k, ek, oracle, **({"n_calcs": 40} | kwargs))
+    kw["zeta"], kw["extended_omega"] = d.fr("g_coset"), d.fr("extended_omega")
+    n = 1 << k
+    names = ("fixed", "advice", "instance", "perm_z", "perm_sigma", "lookup_z", "lookup_m", "shuffle_z")
+    coeff = copy.copy(kw)
+    for name in names:
+        coeff[name] = [np.ascontiguousarray(col[:n]) for col in kw[name]]           # random coefficient vectors
+    coeff["l0"], coeff["l_last"] = np.ascontiguousarray(kw["l0"][:n]), np.ascontiguousarray(kw["l_last"][:n])
+    ext = copy.copy(kw)
+    for name in names:
+        ext[name] = [oracle.coeff_to_extended(col, d, threads=8) for col in coeff[name]]
+    ext["l0"], ext["l_last"] = oracle.coeff_to_extended(coeff["l0"], d, threads=8), oracle.coeff_to_extended(coeff["l_last"], d, threads=8)
+    want = oracle_evaluate_h(oracle, ev.Builder().build(**ext))
+    got = ev.evaluate_h_coeff(ev.Builder().build(**coeff))
+    assert np.array_equal(got, want)
+    assert np.array_equal(ev.evaluate_h(ev.Builder().build(**ext)), want)            # the extended-coset entry point agrees
+
+
+def test_host_lincomb(oracle):
+    """h2_lincomb (host buffers; the GWC cuda branch's shape, gwc/prover.rs:57-151): res = sum_j coeffs[j] * polys[j]"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import arithmetic as ar
+
+    n, count = 5000, 5
+    polys = [oracle.random_fr(700 + i, n) for i in range(count)]
+    coeffs = oracle.random_fr(777, count)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    for p, c in zip(polys, coeffs):
+        want = oracle.eval_op(ar.OP_SUM, want, oracle.eval_op(ar.OP_MUL_C, p, None, 0, 0, c), 0, 0, None)
+    res = np.zeros((n, 4), dtype=np.uint64)
+    ptrs = (ctypes.c_void_p * count)(*[p.ctypes.data for p in polys])
+    assert h2.lib().h2_lincomb(res.ctypes.data, ptrs, coeffs.ctypes.data, count, n) == 0
+    assert np.array_equal(res, want)

@@ -15,6 +15,7 @@ from h2util import ROOT
 REF = "/root/reference"
 PATCH = os.path.join(ROOT, "integration", "halo2_proofs_hip.patch")
 HIP_RS = os.path.join(ROOT, "integration", "hip.rs")
+EVAL_HIP_RS = os.path.join(ROOT, "integration", "evaluation_hip.rs")
 needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "halo2_proofs")), reason="the reference tree is not on this machine")
 
 
@@ -42,6 +43,30 @@ def test_patch_applies_to_the_reference(tmp_path):
     for fn in ("gpu_multiexp_single_gpu_with_bound", "gpu_multiexp_bound", "gpu_multiexp_bound_and_fft", "gpu_fft", "gpu_ifft"):
         assert re.search(r'#\[cfg\(feature = "hip"\)\]\npub fn %s<' % fn, arith), fn
     assert arith.count('any(feature = "cuda", feature = "hip")') == 2          # both dispatchers
+    # round 3: the rest of SURVEY.md 8(b) -- evaluate_h / evaluate_with_theta, the coset transforms, GWC batching, the
+    # struct shapes, Params registration
+    any_ = 'any(feature = "cuda", feature = "hip")'
+    assert (tmp_path / "halo2_proofs/src/plonk/evaluation_hip.rs").read_text() == open(EVAL_HIP_RS).read()
+    plonk = (tmp_path / "halo2_proofs/src/plonk.rs").read_text()
+    assert '#[cfg(feature = "hip")]\nmod evaluation_hip;' in plonk
+    assert plonk.count(any_) == 5 and 'feature = "cuda")]' not in plonk.replace(any_, "")     # plonk.rs:226-240
+    ev = (tmp_path / "halo2_proofs/src/plonk/evaluation.rs").read_text()
+    assert '#[cfg(not(%s))]\n    pub(in crate::plonk) fn evaluate_h(' % any_ in ev                # the CPU twin leaves
+    assert ev.count("super::evaluation_hip::evaluate_lc(") == 2                                 # evaluate, evaluate_with_theta
+    dom = (tmp_path / "halo2_proofs/src/poly/domain.rs").read_text()
+    for call in ("crate::hip::coeff_to_extended(", "crate::hip::extended_to_coeff(", "crate::hip::divide_by_vanishing_poly("):
+        assert dom.count(call) == 1, call
+    com = (tmp_path / "halo2_proofs/src/poly/commitment.rs").read_text()
+    assert com.count("crate::hip::register_params(&params.g, &params.g_lagrange);") == 2        # unsafe_setup, read
+    assert "impl<C: CurveAffine> Drop for Params<C>" in com
+    gwc = (tmp_path / "halo2_proofs/src/poly/multiopen/gwc/prover.rs").read_text()
+    assert "crate::hip::lincomb(&polys, &coeffs)" in gwc
+    prover = (tmp_path / "halo2_proofs/src/plonk/prover.rs").read_text()
+    assert "crate::hip::device_count().to_string()" in prover
+    for rel in ("plonk/keygen.rs", "plonk/permutation.rs", "plonk/permutation/keygen.rs", "plonk/permutation/prover.rs", "plonk/prover.rs"):
+        text = (tmp_path / "halo2_proofs/src" / rel).read_text()
+        left = [l for l in text.splitlines() if 'feature = "cuda"' in l and any_ not in l]
+        assert left == (['            #[cfg(feature = "cuda")]'] if rel == "plonk/prover.rs" else []), (rel, left)
 
 
 @needs_ref
@@ -73,3 +98,47 @@ def test_shim_declares_only_exported_symbols_with_the_header_arity():
         c_params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
         rs_params = [p for p in params.split(",") if p.strip()]
         assert len(c_params) == len(rs_params), (name, c_params, rs_params)
+
+
+def test_descriptor_layout_of_the_rust_mirror(tmp_path):
+    """`#[repr(C)] H2EvalhDesc` (integration/hip.rs) against `h2_evalh_desc` (include/halo2_hip.h): a C program prints
+    offsetof() of every field; names, order, offsets and sizes must be the ones hip.rs declares (H2_EVALH_DESC_OFFSETS,
+    *_SIZE), the struct's fields must come in that order with pointer / u32 / [u64; 4] types matching the header, and
+    the enum constants must agree"""
+    rs = open(HIP_RS).read()
+    table = rs[rs.index("pub const H2_EVALH_DESC_OFFSETS"):]
+    table = table[:table.index("];")]
+    declared = [(m.group(1), int(m.group(2))) for m in re.finditer(r'\("(\w+)", (\d+)\)', table)]
+    assert len(declared) >= 40
+    header = open(os.path.join(ROOT, "include", "halo2_hip.h")).read()
+    body = header[header.index("typedef struct {\n    uint32_t k, extended_k;"):]
+    body = re.sub(r"/\*.*?\*/", "", body[:body.index("} h2_evalh_desc;")], flags=re.S)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if not decl:
+            continue
+        for part in decl.split(","):                      # "const uint64_t *l0", " *l_last", "uint64_t y[4]", " beta[4]"
+            c_fields.append(re.findall(r"(\w+)\s*(?:\[\d+\])?\s*$", part.strip())[0])
+    assert [n for n, _ in declared] == c_fields, (declared, c_fields)
+    # the struct of hip.rs lists the same fields in the same order
+    struct = rs[rs.index("pub struct H2EvalhDesc {"):]
+    struct = struct[:struct.index("\n}\n")]
+    assert re.findall(r"pub (\w+):", struct) == c_fields
+    prog = ["#include <stdio.h>", "#include <stddef.h>", '#include "halo2_hip.h"', "int main(void) {"]
+    prog += ['    printf("%s %%zu\\n", offsetof(h2_evalh_desc, %s));' % (n, n) for n in c_fields]
+    prog += ['    printf("sizeof %zu %zu %zu\\n", sizeof(h2_evalh_desc), sizeof(h2_value_source), sizeof(h2_calculation));',
+             '    printf("enums %d %d %d %d %d %d\\n", H2_VS_INSTANCE, H2_CALC_STORE, H2_CHALLENGE_GAMMA, H2_ANY_INSTANCE, H2_CALC_LC_CHALLENGE, H2_VS_FIXED);',
+             "    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)], text=True).split("\n")
+    got = [(l.split()[0], int(l.split()[1])) for l in lines[:len(c_fields)]]
+    assert got == declared
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (H2_\w+): (?:usize|u32) = (\d+);", rs)}
+    assert lines[len(c_fields)].split()[1:] == [str(consts["H2_EVALH_DESC_SIZE"]), str(consts["H2_VALUE_SOURCE_SIZE"]),
+                                                str(consts["H2_CALCULATION_SIZE"])]
+    assert lines[len(c_fields) + 1].split()[1:] == [str(consts[n]) for n in ("H2_VS_INSTANCE", "H2_CALC_STORE", "H2_CHALLENGE_GAMMA",
+                                                                               "H2_ANY_INSTANCE", "H2_CALC_LC_CHALLENGE", "H2_VS_FIXED")]

@@ -1,9 +1,17 @@
 #!/usr/bin/env python3
 """tools/make_hip_patch.py -- builds integration/halo2_proofs_hip.patch: the `hip` cargo feature of halo2_proofs.
 
-Applies a fixed list of textual edits to a scratch copy of the reference crate (re-targeting the host-buffer boundary
-of SURVEY.md 8(b): best_fft, gpu_ifft, gpu_multiexp*, commit_lagrange_and_ifft, commit_lagrange_with_bound) and writes
-the unified diff with ONE line of context, plus integration/hip.rs as the new file halo2_proofs/src/hip.rs.
+Applies a fixed list of textual edits to a scratch copy of the reference crate and writes the unified diff with ONE line
+of context, plus integration/hip.rs as the new file halo2_proofs/src/hip.rs and integration/evaluation_hip.rs as
+halo2_proofs/src/plonk/evaluation_hip.rs.  Re-targeted (every row of SURVEY.md 8(b)):
+  * arithmetic.rs: best_fft, gpu_ifft, gpu_multiexp*, gpu_multiexp_bound_and_fft; commitment.rs: commit_lagrange_and_ifft,
+    commit_lagrange_with_bound, Params::{unsafe_setup, read} -> register_params (+ Drop);
+  * poly/domain.rs: ifft / lagrange_to_coeff_st, coeff_to_extended, extended_to_coeff, divide_by_vanishing_poly;
+  * plonk/evaluation.rs: Evaluator::evaluate_h (the cuda signature: coefficient forms), evaluate / evaluate_with_theta;
+  * poly/multiopen/gwc/prover.rs: the batching loop;
+  * the struct shapes and data flow that `cuda` switches (plonk.rs:226-240, keygen.rs, permutation{,/keygen,/prover}.rs,
+    prover.rs: no extended cosets in the proving key / per-proof state) are switched by `hip` too: `any(cuda, hip)`;
+  * plonk/prover.rs:56-74 N_GPU default = the library's device pool.
 tests/test_integration_patch.py checks that the committed patch still applies (`git apply --check`) to a fresh copy.
 
     python tools/make_hip_patch.py [/root/reference]
@@ -16,7 +24,12 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["halo2_proofs/Cargo.toml", "halo2_proofs/build.rs", "halo2_proofs/src/lib.rs", "halo2_proofs/src/arithmetic.rs",
-         "halo2_proofs/src/poly/commitment.rs", "halo2_proofs/src/poly/domain.rs"]
+         "halo2_proofs/src/poly/commitment.rs", "halo2_proofs/src/poly/domain.rs", "halo2_proofs/src/plonk.rs",
+         "halo2_proofs/src/plonk/keygen.rs", "halo2_proofs/src/plonk/permutation.rs",
+         "halo2_proofs/src/plonk/permutation/keygen.rs", "halo2_proofs/src/plonk/permutation/prover.rs",
+         "halo2_proofs/src/plonk/prover.rs", "halo2_proofs/src/plonk/evaluation.rs",
+         "halo2_proofs/src/poly/multiopen/gwc/prover.rs"]
+NEW_FILES = {"halo2_proofs/src/hip.rs": "hip.rs", "halo2_proofs/src/plonk/evaluation_hip.rs": "evaluation_hip.rs"}
 
 HIP_FUNCTIONS = '''#[cfg(feature = "hip")]
 pub fn gpu_multiexp_single_gpu_with_bound<C: CurveAffine>(
@@ -86,6 +99,237 @@ def replace_once(text, old, new, what):
     return text.replace(old, new, 1)
 
 
+def switch_shape(text, expect):
+    """the struct-shape / data-flow switches: whatever `cuda` selects, `hip` selects too"""
+    n = text.count('#[cfg(feature = "cuda")]') + text.count('#[cfg(not(feature = "cuda"))]')
+    assert n == expect, "expected %d cuda cfg sites, found %d" % (expect, n)
+    text = text.replace('#[cfg(feature = "cuda")]', '#[cfg(%s)]' % ANY)
+    return text.replace('#[cfg(not(feature = "cuda"))]', '#[cfg(not(%s))]' % ANY)
+
+
+N_GPU_CUDA = '''            #[cfg(feature = "cuda")]
+            {
+                ec_gpu_gen::rust_gpu_tools::Device::all().len().to_string()
+            }
+            #[cfg(not(feature = "cuda"))]
+            {
+                "1".to_owned()
+            }
+'''
+N_GPU_HIP = '''            #[cfg(CUDA_ONLY)]
+            {
+                ec_gpu_gen::rust_gpu_tools::Device::all().len().to_string()
+            }
+            #[cfg(feature = "hip")]
+            {
+                // the library's device pool (HALO2_PROOFS_N_GPU is read there too)
+                crate::hip::device_count().to_string()
+            }
+            #[cfg(not(CUDA_OR_HIP))]
+            {
+                "1".to_owned()
+            }
+'''
+
+COEFF_TO_EXTENDED_OLD = '''        assert_eq!(a.values.len(), 1 << self.k);
+
+        //let timer = start_timer!(|| format!("prepare {}", self.k));
+        self.distribute_powers_zeta(&mut a.values, true);
+        //end_timer!(timer);
+
+        a.values.resize(self.extended_len(), G::group_zero());
+        best_fft(&mut a.values, self.extended_omega, self.extended_k);
+
+        Polynomial {
+            values: a.values,
+            _marker: PhantomData,
+        }
+'''
+COEFF_TO_EXTENDED_NEW = '''        assert_eq!(a.values.len(), 1 << self.k);
+
+        // zeta-power pre-scale, zero padding and the extended NTT: one fused device pass over the 2^k inputs
+        #[cfg(feature = "hip")]
+        {
+            let values = crate::hip::coeff_to_extended(
+                &a.values,
+                self.k,
+                self.extended_k,
+                &self.g_coset,
+                &self.g_coset_inv,
+                &self.extended_omega,
+            );
+            a.values = values;
+        }
+
+        #[cfg(not(feature = "hip"))]
+        {
+            //let timer = start_timer!(|| format!("prepare {}", self.k));
+            self.distribute_powers_zeta(&mut a.values, true);
+            //end_timer!(timer);
+
+            a.values.resize(self.extended_len(), G::group_zero());
+            best_fft(&mut a.values, self.extended_omega, self.extended_k);
+        }
+
+        Polynomial {
+            values: a.values,
+            _marker: PhantomData,
+        }
+'''
+EXTENDED_TO_COEFF_OLD = '''        assert_eq!(a.values.len(), self.extended_len());
+
+        // Inverse FFT
+        Self::ifft(
+            &mut a.values,
+            self.extended_omega_inv,
+            self.extended_k,
+            self.extended_ifft_divisor,
+        );
+
+        // Distribute powers to move from coset; opposite from the
+        // transformation we performed earlier.
+        self.distribute_powers_zeta(&mut a.values, false);
+
+        // Truncate it to match the size of the quotient polynomial; the
+        // evaluation domain might be slightly larger than necessary because
+        // it always lies on a power-of-two boundary.
+        a.values
+            .truncate((&self.n * self.quotient_poly_degree) as usize);
+
+        a.values
+'''
+EXTENDED_TO_COEFF_NEW = '''        assert_eq!(a.values.len(), self.extended_len());
+
+        // inverse extended NTT with 1 / n_ext and the zeta^-1 powers folded into its last pass; only the
+        // n * quotient_poly_degree coefficients the caller keeps come back over PCIe
+        #[cfg(feature = "hip")]
+        {
+            a.values = crate::hip::extended_to_coeff(
+                &a.values,
+                (&self.n * self.quotient_poly_degree) as usize,
+                self.extended_k,
+                &self.g_coset,
+                &self.g_coset_inv,
+                &self.extended_omega_inv,
+                &self.extended_ifft_divisor,
+            );
+        }
+
+        #[cfg(not(feature = "hip"))]
+        {
+            // Inverse FFT
+            Self::ifft(
+                &mut a.values,
+                self.extended_omega_inv,
+                self.extended_k,
+                self.extended_ifft_divisor,
+            );
+
+            // Distribute powers to move from coset; opposite from the
+            // transformation we performed earlier.
+            self.distribute_powers_zeta(&mut a.values, false);
+
+            // Truncate it to match the size of the quotient polynomial; the
+            // evaluation domain might be slightly larger than necessary because
+            // it always lies on a power-of-two boundary.
+            a.values
+                .truncate((&self.n * self.quotient_poly_degree) as usize);
+        }
+
+        a.values
+'''
+DIVIDE_OLD = '''        // Divide to obtain the quotient polynomial in the coset evaluation
+        // domain.
+        parallelize(&mut a.values, |h, mut index| {
+            for h in h {
+                h.group_scale(&self.t_evaluations[index % self.t_evaluations.len()]);
+                index += 1;
+            }
+        });
+'''
+DIVIDE_NEW = '''        // Divide to obtain the quotient polynomial in the coset evaluation
+        // domain.
+        #[cfg(feature = "hip")]
+        crate::hip::divide_by_vanishing_poly(&mut a.values, &self.t_evaluations);
+
+        #[cfg(not(feature = "hip"))]
+        parallelize(&mut a.values, |h, mut index| {
+            for h in h {
+                h.group_scale(&self.t_evaluations[index % self.t_evaluations.len()]);
+                index += 1;
+            }
+        });
+'''
+
+EVALUATE_HIP = '''    #[cfg(feature = "hip")]
+    {
+        return super::evaluation_hip::evaluate_lc(
+            &[expression.clone()],
+            size,
+            rot_scale,
+            fixed,
+            advice,
+            instance,
+            _theta,
+        );
+    }
+
+'''
+EVALUATE_THETA_HIP = '''        #[cfg(feature = "hip")]
+        {
+            return super::evaluation_hip::evaluate_lc(expressions, size, rot_scale, fixed, advice, instance, theta);
+        }
+
+'''
+
+GWC_HIP = '''            #[cfg(feature = "hip")]
+            let poly_batch = {
+                let queries = &commitment_at_a_point.queries;
+                let m = queries.len();
+                if m <= 4 {
+                    let mut poly_batch = zero();
+                    for query in queries.iter() {
+                        assert_eq!(query.get_point(), z);
+
+                        let poly = query.get_commitment().poly;
+                        poly_batch = poly_batch * *v + poly;
+                    }
+                    poly_batch
+                } else {
+                    // poly_batch = sum_i v^(m-1-i) p_i: one upload per operand and one fused pass (the cuda branch below
+                    // re-uploads every p_i for an eval_mul_c / eval_sum pair)
+                    let mut coeffs = vec![C::Scalar::one(); m];
+                    for i in (0..m - 1).rev() {
+                        coeffs[i] = coeffs[i + 1] * *v;
+                    }
+                    let polys: Vec<&[C::Scalar]> = queries
+                        .iter()
+                        .map(|query| {
+                            assert_eq!(query.get_point(), z);
+                            &query.get_commitment().poly.values[..]
+                        })
+                        .collect();
+                    Polynomial {
+                        values: crate::hip::lincomb(&polys, &coeffs),
+                        _marker: PhantomData,
+                    }
+                }
+            };
+
+'''
+
+PARAMS_DROP = '''/// `hip`: the device copies (and shifted-base tables) of `g` / `g_lagrange` registered by `unsafe_setup` / `read`
+/// go with the parameters.
+#[cfg(feature = "hip")]
+impl<C: CurveAffine> Drop for Params<C> {
+    fn drop(&mut self) {
+        crate::hip::unregister_params(&self.g, &self.g_lagrange);
+    }
+}
+
+'''
+
+
 def edit(rel, text):
     if rel.endswith("Cargo.toml"):
         return replace_once(text, 'cuda = ["ec-gpu-gen/cuda", "pairing/gpu"]\n',
@@ -103,6 +347,47 @@ def edit(rel, text):
                             '        if #[cfg(%s)]{\n            return gpu_fft(a, omega, log_n);' % ANY, "fft dispatch")
         return text
     if rel.endswith("commitment.rs"):
+        # Params::unsafe_setup (:56-124) and Params::read (:256-294): the SRS is registered with the library once
+        text = replace_once(text, """        let additional_data = Vec::from(s_g2.to_bytes().as_ref());
+        Params {
+            k,
+            n,
+            g,
+            g_lagrange,
+            additional_data,
+        }
+""", """        let additional_data = Vec::from(s_g2.to_bytes().as_ref());
+        let params = Params {
+            k,
+            n,
+            g,
+            g_lagrange,
+            additional_data,
+        };
+        #[cfg(feature = "hip")]
+        crate::hip::register_params(&params.g, &params.g_lagrange);
+        params
+""", "unsafe_setup tail")
+        text = replace_once(text, """        Ok(Params {
+            k,
+            n: n as u64,
+            g,
+            g_lagrange,
+            additional_data,
+        })
+""", """        let params = Params {
+            k,
+            n: n as u64,
+            g,
+            g_lagrange,
+            additional_data,
+        };
+        #[cfg(feature = "hip")]
+        crate::hip::register_params(&params.g, &params.g_lagrange);
+        Ok(params)
+""", "Params::read tail")
+        text = replace_once(text, "/// These are the verifier parameters for the polynomial commitment scheme.\n",
+                            PARAMS_DROP + "/// These are the verifier parameters for the polynomial commitment scheme.\n", "Params Drop")
         text = replace_once(text, '    #[cfg(feature = "cuda")]\n    /// This commits to a polynomial using its evaluations over the $2^k$ size',
                             '    #[cfg(%s)]\n    /// This commits to a polynomial using its evaluations over the $2^k$ size' % ANY, "commit_lagrange_and_ifft gpu")
         text = replace_once(text, '    #[cfg(not(feature = "cuda"))]\n    /// This commits to a polynomial using its evaluations over the $2^k$ size',
@@ -121,6 +406,38 @@ def edit(rel, text):
         text = replace_once(text, '        #[cfg(feature = "cuda")]\n        crate::arithmetic::gpu_ifft(a, omega_inv, log_n, divisor)',
                             '        #[cfg(%s)]\n        crate::arithmetic::gpu_ifft(a, omega_inv, log_n, divisor)' % ANY, "ifft gpu")
         text = replace_once(text, '    #[cfg(not(feature = "cuda"))]\n    fn ifft_st(', '    #[cfg(not(%s))]\n    fn ifft_st(' % ANY, "ifft_st")
+        text = replace_once(text, COEFF_TO_EXTENDED_OLD, COEFF_TO_EXTENDED_NEW, "coeff_to_extended body")
+        text = replace_once(text, EXTENDED_TO_COEFF_OLD, EXTENDED_TO_COEFF_NEW, "extended_to_coeff body")
+        text = replace_once(text, DIVIDE_OLD, DIVIDE_NEW, "divide_by_vanishing_poly body")
+        return text
+    if rel.endswith("src/plonk.rs"):
+        text = replace_once(text, "mod evaluation;\n", 'mod evaluation;\n#[cfg(feature = "hip")]\nmod evaluation_hip;\n', "mod evaluation")
+        return switch_shape(text, 5)
+    if rel.endswith("plonk/keygen.rs"):
+        return switch_shape(text, 8)
+    if rel.endswith("plonk/permutation.rs"):
+        return switch_shape(text, 1)
+    if rel.endswith("permutation/keygen.rs"):
+        return switch_shape(text, 2)
+    if rel.endswith("permutation/prover.rs"):
+        return switch_shape(text, 1)
+    if rel.endswith("plonk/prover.rs"):
+        text = replace_once(text, N_GPU_CUDA, N_GPU_HIP, "N_GPU default")
+        text = switch_shape(text, 19 - 2)          # the two sites of the N_GPU block became cuda / hip / neither
+        text = text.replace("#[cfg(CUDA_ONLY)]", '#[cfg(feature = "cuda")]')
+        return text.replace("#[cfg(not(CUDA_OR_HIP))]", "#[cfg(not(%s))]" % ANY)
+    if rel.endswith("plonk/evaluation.rs"):
+        # the CPU evaluate_h leaves when either GPU feature supplies one (the hip body is plonk/evaluation_hip.rs)
+        text = replace_once(text, '    #[cfg(not(feature = "cuda"))]\n    pub(in crate::plonk) fn evaluate_h(',
+                            '    #[cfg(not(%s))]\n    pub(in crate::plonk) fn evaluate_h(' % ANY, "cpu evaluate_h")
+        cpu_eval = '    #[cfg(not(feature = "cuda"))]\n    {\n        let mut values = vec![F::zero(); size];\n        let isize = size as i32;\n'
+        text = replace_once(text, cpu_eval, EVALUATE_HIP + cpu_eval.replace('not(feature = "cuda")', "not(%s)" % ANY), "evaluate cpu block")
+        cpu_theta = '        #[cfg(not(feature = "cuda"))]\n        {\n            let mut values = vec![F::zero(); size];\n            let isize = size as i32;\n'
+        text = replace_once(text, cpu_theta, EVALUATE_THETA_HIP + cpu_theta.replace('not(feature = "cuda")', "not(%s)" % ANY), "evaluate_with_theta cpu block")
+        return text
+    if rel.endswith("gwc/prover.rs"):
+        cpu = '            #[cfg(not(feature = "cuda"))]\n            let poly_batch = {\n'
+        text = replace_once(text, cpu, GWC_HIP + cpu.replace('not(feature = "cuda")', "not(%s)" % ANY), "gwc cpu batch")
         return text
     raise AssertionError(rel)
 
@@ -139,7 +456,8 @@ def main():
                 text = f.read()
             with open(path, "w") as f:
                 f.write(edit(rel, text))
-        shutil.copy(os.path.join(ROOT, "integration", "hip.rs"), os.path.join(tmp, "b", "halo2_proofs", "src", "hip.rs"))
+        for rel, src in NEW_FILES.items():
+            shutil.copy(os.path.join(ROOT, "integration", src), os.path.join(tmp, "b", rel))
         res = subprocess.run(["diff", "-U1", "-r", "-N", "a", "b"], cwd=tmp, capture_output=True, text=True)
         assert res.returncode == 1, res.stderr
         lines = [l for l in res.stdout.splitlines(keepends=True) if not l.startswith("diff -U1")]
