@@ -199,3 +199,99 @@ def exchange_cosets(mine, c, shards, group=None, stream=None):
             if not (j in mine and rank != src):
                 out.append(buf.to(template.device) if staged else buf)
     return out
+
+
+# ---- index-range sharding of the O(n) passes --------------------------------------------------
+# Every rank holds the same full-size vectors and works on the rows / coefficients [lo, hi) of its contiguous range (the
+# range its share of every range-split MSM consumes).  Elementwise passes and linear combinations need nothing else; the
+# three operations with a dependency ACROSS the range -- prefix scans, Kate division, Horner evaluation -- exchange one field
+# element per rank (an all-gather of world x 32 B) and finish locally.  The helpers below are that arithmetic on host
+# integers; the device work is prover.py's.
+MASK64 = (1 << 64) - 1
+
+
+def allgather_scalars(values, group=None, device=None):
+    """every rank contributes len(values) integers below 2^256; returns [rank][i] on every rank.  One small all-gather
+    (RCCL: from device memory; gloo: host tensors)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    a = np.array([[(int(v) >> (64 * k)) & MASK64 for k in range(4)] for v in values], dtype=np.uint64).reshape(-1, 4)
+    mine = torch.from_numpy(a.view(np.int64).copy())
+    if device is not None and _backend(group) == "nccl":
+        mine = mine.to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    res = []
+    for t in out:
+        rows = t.cpu().numpy().view(np.uint64).reshape(-1, 4)
+        res.append([int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192) for r in rows])
+    return res
+
+
+def scan_carries(totals, init, product=True):
+    """prefix scan over equal contiguous ranges: `totals[r]` = the product (sum) of rank r's own factors (terms);
+    returns the value entering each range, carry[r] = init * prod_{s < r} totals[s]  (init + sum ...)."""
+    out, acc = [], init % R_MOD
+    for t in totals:
+        out.append(acc)
+        acc = acc * t % R_MOD if product else (acc + t) % R_MOD
+    return out
+
+
+def kate_carries(partials, b, m):
+    """Kate division q(X) = a(X) / (X - b) over ranges of m coefficients: q[j] = sum_{t > j} a[t] b^(t - j - 1).
+    `partials[s]` = sum_{t in range s} a[t] b^(t - lo_s) (the local Horner value of range s at b).  Returns, per rank r,
+    C_r = sum_{t >= hi_r} a[t] b^(t - hi_r) = sum_{s > r} partials[s] b^((s - r - 1) m): the recurrence value entering range
+    r from above (it is also q[hi_r - 1])."""
+    world = len(partials)
+    bm = pow(b, m, R_MOD)
+    out, acc = [0] * world, 0
+    for r in range(world - 2, -1, -1):
+        acc = (partials[r + 1] + bm * acc) % R_MOD
+        out[r] = acc
+    return out
+
+
+def combine_range_evals(parts, x, m):
+    """p(x) = sum_r x^(r m) parts[r] with parts[r] = sum_{t in range r} p[t] x^(t - lo_r) (Horner over the ranges)"""
+    xm, acc = pow(x, m, R_MOD), 0
+    for v in reversed(parts):
+        acc = (acc * xm + v) % R_MOD
+    return acc
+
+
+def scatter_cosets(mine, c, shards, lo, hi, group=None, stream=None):
+    """`mine`: {coset j: (n, 4) device tensor} for the cosets this rank evaluated; every rank needs only the coefficients
+    [lo_r, hi_r) of every coset polynomial (the un-mixing into the quotient's pieces is a linear combination, and everything
+    after it works on ranges): the owner of coset j (rank j mod shards) scatters the c x n / world slices instead of
+    broadcasting n coefficients to everybody.  Returns a list of c full-size tensors of which only [lo, hi) is valid."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    staged = _backend(group) != "nccl"
+    template = next(iter(mine.values())) if mine else None
+    assert template is not None, "every rank owns at least one coset (ranks beyond the cosets replicate a shard)"
+    n = template.shape[0]
+    assert n % world == 0 and hi - lo == n // world
+    out = []
+    with _on_stream(stream):
+        for j in range(c):
+            src = j % shards
+            full = mine[j] if j in mine else torch.empty_like(template)
+            recv = full[lo:hi]
+            if rank == src:
+                parts = [full[r * (n // world):(r + 1) * (n // world)] for r in range(world)]
+                if staged:
+                    parts = [p.cpu() for p in parts]
+                buf = parts[rank].clone() if staged else torch.empty_like(recv)
+                dist.scatter(buf, scatter_list=parts, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+            else:
+                buf = torch.empty((hi - lo, 4), dtype=template.dtype) if staged else recv
+                dist.scatter(buf, scatter_list=None, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+                if staged:
+                    recv.copy_(buf.to(template.device))
+            out.append(full)
+    return out

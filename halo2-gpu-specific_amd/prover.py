@@ -528,6 +528,108 @@ class Device:
         cur = self.get_rows(t, 0, len(low))
         self.set_rows(t, 0, [(c - l) % R_MOD for c, l in zip(cur, low)])
 
+    # -- index-range sharding of the O(n) passes (one proof over several ranks; DESIGN.md section 6 (c)) ------------------
+    def row_range(self, n):
+        """[lo, hi): the rows / coefficients of an n-vector this rank works on -- the contiguous range its share of every
+        range-split MSM consumes (arithmetic.rs:425-435) -- or the whole vector on one device.  Vectors stay full-size
+        allocations; a rank only ever computes and reads its own range of the ones that are sharded."""
+        if self.group_size > 1 and n % self.group_size == 0 and n // self.group_size >= 8:
+            from .parallel import msm_split_range
+
+            return msm_split_range(n, self.group_size, self.group_rank)
+        return 0, n
+
+    def _exchange(self, values):
+        from .parallel import allgather_scalars
+
+        return allgather_scalars(values, group=self.group, device=self.dev)
+
+    def prefix_scan(self, f, n, init, product, probe):
+        """z[0] = init, z[i] = z[i-1] * f[i-1] (product) / + f[i-1]: the grand-product / grand-sum columns
+        (permutation/prover.rs:151-160, logup/prover.rs:353-367, shuffle/prover.rs).  Returns (z, z[probe]).
+        Sharded: `f` is this rank's rows [lo, hi) of the factors / terms (hi - lo elements); the local scan starts from the
+        neutral element, the totals of the ranges cross in ONE all-gather of a field element per rank and the range is
+        corrected by the value entering it.  z is a full-size vector valid on [lo, hi) (`gather_rows` completes it)."""
+        lo, hi = self.row_range(n)
+        kernel = self.L.h2_dev_prefix_product if product else self.L.h2_dev_prefix_sum
+        z = self.empty(n)
+        if (lo, hi) == (0, n):
+            check(kernel(f.data_ptr(), n, _fr(init), z.data_ptr(), self.stream), "h2_dev_prefix_scan")
+            return z, self.get_rows(z, probe, 1)[0]
+        from .parallel import scan_carries
+
+        m = hi - lo
+        tmp = self.empty(m + 1)                      # tmp[t] = f[lo] .. f[lo + t - 1] folded; tmp[m] = this range's total
+        check(kernel(f.data_ptr(), m + 1, _fr(1 if product else 0), tmp.data_ptr(), self.stream), "h2_dev_prefix_scan")
+        total = self.get_rows(tmp, m, 1)[0]
+        at = self.get_rows(tmp, probe - lo, 1)[0] if lo <= probe < hi else 0
+        gathered = self._exchange([total, at])
+        carries = scan_carries([g[0] for g in gathered], init, product)
+        self.eval_op(0 if product else 1, z[lo:hi], tmp[:m], c=carries[self.group_rank], size=m)   # H2_OP_MUL_C / SUM_C
+        owner = probe // m
+        value = carries[owner] * gathered[owner][1] % R_MOD if product else (carries[owner] + gathered[owner][1]) % R_MOD
+        return z, value
+
+    def gather_rows(self, t, n):
+        """complete a vector of which every rank computed its own range (all-gather over xGMI)"""
+        lo, hi = self.row_range(n)
+        if (lo, hi) != (0, n):
+            from .parallel import allgather_rows
+
+            allgather_rows(t[:n], lo, hi, group=self.group, stream=self.tstream)
+        return t
+
+    def eval_polynomial_ranges(self, polys, n, points):
+        """[poly_j(point_j)] with every polynomial cut into the ranks' coefficient ranges: p(x) = sum_r x^(lo_r) p_r(x);
+        the partial values cross in one all-gather of len(polys) field elements per rank.  `polys` need only be valid on
+        this rank's range."""
+        lo, hi = self.row_range(n)
+        if (lo, hi) == (0, n):
+            return self.eval_polynomial_batch(polys, n, points)
+        from .parallel import combine_range_evals
+
+        m = hi - lo
+        parts = self.eval_polynomial_batch([p[lo:hi] for p in polys], m, points)
+        gathered = self._exchange(parts)
+        return [combine_range_evals([g[j] for g in gathered], points[j] % R_MOD, m) for j in range(len(polys))]
+
+    def lincomb_range(self, res, polys, coeffs, n):
+        """res[lo:hi) = sum_j coeffs[j] * polys[j][lo:hi) over this rank's range (the whole vector on one device)"""
+        lo, hi = self.row_range(n)
+        self.lincomb(res[lo:hi], [p[lo:hi] for p in polys], coeffs, hi - lo)
+        return res
+
+    def sub_low_range(self, t, low, n):
+        """t[i] -= low[i] for the first few coefficients: they live in the first rank's range"""
+        lo, hi = self.row_range(n)
+        assert len(low) <= hi - lo
+        if lo == 0:
+            self.sub_low(t, low)
+
+    def kate_division_ranges(self, a, n, b, out):
+        """out = a / (X - b) (arithmetic.rs:754-773; out[n-1] = 0), `a` valid on this rank's range, `out` filled on it:
+        out[j] = sum_{t > j} a[t] b^(t - j - 1).  The part of the sum inside the range is the same kernel on the range; the
+        part above it is C b^(hi - 1 - j) with C = the recurrence value entering the range from above -- the local Horner
+        values of the ranges at b cross in one all-gather, C follows on the host (parallel.kate_carries)."""
+        lo, hi = self.row_range(n)
+        if (lo, hi) == (0, n):
+            return self.kate_division(a, n, b, out)
+        from .parallel import kate_carries
+
+        m = hi - lo
+        self.kate_division(a[lo:hi], m, b, out[lo:hi])               # the last coefficient of the range is zeroed
+        part = self.eval_polynomial(a[lo:hi], m, b)
+        carry = kate_carries([g[0] for g in self._exchange([part])], b % R_MOD, m)[self.group_rank]
+        if carry:
+            b %= R_MOD
+            if b == 0:                                                # only out[hi - 1] = C
+                self.set_rows(out, hi - 1, [carry])
+            else:
+                corr = self.eval_op(8, self.empty(m), c=carry * pow(b, m - 1, R_MOD) % R_MOD)      # H2_OP_CONSTANT
+                check(self.L.h2_dev_distribute_powers(corr.data_ptr(), m, _fr(_inv(b)), self.stream), "h2_dev_distribute_powers")
+                self.eval_op(2, out[lo:hi], out[lo:hi], corr, size=m)                              # H2_OP_SUM
+        return out
+
 
 def sharding_description(device):
     """how one proof is spread over the ranks of `device`'s process group (bench.py reports it)"""
@@ -535,8 +637,11 @@ def sharding_description(device):
         return "one proof on one device"
     return ("one proof over %d rank(s): every MSM range-split over the ranks (partial points: one all-gather per batch, folded "
             "on the device); extended-domain phase (coset NTTs, evaluate_h, vanishing division, inverse transform) split by "
-            "coset of the n-th roots of unity, one n-vector per coset broadcast; the n-sized scans / elementwise passes "
-            "replicated" % device.group_size)
+            "coset of the n-th roots of unity, the per-coset quotients scattered as coefficient ranges; the O(n) passes of the "
+            "permutation / lookup / shuffle products (terms, batch inversion, prefix scans), the evaluations and the multiopen "
+            "argument (linear combinations, Kate divisions) on the rank's row / coefficient range, one field element per rank "
+            "exchanged per scan / division / evaluation batch; witness-dependent inverse transforms replicated"
+            % device.group_size)
 
 
 def _forget_tables(L, ptrs):
@@ -1132,19 +1237,27 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # every set, (beta + f) of every lookup input and table, the shuffle products -- depends only on beta and gamma: it
     # is laid out in ONE buffer (per circuit instance) and inverted by ONE batch inversion, so the inversion's serial
     # a^(r-2) chain (~0.3 ms of pure latency per call) is paid once per proof instead of once per column.
+    # One proof over several ranks: every pass of this phase -- the numerator / denominator terms, the batch inversion, the
+    # products, the scans -- runs on this rank's rows [lo_s, hi_s) only (a prefix scan exchanges one field element per rank,
+    # Device.prefix_scan); the range is exactly what the rank's share of the z commitments consumes, and the ranks complete
+    # each other's z columns over xGMI before the inverse transforms (Device.gather_rows).
+    lo_s, hi_s = D.row_range(n)
+    m_s = hi_s - lo_s
+    rows = lambda t: t[lo_s:hi_s]  # noqa: E731
+    omega_lo = pow(dom.omega, lo_s, R_MOD)
     for C in circuits:
         lookups, shuffles = C["lookups"], C["shuffles"]
         colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
         slots = nsets + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
-        nums = D.empty(max(nsets, 1) * n)
-        inv = D.empty(max(slots, 1) * n)
-        slot = lambda i, inv=inv: inv[i * n:(i + 1) * n]  # noqa: E731
+        nums = D.empty(max(nsets, 1) * m_s)
+        inv = D.empty(max(slots, 1) * m_s)
+        slot = lambda i, inv=inv: inv[i * m_s:(i + 1) * m_s]  # noqa: E731
         for k_, si in enumerate(range(0, len(cols), chunk)):
             for ci in range(si, min(si + chunk, len(cols))):
                 values = colvals[cols[ci][0]][cols[ci][1]]
-                check(L.h2_dev_permutation_terms(nums[k_ * n:].data_ptr(), slot(k_).data_ptr(), values.data_ptr(),
-                                                 pk.sigma_values[ci].data_ptr(), n, _fr(beta), _fr(gamma),
-                                                 _fr(pow(DELTA, ci, R_MOD)), _fr(dom.omega), 1 if ci == si else 0,
+                check(L.h2_dev_permutation_terms(nums[k_ * m_s:].data_ptr(), slot(k_).data_ptr(), rows(values).data_ptr(),
+                                                 rows(pk.sigma_values[ci]).data_ptr(), m_s, _fr(beta), _fr(gamma),
+                                                 _fr(pow(DELTA, ci, R_MOD) * omega_lo), _fr(dom.omega), 1 if ci == si else 0,
                                                  D.stream), "h2_dev_permutation_terms")
         at = nsets
         for st in lookups:
@@ -1152,37 +1265,36 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             for cols_in in st["inputs"]:
                 st["inv_inputs"].append([])
                 for col in cols_in:                                     # beta + f_i
-                    st["inv_inputs"][-1].append(D.eval_op(1, slot(at), col, c=beta))          # H2_OP_SUM_C
+                    st["inv_inputs"][-1].append(D.eval_op(1, slot(at), rows(col), c=beta, size=m_s))          # H2_OP_SUM_C
                     at += 1
-            st["inv_table"] = D.eval_op(1, slot(at), st["table"], c=beta)  # beta + t
+            st["inv_table"] = D.eval_op(1, slot(at), rows(st["table"]), c=beta, size=m_s)  # beta + t
             at += 1
         C["shuffle_inv"] = []
         for group in shuffles:                                          # prod_i (beta^(i+1) + shuffle_i)
             dst = slot(at)
             for i, (_, shf) in enumerate(group):
                 if i == 0:
-                    D.eval_op(1, dst, shf, c=beta)
+                    D.eval_op(1, dst, rows(shf), c=beta, size=m_s)
                 else:
-                    D.eval_op(6, dst, shf, dst, c=pow(beta, i + 1, R_MOD))       # H2_OP_LCBETA: (l + c) * r
+                    D.eval_op(6, dst, rows(shf), dst, c=pow(beta, i + 1, R_MOD), size=m_s)       # H2_OP_LCBETA: (l + c) * r
             C["shuffle_inv"].append(dst)
             at += 1
         assert at == slots
         if slots:
-            check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * n).data_ptr(), slots * n, D.stream), "h2_dev_batch_invert")
+            check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * m_s).data_ptr(), slots * m_s, D.stream), "h2_dev_batch_invert")
         if nsets:
-            D.eval_op(3, nums, nums, inv[:nsets * n])                                     # H2_OP_MUL over all sets
+            D.eval_op(3, nums, nums, inv[:nsets * m_s])                                     # H2_OP_MUL over all sets
         C["nums"], C["inv"] = nums, inv
+
     # ---- permutation grand products (permutation/prover.rs:89-165), circuit by circuit -------------------------
     for C in circuits:
         C["z"], last_z = [], 1
         for k_ in range(nsets):
-            z = D.empty(n)
-            check(L.h2_dev_prefix_product(C["nums"][k_ * n:].data_ptr(), n, _fr(last_z), z.data_ptr(), D.stream), "h2_dev_prefix_product")
+            z, last_z = D.prefix_scan(C["nums"][k_ * m_s:(k_ + 1) * m_s], n, last_z, True, usable)
             D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
-            last_z = D.get_rows(z, usable, 1)[0]
             C["z"].append(z)
         del C["nums"]
-    num = D.empty(n)
+    num = D.empty(m_s)
     # ---- lookup grand sums (logup/prover.rs:243-415; blinding prover.rs:446-465) -------------------------------
     for C in circuits:
         for st in C["lookups"]:
@@ -1191,13 +1303,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             for si, inverted in enumerate(st["inv_inputs"]):
                 src = inverted[0]                                       # sum_i 1 / (beta + f_i)
                 for other in inverted[1:]:
-                    src = D.eval_op(2, num, src, other)                 # H2_OP_SUM
+                    src = D.eval_op(2, num, src, other, size=m_s)       # H2_OP_SUM
                 if si == 0:                                             # - m / (beta + t)
-                    D.eval_op(3, st["inv_table"], st["inv_table"], st["m"])
-                    src = D.eval_op(4, num, src, st["inv_table"])       # H2_OP_SUB
-                z = D.empty(n)
-                check(L.h2_dev_prefix_sum(src.data_ptr(), n, _fr(last), z.data_ptr(), D.stream), "h2_dev_prefix_sum")
-                last = D.get_rows(z, usable, 1)[0]
+                    D.eval_op(3, st["inv_table"], st["inv_table"], rows(st["m"]), size=m_s)
+                    src = D.eval_op(4, num, src, st["inv_table"], size=m_s)       # H2_OP_SUB
+                z, last = D.prefix_scan(src, n, last, False, usable)
                 D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
                 st["z"].append(z)
             if last != 0:
@@ -1208,10 +1318,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         C["shuffle_z"] = []
         for group, inverted in zip(C["shuffles"], C["shuffle_inv"]):
             for i, (inp, _) in enumerate(group):
-                D.eval_op(6, inverted, inp, inverted, c=pow(beta, i + 1, R_MOD))
-            z = D.empty(n)
-            check(L.h2_dev_prefix_product(inverted.data_ptr(), n, _fr(1), z.data_ptr(), D.stream), "h2_dev_prefix_product")
-            if D.get_rows(z, usable, 1)[0] != 1:
+                D.eval_op(6, inverted, rows(inp), inverted, c=pow(beta, i + 1, R_MOD), size=m_s)
+            z, closing = D.prefix_scan(inverted, n, 1, True, usable)
+            if closing != 1:
                 raise ValueError("shuffle product does not return to one")
             D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
             C["shuffle_z"].append(z)
@@ -1224,6 +1333,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254)
     for P in z_commitments:
         transcript.write_point(P)
+    for z in all_z:
+        D.gather_rows(z, n)                       # (one proof over several ranks: every rank computed its own rows)
     for C in circuits:
         C["z_polys"] = [D.intt(z, dom) for z in C["z"]]
         for st in C["lookups"]:
@@ -1315,7 +1426,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         # constant gamma_j - 1 (gamma_j = g_j^n) and h(X) = sum_m X^(n m) h_m(X) reads P_j(X) = sum_m gamma_j^m h_m(X): the
         # evaluator runs on n points per coset with zeta := g_j, extended_omega := omega, extended_k := k; the inverse
         # coset transform gives P_j; one n-vector per coset is exchanged; the pieces are h_m = sum_j Vinv[m][j] P_j.
-        from .parallel import coset_unmix_matrix, exchange_cosets
+        from .parallel import coset_unmix_matrix, exchange_cosets, scatter_cosets
 
         c, shards, owned = plan
         mine = {}
@@ -1324,13 +1435,18 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             h_j = evaluate_quotient(lambda t, j=j: D.coeff_to_coset(t, dom, j), pk.coset[j], dom.k, g_j, dom.omega, n)
             D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
             mine[j] = D.coset_to_coeff(h_j, dom, j)
-        if D.group_size > 1:
+        # Everything after the quotient -- the un-mixing, the h pieces' commitments, the evaluations, the multiopen argument --
+        # works on coefficient RANGES (Device.row_range): a rank needs only its own n / P coefficients of every coset
+        # polynomial, so their owners scatter slices (c x n / P x 32 B per rank) instead of broadcasting whole vectors.
+        if D.group_size > 1 and D.row_range(n) != (0, n):
+            polys_j = scatter_cosets(mine, c, shards, *D.row_range(n), group=D.group, stream=D.tstream)
+        elif D.group_size > 1:
             polys_j = exchange_cosets(mine, c, shards, group=D.group, stream=D.tstream)
         else:
             polys_j = [mine[j] for j in range(c)]
         gammas = [pow(ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD, n, R_MOD) for j in range(c)]
         unmix = coset_unmix_matrix(gammas, dom.quotient_poly_degree)
-        pieces = [D.lincomb(D.empty(n), polys_j, row, n) for row in unmix]
+        pieces = [D.lincomb_range(D.empty(n), polys_j, row, n) for row in unmix]
         del polys_j, mine
         pk.coset.trim()
     mark("vanishing transforms")
@@ -1342,7 +1458,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     # ---- evaluations (prover.rs:700-790): every (polynomial, point) pair of the proof in one batched launch ------
     # h(X) = sum_i x^(n i) piece_i (vanishing/prover.rs:120-124)
-    h_poly = D.lincomb(D.empty(n), pieces, [pow(xn, i, R_MOD) for i in range(len(pieces))], n)
+    h_poly = D.lincomb_range(D.empty(n), pieces, [pow(xn, i, R_MOD) for i in range(len(pieces))], n)
     wanted, written = [], []            # (key, poly, rotation); the subset the transcript receives, in its order
 
     def want(key, poly, rot, write=True):
@@ -1382,7 +1498,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             want(("shuffle_z", ci, i), p, 0)
             want(("shuffle_z", ci, i), p, 1)
     want(("h",), h_poly, 0, write=False)                               # opened, not written (vanishing/prover.rs:140-155)
-    values = D.eval_polynomial_batch([p for _, p, _ in wanted], n, [dom.rotate_omega(x, r) for _, _, r in wanted])
+    values = D.eval_polynomial_ranges([p for _, p, _ in wanted], n, [dom.rotate_omega(x, r) for _, _, r in wanted])
     evals = {(key, rot): v for (key, _, rot), v in zip(wanted, values)}
     for key, rot in written:
         transcript.write_scalar(evals[(key, rot)])
@@ -1435,7 +1551,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 def _gwc(D, params, transcript, queries, polys, n):
     """poly/multiopen/gwc/prover.rs:20-175: per opening point, batch = sum_i v^(m-1-i) p_i, witness =
     (batch - batch(z)) / (X - z).  The reference's cuda branch (:57-151) uploads every p_i again for its eval_mul_c /
-    eval_sum pair; here they never left the device and one lincomb forms the batch."""
+    eval_sum pair; here they never left the device and one lincomb forms the batch.  One proof over several ranks: every
+    vector pass runs on the rank's coefficient range (Device.*_range(s)); the commitments are range-split anyway."""
     v = transcript.squeeze_challenge_scalar()
     groups = {}
     for qu in queries:
@@ -1445,9 +1562,9 @@ def _gwc(D, params, transcript, queries, polys, n):
         group = groups[rot]
         z, m = group[0][2], len(group)
         vpow = [pow(v, m - 1 - i, R_MOD) for i in range(m)]
-        batch = D.lincomb(D.empty(n), [polys[key] for key, _, _, _ in group], vpow, n)
-        D.sub_low(batch, [sum(c * e for c, (_, _, _, e) in zip(vpow, group)) % R_MOD])   # = batch(z)
-        witnesses.append(D.kate_division(batch, n, z, D.empty(n)))
+        batch = D.lincomb_range(D.empty(n), [polys[key] for key, _, _, _ in group], vpow, n)
+        D.sub_low_range(batch, [sum(c * e for c, (_, _, _, e) in zip(vpow, group)) % R_MOD], n)   # = batch(z)
+        witnesses.append(D.kate_division_ranges(batch, n, z, D.empty(n)))
     for P in D.msm_batch(witnesses, params.g, n, 254):
         transcript.write_point(P)
 
@@ -1455,7 +1572,8 @@ def _gwc(D, params, transcript, queries, polys, n):
 def _shplonk(D, params, transcript, queries, polys, n):
     """poly/multiopen/shplonk/prover.rs:89-225.  Every fold `acc * c + p` of the reference is a linear combination
     with powers of the challenge; the device computes each one in a single pass (h2_dev_lincomb) and the host
-    adjusts the <= 3 low coefficients the low-degree equivalents r_i(X) touch."""
+    adjusts the <= 3 low coefficients the low-degree equivalents r_i(X) touch.  One proof over several ranks: every
+    vector pass runs on the rank's coefficient range; a Kate division exchanges one field element per rank."""
     y = transcript.squeeze_challenge_scalar()
     sets, super_points = _intermediate_sets(queries)
     for rs in sets:
@@ -1467,19 +1585,19 @@ def _shplonk(D, params, transcript, queries, polys, n):
     for rs in sets:
         m = len(rs["commitments"])
         ypow = [pow(y, m - 1 - i, R_MOD) for i in range(m)]
-        n_x = D.lincomb(D.empty(n), [polys[key] for key, _ in rs["commitments"]], ypow, n)
+        n_x = D.lincomb_range(D.empty(n), [polys[key] for key, _ in rs["commitments"]], ypow, n)
         width = len(rs["points"])
         low = [sum(ypow[i] * rs["low"][i][j] for i in range(m)) % R_MOD for j in range(width)]
-        D.sub_low(n_x, low)
+        D.sub_low_range(n_x, low, n)
         cur = n_x
         for pt in rs["points"]:
             nxt = ping if cur is not ping else pong
-            D.kate_division(cur, n, pt, nxt)
+            D.kate_division_ranges(cur, n, pt, nxt)
             cur = nxt
         quotients.append(D.clone(cur))
     R = len(sets)
     vpow = [pow(v, R - 1 - r, R_MOD) for r in range(R)]
-    h_x = D.lincomb(D.empty(n), quotients, vpow, n)
+    h_x = D.lincomb_range(D.empty(n), quotients, vpow, n)
     del quotients
     transcript.write_point(D.msm(h_x, params.g, n))
     u = transcript.squeeze_challenge_scalar()
@@ -1497,9 +1615,9 @@ def _shplonk(D, params, transcript, queries, polys, n):
             const = (const + c * _horner(rs["low"][i], u)) % R_MOD
     lin_polys.append(h_x)
     lin_coeffs.append((-zt_eval * scale) % R_MOD)
-    l_x = D.lincomb(ping, lin_polys, lin_coeffs, n)
-    D.sub_low(l_x, [const])
-    if D.eval_polynomial(l_x, n, u) != 0:
+    l_x = D.lincomb_range(ping, lin_polys, lin_coeffs, n)
+    D.sub_low_range(l_x, [const], n)
+    if D.eval_polynomial_ranges([l_x], n, [u])[0] != 0:
         raise AssertionError("shplonk: l(u) != 0")   # the reference's must_be_zero (prover.rs:204-207)
-    D.kate_division(l_x, n, u, pong)
+    D.kate_division_ranges(l_x, n, u, pong)
     transcript.write_point(D.msm(pong, params.g, n))

@@ -292,12 +292,16 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
         assert got == rp.create_proof(rpk, syn[0], ProverRng(31), use_gwc=use_gwc, instances=inst)
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("k", [10, 17])
-def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, k):
-    """config 5's data flow with two ranks (here two processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
-    device): every MSM range-split + all-gather + fold, the extended domain split by coset + broadcast + un-mixing.  Both
-    ranks must emit the single-device proof."""
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,which,k", [(2, "mini", 10), (2, "mini", 17), (4, "mini", 12), (8, "mini", 10), (2, "lookup", 9),
+                                           (4, "lookup", 8), (4, "wide", 9)])
+def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
+    """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
+    device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
+    scattered as coefficient ranges + un-mixed; the permutation / lookup / shuffle products, the evaluations and the
+    multiopen argument (SHPLONK and GWC) on row / coefficient ranges with one field element per rank exchanged per scan /
+    Kate division.  Every rank must emit the single-device proof, for the mini-PLONK circuit, the lookup + shuffle +
+    instance circuit (degree 6: 5 cosets over 2 or 4 ranks) and the wide circuit (degree 5, eight grand sums)."""
     import subprocess
     import sys
 
@@ -305,24 +309,40 @@ def test_two_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device,
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
-    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    cs, adv, fixed, copies, inst = _multi_rank_case(which, k)
     params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
-    pk = prover.keygen(device, params, circuits.mini_plonk(), fixed, copies)
-    want = prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(9))
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    want = [prover.create_proof_ext(device, params, pk, adv, ProverRng(9), gwc, instances=inst) for gwc in (False, True)]
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % (ROOT, k, S_TRAPDOOR))
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    script.write_text(_WORKER % (ROOT, os.path.join(ROOT, "tests"), which, k, S_TRAPDOOR))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
-                         capture_output=True, text=True, timeout=500, env=dict(os.environ, H2_TEST_BACKEND="gloo"))
+                         capture_output=True, text=True, timeout=800, env=dict(os.environ, H2_TEST_BACKEND="gloo"))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    proofs = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("PROOF ")]
-    assert len(proofs) == 2 and all(bytes.fromhex(h) == want for h in proofs)
+    for tag, proof in (("PROOF", want[0]), ("GWC", want[1])):
+        got = [l.split()[1] for l in res.stdout.splitlines() if l.startswith(tag + " ")]
+        assert len(got) == world and all(bytes.fromhex(h) == proof for h in got), tag
     secure = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("SECURE ")]
-    assert len(secure) == 2 and secure[0] == secure[1] != proofs[0]
-    vk = rp.Keys()
-    vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
-    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
-    assert rp.verify_proof(vk, bytes.fromhex(secure[0]))
+    assert len(secure) == world and len(set(secure)) == 1 and secure[0] != want[0].hex()
+    if which == "mini":
+        vk = rp.Keys()
+        vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
+        vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+        assert rp.verify_proof(vk, bytes.fromhex(secure[0]))
+
+
+def _multi_rank_case(which, k):
+    """(constraint system, advice, fixed, copies, instances) of the circuits the multi-rank tests prove"""
+    from halo2_gpu_specific_amd import circuits
+
+    if which == "mini":
+        adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+        return circuits.mini_plonk(), adv, fixed, copies, []
+    if which == "wide":
+        adv, fixed, copies = circuits.wide_synthesize(k, 4)
+        return circuits.wide(4), adv, fixed, copies, []
+    syn = rp.LookupShuffle.synthesize(k)
+    return (lookup_shuffle_cs(), cols_to_arr(syn[0]), cols_to_arr(syn[1]), [(l[0], l[1], r[0], r[1]) for l, r in syn[2]], syn[3])
 
 
 def _visible_devices():
@@ -369,7 +389,7 @@ def test_two_rank_rccl_proof_equals_single_device_proof(oracle, device, tmp_path
     pk = prover.keygen(device, params, circuits.mini_plonk(), fixed, copies)
     want = prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(9))
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % (ROOT, k, S_TRAPDOOR))
+    script.write_text(_WORKER % (ROOT, os.path.join(ROOT, "tests"), "mini", k, S_TRAPDOOR))
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=500)
@@ -381,26 +401,31 @@ def test_two_rank_rccl_proof_equals_single_device_proof(oracle, device, tmp_path
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, %r)
+sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
 rank = int(os.environ["RANK"]); local = int(os.environ.get("LOCAL_RANK", rank))
-if os.environ.get("H2_TEST_BACKEND") == "gloo":      # two ranks sharing cuda:0 (RCCL refuses two ranks on one device)
+if os.environ.get("H2_TEST_BACKEND") == "gloo":      # ranks sharing cuda:0 (RCCL refuses two ranks on one device)
     local = 0
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
 else:
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-from halo2_gpu_specific_amd import circuits, prover
+from halo2_gpu_specific_amd import prover
 from halo2_gpu_specific_amd.rng import ProverRng
+from test_gpu_plonk import _multi_rank_case
 D = prover.Device(local)
-k = %d
+which, k = %r, %d
 params = prover.Params.unsafe_setup(D, k, %d)
-adv, fixed, copies = circuits.mini_plonk_synthesize(k)
-pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
-proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(9))
+cs, adv, fixed, copies, inst = _multi_rank_case(which, k)
+pk = prover.keygen(D, params, cs, fixed, copies)
+assert D.row_range(1 << k) != (0, 1 << k)            # the O(n) passes really are range-sharded
+proof = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), False, instances=inst)
 sys.stdout.write("PROOF " + proof.hex() + "\n")
+gwc = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), True, instances=inst)
+sys.stdout.write("GWC " + gwc.hex() + "\n")
 # OS-entropy blinding: rank 0's key is broadcast (ProverRng.shared), so the ranks still agree on every byte
-secure = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng())
+secure = prover.create_proof_ext(D, params, pk, adv, ProverRng(), False, instances=inst)
 sys.stdout.write("SECURE " + secure.hex() + "\n")
 sys.stdout.flush()
 dist.barrier()

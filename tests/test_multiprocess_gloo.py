@@ -95,3 +95,87 @@ def test_split_msm_allgather_world2(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert "OK %d" % rank in out
+
+
+RANGE_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from halo2_gpu_specific_amd import parallel
+from h2util import Oracle, R_MOD, from_mont, to_mont, fr_mont
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+oracle = Oracle.get()
+n = 1 << 10
+lo, hi = parallel.msm_split_range(n, world, rank)
+m = hi - lo
+# ---- Kate division by ranges: the oracle's kate_division (arithmetic.rs:754-773) of the whole vector against the local
+# division of every range + the carry from one all-gather of a field element per rank (Device.kate_division_ranges)
+a = oracle.random_fr(31, n)
+b = from_mont(oracle.random_fr(32, 1))[0]
+want = np.zeros((n - 1, 4), dtype=np.uint64)
+oracle.lib.oracle_kate_division(a.ctypes.data, n, fr_mont(b).ctypes.data, want.ctypes.data)
+want = from_mont(want) + [0]
+local = np.zeros((m - 1, 4), dtype=np.uint64)
+oracle.lib.oracle_kate_division(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(b).ctypes.data, local.ctypes.data)
+local = from_mont(local) + [0]
+part = np.zeros(4, dtype=np.uint64)
+oracle.lib.oracle_eval_polynomial(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(b).ctypes.data, part.ctypes.data)
+gathered = parallel.allgather_scalars([from_mont(part.reshape(1, 4))[0]])
+carry = parallel.kate_carries([g[0] for g in gathered], b, m)[rank]
+got = [(local[t] + carry * pow(b, m - 1 - t, R_MOD)) %% R_MOD for t in range(m)]
+assert got == want[lo:hi], "rank %%d: Kate division by ranges differs" %% rank
+# ---- evaluation by ranges (Device.eval_polynomial_ranges): p(x) = sum_r x^(lo_r) p_r(x)
+x = from_mont(oracle.random_fr(33, 1))[0]
+full = np.zeros(4, dtype=np.uint64)
+oracle.lib.oracle_eval_polynomial(a.ctypes.data, n, fr_mont(x).ctypes.data, full.ctypes.data)
+oracle.lib.oracle_eval_polynomial(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(x).ctypes.data, part.ctypes.data)
+parts = parallel.allgather_scalars([from_mont(part.reshape(1, 4))[0]])
+assert parallel.combine_range_evals([g[0] for g in parts], x, m) == from_mont(full.reshape(1, 4))[0]
+# ---- grand product / grand sum by ranges (Device.prefix_scan): z[0] = init, z[i] = z[i-1] * f[i-1]
+f = from_mont(a)
+init = 12345
+for product in (True, False):
+    z = [init]
+    for i in range(n - 1):
+        z.append(z[-1] * f[i] %% R_MOD if product else (z[-1] + f[i]) %% R_MOD)
+    tot = 1 if product else 0
+    loc = []
+    for t in range(m):
+        loc.append(tot)
+        tot = tot * f[lo + t] %% R_MOD if product else (tot + f[lo + t]) %% R_MOD
+    carries = parallel.scan_carries([g[0] for g in parallel.allgather_scalars([tot])], init, product)
+    mine = [(carries[rank] * v if product else carries[rank] + v) %% R_MOD for v in loc]
+    assert mine == z[lo:hi], "rank %%d: scan by ranges differs" %% rank
+# ---- the per-coset quotients scattered as coefficient ranges (parallel.scatter_cosets): owner j %% shards sends rank r its range
+c = 3
+shards, owned = parallel.coset_plan(c, world, rank)
+polys = [oracle.random_fr(50 + j, n) for j in range(c)]
+mine = {j: torch.from_numpy(polys[j].view(np.int64).copy()) for j in owned}
+out = parallel.scatter_cosets(mine, c, shards, lo, hi)
+for j in range(c):
+    assert np.array_equal(out[j][lo:hi].numpy().view(np.uint64), polys[j][lo:hi]), (rank, j)
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_range_sharded_scans_division_evaluation_world2(tmp_path):
+    """the O(n) passes of one proof on every rank's row / coefficient range -- the carries of
+    prefix scans and Kate divisions and the partial Horner values cross in one all-gather of a field element per rank, the
+    per-coset quotients are scattered as ranges; here the local pieces come from the CPU oracle, on the GPU box from the
+    kernels (tests/test_gpu_plonk.py::test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(RANGE_WORKER % {"root": ROOT})
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "OK %d" % rank in out
