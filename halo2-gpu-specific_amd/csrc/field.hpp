@@ -20,6 +20,8 @@ namespace h2 {
 struct FrParams {
     static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t MOD2[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
+                                         0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};  // 2r (the lazy domain of the NTT)
     static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
     static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
                                         0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod r
@@ -30,6 +32,8 @@ struct FrParams {
 struct FqParams {
     static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t MOD2[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
+                                         0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};  // 2q
     static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
     static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
                                         0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod q
@@ -233,6 +237,143 @@ H2_DEV Fp<P> fp_dbl(const Fp<P>& a) {
     return fp_add(a, a);
 }
 
+// ---- the lazy domain of the NTT stage loops ------------------------------------------------------------------
+// Between the load of a pass and its store nothing needs to be a canonical residue: 4p < 2^256, so values may stay anywhere
+// below 4p.  A product by a (canonical) twiddle accepts ANY 256-bit first operand and returns a value below 2p without its
+// final conditional subtraction (fp_mul_wide); a butterfly's sum of two values below 2p is a bare 8-limb addition, its
+// difference u - t + 2p a subtraction and an addition (both below 4p); only a value that takes the NON-multiplied branch
+// of the next butterfly is brought below 2p first (fp_lazy_red2p).  Per radix-2 butterfly that is ~40 instructions next
+// to the product instead of 48 + the product's own 16-24 of reduction; the canonical residue comes back once, at the
+// pass's store (fp_lazy_canon).  Same field elements as the canonical arithmetic at every point (mod p), hence bit-exact
+// results after the final canonicalisation.
+// a < 4p  ->  a or a - 2p, below 2p
+template <class P>
+H2_DEV Fp<P> fp_lazy_red2p(const Fp<P>& a) {
+#ifdef H2_ASM_CHAINS
+    Fp<P> t, r;
+    uint64_t cb;
+    t.l[0] = sub_co(a.l[0], P::MOD2[0], cb);
+#pragma unroll
+    for (int i = 1; i < 8; i++) t.l[i] = subb_co(a.l[i], P::MOD2[i], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(t.l[i], a.l[i], cb);  // borrow: a < 2p, keep a
+    return r;
+#else
+    Fp<P> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - P::MOD2[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+    return r;
+#endif
+}
+// a + b as 256-bit integers (a, b < 2p -> below 4p: no carry out)
+template <class P>
+H2_DEV Fp<P> fp_lazy_add(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> s;
+#ifdef H2_ASM_CHAINS
+    uint64_t c;
+    s.l[0] = add_co(a.l[0], b.l[0], c);
+#pragma unroll
+    for (int i = 1; i < 8; i++) s.l[i] = addc_co(a.l[i], b.l[i], c);
+#else
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        s.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+#endif
+    return s;
+}
+// a - b + 2p as 256-bit integers (a, b < 2p -> in (0, 4p)); the two chains run one limb apart
+template <class P>
+H2_DEV Fp<P> fp_lazy_sub(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> d, u;
+#ifdef H2_ASM_CHAINS
+    uint64_t ca, cb;
+    d.l[0] = sub_co(a.l[0], b.l[0], ca);
+    d.l[1] = subb_co(a.l[1], b.l[1], ca);
+    u.l[0] = add_co(d.l[0], P::MOD2[0], cb);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        d.l[i] = subb_co(a.l[i], b.l[i], ca);
+        u.l[i - 1] = addc_co(d.l[i - 1], P::MOD2[i - 1], cb);
+    }
+    u.l[7] = addc_co(d.l[7], P::MOD2[7], cb);
+#else
+    uint64_t borrow = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.l[i] + P::MOD2[i];
+        u.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+#endif
+    return u;  // the wrap of d and the carry out of u cancel: the true value is below 2^256
+}
+// (a + b) brought below 2p / (a - b) brought into [0, 2p)   (a, b < 2p): fp_add / fp_sub with the modulus 2p
+template <class P>
+H2_DEV Fp<P> fp_lazy_add_red(const Fp<P>& a, const Fp<P>& b) {
+#ifdef H2_ASM_CHAINS
+    Fp<P> s, t, r;
+    uint64_t ca, cb;
+    s.l[0] = add_co(a.l[0], b.l[0], ca);
+    s.l[1] = addc_co(a.l[1], b.l[1], ca);
+    t.l[0] = sub_co(s.l[0], P::MOD2[0], cb);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        s.l[i] = addc_co(a.l[i], b.l[i], ca);
+        t.l[i - 1] = subb_co(s.l[i - 1], P::MOD2[i - 1], cb);
+    }
+    t.l[7] = subb_co(s.l[7], P::MOD2[7], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(t.l[i], s.l[i], cb);  // borrow: s < 2p, keep s
+    return r;
+#else
+    return fp_lazy_red2p(fp_lazy_add(a, b));
+#endif
+}
+template <class P>
+H2_DEV Fp<P> fp_lazy_sub_red(const Fp<P>& a, const Fp<P>& b) {
+#ifdef H2_ASM_CHAINS
+    Fp<P> d, u, r;
+    uint64_t ca, cb;
+    d.l[0] = sub_co(a.l[0], b.l[0], ca);
+    d.l[1] = subb_co(a.l[1], b.l[1], ca);
+    u.l[0] = add_co(d.l[0], P::MOD2[0], cb);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        d.l[i] = subb_co(a.l[i], b.l[i], ca);
+        u.l[i - 1] = addc_co(d.l[i - 1], P::MOD2[i - 1], cb);
+    }
+    u.l[7] = addc_co(d.l[7], P::MOD2[7], cb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = sel_co(d.l[i], u.l[i], ca);  // borrow: a < b, take d + 2p
+    return r;
+#else
+    return fp_lazy_red2p(fp_lazy_sub(a, b));
+#endif
+}
+// a < 4p -> the canonical residue
+template <class P>
+H2_DEV Fp<P> fp_lazy_canon(const Fp<P>& a) {
+    return fp_reduce_once(fp_lazy_red2p(a));
+}
+
 // acc(96 bit = lo64 : hi32) += a * b.
 // v_mad_u64_u32 D, carry(SGPR pair), a, b, D ; v_addc_co_u32 hi, carry, hi, 0, carry
 H2_DEV void mad_acc(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
@@ -256,6 +397,8 @@ template <class P>
 __device__ __forceinline__ Fp<P> fp_sqr_dev(const Fp<P>& a);  // a * a with 36 operand products instead of 64
 template <class P>
 __device__ __forceinline__ Fp<P> fp_mul2_dev(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d);  // a b + c d, ONE reduction
+template <class P>
+__device__ __forceinline__ Fp<P> fp_mul_wide_dev(const Fp<P>& a, const Fp<P>& b);  // a < 2^256, b canonical -> < 2p, unreduced
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
 #define H2_MAD_FREE_V(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y))
 #define H2_MAD_FREE_S(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y))
@@ -390,6 +533,36 @@ H2_DEV Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>
     return fp_mul2_dev(a, b, c, d);
 #else
     return fp_add(fp_mul(a, b), fp_mul(c, d));
+#endif
+}
+
+// a * b / 2^256 mod p for ANY 256-bit a and a canonical b, as a value below 2p (not reduced further): the product of the
+// lazy domain above.  Host / portable path: the generic column scan (its carries are complete) without the final step.
+template <class P>
+H2_DEV Fp<P> fp_mul_wide(const Fp<P>& a, const Fp<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
+    return fp_mul_wide_dev(a, b);
+#else
+    Fp<P> r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    uint32_t m[8];
+    for (int i = 0; i < 8; i++) {
+        for (int j = 0; j <= i; j++) mad_acc(lo, hi, a.l[j], b.l[i - j]);
+        for (int j = 0; j < i; j++) mad_acc(lo, hi, m[j], P::MOD[i - j]);
+        m[i] = (uint32_t)lo * P::INV;
+        mad_acc(lo, hi, m[i], P::MOD[0]);
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    for (int i = 8; i < 16; i++) {
+        for (int j = i - 7; j < 8; j++) mad_acc(lo, hi, a.l[j], b.l[i - j]);
+        for (int j = i - 7; j < 8; j++) mad_acc(lo, hi, m[j], P::MOD[i - j]);
+        r.l[i - 8] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    return r;
 #endif
 }
 

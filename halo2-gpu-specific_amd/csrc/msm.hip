@@ -948,7 +948,8 @@ __global__ void __launch_bounds__(256) k_copy_hot(const uint2* tmp, const uint32
 }
 
 // ---------------------------------------------------------------- k_acc_slice (hot loop)
-__global__ void __launch_bounds__(256) k_acc_slice(const Affine* bases, const Affine* block_sums, const uint32_t* sorted,
+template <int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_acc_slice(const Affine* bases, const Affine* block_sums, const uint32_t* sorted,
                                                    const uint32_t* starts, uint32_t nbt, uint32_t log_s, XYZZ* partials) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // slice index
     const uint32_t total = starts[nbt];                        // number of (non-zero digit) entries
@@ -1763,8 +1764,14 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
                 hipLaunchKernelGGL(k_copy_hot, dim3(1024), dim3(256), 0, stream, tmp, pbase,
                                    (col * s.Wc + s.W) << s.hi_bits, sorted);
     unsigned nslices = (unsigned)(((s.entries + (1u << s.log_s) - 1) >> s.log_s));
-    hipLaunchKernelGGL(k_acc_slice, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
-                       (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
+    // waves per SIMD the accumulation is compiled for: 4 (110 VGPRs, no spills) or 5 (96 VGPRs, 14 spilled): H2_MSM_ACC_WAVES
+    static const int acc_waves = getenv("H2_MSM_ACC_WAVES") ? atoi(getenv("H2_MSM_ACC_WAVES")) : 4;
+    if (acc_waves == 5)
+        hipLaunchKernelGGL(k_acc_slice<5>, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
+                           (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
+    else
+        hipLaunchKernelGGL(k_acc_slice<4>, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
+                           (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
     static const uint32_t lane_from = getenv("H2_MSM_FINISH_LANE_LOG") ? 1u << atoi(getenv("H2_MSM_FINISH_LANE_LOG")) : 1u << 21;
     if (s.nbt >= lane_from)
         hipLaunchKernelGGL(k_finish_lane, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,

@@ -134,8 +134,15 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const 
     hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-template <bool RADIX4>
-__global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
+// LAZY: the lazy domain of field.hpp -- values below 4p in LDS and between the passes, products by fp_mul_wide (no final
+// subtraction), bare additions; canonical residues come back at the last pass's store.  Same field elements, same output.
+template <bool RADIX4, bool LAZY>
+__global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
+    // x * w for a canonical twiddle w: canonical arithmetic, or any x < 2^256 -> a value below 2p
+    auto tmul = [](const Fr& x, const Fr& w) -> Fr {
+        if constexpr (LAZY) return fp_mul_wide(x, w);
+        else return fp_mul(x, w);
+    };
     const uint32_t B = a.B, R = 1u << B, log_c = a.log_c, C = 1u << log_c;
     uint4* t_lo = h2_smem;                  // R*C low halves
     uint4* t_hi = t_lo + (R << log_c);      // R*C high halves
@@ -201,7 +208,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                 Fr w;
 #pragma unroll
                 for (int l = 0; l < 8; l++) w.l[l] = m == 1 ? a.pre3[1].l[l] : a.pre3[2].l[l];
-                if (m != 0) x[q] = fp_mul(x[q], w);
+                if (m != 0) x[q] = tmul(x[q], w);
             }
         }
         if (a.nprev != 0) {
@@ -214,13 +221,13 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                     for (uint32_t q = 0; q < 2; q++)
                         w[q] = fp_load(a.tw_direct + (a.direct_kmajor ? ((Kk[q0 + q] << B) | rho[q0 + q]) : ((rho[q0 + q] << a.t_log) | Kk[q0 + q])));
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = fp_mul(x[q0 + q], w[q]);
+                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], w[q]);
                 }
             } else if (a.log_n <= LO_BITS) {
 #pragma unroll
                 for (uint32_t q = 0; q < NE; q++) {
                     const uint32_t ex = (uint32_t)(((uint64_t)rho[q] * Kk[q]) << a.s_log) & n_mask;
-                    x[q] = fp_mul(x[q], fp_load(a.tw_lo + ex));
+                    x[q] = tmul(x[q], fp_load(a.tw_lo + ex));
                 }
             } else {
                 // two at a time: 16 twiddle halves in flight next to the elements keeps the kernel within 128 VGPRs
@@ -234,7 +241,7 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                         wh[q] = fp_load(a.tw_hi + (ex >> LO_BITS));
                     }
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = fp_mul(x[q0 + q], fp_mul(wl[q], wh[q]));
+                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], fp_mul(wl[q], wh[q]));
                 }
             }
         }
@@ -283,18 +290,40 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                 Fr x0 = lds_get(t_lo, t_hi, i0), x1 = lds_get(t_lo, t_hi, i0 + step);
                 Fr x2 = lds_get(t_lo, t_hi, i0 + 2 * step), x3 = lds_get(t_lo, t_hi, i0 + 3 * step);
                 const bool unit = s == 0 || (by_r && r == 0);  // the twiddles of index r are 1 (wave-uniform test)
-                if (!unit) {
-                    const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
-                    x1 = fp_mul(x1, wa);
-                    x3 = fp_mul(x3, wa);
+                if constexpr (LAZY) {
+                    // rows below 4p: the operands of a product go in as they are, the others are brought below 2p
+                    x0 = fp_lazy_red2p(x0);
+                    x2 = fp_lazy_red2p(x2);
+                    if (!unit) {
+                        const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
+                        x1 = fp_mul_wide(x1, wa);
+                        x3 = fp_mul_wide(x3, wa);
+                    } else {
+                        x1 = fp_lazy_red2p(x1);
+                        x3 = fp_lazy_red2p(x3);
+                    }
+                    const Fr y0 = fp_lazy_add_red(x0, x1), y1 = fp_lazy_sub_red(x0, x1);   // below 2p: added to next
+                    Fr y2 = fp_lazy_add(x2, x3), y3 = fp_lazy_sub(x2, x3);                  // below 4p: multiplied next
+                    y2 = unit ? fp_lazy_red2p(y2) : fp_mul_wide(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
+                    y3 = fp_mul_wide(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
+                    lds_put(t_lo, t_hi, i0, fp_lazy_add(y0, y2));
+                    lds_put(t_lo, t_hi, i0 + 2 * step, fp_lazy_sub(y0, y2));
+                    lds_put(t_lo, t_hi, i0 + step, fp_lazy_add(y1, y3));
+                    lds_put(t_lo, t_hi, i0 + 3 * step, fp_lazy_sub(y1, y3));
+                } else {
+                    if (!unit) {
+                        const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
+                        x1 = fp_mul(x1, wa);
+                        x3 = fp_mul(x3, wa);
+                    }
+                    Fr y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
+                    if (!unit) y2 = fp_mul(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
+                    y3 = fp_mul(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
+                    lds_put(t_lo, t_hi, i0, fp_add(y0, y2));
+                    lds_put(t_lo, t_hi, i0 + 2 * step, fp_sub(y0, y2));
+                    lds_put(t_lo, t_hi, i0 + step, fp_add(y1, y3));
+                    lds_put(t_lo, t_hi, i0 + 3 * step, fp_sub(y1, y3));
                 }
-                Fr y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
-                if (!unit) y2 = fp_mul(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
-                y3 = fp_mul(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
-                lds_put(t_lo, t_hi, i0, fp_add(y0, y2));
-                lds_put(t_lo, t_hi, i0 + 2 * step, fp_sub(y0, y2));
-                lds_put(t_lo, t_hi, i0 + step, fp_add(y1, y3));
-                lds_put(t_lo, t_hi, i0 + 3 * step, fp_sub(y1, y3));
             }
             __syncthreads();
         }
@@ -321,9 +350,17 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
             }
             const uint32_t iu = (i << log_c) + c, iv = ((i + h) << log_c) + c;
             Fr u = lds_get(t_lo, t_hi, iu), v = lds_get(t_lo, t_hi, iv);
-            if (s != 0 && !(by_r && r == 0)) v = fp_mul(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
-            lds_put(t_lo, t_hi, iu, fp_add(u, v));
-            lds_put(t_lo, t_hi, iv, fp_sub(u, v));
+            const bool skip = s == 0 || (by_r && r == 0);
+            if constexpr (LAZY) {
+                u = fp_lazy_red2p(u);
+                v = skip ? fp_lazy_red2p(v) : fp_mul_wide(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
+                lds_put(t_lo, t_hi, iu, fp_lazy_add(u, v));
+                lds_put(t_lo, t_hi, iv, fp_lazy_sub(u, v));
+            } else {
+                if (!skip) v = fp_mul(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
+                lds_put(t_lo, t_hi, iu, fp_add(u, v));
+                lds_put(t_lo, t_hi, iv, fp_sub(u, v));
+            }
         }
         __syncthreads();
     }
@@ -349,8 +386,14 @@ __global__ void __launch_bounds__(512) k_ntt_pass(PassArgs a) {
                 Fr w;
 #pragma unroll
                 for (int l = 0; l < 8; l++) w.l[l] = m == 0 ? a.post3[0].l[l] : (m == 1 ? a.post3[1].l[l] : a.post3[2].l[l]);
-                y[q] = fp_mul(y[q], w);
+                if constexpr (LAZY) y[q] = fp_reduce_once(fp_mul_wide(y[q], w));
+                else y[q] = fp_mul(y[q], w);
             }
+        } else if (LAZY && a.is_last) {
+            // the transform's output is canonical (an intermediate pass hands its values on below 4p: the next pass's
+            // inter-pass twiddle product takes them as they are)
+#pragma unroll
+            for (uint32_t q = 0; q < NE; q++) y[q] = fp_lazy_canon(y[q]);
         }
 #pragma unroll
         for (uint32_t q = 0; q < NE; q++)
@@ -600,7 +643,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         a.in = src; a.out = dst; a.tw_bfly = pl->tables; a.tw_lo = pl->tw_lo; a.tw_hi = pl->tw_hi;
         set_scale3(a, pre3, post3); a.log_n = 0; a.B = 0; a.s_log = 0; a.t_log = 0; a.nprev = 0;
         a.is_last = 1; a.in_len = in_len; a.log_c = 0;
-        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
+        hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
         H2_HIP(hipGetLastError());
         return;
     }
@@ -746,15 +789,24 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                 static bool raised[64] = {};  // per device
                 const int dev = ctx->device;
                 if (dev < 0 || dev >= 64 || !raised[dev]) {
-                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     if (dev >= 0 && dev < 64) raised[dev] = true;
                 }
             }
-            if (a.radix4)
-                hipLaunchKernelGGL(k_ntt_pass<true>, dim3(ntiles), dim3(threads), lds, stream, a);
+            // the lazy domain (field.hpp: values below 4p between load and store, products without their final subtraction);
+            // H2_NTT_LAZY=0 keeps canonical residues everywhere -- same output either way
+            static const bool lazy = !(getenv("H2_NTT_LAZY") && atoi(getenv("H2_NTT_LAZY")) == 0);
+            if (a.radix4 && lazy)
+                hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(ntiles), dim3(threads), lds, stream, a);
+            else if (a.radix4)
+                hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(ntiles), dim3(threads), lds, stream, a);
+            else if (lazy)
+                hipLaunchKernelGGL((k_ntt_pass<false, true>), dim3(ntiles), dim3(threads), lds, stream, a);
             else
-                hipLaunchKernelGGL(k_ntt_pass<false>, dim3(ntiles), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(ntiles), dim3(threads), lds, stream, a);
         }
         if (used_table) {  // launched: an eviction from here on synchronises the device before it frees
             std::lock_guard<std::mutex> g(g_tab_mu);

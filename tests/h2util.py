@@ -194,6 +194,9 @@ class Oracle:
         L.oracle_domain_new.restype = i32
         L.oracle_extended_to_coeff.restype = sz
         self.threads = os.cpu_count() or 1
+        # libgomp does not scale the rayon-shaped FFT recursion past ~32 threads (65 s per 2^24 transform on 256 hardware
+        # threads against 1.6 s on 32: DESIGN.md section 5); the MSM restatement does scale
+        self.fft_threads = min(self.threads, 32)
 
     # ---- thin pythonic wrappers (arrays are uint64, C-contiguous) ----
     def op2(self, name, a, b):
@@ -218,7 +221,7 @@ class Oracle:
 
     def best_fft(self, a, omega, log_n, threads=None):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
-        self.lib.oracle_best_fft(_ptr(a), _ptr(np.ascontiguousarray(omega)), log_n, threads or self.threads)
+        self.lib.oracle_best_fft(_ptr(a), _ptr(np.ascontiguousarray(omega)), log_n, threads or self.fft_threads)
         return a
 
     def best_fft_st(self, a, omega, log_n):
@@ -229,7 +232,7 @@ class Oracle:
     def ifft(self, a, omega_inv, log_n, divisor, threads=None):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
         self.lib.oracle_ifft(
-            _ptr(a), _ptr(np.ascontiguousarray(omega_inv)), log_n, _ptr(np.ascontiguousarray(divisor)), threads or self.threads
+            _ptr(a), _ptr(np.ascontiguousarray(omega_inv)), log_n, _ptr(np.ascontiguousarray(divisor)), threads or self.fft_threads
         )
         return a
 
@@ -278,7 +281,7 @@ class Oracle:
         out = np.zeros((1 << d.extended_k, 4), dtype=np.uint64)
         self.lib.oracle_coeff_to_extended(
             _ptr(a), d.k, d.extended_k, _ptr(d.fr("g_coset")), _ptr(d.fr("g_coset_inv")), _ptr(d.fr("extended_omega")),
-            _ptr(out), threads or self.threads,
+            _ptr(out), threads or self.fft_threads,
         )
         return out
 
@@ -286,7 +289,7 @@ class Oracle:
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
         m = self.lib.oracle_extended_to_coeff(
             _ptr(a), d.k, d.extended_k, d.quotient_poly_degree, _ptr(d.fr("g_coset")), _ptr(d.fr("g_coset_inv")),
-            _ptr(d.fr("extended_omega_inv")), _ptr(d.fr("extended_ifft_divisor")), threads or self.threads,
+            _ptr(d.fr("extended_omega_inv")), _ptr(d.fr("extended_ifft_divisor")), threads or self.fft_threads,
         )
         return a[:m].copy()
 

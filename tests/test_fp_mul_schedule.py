@@ -23,8 +23,9 @@ def limbs(v):
     return [(v >> (32 * i)) & M32 for i in range(8)]
 
 
-def run(lines, p, ops):
-    """ops: {"a": int, "b": int, ...}; returns the schedule's result after the final conditional subtraction"""
+def run(lines, p, ops, raw=False):
+    """ops: {"a": int, "b": int, ...}; returns the schedule's result after the final conditional subtraction (`raw`: before
+    it -- the wide schedule returns its value unreduced)"""
     mod = limbs(p)
     inv = (-pow(p, -1, 1 << 32)) & M32
     env = {k: limbs(v) for k, v in ops.items()}
@@ -80,6 +81,8 @@ def run(lines, p, ops):
         assert ln.startswith("//") or not ln, "unparsed schedule line: " + ln
     out = sum(x << (32 * i) for i, x in enumerate(r))
     assert out < 2 * p, "schedule result not below 2p"
+    if raw:
+        return out
     return out - p if out >= p else out
 
 
@@ -115,3 +118,20 @@ def test_two_products_one_reduction_schedule(name):
     for i, (a, b) in enumerate(pairs):
         c, d = pairs[(7 * i + 3) % len(pairs)]
         assert run(dual, p, {"a": a, "b": b, "c": c, "d": d}) == (a * b + c * d) * rinv % p
+
+
+@pytest.mark.parametrize("name", sorted(gen.FIELDS))
+def test_wide_operand_schedule_of_the_lazy_ntt_domain(name):
+    """fp_mul_wide: the first operand is ANY 256-bit value (the NTT stage loops keep values below 4p), the second a
+    canonical residue; the unreduced result is below 2p and congruent to a * b / 2^256"""
+    p = gen.FIELDS[name]
+    rinv = pow(1 << 256, -1, p)
+    rng = random.Random(3)
+    wide, stats = gen.schedule(p, wide=True)
+    assert stats["free"] + stats["set"] + stats["acc"] == 128      # 64 operand + 56 reduction + 8 m_i p_0 terms
+    firsts = [0, 1, p, 2 * p - 1, 2 * p, 4 * p - 1, (1 << 256) - 1, (1 << 255), 3 * p + 12345] + [rng.randrange(1 << 256) for _ in range(300)]
+    seconds = [0, 1, p - 1, p - 2, (1 << 253), (p + 1) // 2] + [rng.randrange(p) for _ in range(40)]
+    for i, a in enumerate(firsts):
+        for b in (seconds if i < 9 else seconds[i % 7::7]):
+            out = run(wide, p, {"a": a, "b": b}, raw=True)
+            assert out < 2 * p and out % p == a * b * rinv % p, (hex(a), hex(b))

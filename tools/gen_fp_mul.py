@@ -27,14 +27,17 @@ W = (1 << 32) - 1
 TOP = (1 << 30) - 1  # limb 7 of an input < 2^254
 
 
-def schedule(p, square=False, dual=False):
-    """dual: a * b + c * d under ONE reduction (twice the operand products per column, the same 64 reduction products).
+def schedule(p, square=False, dual=False, wide=False):
+    """wide: the first operand may be ANY 256-bit value (the lazily reduced values of the NTT stage loops, below 4p), the
+    second a canonical residue; the result (a b + m p) / 2^256 < (2^256 p + 2^256 p) / 2^256 = 2p is NOT reduced further.
+    dual: a * b + c * d under ONE reduction (twice the operand products per column, the same 64 reduction products).
     square: a * a with every cross product a_j a_k (j < k) taken once against the DOUBLED operand -- row j multiplies
     a_j by the limbs of 2 * (a >> 32 (j + 1)) << 32 (j + 1): d_k = limb k of 2a for k >= j + 2 and f_j = d_(j+1) with
     bit 0 cleared (that bit is the top bit of a_j, which belongs to 2 a_j, not to the tail) -- 8 squares + 28 cross
     products instead of 64."""
     mod = [(p >> (32 * i)) & W for i in range(8)]
     amax = [W] * 7 + [TOP]
+    awide = [W] * 8 if wide else amax  # limbs of the first operand
     dmax = [W] * 7 + [2 * TOP + 1]  # limbs of 2a: 2a < 2^255
     lines, stats = [], {"free": 0, "set": 0, "acc": 0}
     carry_in = 0  # exact upper bound of the accumulator at the start of the column
@@ -43,7 +46,7 @@ def schedule(p, square=False, dual=False):
         for j in range(max(0, i - 7), min(i, 7) + 1):
             k = i - j
             if not square:
-                terms.append((amax[j] * amax[k], "a.l[%d]" % j, "b.l[%d]" % k, "v"))
+                terms.append((awide[j] * amax[k], "a.l[%d]" % j, "b.l[%d]" % k, "v"))
                 if dual:
                     terms.append((amax[j] * amax[k], "c.l[%d]" % j, "d.l[%d]" % k, "v"))
             elif k == j:
@@ -148,6 +151,22 @@ def main():
         out.append("}")
         out.append("")
         print(name, "dual", stats)
+        # (any 256-bit value) * (canonical residue) -> a value below 2p, no final subtraction: the NTT stage loops
+        lines, stats = schedule(p, wide=True)
+        out.append("// %s wide: first operand < 2^256, second < 2^254; result < 2p, NOT reduced: %d bare multiply-adds, %d carry-setting, %d carry-accumulating"
+                   % (name, stats["free"], stats["set"], stats["acc"]))
+        out.append("template <>")
+        out.append("__device__ __forceinline__ Fp<%s> fp_mul_wide_dev<%s>(const Fp<%s>& a, const Fp<%s>& b) {" % ((name,) * 4))
+        out.append("    using P = %s;" % name)
+        out.append("    Fp<P> r;")
+        out.append("    uint64_t lo = 0, cy;")
+        out.append("    uint32_t hi = 0;")
+        out += lines
+        out.append("    (void)cy; (void)hi;")
+        out.append("    return r;  // (a b + m p) / 2^256 < 2p: the word above r.l[7] is zero")
+        out.append("}")
+        out.append("")
+        print(name, "wide", stats)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "halo2-gpu-specific_amd", "csrc", "fp_mul_gen.hpp")
     with open(path, "w") as f:
         f.write("\n".join(out))
