@@ -134,12 +134,34 @@ class ConstraintSystem:
         self.minimum_degree = None
         self.lookup_tracer = {}      # table identifier -> (name, [table Expression], [(name, [input Expression])])
         self.shuffle_tracer = []     # (name, [input Expression], [shuffle Expression])
+        self.range_checks = []       # (origin advice index, sort advice index, min, max, step): range_check::Argument
 
     # -- columns ------------------------------------------------------------------------------------------
     def advice_column(self):
         self.num_advice += 1
         self.num_advice_queries.append(0)
         return ("advice", self.num_advice - 1)
+
+    def advice_column_range(self, l_0, l_active, l_last_active, vmin, vmax, step):
+        """`advice_column_range` (plonk/circuit.rs:1769-1826; plonk/range_check.rs): an advice column whose values lie in
+        {vmin, ..., vmax}.  Allocates the column (`origin`) and a companion (`sort`) that holds the same multiset in
+        ascending order, a gate -- sort starts at vmin (l_0), ends at vmax (l_last_active), and neighbouring rows differ
+        by 0 .. step -- and a shuffle between the two; the prover completes the witness (prover.complete_range_check_witness:
+        every value of the range is planted in the unused cells, `sort` is the counting sort).  Returns `origin`."""
+        assert step != 0 and vmin <= vmax
+        origin, sort = self.advice_column(), self.advice_column()
+        q0 = self.query_fixed(l_0)
+        first = q0 * (Constant(vmin % R_MOD) - self.query_advice(sort))
+        ql = self.query_fixed(l_last_active)
+        last = ql * (Constant(vmax % R_MOD) - self.query_advice(sort))
+        acc = None
+        for i in range(step + 1):
+            e = self.query_advice(sort, 1) - self.query_advice(sort) - Constant((step - i) % R_MOD)
+            acc = e if acc is None else acc * e
+        self.create_gate("range check", [first, last, (self.query_fixed(l_active) - self.query_fixed(l_last_active)) * acc])
+        self.shuffle("range check col", [(self.query_advice(origin), self.query_advice(sort))])
+        self.range_checks.append((origin[1], sort[1], vmin, vmax, step))
+        return origin
 
     def fixed_column(self):
         self.num_fixed += 1

@@ -93,3 +93,31 @@ def wide_synthesize(k, quads=16, alloc=None):
     r = np.arange(m, dtype=np.int64)
     copies = np.stack([np.zeros(m, dtype=np.int64), r, np.ones(m, dtype=np.int64), r + 1], axis=1)
     return adv, fixed, copies
+
+
+def range_check(vmin=0, vmax=0xFFFF, step=2):
+    """`configure` of examples/range-check.rs:38-60: fixed l_0, l_active, l_last_active and one `advice_column_range`
+    over 0 ..= 65535 with step 2 (a second advice column, a degree-4 gate and a shuffle come with it)"""
+    cs = ConstraintSystem("range-check-%d-%d-%d" % (vmin, vmax, step))
+    l_0, l_active, l_last_active = cs.fixed_column(), cs.fixed_column(), cs.fixed_column()
+    cs.advice_column_range(l_0, l_active, l_last_active, vmin, vmax, step)
+    cs.chunk_shuffles()
+    return cs
+
+
+def range_check_synthesize(k, seed=0x52414E4745, alloc=None, vmin=0, vmax=0xFFFF, count=0xFFFF):
+    """`synthesize` of examples/range-check.rs:62-93: l_0 = 1 on row 0, l_last_active = 1 on the last usable row,
+    l_active = 1 on every usable row; 65535 random 16-bit values on the rows 0 .. 65534 of the range-checked column (a
+    seeded generator instead of OsRng).  The `sort` column and the planted range values are the prover's job
+    (prover.complete_range_check_witness, as in the reference's create_proof).  Returns (advice[2], fixed[3], copies)."""
+    n = 1 << k
+    usable = n - 6
+    assert count < usable, "the witness does not fit 2^%d rows" % k
+    adv = alloc(2, n) if alloc else [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    fixed[0][0, 0] = 1
+    fixed[1][:usable, 0] = 1
+    fixed[2][usable - 1, 0] = 1
+    rng = np.random.Generator(np.random.PCG64(seed))
+    adv[0][:count, 0] = rng.integers(vmin, vmax + 1, size=count, dtype=np.uint64)
+    return adv, fixed, np.zeros((0, 4), dtype=np.int64)

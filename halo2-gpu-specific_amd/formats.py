@@ -213,7 +213,9 @@ def cs_store(cs):
         for _, inputs, shuffle in group:
             _expressions_store(cs, inputs, out)
             _expressions_store(cs, shuffle, out)
-    out.append(_u32(0))                                         # range_check arguments: none
+    out.append(_u32(len(cs.range_checks)))                      # range_check arguments (helpers.rs:444-451)
+    for origin, sort, vmin, vmax, step in cs.range_checks:
+        out += [_u32(origin), _u32(sort), _u32(vmin), _u32(vmax), _u32(step)]
     out.append(_u32(0))                                         # named_advices
     out.append(_u32(len(cs.gates)))
     for _, polys in cs.gates:
@@ -229,7 +231,7 @@ def cs_store(cs):
 
 def cs_fetch(r, name="circuit"):
     """read_cs (helpers.rs:458-561) -> ConstraintSystem; refuses what this prover does not implement (selectors that
-    were not compiled away, constant columns, range-check arguments)"""
+    were not compiled away, constant columns)"""
     cs = circuit.ConstraintSystem(name)
     cs.num_advice, cs.num_instance = r.u32(), r.u32()
     if r.u32():
@@ -256,8 +258,8 @@ def cs_fetch(r, name="circuit"):
             inputs = _expressions_fetch(r)
             group.append(("", inputs, _expressions_fetch(r)))
         cs.shuffles.append(group)
-    if r.u32():
-        raise IOError("circuit data with range-check arguments")
+    for _ in range(r.u32()):                                    # range_check arguments (helpers.rs:520-536)
+        cs.range_checks.append((r.u32(), r.u32(), r.u32(), r.u32(), r.u32()))
     for _ in range(r.u32()):                                    # named_advices: (String, u32)
         r.take(r.u32())
         r.u32()

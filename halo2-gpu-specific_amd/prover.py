@@ -1038,6 +1038,45 @@ def _jit_function(pk):
     return jit.load(path)
 
 
+def range_check_assigner(vmin, vmax, step):
+    """RangeCheckRelAssigner (plonk/range_check.rs:40-63): vmin, vmin + step, ... capped at vmax, then vmax itself"""
+    out, cur = [], vmin
+    while True:
+        value = cur
+        if value < vmax:
+            cur = min(value + step, vmax)
+            out.append(value)
+        elif cur == vmax:
+            cur += step
+            out.append(value)
+        else:
+            return out
+
+
+def complete_range_check_witness(cs, n, advice, first_unassigned=None):
+    """What `create_proof` does to the witness of every `advice_column_range` after synthesis (plonk/prover.rs:1699-1783):
+    every value of the range is planted in the unused cells of the range-checked column from the last usable row upwards
+    (so that its sorted copy starts at min, ends at max and has no gap wider than step), and the companion column
+    becomes the counting sort of the usable rows (`sort`, prover.rs:164-200).  In place on canonical (n, 4) u64 host
+    columns, like the reference; `first_unassigned[column]` (optional) is checked as the reference asserts it."""
+    usable = n - (cs.blinding_factors() + 1)
+    last_active = usable - 1
+    for origin, sort, vmin, vmax, step in cs.range_checks:
+        col = advice[origin]
+        values = np.array(range_check_assigner(vmin, vmax, step), dtype=np.uint64)
+        lo = last_active + 1 - len(values)
+        if lo < 0 or (first_unassigned is not None and first_unassigned.get(origin, 0) > lo):
+            raise ValueError("range check: the range does not fit the unused cells of its column")
+        col[lo:last_active + 1, 0] = values[::-1]
+        col[lo:last_active + 1, 1:] = 0
+        body = col[:usable]
+        if body[:, 1:].any() or int(body[:, 0].max()) > vmax or int(body[:, 0].min()) < vmin:
+            raise ValueError("range check: a value of the column lies outside its range")   # the reference's HashMap lookup panics
+        advice[sort][:usable, 0] = np.sort(body[:, 0], kind="stable")
+        advice[sort][:usable, 1:] = 0
+    return advice
+
+
 def create_proof_from_witness(device, params, pk, witness, rng, use_gwc=True, timings=None, instances=()):
     """plonk/prover.rs:916-1500: the advice columns come from a witness file (formats.witness_fetch), i.e. in the
     in-memory Montgomery representation"""
@@ -1081,6 +1120,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     ncirc, nadv = len(advice_sets), len(advice_sets[0])
     if any(len(a) != nadv for a in advice_sets):
         raise ValueError("every circuit instance needs the same advice columns")
+    if cs.range_checks:
+        if montgomery:
+            raise ValueError("range-check witness completion needs canonical advice columns")
+        for a in advice_sets:                                 # prover.rs:1699-1783: plant the range, sort the companion
+            complete_range_check_witness(cs, n, a)
     advice = [col for a in advice_sets for col in a]          # circuit-major: the order every phase walks them in
 
     # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------

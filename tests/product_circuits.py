@@ -12,6 +12,10 @@ def wide_cs(quads):
     return circuits.wide(quads)
 
 
+def range_check_cs(vmin, vmax, step):
+    return circuits.range_check(vmin, vmax, step)
+
+
 def rot_gate_cs():
     """the product-side description of ref_plonk.RotGate"""
     cs = hc.ConstraintSystem("rot-gate")

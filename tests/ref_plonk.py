@@ -255,6 +255,8 @@ class MiniPlonk:
         make = {"mini-plonk": pc.mini_plonk_cs, "rot-gate": pc.rot_gate_cs, "lookup-shuffle": pc.lookup_shuffle_cs}
         if cls.name.startswith("wide-"):
             return cs_store(pc.wide_cs(int(cls.name[5:])))
+        if cls.name.startswith("range-check-"):
+            return cs_store(pc.range_check_cs(*[int(v) for v in cls.name.split("-")[2:]]))
         return cs_store(make[cls.name]())
 
     @staticmethod
@@ -432,6 +434,52 @@ def wide_class(quads):
             return adv, fixed, copies
 
     return Wide
+
+
+def range_check_class(vmin, vmax, step):
+    """the big-integer twin of halo2-gpu-specific_amd.circuits.range_check (examples/range-check.rs; the gate and the
+    shuffle of `advice_column_range`, plonk/circuit.rs:1769-1826): advice origin (0) and sort (1); fixed l_0, l_active,
+    l_last_active; no permutation columns"""
+
+    class RangeCheck:
+        num_advice, num_fixed = 2, 3
+        advice_queries = [(1, 0), (1, 1), (0, 0)]
+        fixed_queries = [(0, 0), (2, 0), (1, 0)]
+        perm_columns = []
+        degree = max(3, step + 2)
+        blinding_factors = 5
+        name = "range-check-%d-%d-%d" % (vmin, vmax, step)
+        cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
+
+        @staticmethod
+        def gates(adv, fix):
+            cur, nxt = adv(1, 0), adv(1, 1)
+            prod = 1
+            for i in range(step + 1):
+                prod = prod * (nxt - cur - (step - i)) % R
+            return [fix(0, 0) * (vmin - cur) % R, fix(2, 0) * (vmax - cur) % R, (fix(1, 0) - fix(2, 0)) * prod % R]
+
+        shuffles = [[(lambda adv, fix, inst: [adv(0, 0)], lambda adv, fix, inst: [adv(1, 0)])]]
+
+        @staticmethod
+        def complete(k, origin):
+            """plant the range from the last usable row upwards, sort (plonk/prover.rs:1699-1783)"""
+            n = 1 << k
+            usable = n - 6
+            origin = list(origin)
+            planted, cur = [], vmin
+            while cur < vmax:
+                planted.append(cur)
+                cur = min(cur + step, vmax)
+            planted.append(vmax)
+            row = usable - 1
+            for v in planted:
+                origin[row] = v
+                row -= 1
+            assert row >= 0
+            return [origin, sorted(origin[:usable]) + [0] * (n - usable)]
+
+    return RangeCheck
 
 
 def permutation_mapping(ncols, n, copies):

@@ -1,0 +1,98 @@
+"""The range-check argument of the reference (`advice_column_range`, plonk/circuit.rs:1769-1826; plonk/range_check.rs;
+witness completion in create_proof, plonk/prover.rs:1699-1783; examples/range-check.rs) on the device prover: the
+circuit of the example proves to the bytes of its big-integer twin at small sizes, at the example's own size (k = 18,
+0 ..= 65535, step 2) the proof is accepted by the twin's verifier, and a CircuitData file carrying the argument rebuilds
+the same key."""
+import numpy as np
+import pytest
+
+import ref_plonk as rp
+from test_gpu_plonk import srs
+from test_plonk_host import S_TRAPDOOR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    from halo2_gpu_specific_amd import prover
+
+    return prover.Device()
+
+
+@pytest.mark.parametrize("k,vmax,step,count", [(7, 30, 2, 60), (8, 61, 4, 150), (9, 100, 1, 300)])
+def test_range_check_proof_bytes_match_big_integer_prover(oracle, device, k, vmax, step, count):
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    cs = circuits.range_check(0, vmax, step)
+    W = rp.range_check_class(0, vmax, step)
+    adv, fixed, copies = circuits.range_check_synthesize(k, vmin=0, vmax=vmax, count=count)
+    radv = W.complete(k, [int(v) for v in adv[0][:, 0]])
+    rfixed = [[int(v) for v in f[:, 0]] for f in fixed]
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    rpk = rp.keygen(W, k, S_TRAPDOOR, rfixed, [])
+    assert pk.transcript_repr == rpk.transcript_repr and pk.fixed_commitments == rpk.fixed_commitments
+    for seed, use_gwc in ((1, False), (2, True)):
+        mine = [c.copy() for c in adv]
+        proof = prover.create_proof_ext(device, params, pk, mine, ProverRng(seed), use_gwc)
+        # the prover completed the witness in place as the reference does: planted range, sorted companion
+        assert [int(v) for v in mine[0][:(1 << k) - 6, 0]] == radv[0][:(1 << k) - 6]
+        assert [int(v) for v in mine[1][:(1 << k) - 6, 0]] == radv[1][:(1 << k) - 6]
+        want = rp.create_proof(rpk, radv, ProverRng(seed), use_gwc=use_gwc)
+        first = next((i for i in range(min(len(proof), len(want))) if proof[i] != want[i]), None)
+        assert len(proof) == len(want) and first is None, "differs from the big-integer prover at byte %s" % first
+        assert rp.verify_proof(rpk, proof, use_gwc=use_gwc)
+    bad = [c.copy() for c in adv]
+    bad[0][3, 0] = np.uint64(vmax + 9)
+    with pytest.raises(ValueError):                       # the reference's `sort` panics on a value outside the range
+        prover.create_proof_ext(device, params, pk, bad, ProverRng(1), False)
+    # ... and a proof over a forged companion column (the value smuggled past the completion step) is rejected
+    forged = W.complete(k, [int(v) for v in bad[0][:, 0]])
+    assert not rp.verify_proof(rpk, rp.create_proof(rpk, forged, ProverRng(1)))
+
+
+def test_range_check_example_size(oracle, device):
+    """examples/range-check.rs: k = 18, one column range-checked into 0 ..= 65535 with step 2, 65535 random values"""
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 18
+    cs = circuits.range_check()
+    adv, fixed, copies = circuits.range_check_synthesize(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    proof = prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(7))
+    usable = (1 << k) - 6
+    assert np.array_equal(np.sort(adv[0][:usable, 0]), adv[1][:usable, 0]) and int(adv[1][usable - 1, 0]) == 0xFFFF
+    vk = rp.Keys()
+    vk.cs, vk.dom, vk.s = rp.range_check_class(0, 0xFFFF, 2), rp.Domain(k, cs.degree()), S_TRAPDOOR
+    vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+    assert rp.verify_proof(vk, proof)
+    flipped = bytearray(proof)
+    flipped[40] ^= 1
+    try:
+        assert not rp.verify_proof(vk, bytes(flipped))
+    except AssertionError:
+        pass                                               # a flipped byte may also stop being a curve point
+
+
+def test_circuit_data_with_a_range_check_argument(oracle, device, tmp_path):
+    """CircuitData::{write, read} (plonk.rs:126-204; write_cs / read_cs carry the range-check relations,
+    helpers.rs:444-451, 520-536): a key rebuilt from the file knows the argument and proves to the same bytes"""
+    from halo2_gpu_specific_amd import circuits, formats, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 8
+    cs = circuits.range_check(0, 61, 4)
+    adv, fixed, copies = circuits.range_check_synthesize(k, vmin=0, vmax=61, count=150)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    want = prover.create_proof_with_shplonk(device, params, pk, [c.copy() for c in adv], ProverRng(3))
+    path = tmp_path / "range.circuit.data"
+    formats.circuit_data_write(path, device, params, pk)
+    info = formats.circuit_data_read(path)
+    assert info["cs"].range_checks == [(0, 1, 0, 61, 4)]
+    pk2 = prover.keygen_from_info(device, params, info)
+    assert prover.create_proof_with_shplonk(device, params, pk2, [c.copy() for c in adv], ProverRng(3)) == want

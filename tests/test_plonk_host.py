@@ -533,7 +533,7 @@ def test_constraint_system_bytes_follow_write_cs():
     assert formats.cs_store(cs) == want
 
 
-@pytest.mark.parametrize("make", [circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs])
+@pytest.mark.parametrize("make", [circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs, circuits.range_check, lambda: circuits.wide(2)])
 def test_constraint_system_round_trip(make):
     from halo2_gpu_specific_amd import formats
 
@@ -545,6 +545,7 @@ def test_constraint_system_round_trip(make):
     back.set_minimum_degree(cs.degree())
     assert formats.cs_store(back) == raw
     assert (back.degree(), back.blinding_factors(), back.perm_columns) == (cs.degree(), cs.blinding_factors(), cs.perm_columns)
+    assert back.range_checks == cs.range_checks
     # the prover sees the same program: Evaluator::new on the fetched system
     g0, parts0, lk0, sh0 = hc.compile_evaluator(cs)
     g1, parts1, lk1, sh1 = hc.compile_evaluator(back)
@@ -601,3 +602,36 @@ def test_circuit_data_file_round_trip(tmp_path):
     with pytest.raises(IOError):
         open(path, "wb").write(raw[:-3])
         formats.circuit_data_read(path)
+
+
+def test_range_check_argument_front_end_and_witness_completion():
+    """`advice_column_range` (plonk/circuit.rs:1769-1826) and the witness completion of create_proof
+    (plonk/prover.rs:1699-1783, `sort` :164-200) on the host: the constraint system of examples/range-check.rs, the
+    RangeCheckRelAssigner sequence, the planted range and the sorted companion against the big-integer twin, and the
+    twin's prover / verifier accept the completed witness and reject a value outside the range"""
+    import ref_plonk as rp
+    from halo2_gpu_specific_amd import prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    cs = circuits.range_check()
+    assert (cs.degree(), cs.blinding_factors(), cs.num_advice, cs.num_fixed) == (4, 5, 2, 3)
+    assert cs.advice_queries == [(1, 0), (1, 1), (0, 0)] and cs.fixed_queries == [(0, 0), (2, 0), (1, 0)]
+    assert cs.perm_columns == [] and len(cs.shuffles) == 1 and cs.range_checks == [(0, 1, 0, 0xFFFF, 2)]
+    seq = prover.range_check_assigner(0, 0xFFFF, 2)
+    assert len(seq) == 32769 and seq[:2] == [0, 2] and seq[-2:] == [65534, 65535]
+    assert prover.range_check_assigner(3, 10, 4) == [3, 7, 10] and prover.range_check_assigner(5, 5, 1) == [5]
+    k, vmax, step = 7, 30, 2
+    small = circuits.range_check(0, vmax, step)
+    adv, fixed, _ = circuits.range_check_synthesize(k, vmin=0, vmax=vmax, count=60)
+    W = rp.range_check_class(0, vmax, step)
+    want = W.complete(k, [int(v) for v in adv[0][:, 0]])
+    prover.complete_range_check_witness(small, 1 << k, adv)
+    assert [int(v) for v in adv[0][:, 0]] == want[0] and [int(v) for v in adv[1][:, 0]] == want[1]
+    rpk = rp.keygen(W, k, S_TRAPDOOR, [[int(v) for v in f[:, 0]] for f in fixed], [])
+    assert rp.verify_proof(rpk, rp.create_proof(rpk, want, ProverRng(1)))
+    bad = [c.copy() for c in adv]
+    bad[0][2, 0] = vmax + 1
+    with pytest.raises(ValueError):
+        prover.complete_range_check_witness(small, 1 << k, bad)
+    with pytest.raises(ValueError):                         # the range does not fit the unused cells
+        prover.complete_range_check_witness(small, 1 << k, [c.copy() for c in adv], first_unassigned={0: 120})

@@ -25,5 +25,17 @@ rocprofv3 --kernel-trace --stats -d "$out/p_k22" -o k22 -- python3 tools/prove_b
 python3 tools/rocprof_summary.py "$(find "$out/p_k22" -name '*results.db' | head -1)" "$out/create_proof_k22_kernel_stats.txt" > /dev/null
 python3 tools/prove_bench.py 24 3 > "$out/create_proof_k24.txt" 2>&1
 python3 tools/lookup_bench.py 18 > "$out/lookup_k18.txt" 2>&1
+# round 3: the NTT leg alone under the profiler (the k_ntt_pass average the roofline quotes), its SQ counters, the wide circuit
+rocprofv3 --kernel-trace --stats -d "$out/p_ntt" -o ntt -- python3 bench.py --steps 20 --warmup 5 --no-msm --prove-k 0 --k24 0 --wide-k 0 --no-cpu-baseline > "$out/bench_ntt_only_line.json" 2>/dev/null
+python3 tools/rocprof_summary.py "$(find "$out/p_ntt" -name '*results.db' | head -1)" "$out/bench_ntt_only_kernel_stats.txt" > /dev/null
+bash tools/experiments/nttpmc.sh > "$out/ntt_pass_pmc.txt" 2>&1
+rm -rf gpurun_out/pmc1 gpurun_out/pmc2
+python3 tools/wide_bench.py 20 16 > "$out/create_proof_wide_k20.txt" 2>&1
+python3 tools/wide_bench.py 20 16 coset >> "$out/create_proof_wide_k20.txt" 2>&1
+python3 tools/wide_bench.py 22 16 > "$out/create_proof_wide_k22.txt" 2>&1
+python3 tools/wide_bench.py 22 16 coset >> "$out/create_proof_wide_k22.txt" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/p_wide" -o w -- python3 tools/wide_bench.py 20 16 > /dev/null 2>&1
+python3 tools/rocprof_summary.py "$(find "$out/p_wide" -name '*results.db' | head -1)" "$out/create_proof_wide_k20_kernel_stats.txt" > /dev/null
+python3 tools/rocprof_timeline.py "$(find "$out/p_wide" -name '*results.db' | head -1)" 1200 0 > "$out/create_proof_wide_k20_timeline.txt"
 rm -rf "$out"/p_*
 ls -la "$out"
