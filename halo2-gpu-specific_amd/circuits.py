@@ -121,3 +121,68 @@ def range_check_synthesize(k, seed=0x52414E4745, alloc=None, vmin=0, vmax=0xFFFF
     rng = np.random.Generator(np.random.PCG64(seed))
     adv[0][:count, 0] = rng.integers(vmin, vmax + 1, size=count, dtype=np.uint64)
     return adv, fixed, np.zeros((0, 4), dtype=np.int64)
+
+
+def lookup_api():
+    """`configure` of examples/lookup_api.rs:53-103: three advice columns, fixed s_0, s_1 and a table column; one gate
+    s_0 * (input_0 - input_1); three `lookup`s into the table column (input_0, 2 * input_1, input_2) and one `lookup_any`
+    of (s_0 input_0, s_1 input_0) into (s_0 input_1, s_1 input_2) -- the traced front end: lookups into one table are
+    collected and packed into input sets by the chunking pass (ConstraintSystem.chunk_lookups)"""
+    cs = ConstraintSystem("lookup-api")
+    i0, i1, i2 = cs.advice_column(), cs.advice_column(), cs.advice_column()
+    s0, s1 = cs.fixed_column(), cs.fixed_column()
+    table = cs.fixed_column()
+    cs.create_gate("", [cs.query_fixed(s0) * (cs.query_advice(i0) * 1 - cs.query_advice(i1))])
+    cs.lookup("table1", [(cs.query_advice(i0), cs.query_fixed(table))])
+    cs.lookup("table2", [(cs.query_advice(i1) * 2, cs.query_fixed(table))])
+    cs.lookup("table3", [(cs.query_advice(i2), cs.query_fixed(table))])
+    q0, q1, q2 = cs.query_advice(i0), cs.query_advice(i1), cs.query_advice(i2)
+    f0, f1 = cs.query_fixed(s0), cs.query_fixed(s1)
+    cs.lookup("any", [(f0 * q0, f0 * q1), (f1 * q0, f1 * q2)])
+    cs.chunk_lookups()
+    return cs
+
+
+def lookup_api_synthesize(k):
+    """`synthesize` of examples/lookup_api.rs:121-160; the table column holds 0 .. 8 and its default (0) below"""
+    n = 1 << k
+    adv = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    adv[0][0, 0], adv[1][0, 0], fixed[0][0, 0] = 1, 1, 1
+    adv[0][1, 0], adv[2][1, 0], fixed[1][1, 0] = 3, 3, 1
+    fixed[2][:9, 0] = np.arange(9, dtype=np.uint64)
+    return adv, fixed, np.zeros((0, 4), dtype=np.int64)
+
+
+def shuffle_api_group():
+    """`configure` of examples/shuffle_api_group.rs:53-113: five input and five shuffle advice columns, two + two fixed
+    selectors; a gate s_in0 * (in0 - in1); four traced `shuffle`s (a two-column one, a plain one, one under one selector
+    pair, one under two) that the chunking pass groups by degree (ConstraintSystem.chunk_shuffles)"""
+    cs = ConstraintSystem("shuffle-api-group")
+    ins = [cs.advice_column() for _ in range(5)]
+    shs = [cs.advice_column() for _ in range(5)]
+    s_in = [cs.fixed_column() for _ in range(2)]
+    s_sh = [cs.fixed_column() for _ in range(2)]
+    cs.create_gate("", [cs.query_fixed(s_in[0]) * (cs.query_advice(ins[0]) - cs.query_advice(ins[1]))])
+    cs.shuffle("shuffle1", [(cs.query_advice(ins[0]), cs.query_advice(shs[0])), (cs.query_advice(ins[1]), cs.query_advice(shs[1]))])
+    cs.shuffle("shuffle2", [(cs.query_advice(ins[2]), cs.query_advice(shs[2]))])
+    cs.shuffle("shuffle3", [(cs.query_advice(ins[3]) * cs.query_fixed(s_in[0]), cs.query_advice(shs[3]) * cs.query_fixed(s_sh[0]))])
+    cs.shuffle("shuffle4", [(cs.query_advice(ins[4]) * cs.query_fixed(s_in[0]) * cs.query_fixed(s_in[1]),
+                             cs.query_advice(shs[4]) * cs.query_fixed(s_sh[0]) * cs.query_fixed(s_sh[1]))])
+    cs.chunk_shuffles()
+    return cs
+
+
+def shuffle_api_group_synthesize(k, input0=(1, 2, 4, 1), input1=(4, 1, 1, 2)):
+    """`synthesize` of examples/shuffle_api_group.rs:143-176: every input column holds `input0`, every shuffle column
+    `input1` (a permutation of it), the selectors are 1 on those rows"""
+    n = 1 << k
+    adv = [np.zeros((n, 4), dtype=np.uint64) for _ in range(10)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(4)]
+    m = len(input0)
+    for c in range(5):
+        adv[c][:m, 0] = np.array(input0, dtype=np.uint64)
+        adv[5 + c][:m, 0] = np.array(input1, dtype=np.uint64)
+    for f in fixed:
+        f[:m, 0] = 1
+    return adv, fixed, np.zeros((0, 4), dtype=np.int64)

@@ -16,6 +16,14 @@ def range_check_cs(vmin, vmax, step):
     return circuits.range_check(vmin, vmax, step)
 
 
+def lookup_api_cs():
+    return circuits.lookup_api()
+
+
+def shuffle_api_group_cs():
+    return circuits.shuffle_api_group()
+
+
 def rot_gate_cs():
     """the product-side description of ref_plonk.RotGate"""
     cs = hc.ConstraintSystem("rot-gate")
