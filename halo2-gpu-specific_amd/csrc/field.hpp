@@ -566,18 +566,21 @@ H2_DEV Fp<P> fp_mul_wide(const Fp<P>& a, const Fp<P>& b) {
 #endif
 }
 
+// The two conversions take RAW caller data (h2_batch_mont, the scalars of an MSM, point encodings): the wide-operand
+// product is correct for ANY 256-bit first operand -- a non-canonical input comes out as its residue -- where the
+// standard schedule's carry analysis assumes operands below 2^254.
 template <class P>
 H2_DEV Fp<P> fp_to_mont(const Fp<P>& canon) {
     Fp<P> rr;
 #pragma unroll
     for (int i = 0; i < 8; i++) rr.l[i] = P::RR[i];
-    return fp_mul(canon, rr);
+    return fp_reduce_once(fp_mul_wide(canon, rr));
 }
 template <class P>
 H2_DEV Fp<P> fp_from_mont(const Fp<P>& a) {
     Fp<P> one = fp_zero<P>();
     one.l[0] = 1;
-    return fp_mul(a, one);
+    return fp_reduce_once(fp_mul_wide(a, one));
 }
 
 // 1 / a in Montgomery form (a R -> a^-1 R; 0 -> 0) by Kaliski's almost-Montgomery inverse: a binary extended GCD on

@@ -115,7 +115,10 @@ int h2_msm_intt(uint64_t *scalars, const uint64_t *bases, size_t n, uint32_t max
                 const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n, uint64_t out_xyz[12]);
 
 /* ---- Montgomery conversion (host buffers) ------------------------------------------------ */
-/* gpu_mont / gpu_unmont: arithmetic.rs:263-306, :218-261 (kernels batch_mont / batch_unmont) */
+/* gpu_mont / gpu_unmont: arithmetic.rs:263-306, :218-261 (kernels batch_mont / batch_unmont).
+ * Input ranges: the conversions (and the scalars of every MSM, which are taken out of Montgomery form first) accept ANY
+ * 256-bit value and return / use its residue; every other entry point takes field elements as the reference holds them
+ * (canonical residues below the modulus, < 2^254: the multiplier's carry analysis relies on it). */
 int h2_batch_mont(uint64_t *a, size_t n);
 int h2_batch_unmont(uint64_t *a, size_t n);
 

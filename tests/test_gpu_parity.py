@@ -51,6 +51,29 @@ def test_batch_mont_unmont():
     assert np.array_equal(a, ints_to_arr(vals))
 
 
+def test_conversions_and_msm_scalars_accept_any_256_bit_value(oracle):
+    """the generated multiplier's carry analysis assumes operands below 2^254, so the entry points that take RAW
+    caller data -- h2_batch_mont / h2_batch_unmont and the scalars of an MSM -- go through the wide-operand product, which
+    is exact for any 256-bit first operand: a non-canonical input gives its residue, not a silently wrong value"""
+    vals = [R_MOD, R_MOD + 1, 2 * R_MOD - 1, 4 * R_MOD + 7, (1 << 256) - 1, (1 << 255) + 12345, (1 << 254), 5 * R_MOD + 3] + [
+        ((i * 0x9E3779B97F4A7C15F39CC0605CEDC834A1B2C3D4E5F60718) << 40) % (1 << 256) for i in range(1, 200)]
+    a = ints_to_arr(vals)
+    ar.gpu_mont(a)
+    assert from_mont(a) == [v % R_MOD for v in vals]
+    b = ints_to_arr(vals)
+    ar.gpu_unmont(b)
+    rinv = pow(1 << 256, -1, R_MOD)
+    assert [limb_int for limb_int in __import__("h2util").arr_to_ints(b)] == [v * rinv % R_MOD for v in vals]
+    # MSM with scalars whose Montgomery images are not canonical: s_i and s_i + r (as memory images) are the same scalar
+    n = 1 << 12
+    pts = oracle.random_g1(4242, n)
+    s = oracle.random_fr(4243, n)
+    want = _affine(oracle, oracle.best_multiexp(s, pts))
+    ints = __import__("h2util").arr_to_ints(s)
+    bumped = ints_to_arr([v + R_MOD * (1 + i % 4) if v + R_MOD * (1 + i % 4) < (1 << 256) else v for i, v in enumerate(ints)])
+    assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(bumped, pts, 254)) == want
+
+
 # ------------------------------------------------------------------ elementwise
 @pytest.mark.parametrize("size", [1, 7, 256, 1000, 1 << 14])
 def test_eval_ops(oracle, size):

@@ -1,7 +1,7 @@
 """Proof-level parity on the GPU: keygen + create_proof on the device-resident C ABI
 (halo2-gpu-specific_amd/prover.py) against the independent big-integer prover / verifier of ref_plonk.py on the
 same SRS trapdoor, witness and seeded blinding stream.  Small k: proof bytes identical.  Larger k: the proof is
-accepted by the reference verifier (the pairing check done with the setup trapdoor)."""
+accepted by the big-integer verifier (the pairing check done with the setup trapdoor)."""
 import os
 
 import numpy as np
@@ -45,7 +45,7 @@ CASES = [("mini", 4), ("mini", 6), ("mini", 9), ("rot", 5), ("rot", 8)]
 
 
 @pytest.mark.parametrize("which,k", CASES)
-def test_proof_bytes_match_reference_prover(oracle, device, which, k):
+def test_proof_bytes_match_big_integer_prover(oracle, device, which, k):
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
@@ -66,15 +66,15 @@ def test_proof_bytes_match_reference_prover(oracle, device, which, k):
         want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc)
         assert len(proof) == len(want)
         first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
-        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+        assert first is None, "proof differs from the big-integer prover at byte %d (field %d)" % (first, first // 32)
         assert rp.verify_proof(rpk, proof, use_gwc=use_gwc)
 
 
 @pytest.mark.parametrize("which,k", [("mini", 5), ("lookup", 6)])
-def test_several_circuit_instances_match_reference_prover(oracle, device, which, k):
+def test_several_circuit_instances_match_big_integer_prover(oracle, device, which, k):
     """`circuits: &[ConcreteCircuit]` (plonk/prover.rs:206-232): two (three) circuit instances in one proof -- the device
     prover runs every phase circuit by circuit and combines the per-circuit quotients by powers of y; bytes equal to the
-    reference prover's single Horner fold over all circuits, accepted by its verifier"""
+    big-integer prover's single Horner fold over all circuits, accepted by its verifier"""
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng
     from test_plonk_host import _second_lookup_shuffle_witness
@@ -98,7 +98,7 @@ def test_several_circuit_instances_match_reference_prover(oracle, device, which,
         want = rp.create_proof(rpk, advs, ProverRng(seed), use_gwc=use_gwc, instances=insts)
         assert len(proof) == len(want)
         first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
-        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+        assert first is None, "proof differs from the big-integer prover at byte %d (field %d)" % (first, first // 32)
         assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=insts, circuits=len(advs))
     # one circuit in the list form is the single-circuit proof
     one = prover.create_proof_ext(device, params, pk, [cols_to_arr(advs[0])], ProverRng(5), False, instances=[insts[0]])
@@ -132,7 +132,7 @@ def test_bad_witness_is_rejected(oracle, device):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("k", [16, int(os.environ.get("H2_TEST_PLONK_K", "22")), 24])
-def test_large_proof_is_accepted_by_reference_verifier(oracle, device, k):
+def test_large_proof_is_accepted_by_big_integer_verifier(oracle, device, k):
     """mini-PLONK at a size where the scans, the multi-pass NTTs and the two-level MSM sort all take their
     multi-workgroup paths, and at BASELINE config 4's full size (k = 22; most of its ~90 s is the oracle's
     `unsafe_setup` of the 2 x 2^22-point SRS on the host cores): checked by the verifier (gate / permutation
@@ -225,7 +225,7 @@ def test_range_split_msm_matches_full_k24(device):
 
 
 def test_proof_bytes_match_committed_hashes(oracle, device):
-    """tests/golden/proof_hash_kat.json (gen_proof_hash_golden.py: the big-integer reference prover run once, k = 10 ..
+    """tests/golden/proof_hash_kat.json (gen_proof_hash_golden.py: the big-integer big-integer prover run once, k = 10 ..
     18): the device prover reproduces the same proof BYTES -- verifier acceptance alone would not catch a
     wrong-but-valid blinding or ordering change at these sizes"""
     import hashlib
@@ -261,7 +261,7 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
     """the multi-GPU decomposition on one device: with force_cosets the quotient is evaluated coset by coset (n-point
     transforms with zeta := zeta w_ext^j, the inverse coset transform, the inverse-Vandermonde un-mixing of the pieces)
     instead of on the whole extended domain -- c = 2 (degree 3), 4 (degree 4) and 8 (degree 6) cosets; the proof bytes
-    must not change, and equal the reference prover's"""
+    must not change, and equal the big-integer prover's"""
     from halo2_gpu_specific_amd import circuits, prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
@@ -493,7 +493,7 @@ dist.destroy_process_group()
 def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
     """instance column + logup lookups (two input sets, a duplicated table row) + a shuffle group, end to end:
     multiplicities from the device hash table, grand sums / products from the scans, the lookup and shuffle terms of
-    the fused evaluate_h -- bytes equal to the reference prover's, SHPLONK and GWC"""
+    the fused evaluate_h -- bytes equal to the big-integer prover's, SHPLONK and GWC"""
     from halo2_gpu_specific_amd import prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
@@ -507,7 +507,7 @@ def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
         want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=inst)
         assert len(proof) == len(want)
         first = next((i for i in range(len(proof)) if proof[i] != want[i]), None)
-        assert first is None, "proof differs from the reference prover at byte %d (field %d)" % (first, first // 32)
+        assert first is None, "proof differs from the big-integer prover at byte %d (field %d)" % (first, first // 32)
         assert rp.verify_proof(rpk, proof, use_gwc=use_gwc, instances=inst)
     # a value missing from the table: the reference panics, the library reports it
     bad = [c[:] for c in adv]
@@ -523,7 +523,7 @@ def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
 
 def test_lookup_proof_at_a_multi_workgroup_size_is_accepted(oracle, device):
     """the lookup / shuffle / instance circuit at k = 12 (hash table, additive and multiplicative scans and the
-    logup kernels of evaluate_h beyond one workgroup), checked by the reference verifier on the device keygen's
+    logup kernels of evaluate_h beyond one workgroup), checked by the big-integer verifier on the device keygen's
     commitments"""
     from halo2_gpu_specific_amd import prover
     from halo2_gpu_specific_amd.rng import ProverRng
@@ -591,7 +591,7 @@ def test_params_file_and_witness_file_round_trip(oracle, device, tmp_path):
 
 
 def test_device_prover_reproduces_committed_proofs(oracle, device):
-    """the committed proof fixtures (tests/golden/proof_kat.json, made by the reference prover): same bytes from the
+    """the committed proof fixtures (tests/golden/proof_kat.json, made by the big-integer prover): same bytes from the
     device prover"""
     from h2util import load_golden
     from halo2_gpu_specific_amd import circuits, prover
@@ -672,7 +672,7 @@ def test_proof_parity_over_random_trapdoors_sizes_and_seeds(oracle, device):
 def test_circuit_data_file_to_proving_key(oracle, device, tmp_path):
     """N4: CircuitData::write -> read -> into_proving_key (plonk.rs:126-204): a key rebuilt from the file (constraint
     system, raw fixed columns, permutation mapping) proves to the same bytes as the key it was written from -- and as
-    the reference prover; a file whose columns disagree with its commitments is refused"""
+    the big-integer prover; a file whose columns disagree with its commitments is refused"""
     from halo2_gpu_specific_amd import formats, prover
     from halo2_gpu_specific_amd.rng import ProverRng
 

@@ -1,5 +1,5 @@
 """CPU tests of the proof-level test infrastructure and of the product's host logic around the device path:
-the big-integer reference prover is accepted by the (trapdoor) verifier, rejects tampering and a bad witness,
+the big-integer big-integer prover is accepted by the (trapdoor) verifier, rejects tampering and a bad witness,
 and the product's host-side pieces (transcript, permutation mapping, gate flattening, domain scalars, rng)
 agree with the independent restatements in ref_plonk.py."""
 import random
@@ -17,7 +17,7 @@ from product_circuits import lookup_shuffle_cs, rot_gate_cs  # noqa: E402,F401 (
 S_TRAPDOOR = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
 
 
-def test_reference_prover_with_lookups_shuffles_instances():
+def test_big_integer_prover_with_lookups_shuffles_instances():
     cs, k = rp.LookupShuffle, 5
     adv, fixed, copies, inst = cs.synthesize(k)
     pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
@@ -94,7 +94,7 @@ def test_lookup_shuffle_constraint_system_mirrors_reference():
 
 
 @pytest.mark.parametrize("cs,k", [(rp.MiniPlonk, 4), (rp.MiniPlonk, 5), (rp.RotGate, 5)])
-def test_reference_prover_is_accepted(cs, k):
+def test_big_integer_prover_is_accepted(cs, k):
     adv, fixed, copies = cs.synthesize(k)
     pk = rp.keygen(cs, k, S_TRAPDOOR, fixed, copies)
     proof = rp.create_proof(pk, adv, ProverRng(11))
@@ -121,7 +121,7 @@ def _second_lookup_shuffle_witness(k):
     return adv, [[43, 7]]
 
 
-def test_reference_prover_with_several_circuit_instances():
+def test_big_integer_prover_with_several_circuit_instances():
     """`circuits: &[ConcreteCircuit]` (plonk/prover.rs:206-232): every phase circuit by circuit, one quotient.  One
     circuit given in the list form is the single-circuit proof; two circuits verify with their own public inputs only."""
     cs, k = rp.MiniPlonk, 4
@@ -166,7 +166,7 @@ def test_pairing_self_checks():
     assert bp.pairing(bp.G2, None) == bp.ONE12
 
 
-def test_reference_verifier_with_the_real_pairing():
+def test_big_integer_verifier_with_the_real_pairing():
     """N3: the acceptance decision through e(L, [s]G2) = e(R, G2) instead of the trapdoor, both multiopen schemes"""
     adv, fixed, copies = rp.MiniPlonk.synthesize(4)
     pk = rp.keygen(rp.MiniPlonk, 4, S_TRAPDOOR, fixed, copies)
@@ -184,7 +184,7 @@ def test_reference_verifier_with_the_real_pairing():
     assert not rp.verify_proof(pk, rp.create_proof(pk, wrong, ProverRng(21)), pairing=True)
 
 
-def test_reference_verifier_rejects_bad_witness():
+def test_big_integer_verifier_rejects_bad_witness():
     adv, fixed, copies = rp.MiniPlonk.synthesize(4)
     pk = rp.keygen(rp.MiniPlonk, 4, S_TRAPDOOR, fixed, copies)
     bad = [c[:] for c in adv]
@@ -440,8 +440,8 @@ def _golden_case(case):
     return cs, syn[0], syn[1], syn[2], inst
 
 
-def test_reference_prover_reproduces_committed_proofs():
-    """tests/golden/proof_kat.json (gen_proof_golden.py): the reference prover's conventions are pinned byte for byte"""
+def test_big_integer_prover_reproduces_committed_proofs():
+    """tests/golden/proof_kat.json (gen_proof_golden.py): the big-integer prover's conventions are pinned byte for byte"""
     from h2util import load_golden
 
     for case in load_golden("proof_kat.json"):
