@@ -21,6 +21,11 @@
 #![cfg(feature = "hip")]
 #![allow(missing_docs)]
 
+// `hip` supplies the same items `cuda` does (the gpu_* functions, `Evaluator::evaluate_h` with the coefficient-form
+// signature): one accelerator back end per build.
+#[cfg(feature = "cuda")]
+compile_error!("the `hip` and `cuda` features are mutually exclusive");
+
 use crate::arithmetic::{CurveAffine, Group};
 use std::os::raw::{c_char, c_int, c_void};
 
