@@ -294,7 +294,7 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,which,k", [(2, "mini", 10), (2, "mini", 17), (4, "mini", 12), (8, "mini", 10), (2, "lookup", 9),
-                                           (4, "lookup", 8), (4, "wide", 9)])
+                                           (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8)])
 def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
     """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
@@ -419,7 +419,8 @@ which, k = %r, %d
 params = prover.Params.unsafe_setup(D, k, %d)
 cs, adv, fixed, copies, inst = _multi_rank_case(which, k)
 pk = prover.keygen(D, params, cs, fixed, copies)
-assert D.row_range(1 << k) != (0, 1 << k)            # the O(n) passes really are range-sharded
+# the O(n) passes really are range-sharded (a world that does not divide 2^k keeps them replicated: uneven MSM ranges only)
+assert (D.row_range(1 << k) != (0, 1 << k)) == ((1 << k) %% dist.get_world_size() == 0)
 proof = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), False, instances=inst)
 sys.stdout.write("PROOF " + proof.hex() + "\n")
 gwc = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), True, instances=inst)
