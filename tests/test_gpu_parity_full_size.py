@@ -7,7 +7,8 @@ form of the HIP path and not on sampled outputs:
 * the full 2^25-point NTT (the extended domain of a k = 24 proof, 8 + 8 + 9-bit passes) vs `oracle.best_fft`
   (arithmetic.rs:556-705), all 2^25 elements;
 * `coeff_to_extended` -> `divide_by_vanishing_poly` -> `extended_to_coeff` at k = 24 / extended 2^25
-  (poly/domain.rs:270-287, :354-373, :328-350), all elements.
+  (poly/domain.rs:270-287, :354-373, :328-350), all elements;
+* `gpu_multiexp_bound_and_fft` (commit_lagrange_and_ifft) at 2^24: the point and every coefficient.
 
 The oracle side costs ~10 s of host time per MSM / transform on the GPU box's cores."""
 import os
@@ -70,6 +71,17 @@ def test_msm_2p24_over_table_vs_oracle(oracle, bases24, columns24, want24):
             assert _affine(oracle, dev.msm(col, 254)) == want24[name], name
     finally:
         dev.forget()
+
+
+def test_commit_lagrange_and_ifft_2p24_vs_oracle(oracle, bases24, columns24, want24):
+    """gpu_multiexp_bound_and_fft (arithmetic.rs:375-410; Params::commit_lagrange_and_ifft, poly/commitment.rs:144-197) at
+    k = 24: one upload feeds the MSM and the in-place inverse transform; the point equals the oracle's MSM and every
+    coefficient the oracle's `ifft`"""
+    d, _ = oracle.domain(1, LOG_N)
+    vals = columns24["uniform"].copy()
+    got = ar.gpu_multiexp_bound_and_fft(vals, bases24, 254, d.fr("omega_inv"), d.fr("ifft_divisor"), LOG_N)
+    assert _affine(oracle, got) == want24["uniform"]
+    assert np.array_equal(vals, oracle.ifft(columns24["uniform"], d.fr("omega_inv"), LOG_N, d.fr("ifft_divisor"), threads=FFT_THREADS))
 
 
 def test_ntt_2p25_every_element_vs_oracle(oracle):
