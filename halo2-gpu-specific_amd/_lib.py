@@ -32,6 +32,16 @@ SYMBOLS = {
     "h2_device_count": (ctypes.c_int, []),
     "h2_last_error": (ctypes.c_char_p, []),
     "h2_synchronize": (ctypes.c_int, []),
+    "h2_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "h2_dev_alloc": (ctypes.c_int, [_sz, _vp]),
+    "h2_dev_free": (ctypes.c_int, [_vp]),
+    "h2_host_alloc_pinned": (ctypes.c_int, [_sz, _vp]),
+    "h2_host_free_pinned": (ctypes.c_int, [_vp]),
+    "h2_stream_create": (ctypes.c_int, [_vp]),
+    "h2_stream_destroy": (ctypes.c_int, [_vp]),
+    "h2_stream_synchronize": (ctypes.c_int, [_vp]),
+    "h2_dev_upload": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "h2_dev_download": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "h2_release_plans": (ctypes.c_int, []),
     "h2_set_table_budget": (ctypes.c_int, [_sz]),
     "h2_library_memory_bytes": (_sz, []),

@@ -81,6 +81,88 @@ int h2_synchronize(void) {
     });
 }
 
+// ------------------------------------------------------------------ device memory / streams for hosts without a HIP binding
+int h2_set_device(int device) {
+    return guarded([&] {
+        H2_HIP(hipSetDevice(device));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_alloc(size_t bytes, void** d_out) {
+    if (!d_out) return bad("h2_dev_alloc: null argument");
+    return guarded([&] {
+        *d_out = nullptr;
+        if (bytes) H2_HIP(hipMalloc(d_out, bytes));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_free(void* d_ptr) {
+    return guarded([&] {
+        if (d_ptr) H2_HIP(hipFree(d_ptr));
+        return (int)H2_OK;
+    });
+}
+
+int h2_host_alloc_pinned(size_t bytes, void** out) {
+    if (!out) return bad("h2_host_alloc_pinned: null argument");
+    return guarded([&] {
+        *out = nullptr;
+        if (bytes) H2_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+        return (int)H2_OK;
+    });
+}
+
+int h2_host_free_pinned(void* ptr) {
+    return guarded([&] {
+        if (ptr) H2_HIP(hipHostFree(ptr));
+        return (int)H2_OK;
+    });
+}
+
+int h2_stream_create(void** stream_out) {
+    if (!stream_out) return bad("h2_stream_create: null argument");
+    return guarded([&] {
+        hipStream_t s = nullptr;
+        H2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream_out = (void*)s;
+        return (int)H2_OK;
+    });
+}
+
+int h2_stream_destroy(void* stream) {
+    return guarded([&] {
+        if (stream) H2_HIP(hipStreamDestroy((hipStream_t)stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_stream_synchronize(void* stream) {
+    return guarded([&] {
+        H2_HIP(hipStreamSynchronize(pick_stream(current_ctx(), stream)));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_upload(void* d_dst, const void* src, size_t bytes, void* stream) {
+    if (bytes && (!d_dst || !src)) return bad("h2_dev_upload: null argument");
+    return guarded([&] {
+        if (bytes) H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, pick_stream(current_ctx(), stream)));
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_download(void* dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes && (!dst || !d_src)) return bad("h2_dev_download: null argument");
+    return guarded([&] {
+        hipStream_t s = pick_stream(current_ctx(), stream);
+        if (bytes) H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        H2_HIP(hipStreamSynchronize(s));
+        return (int)H2_OK;
+    });
+}
+
 // ------------------------------------------------------------------ library-held device memory
 int h2_release_plans(void) {
     return guarded([&] {

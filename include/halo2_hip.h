@@ -313,6 +313,24 @@ int h2_dev_evaluate_h(const h2_evalh_desc *desc, void *d_values, void *stream);
  * value parts / lookup and shuffle calculations as the descriptor it is used with.  The module stays loaded. */
 int h2_jit_load(const char *code_object_path, const char *kernel_name, const void **function_out);
 
+/* ---- device memory and streams for hosts without a HIP binding of their own ------------------
+ * The h2_dev_* entry points below take HIP device pointers and a HIP stream.  A host that already links HIP (or, like
+ * the Python harness, borrows torch's allocator and streams) passes its own; a host that does not -- the Rust side of
+ * INTEGRATION.md holding `Polynomial` values on the device between calls -- gets what it needs from these: plain
+ * hipMalloc / hipFree / hipMemcpyAsync / stream wrappers on the CURRENT device (h2_set_device; device 0 by default).
+ * h2_dev_download synchronises `stream` before it returns; h2_dev_upload is asynchronous for pinned host memory
+ * (h2_host_alloc_pinned) and otherwise returns when the source has been read. */
+int h2_set_device(int device);
+int h2_dev_alloc(size_t bytes, void **d_out);
+int h2_dev_free(void *d_ptr);
+int h2_host_alloc_pinned(size_t bytes, void **out);
+int h2_host_free_pinned(void *ptr);
+int h2_stream_create(void **stream_out);
+int h2_stream_destroy(void *stream);
+int h2_stream_synchronize(void *stream);
+int h2_dev_upload(void *d_dst, const void *src, size_t bytes, void *stream);
+int h2_dev_download(void *dst, const void *d_src, size_t bytes, void *stream);
+
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for
  * log_n <= 8).  Results land in d_a (in place from the caller's view).

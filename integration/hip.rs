@@ -248,6 +248,18 @@ extern "C" {
     pub fn h2_bases_register(bases: *const u64, n: usize) -> c_int;
     pub fn h2_bases_unregister(bases: *const u64) -> c_int;
     pub fn h2_g1_sum(points: *const c_void, count: usize, out_xyz: *mut c_void) -> c_int;
+    // device memory and streams for a host without a HIP binding (the device-resident h2_dev_* family of the header takes
+    // these pointers: what `Polynomial` would hold instead of a Vec once the data stays on the device)
+    pub fn h2_set_device(device: c_int) -> c_int;
+    pub fn h2_dev_alloc(bytes: usize, d_out: *mut *mut c_void) -> c_int;
+    pub fn h2_dev_free(d_ptr: *mut c_void) -> c_int;
+    pub fn h2_host_alloc_pinned(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn h2_host_free_pinned(ptr: *mut c_void) -> c_int;
+    pub fn h2_stream_create(stream_out: *mut *mut c_void) -> c_int;
+    pub fn h2_stream_destroy(stream: *mut c_void) -> c_int;
+    pub fn h2_stream_synchronize(stream: *mut c_void) -> c_int;
+    pub fn h2_dev_upload(d_dst: *mut c_void, src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn h2_dev_download(dst: *mut c_void, d_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
     // device memory the library keeps between calls (plans, last-pass twiddle tables): budget / release / report
     pub fn h2_release_plans() -> c_int;
     pub fn h2_set_table_budget(bytes: usize) -> c_int;

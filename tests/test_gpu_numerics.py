@@ -278,3 +278,41 @@ def test_max_scalar_bits_of_column_groups(oracle, n):
     assert L.h2_dev_max_scalar_bits(ptrs, count, n, words.data_ptr(), out, None) == 0, L.h2_last_error()
     assert list(out) == want
     assert L.h2_dev_max_scalar_bits(ptrs, 0, n, None, None, None) == 0
+
+
+def test_device_memory_and_stream_helpers_without_torch(oracle):
+    """h2_dev_alloc / h2_dev_upload / h2_stream_* / h2_dev_download: a host without a HIP binding of its own (the Rust side of
+    INTEGRATION.md) drives the device-resident API with these alone -- an NTT and its inverse on a library-allocated
+    buffer and a library-created stream, pinned staging memory, against the oracle"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from h2util import R_MOD, fr_mont
+
+    L = h2.lib()
+    log_n = 14
+    n = 1 << log_n
+    root = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+    omega = pow(root, 1 << (28 - log_n), R_MOD)
+    x = oracle.random_fr(321, n)
+    want = oracle.best_fft(x, fr_mont(omega), log_n)
+    nbytes = 32 * n
+    d_a, d_tmp, stream, pinned = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.h2_dev_alloc(nbytes, ctypes.byref(d_a)) == 0 and L.h2_dev_alloc(nbytes, ctypes.byref(d_tmp)) == 0
+    assert L.h2_stream_create(ctypes.byref(stream)) == 0 and L.h2_host_alloc_pinned(nbytes, ctypes.byref(pinned)) == 0
+    try:
+        ctypes.memmove(pinned, x.ctypes.data, nbytes)
+        assert L.h2_dev_upload(d_a, pinned, nbytes, stream) == 0
+        w = fr_mont(omega)
+        assert L.h2_dev_ntt(d_a, d_tmp, w.ctypes.data, log_n, stream) == 0, L.h2_last_error()
+        got = np.zeros_like(x)
+        assert L.h2_dev_download(got.ctypes.data, d_a, nbytes, stream) == 0
+        assert np.array_equal(got, want)
+        wi, ninv = fr_mont(pow(omega, -1, R_MOD)), fr_mont(pow(n, -1, R_MOD))
+        assert L.h2_dev_intt(d_a, d_tmp, wi.ctypes.data, ninv.ctypes.data, log_n, stream) == 0
+        assert L.h2_stream_synchronize(stream) == 0
+        assert L.h2_dev_download(got.ctypes.data, d_a, nbytes, None) == 0
+        assert np.array_equal(got, x)
+    finally:
+        assert L.h2_dev_free(d_a) == 0 and L.h2_dev_free(d_tmp) == 0 and L.h2_dev_free(None) == 0
+        assert L.h2_stream_destroy(stream) == 0 and L.h2_host_free_pinned(pinned) == 0
