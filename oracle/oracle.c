@@ -1137,3 +1137,239 @@ EXPORT void oracle_evaluate_h(const h2_evalh_desc *d, u256 *values) {
     free(sh_input);
     free(sh_table);
 }
+
+/* ------------------------------------------------------------------ */
+/* Prover-level passes (plonk/prover.rs:206-850 and the argument provers it calls): the loops between the transforms  */
+/* and the commitments, restated so that tests/oracle_prover.py can run a whole create_proof on the CPU -- the         */
+/* "proof bytes == CPU" check of BASELINE configs[3] at sizes the big-integer prover of tests/ref_plonk.py cannot      */
+/* reach, and the CPU create_proof baseline of bench.py.  Field arithmetic is exact: any evaluation order yields the   */
+/* same canonical residues, so the parallel splits below need not mirror rayon's.                                      */
+/* ------------------------------------------------------------------ */
+
+/* plonk/permutation/prover.rs:151-160 (z.push(last_z); for row in 1..n { tmp *= modified_values[row - 1] }) -- also the
+ * shuffle product (plonk/shuffle/prover.rs).  Serial, as the reference. */
+EXPORT void oracle_prefix_product(const u256 *f, size_t n, const u256 *init, u256 *z) {
+    u256 acc = *init;
+    for (size_t i = 0; i < n; i++) {
+        z[i] = acc;
+        if (i + 1 < n) fr_mul(&acc, &acc, &f[i]);
+    }
+}
+
+/* plonk/logup/prover.rs:353-367: the grand sum, z[0] = init, z[i] = z[i-1] + f[i-1] */
+EXPORT void oracle_prefix_sum(const u256 *f, size_t n, const u256 *init, u256 *z) {
+    u256 acc = *init;
+    for (size_t i = 0; i < n; i++) {
+        z[i] = acc;
+        if (i + 1 < n) fr_add(&acc, &acc, &f[i]);
+    }
+}
+
+/* poly/multiopen/gwc/prover.rs:39-56 (poly_batch = poly_batch * v + poly) and shplonk/prover.rs:110-209 with the powers
+ * of the challenge supplied: res[i] = sum_j coeffs[j] polys[j][i].  res may alias polys[0]. */
+EXPORT void oracle_lincomb(u256 *res, const u256 *const *polys, const u256 *coeffs, size_t count, size_t size) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < size; i++) {
+        u256 acc = fr_ZERO, t;
+        for (size_t j = 0; j < count; j++) {
+            fr_mul(&t, &polys[j][i], &coeffs[j]);
+            fr_add(&acc, &acc, &t);
+        }
+        res[i] = acc;
+    }
+}
+
+/* plonk/permutation/prover.rs:89-128, one column of a set:
+ *   den[i] (*)= beta sigma[i] + gamma + value[i]   (:95-103)
+ *   num[i] (*)= delta_pow omega^i beta + gamma + value[i]   (:110-123; deltaomega starts at delta_pow and is multiplied by
+ *   omega per row).  first != 0: the running products start from one. */
+EXPORT void oracle_permutation_terms(u256 *num, u256 *den, const u256 *value, const u256 *sigma, size_t n,
+                                     const u256 *beta, const u256 *gamma, const u256 *delta_pow, const u256 *omega,
+                                     int first) {
+#pragma omp parallel
+    {
+        int nt = omp_get_num_threads(), id = omp_get_thread_num();
+        size_t chunk = (n + nt - 1) / nt, lo = (size_t)id * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo < hi) {
+            u256 dw, t, u;
+            fr_pow_u64(&dw, omega, (uint64_t)lo);
+            fr_mul(&dw, &dw, delta_pow);
+            for (size_t i = lo; i < hi; i++) {
+                fr_mul(&t, beta, &sigma[i]);
+                fr_add(&t, &t, gamma);
+                fr_add(&t, &t, &value[i]);
+                fr_mul(&u, &dw, beta);
+                fr_add(&u, &u, gamma);
+                fr_add(&u, &u, &value[i]);
+                if (first) {
+                    den[i] = t;
+                    num[i] = u;
+                } else {
+                    fr_mul(&den[i], &den[i], &t);
+                    fr_mul(&num[i], &num[i], &u);
+                }
+                fr_mul(&dw, &dw, omega);
+            }
+        }
+    }
+}
+
+/* plonk/permutation/keygen.rs:197-238: sigma column j in Lagrange form, out[i] = DELTA^{map_col[i]} omega^{map_row[i]} */
+EXPORT void oracle_permutation_sigma(u256 *out, const uint32_t *map_col, const uint32_t *map_row, size_t n,
+                                     const u256 *delta, const u256 *omega) {
+    u256 *w = (u256 *)malloc((n ? n : 1) * sizeof(u256));
+    u256 acc = fr_ONE;
+    for (size_t i = 0; i < n; i++) { /* :203-211 omega_powers */
+        w[i] = acc;
+        fr_mul(&acc, &acc, omega);
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u256 d;
+        fr_pow_u64(&d, delta, map_col[i]);
+        fr_mul(&out[i], &d, &w[map_row[i]]);
+    }
+    free(w);
+}
+
+/* poly/domain.rs:382-398 generalised to any generator: a[i] *= g^i */
+EXPORT void oracle_distribute_powers(u256 *a, size_t n, const u256 *g) {
+#pragma omp parallel
+    {
+        int nt = omp_get_num_threads(), id = omp_get_thread_num();
+        size_t chunk = (n + nt - 1) / nt, lo = (size_t)id * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo < hi) {
+            u256 p;
+            fr_pow_u64(&p, g, (uint64_t)lo);
+            for (size_t i = lo; i < hi; i++) {
+                fr_mul(&a[i], &a[i], &p);
+                fr_mul(&p, &p, g);
+            }
+        }
+    }
+}
+
+/* arithmetic.rs:714-735 eval_polynomial: one Horner chunk per thread, scaled by point^start */
+EXPORT void oracle_eval_polynomial_par(const u256 *poly, size_t n, const u256 *point, int threads, u256 *out) {
+    if (threads < 1) threads = 1;
+    if (n * 2 < (size_t)threads) {
+        oracle_eval_polynomial(poly, n, point, out);
+        return;
+    }
+    size_t chunk = (n + threads - 1) / threads;
+    u256 *parts = (u256 *)calloc((size_t)threads, sizeof(u256));
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int t = 0; t < threads; t++) {
+        size_t start = (size_t)t * chunk;
+        if (start >= n) continue;
+        size_t len = start + chunk < n ? chunk : n - start;
+        u256 v, p;
+        oracle_eval_polynomial(poly + start, len, point, &v);
+        fr_pow_u64(&p, point, (uint64_t)start);
+        fr_mul(&parts[t], &v, &p);
+    }
+    u256 acc = fr_ZERO;
+    for (int t = 0; t < threads; t++) fr_add(&acc, &acc, &parts[t]);
+    *out = acc;
+    free(parts);
+}
+
+/* arithmetic.rs:840-844 batch_invert over the chunks of `parallelize` (each chunk one ff::BatchInvert) */
+EXPORT void oracle_batch_invert_par(u256 *f, size_t n, int threads) {
+    if (threads < 1) threads = 1;
+    size_t chunk = (n + threads - 1) / threads;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int t = 0; t < threads; t++) {
+        size_t start = (size_t)t * chunk;
+        if (start < n) fr_batch_invert(f + start, start + chunk < n ? chunk : n - start);
+    }
+}
+
+/* plonk/prover.rs:237-254 on a column that is still in canonical form */
+EXPORT uint32_t oracle_max_bits_canonical(const u256 *a, size_t n) {
+    uint64_t m[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++)
+            if (a[i].l[k] > m[k]) m[k] = a[i].l[k];
+    /* the largest value has the highest non-zero limb that any value has */
+    for (int k = 3; k >= 0; k--)
+        if (m[k]) return (uint32_t)(64 * k + 64 - __builtin_clzll(m[k]));
+    return 0;
+}
+
+/* plonk/logup/prover.rs:104-180: the multiplicity column.  The reference sorts the compressed table (:123-131), finds every
+ * compressed input value in it by binary search (:140-160) and counts the hits per table row; m = the counts as field
+ * elements.  A duplicated table value collects its hits on its lowest row here (ties sorted by row; the reference's
+ * binary_search_by_key may land on any of the duplicates -- the argument is indifferent).  Returns the number of input
+ * values that are missing from the table (the reference panics). */
+typedef struct {
+    u256 v;
+    uint32_t row;
+} logup_entry;
+static int logup_cmp(const void *pa, const void *pb) {
+    const logup_entry *a = (const logup_entry *)pa, *b = (const logup_entry *)pb;
+    for (int k = 3; k >= 0; k--) {
+        if (a->v.l[k] < b->v.l[k]) return -1;
+        if (a->v.l[k] > b->v.l[k]) return 1;
+    }
+    return a->row < b->row ? -1 : (a->row > b->row ? 1 : 0);
+}
+EXPORT size_t oracle_logup_multiplicity(const u256 *table, const u256 *const *inputs, size_t n_inputs, size_t usable,
+                                        size_t n, u256 *m) {
+    logup_entry *sorted = (logup_entry *)malloc((usable ? usable : 1) * sizeof(logup_entry));
+    uint32_t *count = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    for (size_t i = 0; i < usable; i++) {
+        sorted[i].v = table[i];
+        sorted[i].row = (uint32_t)i;
+    }
+    qsort(sorted, usable, sizeof(logup_entry), logup_cmp);
+    size_t miss = 0;
+    for (size_t j = 0; j < n_inputs; j++) {
+        const u256 *in = inputs[j];
+#pragma omp parallel for schedule(static) reduction(+ : miss)
+        for (size_t i = 0; i < usable; i++) {
+            logup_entry key;
+            key.v = in[i];
+            key.row = 0;
+            size_t lo = 0, hi = usable; /* first entry >= (value, row 0): the lowest row of that value */
+            while (lo < hi) {
+                size_t mid = (lo + hi) / 2;
+                if (logup_cmp(&sorted[mid], &key) < 0) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < usable && fr_eq(&sorted[lo].v, &in[i])) {
+#pragma omp atomic
+                count[sorted[lo].row]++;
+            } else {
+                miss++;
+            }
+        }
+    }
+    for (size_t i = 0; i < n; i++) fr_from_u64(&m[i], i < usable ? count[i] : 0);
+    free(sorted);
+    free(count);
+    return miss;
+}
+
+/* The blinding polynomial of the vanishing argument (plonk/vanishing/prover.rs:47-61 draws Scalar::random per element;
+ * include/halo2_hip.h h2_dev_random_fr fixes the draw as a function of a ChaCha20 key so that it can be replayed):
+ * words = n x 16 keystream words; element i = lo + 2^253 hi mod r, lo / hi = the low 253 bits of words 0..7 / 8..15. */
+EXPORT void oracle_reduce_wide_253(const uint32_t *words, size_t n, u256 *out) {
+    u256 two253c = {{0, 0, 0, (uint64_t)1 << 61}}, two253;
+    fr_from_repr(&two253, &two253c); /* 2^253 < r */
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u256 lo, hi;
+        memcpy(&lo, words + 16 * i, 32);
+        memcpy(&hi, words + 16 * i + 8, 32);
+        lo.l[3] &= ((uint64_t)1 << 61) - 1;
+        hi.l[3] &= ((uint64_t)1 << 61) - 1;
+        fr_from_repr(&lo, &lo);
+        fr_from_repr(&hi, &hi);
+        fr_mul(&hi, &hi, &two253);
+        fr_add(&out[i], &lo, &hi);
+    }
+}
+
+/* how many threads the loops above that take no `threads` argument use (rayon's global pool size) */
+EXPORT void oracle_set_threads(int threads) { omp_set_num_threads(threads < 1 ? 1 : threads); }

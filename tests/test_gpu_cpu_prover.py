@@ -1,0 +1,93 @@
+"""Proof bytes of the device prover == proof bytes of a CPU run (BASELINE configs[3]: "proof bytes == CPU"), on the same
+SRS, witness and randomness: the CPU side is tests/oracle_prover.py -- the host orchestration of prover.py with every
+kernel replaced by the C oracle's restatement of the reference's rayon loop (pinned on small circuits against the
+independent big-integer prover: tests/test_oracle_prover.py).  Up to k = 22 (configs[3]) and k = 24 (configs[4]'s size):
+every launch of a proof -- transforms, commitments, scans, the evaluator, the multiopen passes -- is checked in context
+at the metric's sizes, not only kernel by kernel."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import ref_plonk as rp
+from test_plonk_host import S_TRAPDOOR, lookup_shuffle_cs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    from halo2_gpu_specific_amd import prover
+
+    return prover.Device()
+
+
+def prove_both(device, cs, k, adv, fixed, copies, insts=(), modes=((1, False), (2, True)), cpu_kw=None, fixed_ints=False):
+    """keygen + create_proof on the device and on the CPU; returns the timings of the last proof (device s, cpu s)"""
+    import oracle_prover as op
+    from halo2_gpu_specific_amd import prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    cpu = op.OracleDevice(**(cpu_kw or {}))
+    cparams = op.params_like(cpu, params)
+    t0 = time.perf_counter()
+    cpk = op.keygen(cpu, cparams, cs, fixed, copies)
+    t_keygen = time.perf_counter() - t0
+    assert pk.fixed_commitments == cpk.fixed_commitments and pk.perm_commitments == cpk.perm_commitments
+    assert pk.transcript_repr == cpk.transcript_repr
+    t_dev = t_cpu = 0.0
+    for seed, use_gwc in modes:
+        prover.create_proof_ext(device, params, pk, adv, ProverRng(seed), use_gwc, instances=insts)   # warm
+        t0 = time.perf_counter()
+        proof = prover.create_proof_ext(device, params, pk, adv, ProverRng(seed), use_gwc, instances=insts)
+        t_dev = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        want = prover.create_proof_ext(cpu, cparams, cpk, adv, ProverRng(seed), use_gwc, instances=insts)
+        t_cpu = time.perf_counter() - t0
+        first = next((i for i in range(min(len(proof), len(want))) if proof[i] != want[i]), None)
+        assert first is None and len(proof) == len(want), \
+            "device proof differs from the CPU proof at byte %s (field %s)" % (first, first and first // 32)
+    print("k=%d: device %.3f s, cpu %.1f s (keygen %.1f s) on %d threads" % (k, t_dev, t_cpu, t_keygen, cpu.L.threads))
+    return t_dev, t_cpu
+
+
+@pytest.mark.parametrize("which,k", [("mini", 12), ("lookup", 10), ("wide", 12), ("range", 17)])
+def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
+    from halo2_gpu_specific_amd import circuits
+    from h2util import ints_to_arr
+
+    insts = ()
+    if which == "mini":
+        cs = circuits.mini_plonk()
+        adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    elif which == "wide":
+        cs = circuits.wide(2)
+        adv, fixed, copies = circuits.wide_synthesize(k, 2)
+    elif which == "range":
+        cs = circuits.range_check()
+        adv, fixed, copies = circuits.range_check_synthesize(k)
+    else:
+        cs = lookup_shuffle_cs()
+        adv, fixed, copies, insts = rp.LookupShuffle.synthesize(k)
+        adv, fixed = [ints_to_arr(c) for c in adv], [ints_to_arr(c) for c in fixed]
+        copies = [(l[0], l[1], r[0], r[1]) for l, r in copies]
+    prove_both(device, cs, k, adv, fixed, copies, insts)
+    # the CPU run by the coset route (coefficient forms only) gives the same bytes again
+    if which in ("mini", "lookup"):
+        prove_both(device, cs, k, adv, fixed, copies, insts, modes=((3, False),), cpu_kw={"eval_cache": 0})
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("k", [20, 22] + ([24] if os.environ.get("H2_TEST_CPU_PROVER_K24") == "1" else []))
+def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k):
+    """configs[3] (k = 22) and, with H2_TEST_CPU_PROVER_K24=1, configs[4]'s size (k = 24: ~4 minutes of CPU work; the run
+    of this build is kept in profiles/r3_cpu_prover_parity.txt): the CPU side of k = 24 runs coset by coset (2 x 2^24
+    points instead of one 2^26-point extended domain per column: the same bytes, a quarter of the host memory)"""
+    from halo2_gpu_specific_amd import circuits
+
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k)
+    prove_both(device, circuits.mini_plonk(), k, adv, fixed, copies, modes=((22, False),),
+               cpu_kw={"eval_cache": 0} if k >= 24 else None)

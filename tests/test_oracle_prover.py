@@ -1,0 +1,66 @@
+"""The CPU prover of tests/oracle_prover.py (the host orchestration of prover.py over the C oracle's loops) against the
+independent big-integer prover of tests/ref_plonk.py: proof bytes equal.  This pins the prover-level passes added to
+oracle/oracle.c (prefix scans, permutation terms / sigma, logup multiplicities, linear combinations, the replayable random
+polynomial) -- the CPU reference the device prover is compared with at k = 20 .. 24 on the GPU box."""
+import numpy as np
+import pytest
+
+import ref_plonk as rp
+from h2util import fr_mont, ints_to_arr
+from test_plonk_host import S_TRAPDOOR, lookup_shuffle_cs, rot_gate_cs
+
+
+def oracle_params(oracle, device, k):
+    from halo2_gpu_specific_amd import prover
+
+    n = 1 << k
+    g = np.zeros((n, 8), dtype=np.uint64)
+    gl = np.zeros((n, 8), dtype=np.uint64)
+    s = fr_mont(S_TRAPDOOR)
+    oracle.lib.oracle_unsafe_setup(k, s.ctypes.data, g.ctypes.data, gl.ctypes.data)
+    return prover.Params(device, k, g, gl, tables=False)
+
+
+def cols_to_arr(cols):
+    return [ints_to_arr(c) for c in cols]
+
+
+@pytest.mark.parametrize("which,k", [("mini", 5), ("rot", 6), ("lookup", 6)])
+def test_cpu_prover_bytes_match_big_integer_prover(oracle, which, k):
+    import oracle_prover as op
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    insts = ()
+    if which == "lookup":
+        ref_cs, cs = rp.LookupShuffle, lookup_shuffle_cs()
+        adv, fixed, copies, insts = ref_cs.synthesize(k)
+    else:
+        ref_cs = rp.MiniPlonk if which == "mini" else rp.RotGate
+        cs = circuits.mini_plonk() if which == "mini" else rot_gate_cs()
+        adv, fixed, copies = ref_cs.synthesize(k)
+    rpk = rp.keygen(ref_cs, k, S_TRAPDOOR, fixed, copies)
+    for kw in ({}, {"force_cosets": True}):
+        D = op.OracleDevice(threads=2, **kw)
+        params = oracle_params(oracle, D, k)
+        pk = op.keygen(D, params, cs, cols_to_arr(fixed), [(l[0], l[1], r[0], r[1]) for l, r in copies])
+        assert pk.fixed_commitments == rpk.fixed_commitments
+        assert pk.perm_commitments == rpk.perm_commitments
+        assert pk.transcript_repr == rpk.transcript_repr
+        for seed, use_gwc in ((1, False), (3, True)):
+            proof = prover.create_proof_ext(D, params, pk, cols_to_arr(adv), ProverRng(seed), use_gwc, instances=insts)
+            want = rp.create_proof(rpk, adv, ProverRng(seed), use_gwc=use_gwc, instances=insts)
+            first = next((i for i in range(min(len(proof), len(want))) if proof[i] != want[i]), None)
+            assert first is None and len(proof) == len(want), "differs at byte %s (field %s)" % (first, first and first // 32)
+
+
+def test_product_device_still_needs_a_gpu():
+    """the oracle device is injected by tests only: the product's own Device has no CPU path"""
+    import torch
+
+    from halo2_gpu_specific_amd import prover
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        prover.Device()
