@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--prove-steps", type=int, default=3)
     ap.add_argument("--wide-k", type=int, default=20, help="create_proof_wide leg: circuits.wide with 2^k rows (0 = skip)")
     ap.add_argument("--wide-quads", type=int, default=16, help="create_proof_wide: quads of advice columns (16 -> 64 columns)")
+    ap.add_argument("--cpu-prove-k", type=int, default=20, help="CPU create_proof baseline: mini-PLONK with 2^k rows on the host cores (0 = skip)")
     ap.add_argument("--k24", type=int, default=1, help="1: also run the k = 24 legs (MSM 2^24, create_proof k = 24) the metric is quoted at")
     args = ap.parse_args()
 
@@ -629,7 +630,42 @@ def main():
                     "kind": "port",
                     "sample": "oracle best_multiexp on 2^%d uniform pairs (the GPU's size), best of 3 team sizes, %.3f s" % (mlog_c, best_m),
                 }
+            # create_proof's CPU twin: the same host orchestration with every kernel replaced by the oracle's restatement of
+            # the reference's CPU loop (tests/oracle_prover.py), same SRS / witness / randomness: the bytes must be equal
+            if "create_proof" in out and args.cpu_prove_k:
+                import oracle_prover as op
+                from halo2_gpu_specific_amd import circuits, prover
+                from halo2_gpu_specific_amd.rng import ProverRng
+
+                kc = args.cpu_prove_k
+                D = prover.Device(local_rank)
+                params = prover.Params.unsafe_setup(D, kc, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
+                adv, fixed, copies = circuits.mini_plonk_synthesize(kc)
+                pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
+                prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))
+                g0 = time.perf_counter()
+                proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(3))
+                D.sync()
+                gpu_s = time.perf_counter() - g0
+                cpu = op.OracleDevice()
+                cparams = op.params_like(cpu, params)
+                c0 = time.perf_counter()
+                cpk = op.keygen(cpu, cparams, circuits.mini_plonk(), fixed, copies)
+                ck = time.perf_counter() - c0
+                c0 = time.perf_counter()
+                want = prover.create_proof_with_shplonk(cpu, cparams, cpk, adv, ProverRng(3))
+                ct = time.perf_counter() - c0
+                out["create_proof"]["cpu_baseline"] = {
+                    "k": kc, "seconds": ct, "keygen_seconds": ck, "cores": cpu.L.threads, "host_threads_available": cores,
+                    "kind": "port", "gpu_seconds_same_circuit": gpu_s, "proof_bytes_equal": bool(proof == want),
+                    "sample": "one mini-PLONK create_proof (SHPLONK) at k = %d on the host cores: the host orchestration of prover.py "
+                    "over the C oracle's loops (oracle/oracle.c; serial scans and Kate divisions as the reference), same SRS, "
+                    "witness and randomness as the device proof next to it; at the leg's own k = 22 / 24 the same comparison is "
+                    "tests/test_gpu_cpu_prover.py (44 s / 192 s of CPU)" % kc,
+                }
         except Exception as e:  # noqa: BLE001 - the line must still be printed
+            if "cpu_baseline" in out:
+                out["cpu_baseline_error"] = "%s: %s" % (type(e).__name__, e)
             out.setdefault("cpu_baseline", {"error": "%s: %s" % (type(e).__name__, e)})
 
     if rank == 0:
