@@ -661,7 +661,7 @@ def main():
                     "sample": "one mini-PLONK create_proof (SHPLONK) at k = %d on the host cores: the host orchestration of prover.py "
                     "over the C oracle's loops (oracle/oracle.c; serial scans and Kate divisions as the reference), same SRS, "
                     "witness and randomness as the device proof next to it; at the leg's own k = 22 / 24 the same comparison is "
-                    "tests/test_gpu_cpu_prover.py (44 s / 192 s of CPU)" % kc,
+                    "tests/test_gpu_cpu_prover.py (24 s / 135 s of CPU on 32 threads)" % kc,
                 }
         except Exception as e:  # noqa: BLE001 - the line must still be printed
             if "cpu_baseline" in out:
