@@ -346,7 +346,8 @@ static bool table_lookup(const uint64_t* d_bases, size_t n, uint32_t max_bits, S
     ShiftTable t;
     if (!table_find(d_bases, n, &t)) return false;
     // narrow columns: the plain pipeline's row ranges and fused groups are built for them, and a table saves nothing
-    if (table_digits_used(t, max_bits) >= msm_shape(n, max_bits, false).W) return false;
+    static const bool force = getenv("H2_MSM_TABLE_FORCE") != nullptr;  // experiment: tables of more digits than windows
+    if (!force && table_digits_used(t, max_bits) >= msm_shape(n, max_bits, false).W) return false;
     *out = t;
     return true;
 }
@@ -1652,7 +1653,8 @@ static bool table_pays(const ShiftTable& t, size_t n, uint32_t max_bits, const H
     const double rows = (double)n * (double)(hot.live ? hot.live : 1) / (double)HOT_SAMPLES;
     const double plain = (double)p.W * rows + 10.0 * (double)p.Wt * (double)p.nb;
     const double table = (double)table_digits_used(t, max_bits) * rows + 10.0 * (double)(1u << (t.c - 1));
-    return table < plain;
+    static const bool force = getenv("H2_MSM_TABLE_FORCE") != nullptr;
+    return force || table < plain;
 }
 
 // ---------------------------------------------------------------- drivers

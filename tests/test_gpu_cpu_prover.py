@@ -54,7 +54,7 @@ def prove_both(device, cs, k, adv, fixed, copies, insts=(), modes=((1, False), (
     return t_dev, t_cpu
 
 
-@pytest.mark.parametrize("which,k", [("mini", 12), ("lookup", 10), ("wide", 12), ("range", 17)])
+@pytest.mark.parametrize("which,k", [("mini", 12), ("lookup", 10), ("wide", 12), ("wide16", 15), ("range", 17)])
 def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
     from halo2_gpu_specific_amd import circuits
     from h2util import ints_to_arr
@@ -63,9 +63,10 @@ def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
     if which == "mini":
         cs = circuits.mini_plonk()
         adv, fixed, copies = circuits.mini_plonk_synthesize(k)
-    elif which == "wide":
-        cs = circuits.wide(2)
-        adv, fixed, copies = circuits.wide_synthesize(k, 2)
+    elif which.startswith("wide"):
+        quads = 16 if which == "wide16" else 2          # wide16: bench.py's create_proof_wide circuit (64 advice columns)
+        cs = circuits.wide(quads)
+        adv, fixed, copies = circuits.wide_synthesize(k, quads)
     elif which == "range":
         cs = circuits.range_check()
         adv, fixed, copies = circuits.range_check_synthesize(k)
@@ -74,7 +75,7 @@ def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
         adv, fixed, copies, insts = rp.LookupShuffle.synthesize(k)
         adv, fixed = [ints_to_arr(c) for c in adv], [ints_to_arr(c) for c in fixed]
         copies = [(l[0], l[1], r[0], r[1]) for l, r in copies]
-    prove_both(device, cs, k, adv, fixed, copies, insts)
+    prove_both(device, cs, k, adv, fixed, copies, insts, modes=((1, False),) if which == "wide16" else ((1, False), (2, True)))
     # the CPU run by the coset route (coefficient forms only) gives the same bytes again
     if which in ("mini", "lookup"):
         prove_both(device, cs, k, adv, fixed, copies, insts, modes=((3, False),), cpu_kw={"eval_cache": 0})
@@ -91,3 +92,26 @@ def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k):
     adv, fixed, copies = circuits.mini_plonk_synthesize(k)
     prove_both(device, circuits.mini_plonk(), k, adv, fixed, copies, modes=((22, False),),
                cpu_kw={"eval_cache": 0} if k >= 24 else None)
+
+
+def test_two_circuit_instances_and_budgeted_device_equal_cpu(device):
+    """several circuit instances in one proof (plonk/prover.rs:206-232) and the memory-budgeted route of the device (coset by
+    coset, tables evicted) against the CPU run by the extended domain"""
+    import oracle_prover as op
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 11
+    cs = circuits.mini_plonk()
+    adv_a, fixed, copies = circuits.mini_plonk_synthesize(k, a=5)
+    adv_b = circuits.mini_plonk_synthesize(k, a=9)[0]
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    tight = prover.Device(eval_cache=1)
+    tparams = prover.Params(tight, k, params.g, params.g_lagrange)
+    cpu = op.OracleDevice()
+    cparams = op.params_like(cpu, params)
+    cpk = op.keygen(cpu, cparams, cs, fixed, copies)
+    want = prover.create_proof_ext(cpu, cparams, cpk, [adv_a, adv_b], ProverRng(4), False, instances=[(), ()])
+    for D, pr in ((device, params), (tight, tparams)):
+        pk = prover.keygen(D, pr, cs, fixed, copies)
+        assert prover.create_proof_ext(D, pr, pk, [adv_a, adv_b], ProverRng(4), False, instances=[(), ()]) == want
