@@ -73,6 +73,7 @@ SYMBOLS = {
     "h2_dev_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz, _vp]),
     "h2_dev_batch_mont": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_batch_unmont": (ctypes.c_int, [_vp, _sz, _vp]),
+    "h2_dev_widen_u64": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_max_scalar_bits": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "h2_dev_random_points": (ctypes.c_int, [ctypes.c_uint64, _sz, _vp, _vp]),
     "h2_dev_bases_precompute": (ctypes.c_int, [_vp, _sz, ctypes.c_uint32, _vp]),

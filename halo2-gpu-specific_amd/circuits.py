@@ -65,15 +65,21 @@ def wide(quads=16):
     return cs
 
 
-def wide_synthesize(k, quads=16, alloc=None):
+def wide_synthesize(k, quads=16, alloc=None, compact=False):
     """Witness of `wide`: t[i] = i for i < T = min(usable rows, 2^16); a, b, c < T from multiplicative hashes of (row,
     column), d = a b c on the usable rows; b of quad 0 is a of quad 0 one row up, tied by copy constraints on the first
-    min(usable - 1, 2^16) rows.  Returns (advice[4 * quads], fixed[2], copies) in the layout of mini_plonk_synthesize."""
+    min(usable - 1, 2^16) rows.  Returns (advice[4 * quads], fixed[2], copies) in the layout of mini_plonk_synthesize.
+    `compact`: the advice columns as 1-D u64 arrays (every value is below 2^48): prover.create_proof_ext uploads 8 bytes
+    per cell; `alloc(count, n, compact=True)` then provides them."""
     n = 1 << k
     usable = n - 6
     T = min(usable, 1 << 16)
     ncols = 4 * quads
-    adv = alloc(ncols, n) if alloc else [np.zeros((n, 4), dtype=np.uint64) for _ in range(ncols)]
+    if compact:
+        adv = alloc(ncols, n, compact=True) if alloc else [np.zeros(n, dtype=np.uint64) for _ in range(ncols)]
+    else:
+        adv = alloc(ncols, n) if alloc else [np.zeros((n, 4), dtype=np.uint64) for _ in range(ncols)]
+    cell = (lambda c: c[:usable]) if compact else (lambda c: c[:usable, 0])
     fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
     fixed[0][:usable, 0] = 1
     fixed[1][:T, 0] = np.arange(T, dtype=np.uint64)
@@ -87,8 +93,8 @@ def wide_synthesize(k, quads=16, alloc=None):
         if qd == 0:
             vals[1] = np.concatenate([np.array([3 % T], dtype=np.uint64), vals[0][:-1]])
         for j in range(3):
-            adv[4 * qd + j][:usable, 0] = vals[j]
-        adv[4 * qd + 3][:usable, 0] = vals[0] * vals[1] * vals[2]          # < 2^48
+            cell(adv[4 * qd + j])[:] = vals[j]
+        cell(adv[4 * qd + 3])[:] = vals[0] * vals[1] * vals[2]             # < 2^48
     m = min(usable - 1, 1 << 16)
     r = np.arange(m, dtype=np.int64)
     copies = np.stack([np.zeros(m, dtype=np.int64), r, np.ones(m, dtype=np.int64), r + 1], axis=1)

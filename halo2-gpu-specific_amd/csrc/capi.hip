@@ -593,6 +593,13 @@ int h2_dev_batch_unmont(void* d_a, size_t n, void* stream) {
         return batch_mont_launch((Fr*)d_a, n, false, pick_stream(ctx, stream));
     });
 }
+int h2_dev_widen_u64(const void* d_src, size_t n, void* d_dst, void* stream) {
+    if (n && (!d_src || !d_dst)) return bad("h2_dev_widen_u64: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return widen_u64_launch((const uint64_t*)d_src, n, (Fr*)d_dst, pick_stream(ctx, stream));
+    });
+}
 
 // ------------------------------------------------------------------ adjacent numerics (a24)
 int h2_dev_eval_polynomial(const void* d_poly, size_t n, const uint64_t point[4], uint64_t out[4], void* stream) {

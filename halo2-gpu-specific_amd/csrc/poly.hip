@@ -145,6 +145,30 @@ int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream) {
 }
 
 
+// ---------------------------------------------------------------- compact witness columns
+// A witness column whose values fit 64 bits (booleans, bytes, 16-bit limbs, 48-bit products: most of a zkWasm-shaped trace)
+// crosses PCIe as 8 bytes per cell instead of 32 and is widened here to canonical 4 x u64 scalars: dst[i] = {src[i], 0, 0, 0}.
+__global__ void __launch_bounds__(256) k_widen_u64(const uint64_t* src, size_t n, uint4* dst) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // one lane per 16-byte half of an element: the stores of a wave cover 1 KiB contiguously
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += stride) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((t & 1) == 0) {
+            const uint64_t x = src[t >> 1];
+            v.x = (uint32_t)x;
+            v.y = (uint32_t)(x >> 32);
+        }
+        dst[t] = v;
+    }
+}
+
+int widen_u64_launch(const uint64_t* src, size_t n, Fr* dst, hipStream_t stream) {
+    if (n == 0) return H2_OK;
+    hipLaunchKernelGGL(k_widen_u64, dim3(grid_for(2 * n)), dim3(256), 0, stream, src, n, (uint4*)dst);
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
 // ---------------------------------------------------------------- find_max_scalar_bits for a group of columns
 // plonk/prover.rs:237-254 takes the maximum of a column and its bit length; the bit length of the maximum is the bit
 // length of the OR of all values, and an OR needs no ordering: one launch ORs the limbs of up to 16 canonical columns

@@ -7,6 +7,7 @@ int eval_op_launch(int op, Fr* res, const Fr* l, const Fr* r, int32_t l_rot, int
                    const uint64_t c[4], hipStream_t stream);
 int divide_by_vanishing_launch(Fr* a, size_t size, const Fr* t, size_t t_len, hipStream_t stream);
 int batch_mont_launch(Fr* a, size_t n, bool to_mont, hipStream_t stream);
+int widen_u64_launch(const uint64_t* src, size_t n, Fr* dst, hipStream_t stream);
 int max_scalar_bits_launch(const Fr* const* d_cols, size_t count, size_t n, uint32_t* d_words, uint32_t* out_bits,
                            hipStream_t stream);
 int eval_polynomial_launch(const Fr* d_poly, size_t n, const uint64_t point[4], Fr* d_tmp, uint64_t out[4],

@@ -186,16 +186,31 @@ class Device:
         with self.torch.cuda.stream(self.tstream):
             src = self._pinned.get(a.ctypes.data)
             if src is not None and src.numel() == a.size:
-                return src.to(self.dev, non_blocking=True)
-            import warnings
+                t = src.to(self.dev, non_blocking=True)
+            else:
+                import warnings
 
-            with warnings.catch_warnings():      # read-only sources (a memory-mapped witness file) are only read
-                warnings.simplefilter("ignore", UserWarning)
-                return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+                with warnings.catch_warnings():      # read-only sources (a memory-mapped witness file) are only read
+                    warnings.simplefilter("ignore", UserWarning)
+                    t = self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+        return self.widen(t) if a.ndim == 1 else t
+
+    def widen(self, small, stream=None):
+        """a compact column (n u64 values on the device, 8 B per cell over PCIe) -> canonical (n, 4) scalars"""
+        n = small.shape[0]
+        out = self.empty(n)
+        check(self.L.h2_dev_widen_u64(small.data_ptr(), n, out.data_ptr(), self.stream if stream is None else stream),
+              "h2_dev_widen_u64")
+        small.record_stream(self.tstream)
+        return out
 
     def upload_async(self, a):
         """-> (device tensor, event or None): a pinned source is copied by DMA on the copy stream and the event marks
-        its arrival; anything else goes through the synchronous path"""
+        its arrival; anything else goes through the synchronous path.  `a`: a canonical (n, 4) u64 column, a COMPACT column
+        (1-D u64: every value below 2^64 -- 8 bytes per cell cross PCIe and the device widens them), or a device tensor
+        (a witness that is already resident: copied, since the prover blinds and converts its columns in place)."""
+        if self.torch.is_tensor(a):
+            return self.clone(a), None
         a = np.ascontiguousarray(a)
         src = self._pinned.get(a.ctypes.data)
         if src is None or src.numel() != a.size:
@@ -203,6 +218,10 @@ class Device:
         torch = self.torch
         with torch.cuda.stream(self.copy_stream):
             t = src.to(self.dev, non_blocking=True)
+            if a.ndim == 1:                    # widened on the copy stream too: behind its own arrival, ahead of nothing
+                small, t = t, torch.empty((a.shape[0], 4), dtype=torch.int64, device=self.dev)
+                check(self.L.h2_dev_widen_u64(small.data_ptr(), a.shape[0], t.data_ptr(), _vp(self.copy_stream.cuda_stream)),
+                      "h2_dev_widen_u64")
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         t.record_stream(self.tstream)          # allocated under the copy stream, consumed on the compute stream
@@ -254,12 +273,13 @@ class Device:
         check(self.L.h2_dev_max_scalar_bits(ptrs, count, n, words.data_ptr(), out, self.stream), "h2_dev_max_scalar_bits")
         return list(out)
 
-    def pinned_columns(self, count, n):
+    def pinned_columns(self, count, n, compact=False):
         """`count` zeroed (n, 4) u64 numpy columns in page-locked host memory: a witness synthesised into them
-        reaches the device by DMA instead of through the driver's staging copies"""
+        reaches the device by DMA instead of through the driver's staging copies.  `compact`: 1-D columns of n u64 values
+        (a quarter of the bytes over PCIe) for columns whose values all fit 64 bits."""
         out = []
         for _ in range(count):
-            t = self.torch.zeros((n, 4), dtype=self.torch.int64).pin_memory()
+            t = self.torch.zeros((n,) if compact else (n, 4), dtype=self.torch.int64).pin_memory()
             a = t.numpy().view(np.uint64)
             self._pinned[a.ctypes.data] = t
             out.append(a)
@@ -1062,18 +1082,23 @@ def complete_range_check_witness(cs, n, advice, first_unassigned=None):
     usable = n - (cs.blinding_factors() + 1)
     last_active = usable - 1
     for origin, sort, vmin, vmax, step in cs.range_checks:
-        col = advice[origin]
+        col, companion = advice[origin], advice[sort]
+        if not isinstance(col, np.ndarray) or not isinstance(companion, np.ndarray):
+            raise TypeError("range check: the range-checked column and its companion must be host columns")
+        low = lambda c: c if c.ndim == 1 else c[:, 0]            # noqa: E731  (compact columns hold limb 0 only)
         values = np.array(range_check_assigner(vmin, vmax, step), dtype=np.uint64)
         lo = last_active + 1 - len(values)
         if lo < 0 or (first_unassigned is not None and first_unassigned.get(origin, 0) > lo):
             raise ValueError("range check: the range does not fit the unused cells of its column")
-        col[lo:last_active + 1, 0] = values[::-1]
-        col[lo:last_active + 1, 1:] = 0
-        body = col[:usable]
-        if body[:, 1:].any() or int(body[:, 0].max()) > vmax or int(body[:, 0].min()) < vmin:
+        low(col)[lo:last_active + 1] = values[::-1]
+        if col.ndim == 2:
+            col[lo:last_active + 1, 1:] = 0
+        body = low(col)[:usable]
+        if (col.ndim == 2 and col[:usable, 1:].any()) or int(body.max()) > vmax or int(body.min()) < vmin:
             raise ValueError("range check: a value of the column lies outside its range")   # the reference's HashMap lookup panics
-        advice[sort][:usable, 0] = np.sort(body[:, 0], kind="stable")
-        advice[sort][:usable, 1:] = 0
+        low(companion)[:usable] = np.sort(body, kind="stable")
+        if companion.ndim == 2:
+            companion[:usable, 1:] = 0
     return advice
 
 
@@ -1087,6 +1112,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     """plonk/prover.rs:206-850.  advice: list of (n, 4) u64 columns, canonical integers (or Montgomery residues with
     montgomery=True); rows past the usable range are overwritten with blinding values; instances: one list of
     canonical integers per instance column; rng: a rng.ProverRng.  Returns the proof bytes.
+    A column may also be COMPACT -- a 1-D u64 array of n values below 2^64 (booleans, bytes, limbs: 8 bytes per cell over
+    PCIe instead of 32, widened on the device) -- or a device tensor of canonical scalars (a witness already resident).
 
     Several circuit instances in one proof (`circuits: &[ConcreteCircuit]`, prover.rs:206-232): pass `advice` as a list
     of such column lists and `instances` as the matching list of instance-column lists.  Every phase then runs circuit
@@ -1161,7 +1188,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         for col in advice:
             t = D.empty(n)
             with D.torch.cuda.stream(D.tstream):
-                t[lo_r:hi_r] = D.upload(np.ascontiguousarray(col[lo_r:hi_r]))
+                t[lo_r:hi_r] = col[lo_r:hi_r] if D.torch.is_tensor(col) else D.upload(np.ascontiguousarray(col[lo_r:hi_r]))
             uploads.append((t, None))
     else:
         uploads = [D.upload_async(col) for col in advice]

@@ -400,6 +400,12 @@ int h2_dev_eval_op(int op, void *d_res, const void *d_l, const void *d_r, int32_
 int h2_dev_divide_by_vanishing_poly(void *d_a, size_t size, const void *d_t_evaluations, size_t t_len, void *stream);
 int h2_dev_batch_mont(void *d_a, size_t n, void *stream);
 int h2_dev_batch_unmont(void *d_a, size_t n, void *stream);
+/* Compact witness columns.  The reference hands create_proof 32-byte cells whatever they hold (plonk/prover.rs:255-312:
+ * `advice: Vec<Polynomial<C::Scalar, LagrangeCoeff>>`), and its cuda path uploads them as such; most cells of a real trace are
+ * booleans, bytes, 16-bit limbs or products of a few of them.  A caller that knows a column fits 64 bits sends 8 bytes per
+ * cell (d_src: n x u64 on the device, e.g. copied from pinned host memory) and widens it here to canonical scalars:
+ * d_dst[i] = {d_src[i], 0, 0, 0} (n x 32 B; canonical form -- follow with h2_dev_batch_mont as for any uploaded column). */
+int h2_dev_widen_u64(const void *d_src, size_t n, void *d_dst, void *stream);
 /* find_max_scalar_bits (plonk/prover.rs:237-254) for `count` CANONICAL columns of n scalars resident on the device, in
  * one launch and one synchronisation: out_bits[i] (host) = bit length of the largest value of column i (0 for an all-zero
  * column) -- the `max_bits` of commit_lagrange_with_bound.  d_words: count * 32 bytes of device scratch. */

@@ -257,7 +257,12 @@ class OracleDevice(P.Device):
 
     def upload(self, a):
         # a copy, as a transfer to a device is: the prover converts and blinds its columns in place
-        return self.torch.from_numpy(np.ascontiguousarray(a).copy().view(np.int64))
+        a = np.ascontiguousarray(a)
+        if a.ndim == 1:                          # a compact column: limb 0 only
+            wide = np.zeros((a.shape[0], 4), dtype=np.uint64)
+            wide[:, 0] = a
+            a = wide
+        return self.torch.from_numpy(a.copy().view(np.int64))
 
     def pinned_columns(self, count, n):
         return [np.zeros((n, 4), dtype=np.uint64) for _ in range(count)]

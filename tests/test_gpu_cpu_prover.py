@@ -115,3 +115,46 @@ def test_two_circuit_instances_and_budgeted_device_equal_cpu(device):
     for D, pr in ((device, params), (tight, tparams)):
         pk = prover.keygen(D, pr, cs, fixed, copies)
         assert prover.create_proof_ext(D, pr, pk, [adv_a, adv_b], ProverRng(4), False, instances=[(), ()]) == want
+
+
+def test_compact_and_resident_witness_columns_give_the_same_bytes(device):
+    """a witness column as 8-byte cells (h2_dev_widen_u64) or as a tensor already on the device: the bytes of the proof
+    made from 32-byte host cells -- for the wide circuit (pinned and pageable sources) and for the range-check argument,
+    whose completion (planted range values, sorted companion) then runs on the compact host columns"""
+    import torch
+
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 12
+    cs = circuits.wide(2)
+    adv, fixed, copies = circuits.wide_synthesize(k, 2)
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    want = prover.create_proof_ext(device, params, pk, adv, ProverRng(9), False)
+    for alloc in (None, device.pinned_columns):
+        small = circuits.wide_synthesize(k, 2, alloc=alloc, compact=True)[0]
+        assert all(c.ndim == 1 and np.array_equal(c, a[:, 0]) for c, a in zip(small, adv))
+        assert prover.create_proof_ext(device, params, pk, small, ProverRng(9), False) == want
+    resident = [device.upload(a) for a in adv]
+    before = [t.clone() for t in resident]
+    assert prover.create_proof_ext(device, params, pk, resident, ProverRng(9), False) == want
+    assert all(torch.equal(a, b) for a, b in zip(resident, before)), "the caller's resident columns were modified"
+    # mixed forms in one witness
+    mixed = [small[i] if i % 3 == 0 else (resident[i] if i % 3 == 1 else adv[i]) for i in range(len(adv))]
+    gwc = prover.create_proof_ext(device, params, pk, adv, ProverRng(9), True)
+    assert prover.create_proof_ext(device, params, pk, mixed, ProverRng(9), True) == gwc
+    # the widening on its own: every value, a ragged length
+    src = torch.randint(-(2**63), 2**63 - 1, (100003,), dtype=torch.int64, device=device.dev)
+    wide = device.widen(src)
+    device.sync()
+    assert torch.equal(wide[:, 0], src) and not wide[:, 1:].any()
+    # range check
+    k = 17
+    cs = circuits.range_check()
+    adv, fixed, copies = circuits.range_check_synthesize(k)
+    params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    small = [a[:, 0].copy() for a in adv]
+    want = prover.create_proof_ext(device, params, pk, adv, ProverRng(3), False)
+    assert prover.create_proof_ext(device, params, pk, small, ProverRng(3), False) == want

@@ -1,6 +1,8 @@
 """create_proof per phase on the wide circuit (circuits.wide: 4 * quads advice columns, degree 5, quads / 2 logup range
-lookups), real SRS from the device setup.   usage: python tools/wide_bench.py [k] [quads] [budget]
-`budget` (e.g. 8G, or `coset`) runs the memory-bounded route: coefficient forms only, the extended domain coset by coset."""
+lookups), real SRS from the device setup.   usage: python tools/wide_bench.py [k] [quads] [budget|-] [wide|compact|resident]
+`budget` (e.g. 8G, or `coset`) runs the memory-bounded route: coefficient forms only, the extended domain coset by coset.
+witness form: `wide` = 32-byte cells in pinned host memory (what the reference hands over), `compact` = 8-byte cells (every
+value of this circuit fits 64 bits; widened on the device), `resident` = the columns already on the device."""
 import os
 import sys
 import time
@@ -17,7 +19,8 @@ from halo2_gpu_specific_amd.rng import ProverRng  # noqa: E402
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 quads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-budget = sys.argv[3] if len(sys.argv) > 3 else None
+budget = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+form = sys.argv[4] if len(sys.argv) > 4 else "wide"
 cs = circuits.wide(quads)
 if budget == "coset":
     D = prover.Device(eval_cache=1)
@@ -27,8 +30,11 @@ else:
     D = prover.Device()
 params = prover.Params.unsafe_setup(D, k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
 t0 = time.perf_counter()
-adv, fixed, copies = circuits.wide_synthesize(k, quads, alloc=D.pinned_columns)
-print("synthesize %.2f s" % (time.perf_counter() - t0))
+adv, fixed, copies = circuits.wide_synthesize(k, quads, alloc=D.pinned_columns, compact=form == "compact")
+if form == "resident":
+    adv = [D.upload(a) for a in adv]
+    D.sync()
+print("synthesize %.2f s (%s witness)" % (time.perf_counter() - t0, form))
 t0 = time.perf_counter()
 pk = prover.keygen(D, params, cs, fixed, copies)
 D.sync()
