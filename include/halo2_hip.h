@@ -23,6 +23,9 @@
  *                 HALO2_PROOFS_N_GPU (plonk/prover.rs:56-74; arithmetic.rs:314-331).
  *   h2_dev_*      operate on HIP device pointers on the caller's stream (void* = hipStream_t,
  *                 NULL = the library's stream for the current device) and do not synchronise.
+ *                 NULL does NOT mean HIP's legacy default stream: the library's stream is non-blocking, so work
+ *                 the caller queued on stream 0 is not ordered against it -- pass a stream of your own (every
+ *                 call then runs in its order), or bracket the calls with h2_synchronize / hipDeviceSynchronize.
  */
 #ifndef HALO2_HIP_H
 #define HALO2_HIP_H

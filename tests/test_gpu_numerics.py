@@ -131,7 +131,8 @@ def test_prefix_sum(oracle, n):
     f = oracle.random_fr(4100 + n % 13, n)
     init = 0x1234567 if n % 2 else 0
     d_f, d_z = _dev(f), _dev(np.zeros((n, 4), dtype=np.uint64))
-    assert L.h2_dev_prefix_sum(d_f.data_ptr(), n, fr_mont(init).ctypes.data, d_z.data_ptr(), None) == 0
+    init_m = fr_mont(init)                  # (a temporary's address would dangle by the time the call runs)
+    assert L.h2_dev_prefix_sum(d_f.data_ptr(), n, init_m.ctypes.data, d_z.data_ptr(), None) == 0
     got = from_mont(_host(d_z))
     fv = from_mont(f)
     acc, want = init, []
@@ -199,8 +200,9 @@ def test_permutation_sigma_and_terms(oracle, n):
     mr = np.array([rnd.randrange(n) for _ in range(n)], dtype=np.uint32)
     d_mc, d_mr = torch.from_numpy(mc.view(np.int32)).cuda(), torch.from_numpy(mr.view(np.int32)).cuda()
     d_sig = _dev(np.zeros((n, 4), dtype=np.uint64))
-    assert L.h2_dev_permutation_sigma(d_sig.data_ptr(), d_mc.data_ptr(), d_mr.data_ptr(), n, fr_mont(DELTA).ctypes.data,
-                                      fr_mont(omega).ctypes.data, None) == 0
+    delta_m, omega_m = fr_mont(DELTA), fr_mont(omega)
+    assert L.h2_dev_permutation_sigma(d_sig.data_ptr(), d_mc.data_ptr(), d_mr.data_ptr(), n, delta_m.ctypes.data,
+                                      omega_m.ctypes.data, None) == 0
     assert L.h2_synchronize() == 0          # stream NULL = the library's own (non-blocking) stream
     sigma = from_mont(_host(d_sig))
     if n <= 2049:
@@ -212,9 +214,10 @@ def test_permutation_sigma_and_terms(oracle, n):
     for j in range(2):
         dp = pow(DELTA, j + 3, R_MOD)
         d_v = _dev(vals[j])
+        beta_m, gamma_m, dp_m = fr_mont(beta), fr_mont(gamma), fr_mont(dp)
         assert L.h2_dev_permutation_terms(d_num.data_ptr(), d_den.data_ptr(), d_v.data_ptr(), d_sig.data_ptr(), n,
-                                          fr_mont(beta).ctypes.data, fr_mont(gamma).ctypes.data, fr_mont(dp).ctypes.data,
-                                          fr_mont(omega).ctypes.data, 1 if j == 0 else 0, None) == 0
+                                          beta_m.ctypes.data, gamma_m.ctypes.data, dp_m.ctypes.data,
+                                          omega_m.ctypes.data, 1 if j == 0 else 0, None) == 0
         v = from_mont(vals[j])
         w = 1
         for i in range(n):

@@ -11,6 +11,7 @@ form of the HIP path and not on sampled outputs:
 * `gpu_multiexp_bound_and_fft` (commit_lagrange_and_ifft) at 2^24: the point and every coefficient.
 
 The oracle side costs ~10 s of host time per MSM / transform on the GPU box's cores."""
+import ctypes
 import os
 
 import numpy as np
@@ -28,6 +29,7 @@ LOG_N = 24
 # libgomp does not scale the oracle's rayon-shaped FFT recursion past ~32 threads (65 s per 2^24 transform on the GPU box's
 # 256 hardware threads against 1.6 s on 32: DESIGN.md section 5); bench.py probes the team size the same way
 FFT_THREADS = min(32, os.cpu_count() or 1)
+ctypes_vp, ctypes_sz, ctypes_i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 
 
 def _affine(oracle, jac):
@@ -115,3 +117,47 @@ def test_coset_divide_inverse_k24_vs_oracle(oracle):
         d.fr("extended_ifft_divisor"),
     )
     assert np.array_equal(got_c, oracle.extended_to_coeff(ext, d, threads=FFT_THREADS))
+
+
+def test_ntt_2p26_every_element_vs_oracle(oracle):
+    """four passes (2 + 8 + 8 + 8 bits): the extended domain of a k = 24 circuit of degree 5 (the wide circuit's shape)"""
+    log_n = 26
+    n = 1 << log_n
+    omega = pow(ROOT, 1 << (S - log_n), R_MOD)
+    x = oracle.random_fr(0x26260000, n)
+    got = ar.best_fft(x.copy(), fr_mont(omega), log_n)
+    want = oracle.best_fft(x, fr_mont(omega), log_n, threads=FFT_THREADS)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.skipif(os.environ.get("H2_TEST_NTT_2P28", "1") == "0", reason="H2_TEST_NTT_2P28=0")
+def test_ntt_2p28_the_whole_two_adic_subgroup(oracle):
+    """the largest transform the field has (Fr's 2-adicity is 28; 8 GiB per vector, 4 + 8 + 8 + 8 bits): outputs sampled
+    against the oracle's Horner evaluation at omega^i (the DFT's definition, arithmetic.rs:714-735), then inverse o forward
+    = identity on every element"""
+    import torch
+
+    from halo2_gpu_specific_amd import lib
+    from halo2_gpu_specific_amd._lib import check
+
+    log_n = 28
+    n = 1 << log_n
+    omega = ROOT
+    L = lib()
+    x = oracle.random_fr(0x28280000, n)
+    dev = torch.device("cuda", 0)
+    a = torch.from_numpy(x.view(np.int64)).to(dev)
+    tmp = torch.empty_like(a)
+    w, w_inv, n_inv = fr_mont(omega), fr_mont(pow(omega, -1, R_MOD)), fr_mont(pow(n, -1, R_MOD))   # alive across the calls
+    check(L.h2_dev_ntt(a.data_ptr(), tmp.data_ptr(), w.ctypes.data, log_n, None), "h2_dev_ntt")
+    torch.cuda.synchronize()
+    out = np.zeros(4, dtype=np.uint64)
+    for i in (0, 1, 0x1234567, n // 2 + 3, n - 1):
+        point = fr_mont(pow(omega, i, R_MOD))
+        oracle.lib.oracle_eval_polynomial_par.argtypes = [ctypes_vp, ctypes_sz, ctypes_vp, ctypes_i32, ctypes_vp]
+        oracle.lib.oracle_eval_polynomial_par.restype = None
+        oracle.lib.oracle_eval_polynomial_par(x.ctypes.data, n, point.ctypes.data, FFT_THREADS, out.ctypes.data)
+        assert np.array_equal(a[i].cpu().numpy().view(np.uint64), out), "output %d" % i
+    check(L.h2_dev_intt(a.data_ptr(), tmp.data_ptr(), w_inv.ctypes.data, n_inv.ctypes.data, log_n, None), "h2_dev_intt")
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu(), torch.from_numpy(x.view(np.int64)))

@@ -114,13 +114,15 @@ m = hi - lo
 a = oracle.random_fr(31, n)
 b = from_mont(oracle.random_fr(32, 1))[0]
 want = np.zeros((n - 1, 4), dtype=np.uint64)
-oracle.lib.oracle_kate_division(a.ctypes.data, n, fr_mont(b).ctypes.data, want.ctypes.data)
+b_m = fr_mont(b)
+oracle.lib.oracle_kate_division(a.ctypes.data, n, b_m.ctypes.data, want.ctypes.data)
 want = from_mont(want) + [0]
 local = np.zeros((m - 1, 4), dtype=np.uint64)
-oracle.lib.oracle_kate_division(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(b).ctypes.data, local.ctypes.data)
+mine_a = np.ascontiguousarray(a[lo:hi])
+oracle.lib.oracle_kate_division(mine_a.ctypes.data, m, b_m.ctypes.data, local.ctypes.data)
 local = from_mont(local) + [0]
 part = np.zeros(4, dtype=np.uint64)
-oracle.lib.oracle_eval_polynomial(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(b).ctypes.data, part.ctypes.data)
+oracle.lib.oracle_eval_polynomial(mine_a.ctypes.data, m, b_m.ctypes.data, part.ctypes.data)
 gathered = parallel.allgather_scalars([from_mont(part.reshape(1, 4))[0]])
 carry = parallel.kate_carries([g[0] for g in gathered], b, m)[rank]
 got = [(local[t] + carry * pow(b, m - 1 - t, R_MOD)) %% R_MOD for t in range(m)]
@@ -128,8 +130,9 @@ assert got == want[lo:hi], "rank %%d: Kate division by ranges differs" %% rank
 # ---- evaluation by ranges (Device.eval_polynomial_ranges): p(x) = sum_r x^(lo_r) p_r(x)
 x = from_mont(oracle.random_fr(33, 1))[0]
 full = np.zeros(4, dtype=np.uint64)
-oracle.lib.oracle_eval_polynomial(a.ctypes.data, n, fr_mont(x).ctypes.data, full.ctypes.data)
-oracle.lib.oracle_eval_polynomial(np.ascontiguousarray(a[lo:hi]).ctypes.data, m, fr_mont(x).ctypes.data, part.ctypes.data)
+x_m = fr_mont(x)
+oracle.lib.oracle_eval_polynomial(a.ctypes.data, n, x_m.ctypes.data, full.ctypes.data)
+oracle.lib.oracle_eval_polynomial(mine_a.ctypes.data, m, x_m.ctypes.data, part.ctypes.data)
 parts = parallel.allgather_scalars([from_mont(part.reshape(1, 4))[0]])
 assert parallel.combine_range_evals([g[0] for g in parts], x, m) == from_mont(full.reshape(1, 4))[0]
 # ---- grand product / grand sum by ranges (Device.prefix_scan): z[0] = init, z[i] = z[i-1] * f[i-1]
