@@ -161,3 +161,20 @@ def test_ntt_2p28_the_whole_two_adic_subgroup(oracle):
     check(L.h2_dev_intt(a.data_ptr(), tmp.data_ptr(), w_inv.ctypes.data, n_inv.ctypes.data, log_n, None), "h2_dev_intt")
     torch.cuda.synchronize()
     assert torch.equal(a.cpu(), torch.from_numpy(x.view(np.int64)))
+
+
+@pytest.mark.skipif(os.environ.get("H2_TEST_MSM_2P26") != "1", reason="opt-in (H2_TEST_MSM_2P26=1): ~2 minutes of oracle time")
+def test_msm_2p26_beyond_the_metric_vs_oracle(oracle):
+    """past the metric's size: 2^26 points (a k = 26 SRS: 4 GiB of bases, a 48 GiB shifted-base table of 12 digits, bucket
+    ids of 21 / 22 bits, 2^26 x 12 = 8 x 10^8 sorted 32-bit entries), windowed and over the table, against the oracle"""
+    n = 1 << 26
+    bases = oracle.random_g1(0x48414C4F32 + 26, n)
+    col = oracle.random_fr(0x48414C4F32 + 2626, n)
+    want = _affine(oracle, oracle.best_multiexp(col, bases))
+    dev = DevMsm(bases)
+    assert _affine(oracle, dev.msm(col, 254)) == want, "windowed"
+    dev.precompute()
+    try:
+        assert _affine(oracle, dev.msm(col, 254)) == want, "over the table"
+    finally:
+        dev.forget()
