@@ -91,7 +91,9 @@ def footprint(cs, dom, cached_cosets=None):
     key_polys = 2 * (F + P)                                   # Lagrange values and coefficient forms
     c = dom.quotient_poly_degree
     cached = c if cached_cosets is None else max(1, min(c, cached_cosets))
-    base = 32 * n * (key_polys + 2 * witness_polys + 4 + c)   # + random / h / scratch vectors, the c per-coset quotients
+    # + random / h / scratch vectors, the c per-coset quotients, and the scratch of two commitments in flight (sorted digit
+    # entries, slice partials, buckets: ~370 B per point each = 23 n-vectors' worth; k = 25 measured: 97 GiB at the peak)
+    base = 32 * n * (key_polys + 2 * witness_polys + 4 + c + 23)
     return {"extended": base + 32 * en * ((F + P + 3) + witness_polys + 2),
             "cosets": base + 32 * n * ((F + P + 3) * cached + witness_polys + 3)}
 
@@ -329,8 +331,13 @@ class Device:
             return "cosets", max(0, min(c, self.eval_cache))
         budget = self.mem_budget
         if budget is None:
-            budget = self.torch.cuda.get_device_properties(self.dev).total_memory
-            if footprint(cs, dom)["extended"] <= budget * 0.8:      # the rest: MSM scratch, library tables, allocator slack
+            # what the device has left NOW -- behind the SRS and its shifted-base tables (96 GiB at k = 26), other keys --
+            # plus what torch's allocator holds but does not use; a fifth of it stays free for library tables and slack
+            torch = self.torch
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            held = self._scratch.numel() if self._scratch is not None else 0     # commitment scratch: reused, and counted
+            budget = int(0.8 * (free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) + held))
+            if footprint(cs, dom)["extended"] <= budget:
                 return "extended", None
         elif footprint(cs, dom)["extended"] <= budget:
             return "extended", None
@@ -855,6 +862,13 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     assert n >= cs.minimum_rows()
     pk = ProvingKey()
     pk.cs, pk.domain = cs, dom
+    plan = D.coset_plan(dom)
+    # one device under a memory budget: when the extended cosets do not fit, the proving key keeps coefficient forms only
+    # and the extended-domain phase runs coset by coset (all quotient_poly_degree of them, tables built on demand).
+    # Decided before anything of this key is allocated: the estimate is compared with the memory that is free NOW.
+    pk.residency, keep = ("cosets", None) if plan is not None else D.residency(cs, dom)
+    if plan is None and pk.residency == "cosets":
+        plan = (dom.quotient_poly_degree, 1, list(range(dom.quotient_poly_degree)))
     # fixed columns: values, coefficient form, extended cosets
     pk.fixed_values = []
     for col in fixed:
@@ -864,12 +878,6 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         pk.fixed_values.append(t)
     pk.fixed_commitments = D.msm_batch(pk.fixed_values, params.g_lagrange, n, 254)
     pk.fixed_polys = [D.intt(D.clone(t), dom) for t in pk.fixed_values]
-    plan = D.coset_plan(dom)
-    # one device under a memory budget: when the extended cosets do not fit, the proving key keeps coefficient forms only
-    # and the extended-domain phase runs coset by coset (all quotient_poly_degree of them, tables built on demand)
-    pk.residency, keep = ("cosets", None) if plan is not None else D.residency(cs, dom)
-    if plan is None and pk.residency == "cosets":
-        plan = (dom.quotient_poly_degree, 1, list(range(dom.quotient_poly_degree)))
     pk.fixed_cosets = [D.coeff_to_extended(t, dom) for t in pk.fixed_polys] if plan is None else None
     # permutation: sigma columns (Lagrange), polys, cosets
     ncols = len(cs.perm_columns)
