@@ -23,7 +23,7 @@ import numpy as np
 from . import evaluation as ev
 from ._lib import check, lib
 from .circuit import compile_compress, compile_evaluator
-from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, g1_add_affine, jacobian_to_affine,
+from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, g1_add_affine, jacobian_to_affine, jacobians_to_affine,
                          point_to_bytes)
 
 ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
@@ -242,6 +242,20 @@ class Device:
         a = np.array([fr_to_mont_limbs(v) for v in values], dtype=np.uint64)
         with self.torch.cuda.stream(self.tstream):
             t[start:start + len(values)] = self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+
+    def set_rows_many(self, items):
+        """[(t, start, values)]: set_rows for several vectors with ONE host-to-device copy (the blinding rows of every
+        product column of a phase: a copy from pageable memory synchronises, ~50 us each)"""
+        items = [it for it in items if len(it[2])]
+        if not items:
+            return
+        flat = np.array([fr_to_mont_limbs(v) for _, _, vals in items for v in vals], dtype=np.uint64)
+        with self.torch.cuda.stream(self.tstream):
+            blob = self.torch.from_numpy(flat.view(np.int64)).to(self.dev)
+            at = 0
+            for t, start, vals in items:
+                t[start:start + len(vals)] = blob[at:at + len(vals)]
+                at += len(vals)
 
     def set_rows_raw(self, t, start, small):
         """t[start : start + len(small)] <- small non-negative integers < 2^63, limb 0 only (no Montgomery form)"""
@@ -480,7 +494,7 @@ class Device:
         out = self.msm_partial(columns, bases, lo, hi, max_bits, also)
         if collective:
             out = allgather_fold_many(out, group=self.group, device=self.dev, stream=self.tstream)
-        return [jacobian_to_affine(r) for r in out]
+        return jacobians_to_affine(out)
 
     def msm_partial(self, columns, bases, lo, hi, max_bits=254, also=None):
         """the MSMs restricted to the index range [lo, hi): raw Jacobian results, (count (+1), 12) u64.
@@ -1104,7 +1118,11 @@ def complete_range_check_witness(cs, n, advice, first_unassigned=None):
         body = low(col)[:usable]
         if (col.ndim == 2 and col[:usable, 1:].any()) or int(body.max()) > vmax or int(body.min()) < vmin:
             raise ValueError("range check: a value of the column lies outside its range")   # the reference's HashMap lookup panics
-        low(companion)[:usable] = np.sort(body, kind="stable")
+        if vmax - vmin < (1 << 24):         # the reference's counting sort (`sort`, prover.rs:164-200): O(n + range)
+            counts = np.bincount((body - np.uint64(vmin)).astype(np.int64), minlength=vmax - vmin + 1)
+            low(companion)[:usable] = np.repeat(np.arange(vmin, vmax + 1, dtype=np.uint64), counts)
+        else:
+            low(companion)[:usable] = np.sort(body, kind="stable")
         if companion.ndim == 2:
             companion[:usable, 1:] = 0
     return advice
@@ -1366,11 +1384,12 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         C["nums"], C["inv"] = nums, inv
 
     # ---- permutation grand products (permutation/prover.rs:89-165), circuit by circuit -------------------------
+    blinding = []         # (z, first blinding row, values): drawn in the reference's order, written in one copy below
     for C in circuits:
         C["z"], last_z = [], 1
         for k_ in range(nsets):
             z, last_z = D.prefix_scan(C["nums"][k_ * m_s:(k_ + 1) * m_s], n, last_z, True, usable)
-            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+            blinding.append((z, n - bf, [rng.fr() for _ in range(bf)]))
             C["z"].append(z)
         del C["nums"]
     num = D.empty(m_s)
@@ -1387,7 +1406,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                     D.eval_op(3, st["inv_table"], st["inv_table"], rows(st["m"]), size=m_s)
                     src = D.eval_op(4, num, src, st["inv_table"], size=m_s)       # H2_OP_SUB
                 z, last = D.prefix_scan(src, n, last, False, usable)
-                D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+                blinding.append((z, n - bf, [rng.fr() for _ in range(bf)]))
                 st["z"].append(z)
             if last != 0:
                 raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
@@ -1401,10 +1420,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             z, closing = D.prefix_scan(inverted, n, 1, True, usable)
             if closing != 1:
                 raise ValueError("shuffle product does not return to one")
-            D.set_rows(z, n - bf, [rng.fr() for _ in range(bf)])
+            blinding.append((z, n - bf, [rng.fr() for _ in range(bf)]))
             C["shuffle_z"].append(z)
         del C["inv"], C["shuffle_inv"]
     del num
+    D.set_rows_many(blinding)
     # commit_lagrange_and_ifft (poly/commitment.rs:144-197) for every z, in the transcript's order: the permutation
     # products of every circuit, then the lookup sums of every circuit, then the shuffle products (prover.rs:595-625)
     all_z = ([z for C in circuits for z in C["z"]] + [z for C in circuits for st in C["lookups"] for z in st["z"]] +

@@ -8,6 +8,8 @@ identity encoded as 32 zero bytes; challenges are `from_bytes_wide` = the 512-bi
 """
 import hashlib
 
+import numpy as np
+
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 _MONT_INV_R = pow(1 << 256, -1, R_MOD)
@@ -40,6 +42,30 @@ def jacobian_to_affine(xyz):
     zi = pow(z, -1, Q_MOD)
     zi2 = zi * zi % Q_MOD
     return (x * zi2 % Q_MOD, y * zi2 % Q_MOD * zi % Q_MOD)
+
+
+def jacobians_to_affine(rows):
+    """jacobian_to_affine for a batch of points with ONE modular inversion (Montgomery's trick; an inversion is ~15 us of
+    Python, the products ~0.3 us: the commitments of a phase are normalised together before they are hashed)"""
+    raw = np.ascontiguousarray(rows, dtype=np.uint64).tobytes()       # one conversion instead of twelve scalars per point
+    pts = [[int.from_bytes(raw[96 * j + 32 * i:96 * j + 32 * i + 32], "little") * _MONT_INV_Q % Q_MOD for i in range(3)]
+           for j in range(len(raw) // 96)]
+    prefix, acc = [], 1
+    for _, _, z in pts:
+        prefix.append(acc)
+        if z:
+            acc = acc * z % Q_MOD
+    inv = pow(acc, -1, Q_MOD)
+    out = [None] * len(pts)
+    for i in range(len(pts) - 1, -1, -1):
+        x, y, z = pts[i]
+        if z == 0:
+            continue
+        zi = inv * prefix[i] % Q_MOD
+        inv = inv * z % Q_MOD
+        zi2 = zi * zi % Q_MOD
+        out[i] = (x * zi2 % Q_MOD, y * zi2 % Q_MOD * zi % Q_MOD)
+    return out
 
 
 def g1_add_affine(P, Q):
