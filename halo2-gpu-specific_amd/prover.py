@@ -239,6 +239,8 @@ class Device:
 
     def set_rows(self, t, start, values):
         """t[start : start + len(values)] <- canonical integers (stored Montgomery)"""
+        if not len(values):                      # (an instance column without public inputs)
+            return
         a = np.array([fr_to_mont_limbs(v) for v in values], dtype=np.uint64)
         with self.torch.cuda.stream(self.tstream):
             t[start:start + len(values)] = self.torch.from_numpy(a.view(np.int64)).to(self.dev)

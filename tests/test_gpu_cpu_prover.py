@@ -158,3 +158,19 @@ def test_compact_and_resident_witness_columns_give_the_same_bytes(device):
     small = [a[:, 0].copy() for a in adv]
     want = prover.create_proof_ext(device, params, pk, adv, ProverRng(3), False)
     assert prover.create_proof_ext(device, params, pk, small, ProverRng(3), False) == want
+
+
+def test_random_circuits_device_bytes_equal_cpu_bytes(device):
+    """tools/prover_fuzz.py: circuits drawn from seeds (random gate expressions with rotations, constants and scalings,
+    random equality columns and copies, optional logup lookup with one or two input sets, optional shuffle, optional
+    instance column) -- the generated gate kernel of each and every phase around it against the CPU prover's interpreter
+    and loops; a longer run of the same generator: `python tools/prover_fuzz.py 600`"""
+    import sys
+
+    from h2util import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prover_fuzz
+
+    for seed in range(1, 17):
+        prover_fuzz.run_case(device, seed)

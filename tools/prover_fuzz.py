@@ -1,0 +1,160 @@
+"""Random circuits through the whole prover: keygen + create_proof on the device (generated gate kernels) against the CPU
+prover over the C oracle (tests/oracle_prover.py: the oracle's evaluator interpreter and loops), same SRS, witness and
+randomness -- the proof bytes must be equal.
+
+A circuit is drawn from a seed: 2-6 advice / 1-3 fixed / 0-1 instance columns, 1-4 gates of random expressions (queries
+at rotations -2 .. 2, constants, sums, products, scalings; degree <= 5), random equality columns and copy constraints,
+optionally a logup lookup (1-2 input sets into a fixed table) and a shuffle.  The witness is random field elements:
+a proof is a deterministic function of (key, witness, randomness) whether or not the gates hold -- the quotient phase
+divides pointwise on the extended domain either way -- so unsatisfied gates and copies exercise the same arithmetic;
+only what the prover itself checks is made true (lookup inputs come from the table, the shuffle is a permutation).
+
+usage: python tools/prover_fuzz.py [seconds] [first seed]
+"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from halo2_gpu_specific_amd import circuit as hc  # noqa: E402
+from halo2_gpu_specific_amd.transcript import R_MOD  # noqa: E402
+
+S_TRAPDOOR = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
+
+
+def _arr(vals):
+    a = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for limb in range(4):
+            a[i, limb] = (v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def random_case(seed):
+    """-> (cs, k, advice, fixed, copies, instances): see the module docstring"""
+    rnd = random.Random(seed)
+    cs = hc.ConstraintSystem("fuzz-%d" % seed)
+    n_adv, n_fix, n_inst = rnd.randint(2, 6), rnd.randint(1, 3), rnd.randint(0, 1)
+    adv = [cs.advice_column() for _ in range(n_adv)]
+    fix = [cs.fixed_column() for _ in range(n_fix)]
+    inst = [cs.instance_column() for _ in range(n_inst)]
+    with_lookup, with_shuffle = rnd.random() < 0.5, rnd.random() < 0.5
+    table_col = cs.fixed_column() if with_lookup else None
+    look_cols = [cs.advice_column() for _ in range(rnd.randint(1, 3))] if with_lookup else []
+    shuf_cols = [cs.advice_column(), cs.advice_column()] if with_shuffle else []
+
+    def leaf():
+        kind = rnd.random()
+        if kind < 0.15:
+            return hc.Constant(rnd.randrange(R_MOD)) if rnd.random() < 0.5 else hc.Constant(rnd.randrange(5))
+        if kind < 0.70 or not (fix or inst):
+            return cs.query_advice(rnd.choice(adv), rnd.randint(-2, 2))
+        if kind < 0.92 or not inst:
+            return cs.query_fixed(rnd.choice(fix), rnd.choice((0, 0, 1, -1)))
+        return cs.query_instance(rnd.choice(inst), rnd.choice((0, 1)))
+
+    def expr(depth, max_degree):
+        if depth == 0 or max_degree <= 1 or rnd.random() < 0.25:
+            return leaf()
+        op = rnd.random()
+        if op < 0.35:
+            return expr(depth - 1, max_degree) + expr(depth - 1, max_degree)
+        if op < 0.55:
+            return expr(depth - 1, max_degree) - expr(depth - 1, max_degree)
+        if op < 0.90:
+            left = max(1, max_degree // 2)
+            return expr(depth - 1, left) * expr(depth - 1, max_degree - left)
+        return expr(depth - 1, max_degree) * rnd.randrange(1, R_MOD)
+
+    for g in range(rnd.randint(1, 4)):
+        polys = [cs.query_fixed(rnd.choice(fix)) * expr(3, 4) for _ in range(rnd.randint(1, 2))]
+        cs.create_gate("g%d" % g, polys)
+    for col in rnd.sample(adv, rnd.randint(1, len(adv))) + ([rnd.choice(fix)] if rnd.random() < 0.5 else []) + inst:
+        cs.enable_equality(col)
+    if with_lookup:
+        tq = cs.query_fixed(table_col)
+        first = [[cs.query_advice(c)] for c in look_cols[:2]]
+        sets = [first] + ([[[cs.query_advice(look_cols[2])]]] if len(look_cols) > 2 else [])
+        cs.lookup_any("lk", [tq], sets)
+    if with_shuffle:
+        cs.shuffle_group([("sh", [cs.query_advice(shuf_cols[0])], [cs.query_advice(shuf_cols[1])])])
+    # (a lookup set of two inputs needs degree 5: its table + inputs + 2)
+    cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
+    k = rnd.randint(5, 9)
+    while (1 << k) < cs.minimum_rows() + 8:
+        k += 1
+    n = 1 << k
+    usable = n - (cs.blinding_factors() + 1)
+    rf = lambda: rnd.randrange(R_MOD) if rnd.random() < 0.8 else rnd.randrange(4)  # noqa: E731
+    all_adv = cs.num_advice
+    advice = [[rf() for _ in range(n)] for _ in range(all_adv)]
+    fixed = [[rnd.randrange(2) if rnd.random() < 0.5 else rf() for _ in range(n)] for _ in range(cs.num_fixed)]
+    if with_lookup:
+        t_idx = table_col[1]
+        distinct = [rnd.randrange(R_MOD) for _ in range(rnd.randint(1, 40))]
+        fixed[t_idx] = [rnd.choice(distinct) for _ in range(n)]
+        for c in look_cols:
+            advice[c[1]] = [fixed[t_idx][rnd.randrange(usable)] for _ in range(n)]
+    if with_shuffle:
+        src = advice[shuf_cols[0][1]]
+        perm = list(range(usable))
+        rnd.shuffle(perm)
+        advice[shuf_cols[1][1]] = [src[perm[i]] if i < usable else 0 for i in range(n)]
+    ncols = len(cs.perm_columns)
+    copies = [(rnd.randrange(ncols), rnd.randrange(usable), rnd.randrange(ncols), rnd.randrange(usable))
+              for _ in range(rnd.randint(0, 12))]
+    # (at least one non-zero public input: the commitment of an all-zero column is the identity, which the transcript
+    # refuses as the reference's does)
+    instances = [[rnd.randrange(1, R_MOD)] + [rf() for _ in range(rnd.randint(0, min(usable, 5) - 1))] for _ in range(n_inst)]
+    return cs, k, [_arr(c) for c in advice], [_arr(c) for c in fixed], copies, instances
+
+
+def run_case(device, seed, cache={}):
+    """one random circuit on the device and on the CPU; returns a description, raises on a mismatch"""
+    import oracle_prover as op
+    from halo2_gpu_specific_amd import prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    cs, k, advice, fixed, copies, instances = random_case(seed)
+    if k not in cache:
+        params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+        cpu = op.OracleDevice(threads=4)
+        cache[k] = (params, cpu, op.params_like(cpu, params))
+    params, cpu, cparams = cache[k]
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    cpk = op.keygen(cpu, cparams, cs, fixed, copies)
+    assert pk.transcript_repr == cpk.transcript_repr, "seed %d: keys differ" % seed
+    for use_gwc in (False, True):
+        got = prover.create_proof_ext(device, params, pk, advice, ProverRng(seed), use_gwc, instances=instances)
+        want = prover.create_proof_ext(cpu, cparams, cpk, advice, ProverRng(seed), use_gwc, instances=instances)
+        if got != want:
+            first = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+            raise AssertionError("seed %d (%s): proof differs at byte %d of %d / %d" % (
+                seed, "gwc" if use_gwc else "shplonk", first, len(got), len(want)))
+    return "seed %d: k=%d degree=%d advice=%d fixed=%d gates=%d lookups=%d shuffles=%d jit=%s  %d bytes" % (
+        seed, k, cs.degree(), cs.num_advice, cs.num_fixed, len(cs.gates), len(cs.lookups), len(cs.shuffles),
+        bool(pk.evalh_code_object), len(got))
+
+
+def main():
+    from halo2_gpu_specific_amd import prover
+
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    device = prover.Device()
+    t_end, done = time.time() + seconds, 0
+    while time.time() < t_end:
+        print(run_case(device, seed), flush=True)
+        seed += 1
+        done += 1
+    print("%d random circuits: device proof bytes == CPU proof bytes (GWC and SHPLONK each)" % done)
+
+
+if __name__ == "__main__":
+    main()
