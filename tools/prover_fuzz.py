@@ -9,7 +9,7 @@ a proof is a deterministic function of (key, witness, randomness) whether or not
 divides pointwise on the extended domain either way -- so unsatisfied gates and copies exercise the same arithmetic;
 only what the prover itself checks is made true (lookup inputs come from the table, the shuffle is a permutation).
 
-usage: python tools/prover_fuzz.py [seconds] [first seed]
+usage: python tools/prover_fuzz.py [seconds] [first seed] [satisfiable]
 """
 import os
 import random
@@ -36,8 +36,26 @@ def _arr(vals):
     return a
 
 
-def random_case(seed):
-    """-> (cs, k, advice, fixed, copies, instances): see the module docstring"""
+def _evaluate(e, row, n, cols):
+    """an Expression at one row over canonical integer columns {kind: [column][row]}"""
+    if isinstance(e, hc.Constant):
+        return e.v
+    if isinstance(e, hc.Query):
+        return cols[e.name][e.column][(row + e.rotation) % n]
+    if isinstance(e, hc.Negated):
+        return -_evaluate(e.e, row, n, cols) % R_MOD
+    if isinstance(e, hc.Sum):
+        return (_evaluate(e.a, row, n, cols) + _evaluate(e.b, row, n, cols)) % R_MOD
+    if isinstance(e, hc.Product):
+        return _evaluate(e.a, row, n, cols) * _evaluate(e.b, row, n, cols) % R_MOD
+    return _evaluate(e.e, row, n, cols) * e.c % R_MOD          # Scaled
+
+
+def random_case(seed, satisfiable=False):
+    """-> (cs, k, advice, fixed, copies, instances): see the module docstring.  `satisfiable`: every gate reads
+    sel (E - d) with a selector that is on where all of E's rotations stay inside the usable rows and d a witness column
+    of its own set to E, and the copy constraints hold (cells of a cycle share one value): the quotient is then a
+    polynomial, and the coset-by-coset routes of the extended-domain phase must give the bytes of the extended route."""
     rnd = random.Random(seed)
     cs = hc.ConstraintSystem("fuzz-%d" % seed)
     n_adv, n_fix, n_inst = rnd.randint(2, 6), rnd.randint(1, 3), rnd.randint(0, 1)
@@ -46,7 +64,8 @@ def random_case(seed):
     inst = [cs.instance_column() for _ in range(n_inst)]
     with_lookup, with_shuffle = rnd.random() < 0.5, rnd.random() < 0.5
     table_col = cs.fixed_column() if with_lookup else None
-    look_cols = [cs.advice_column() for _ in range(rnd.randint(1, 3))] if with_lookup else []
+    # (satisfiable circuits: two inputs in the first set, so that the lookup constraint really has the degree 5 it declares)
+    look_cols = [cs.advice_column() for _ in range(rnd.randint(2 if satisfiable else 1, 3))] if with_lookup else []
     shuf_cols = [cs.advice_column(), cs.advice_column()] if with_shuffle else []
 
     def leaf():
@@ -72,10 +91,20 @@ def random_case(seed):
             return expr(depth - 1, left) * expr(depth - 1, max_degree - left)
         return expr(depth - 1, max_degree) * rnd.randrange(1, R_MOD)
 
+    defined = []                                   # satisfiable: (witness column of its own, the expression it equals)
+    sel_col = cs.fixed_column() if satisfiable else None
     for g in range(rnd.randint(1, 4)):
-        polys = [cs.query_fixed(rnd.choice(fix)) * expr(3, 4) for _ in range(rnd.randint(1, 2))]
+        polys = []
+        for _ in range(rnd.randint(1, 2)):
+            if satisfiable:
+                d_col, e = cs.advice_column(), expr(3, 4)
+                defined.append((d_col, e))
+                polys.append(cs.query_fixed(sel_col) * (e - cs.query_advice(d_col)))
+            else:
+                polys.append(cs.query_fixed(rnd.choice(fix)) * expr(3, 4))
         cs.create_gate("g%d" % g, polys)
-    for col in rnd.sample(adv, rnd.randint(1, len(adv))) + ([rnd.choice(fix)] if rnd.random() < 0.5 else []) + inst:
+    for col in (rnd.sample(adv, rnd.randint(1, len(adv))) + ([rnd.choice(fix)] if rnd.random() < 0.5 else []) +
+                ([] if satisfiable else inst)):
         cs.enable_equality(col)
     if with_lookup:
         tq = cs.query_fixed(table_col)
@@ -85,7 +114,10 @@ def random_case(seed):
     if with_shuffle:
         cs.shuffle_group([("sh", [cs.query_advice(shuf_cols[0])], [cs.query_advice(shuf_cols[1])])])
     # (a lookup set of two inputs needs degree 5: its table + inputs + 2)
-    cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
+    if satisfiable:        # no higher than what the constraints reach, or the top piece of h(X) is zero (see run_case)
+        cs.set_minimum_degree(5 if with_lookup else 3)
+    else:
+        cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
     k = rnd.randint(5, 9)
     while (1 << k) < cs.minimum_rows() + 8:
         k += 1
@@ -112,16 +144,37 @@ def random_case(seed):
     # (at least one non-zero public input: the commitment of an all-zero column is the identity, which the transcript
     # refuses as the reference's does)
     instances = [[rnd.randrange(1, R_MOD)] + [rf() for _ in range(rnd.randint(0, min(usable, 5) - 1))] for _ in range(n_inst)]
+    if satisfiable:
+        cells = {"advice": advice, "fixed": fixed}
+        parent = {}
+
+        def find(c):
+            while parent.setdefault(c, c) != c:
+                parent[c] = parent[parent[c]]
+                c = parent[c]
+            return c
+
+        for c1, r1, c2, r2 in copies:                       # the cells of a cycle take the value of its representative
+            parent[find((c2, r2))] = find((c1, r1))
+        for c, r in list(parent):
+            (k0, i0), (rc, rr) = cs.perm_columns[c], find((c, r))
+            k1, i1 = cs.perm_columns[rc]
+            cells[k0][i0][r] = cells[k1][i1][rr]
+        fixed[sel_col[1]] = [1 if 2 <= r < usable - 2 else 0 for r in range(n)]
+        cols = dict(cells, instance=[v + [0] * (n - len(v)) for v in instances])
+        for d_col, e in defined:
+            advice[d_col[1]] = [_evaluate(e, r, n, cols) if 2 <= r < usable - 2 else rf() for r in range(n)]
     return cs, k, [_arr(c) for c in advice], [_arr(c) for c in fixed], copies, instances
 
 
-def run_case(device, seed, cache={}):
-    """one random circuit on the device and on the CPU; returns a description, raises on a mismatch"""
+def run_case(device, seed, cache={}, satisfiable=False):
+    """one random circuit on the device and on the CPU; returns a description, raises on a mismatch.  `satisfiable`: also
+    by the coset routes of the device (every coset at once, and coset by coset with no table set retained)"""
     import oracle_prover as op
     from halo2_gpu_specific_amd import prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
-    cs, k, advice, fixed, copies, instances = random_case(seed)
+    cs, k, advice, fixed, copies, instances = random_case(seed, satisfiable)
     if k not in cache:
         params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
         cpu = op.OracleDevice(threads=4)
@@ -131,12 +184,32 @@ def run_case(device, seed, cache={}):
     cpk = op.keygen(cpu, cparams, cs, fixed, copies)
     assert pk.transcript_repr == cpk.transcript_repr, "seed %d: keys differ" % seed
     for use_gwc in (False, True):
+        try:
+            want = prover.create_proof_ext(cpu, cparams, cpk, advice, ProverRng(seed), use_gwc, instances=instances)
+        except ValueError as e:
+            # a satisfied circuit whose constraints stay below the declared degree has a zero top piece of h(X): its
+            # commitment is the identity, which the transcript refuses (as the reference's does): not a case
+            if "infinity" not in str(e):
+                raise
+            with_device = None
+            try:
+                prover.create_proof_ext(device, params, pk, advice, ProverRng(seed), use_gwc, instances=instances)
+            except ValueError as e2:
+                with_device = str(e2)
+            assert with_device == str(e), "seed %d: the CPU prover refused (%s), the device did not" % (seed, e)
+            return "seed %d: k=%d degree=%d -- refused by both (%s)" % (seed, k, cs.degree(), e)
         got = prover.create_proof_ext(device, params, pk, advice, ProverRng(seed), use_gwc, instances=instances)
-        want = prover.create_proof_ext(cpu, cparams, cpk, advice, ProverRng(seed), use_gwc, instances=instances)
         if got != want:
             first = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
             raise AssertionError("seed %d (%s): proof differs at byte %d of %d / %d" % (
                 seed, "gwc" if use_gwc else "shplonk", first, len(got), len(want)))
+    if satisfiable:
+        for kw in (dict(force_cosets=True), dict(eval_cache=0)):
+            D2 = prover.Device(**kw)
+            params2 = prover.Params(D2, k, params.g, params.g_lagrange, tables=False)
+            pk2 = prover.keygen(D2, params2, cs, fixed, copies)
+            other = prover.create_proof_ext(D2, params2, pk2, advice, ProverRng(seed), True, instances=instances)
+            assert other == got, "seed %d: the coset route (%s) changed the proof" % (seed, kw)
     return "seed %d: k=%d degree=%d advice=%d fixed=%d gates=%d lookups=%d shuffles=%d jit=%s  %d bytes" % (
         seed, k, cs.degree(), cs.num_advice, cs.num_fixed, len(cs.gates), len(cs.lookups), len(cs.shuffles),
         bool(pk.evalh_code_object), len(got))
@@ -147,10 +220,11 @@ def main():
 
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    satisfiable = len(sys.argv) > 3 and sys.argv[3] == "satisfiable"
     device = prover.Device()
     t_end, done = time.time() + seconds, 0
     while time.time() < t_end:
-        print(run_case(device, seed), flush=True)
+        print(run_case(device, seed, satisfiable=satisfiable), flush=True)
         seed += 1
         done += 1
     print("%d random circuits: device proof bytes == CPU proof bytes (GWC and SHPLONK each)" % done)
