@@ -294,14 +294,18 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,which,k", [(2, "mini", 10), (2, "mini", 17), (4, "mini", 12), (8, "mini", 10), (2, "lookup", 9),
-                                           (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8)])
+                                           (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8),
+                                           (2, "fuzz:201", 8), (4, "fuzz:202", 8), (3, "fuzz:203", 8), (2, "fuzz:204", 9),
+                                           (4, "fuzz:205", 9), (8, "fuzz:206", 9)])
 def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
     """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
     scattered as coefficient ranges + un-mixed; the permutation / lookup / shuffle products, the evaluations and the
     multiopen argument (SHPLONK and GWC) on row / coefficient ranges with one field element per rank exchanged per scan /
     Kate division.  Every rank must emit the single-device proof, for the mini-PLONK circuit, the lookup + shuffle +
-    instance circuit (degree 6: 5 cosets over 2 or 4 ranks) and the wide circuit (degree 5, eight grand sums)."""
+    instance circuit (degree 6: 5 cosets over 2 or 4 ranks), the wide circuit (degree 5, eight grand sums) and random
+    satisfied circuits (tools/prover_fuzz.py: gates with rotations -2 .. 2 reaching across the ranks' row ranges, lookups
+    with two input sets, shuffles, instance columns)."""
     import subprocess
     import sys
 
@@ -341,6 +345,17 @@ def _multi_rank_case(which, k):
     if which == "wide":
         adv, fixed, copies = circuits.wide_synthesize(k, 4)
         return circuits.wide(4), adv, fixed, copies, []
+    if which.startswith("fuzz:"):                      # a random satisfied circuit of tools/prover_fuzz.py
+        import sys
+
+        from h2util import ROOT
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prover_fuzz
+
+        cs, k2, adv, fixed, copies, inst = prover_fuzz.random_case(int(which[5:]), satisfiable=True, k=k)
+        assert k2 == k, "the circuit needs more rows than 2^%d" % k
+        return cs, adv, fixed, copies, inst
     syn = rp.LookupShuffle.synthesize(k)
     return (lookup_shuffle_cs(), cols_to_arr(syn[0]), cols_to_arr(syn[1]), [(l[0], l[1], r[0], r[1]) for l, r in syn[2]], syn[3])
 

@@ -51,7 +51,7 @@ def _evaluate(e, row, n, cols):
     return _evaluate(e.e, row, n, cols) * e.c % R_MOD          # Scaled
 
 
-def random_case(seed, satisfiable=False):
+def random_case(seed, satisfiable=False, k=None):
     """-> (cs, k, advice, fixed, copies, instances): see the module docstring.  `satisfiable`: every gate reads
     sel (E - d) with a selector that is on where all of E's rotations stay inside the usable rows and d a witness column
     of its own set to E, and the copy constraints hold (cells of a cycle share one value): the quotient is then a
@@ -118,7 +118,7 @@ def random_case(seed, satisfiable=False):
         cs.set_minimum_degree(5 if with_lookup else 3)
     else:
         cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
-    k = rnd.randint(5, 9)
+    k = rnd.randint(5, 9) if k is None else k            # (`k` given: the caller's size, raised if the circuit needs more)
     while (1 << k) < cs.minimum_rows() + 8:
         k += 1
     n = 1 << k
