@@ -635,3 +635,31 @@ def test_range_check_argument_front_end_and_witness_completion():
         prover.complete_range_check_witness(small, 1 << k, bad)
     with pytest.raises(ValueError):                         # the range does not fit the unused cells
         prover.complete_range_check_witness(small, 1 << k, [c.copy() for c in adv], first_unassigned={0: 120})
+
+
+def test_constraint_system_round_trip_random_circuits():
+    """write_cs / read_cs (helpers.rs:458-757) over the random circuits of tools/prover_fuzz.py: every expression code
+    (constants, scalings, negations, sums, products, queries at rotations -2 .. 2 of all three column kinds), multi-set
+    lookups, shuffles: the fetched system stores to the same bytes and compiles to the same evaluator program"""
+    import os
+    import sys
+
+    from h2util import ROOT
+    from halo2_gpu_specific_amd import formats
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prover_fuzz
+
+    key = lambda g: ([(c.op, c.a.kind, c.a.index, c.a.rot, c.b.kind, c.b.index, c.b.rot) for c in g.calculations],  # noqa: E731
+                     g.constants, g.rotations)
+    for seed in range(300, 340):
+        cs = prover_fuzz.random_case(seed, satisfiable=seed % 2 == 0, k=6)[0]
+        raw = formats.cs_store(cs)
+        r = formats._Reader(raw)
+        back = formats.cs_fetch(r, cs.name)
+        assert r.pos == len(raw)
+        back.set_minimum_degree(cs.degree())
+        assert formats.cs_store(back) == raw, seed
+        g0, parts0, lk0, sh0 = hc.compile_evaluator(cs)
+        g1, parts1, lk1, sh1 = hc.compile_evaluator(back)
+        assert key(g0) == key(g1) and len(parts0) == len(parts1) and len(lk0) == len(lk1) and len(sh0) == len(sh1), seed
