@@ -51,7 +51,7 @@ def _evaluate(e, row, n, cols):
     return _evaluate(e.e, row, n, cols) * e.c % R_MOD          # Scaled
 
 
-def random_case(seed, satisfiable=False, k=None):
+def random_case(seed, satisfiable=False, k=None, witness_seed=None):
     """-> (cs, k, advice, fixed, copies, instances): see the module docstring.  `satisfiable`: every gate reads
     sel (E - d) with a selector that is on where all of E's rotations stay inside the usable rows and d a witness column
     of its own set to E, and the copy constraints hold (cells of a cycle share one value): the quotient is then a
@@ -118,32 +118,37 @@ def random_case(seed, satisfiable=False, k=None):
         cs.set_minimum_degree(5 if with_lookup else 3)
     else:
         cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
-    k = rnd.randint(5, 9) if k is None else k            # (`k` given: the caller's size, raised if the circuit needs more)
+    k_draw = rnd.randint(5, 9)                          # (always drawn: the stream must not depend on the arguments)
+    k = k_draw if k is None else k                      # `k` given: the caller's size, raised if the circuit needs more
     while (1 << k) < cs.minimum_rows() + 8:
         k += 1
     n = 1 << k
     usable = n - (cs.blinding_factors() + 1)
-    rf = lambda: rnd.randrange(R_MOD) if rnd.random() < 0.8 else rnd.randrange(4)  # noqa: E731
-    all_adv = cs.num_advice
-    advice = [[rf() for _ in range(n)] for _ in range(all_adv)]
+    # circuit-level data first (fixed columns, the lookup table, the copies), from the circuit's stream; then the witness --
+    # with `witness_seed` another witness (advice, instances) of the SAME circuit: the circuits of one proof over several
+    # circuit instances
+    rf = lambda r=rnd: r.randrange(R_MOD) if r.random() < 0.8 else r.randrange(4)  # noqa: E731
     fixed = [[rnd.randrange(2) if rnd.random() < 0.5 else rf() for _ in range(n)] for _ in range(cs.num_fixed)]
     if with_lookup:
         t_idx = table_col[1]
         distinct = [rnd.randrange(R_MOD) for _ in range(rnd.randint(1, 40))]
         fixed[t_idx] = [rnd.choice(distinct) for _ in range(n)]
-        for c in look_cols:
-            advice[c[1]] = [fixed[t_idx][rnd.randrange(usable)] for _ in range(n)]
-    if with_shuffle:
-        src = advice[shuf_cols[0][1]]
-        perm = list(range(usable))
-        rnd.shuffle(perm)
-        advice[shuf_cols[1][1]] = [src[perm[i]] if i < usable else 0 for i in range(n)]
     ncols = len(cs.perm_columns)
     copies = [(rnd.randrange(ncols), rnd.randrange(usable), rnd.randrange(ncols), rnd.randrange(usable))
               for _ in range(rnd.randint(0, 12))]
+    wr = rnd if witness_seed is None else random.Random((seed << 20) ^ witness_seed)
+    advice = [[rf(wr) for _ in range(n)] for _ in range(cs.num_advice)]
+    if with_lookup:
+        for c in look_cols:
+            advice[c[1]] = [fixed[t_idx][wr.randrange(usable)] for _ in range(n)]
+    if with_shuffle:
+        src = advice[shuf_cols[0][1]]
+        perm = list(range(usable))
+        wr.shuffle(perm)
+        advice[shuf_cols[1][1]] = [src[perm[i]] if i < usable else 0 for i in range(n)]
     # (at least one non-zero public input: the commitment of an all-zero column is the identity, which the transcript
     # refuses as the reference's does)
-    instances = [[rnd.randrange(1, R_MOD)] + [rf() for _ in range(rnd.randint(0, min(usable, 5) - 1))] for _ in range(n_inst)]
+    instances = [[wr.randrange(1, R_MOD)] + [rf(wr) for _ in range(wr.randint(0, min(usable, 5) - 1))] for _ in range(n_inst)]
     if satisfiable:
         cells = {"advice": advice, "fixed": fixed}
         parent = {}
@@ -163,7 +168,7 @@ def random_case(seed, satisfiable=False, k=None):
         fixed[sel_col[1]] = [1 if 2 <= r < usable - 2 else 0 for r in range(n)]
         cols = dict(cells, instance=[v + [0] * (n - len(v)) for v in instances])
         for d_col, e in defined:
-            advice[d_col[1]] = [_evaluate(e, r, n, cols) if 2 <= r < usable - 2 else rf() for r in range(n)]
+            advice[d_col[1]] = [_evaluate(e, r, n, cols) if 2 <= r < usable - 2 else rf(wr) for r in range(n)]
     return cs, k, [_arr(c) for c in advice], [_arr(c) for c in fixed], copies, instances
 
 
@@ -203,6 +208,16 @@ def run_case(device, seed, cache={}, satisfiable=False):
             first = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
             raise AssertionError("seed %d (%s): proof differs at byte %d of %d / %d" % (
                 seed, "gwc" if use_gwc else "shplonk", first, len(got), len(want)))
+    if not satisfiable and seed % 4 == 0:
+        # several circuit instances in one proof (plonk/prover.rs:206-232): two more witnesses of the same circuit
+        advs, insts = [advice], [instances]
+        for ws in (1, 2):
+            other = random_case(seed, False, k, witness_seed=ws)
+            advs.append(other[2])
+            insts.append(other[5])
+        got = prover.create_proof_ext(device, params, pk, advs, ProverRng(seed), False, instances=insts)
+        want = prover.create_proof_ext(cpu, cparams, cpk, advs, ProverRng(seed), False, instances=insts)
+        assert got == want, "seed %d: the proof over three circuit instances differs" % seed
     if satisfiable:
         for kw in (dict(force_cosets=True), dict(eval_cache=0)):
             D2 = prover.Device(**kw)
