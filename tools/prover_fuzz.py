@@ -9,7 +9,7 @@ a proof is a deterministic function of (key, witness, randomness) whether or not
 divides pointwise on the extended domain either way -- so unsatisfied gates and copies exercise the same arithmetic;
 only what the prover itself checks is made true (lookup inputs come from the table, the shuffle is a permutation).
 
-usage: python tools/prover_fuzz.py [seconds] [first seed] [satisfiable]
+usage: [H2_FUZZ_KMAX=14] python tools/prover_fuzz.py [seconds] [first seed] [satisfiable]
 """
 import os
 import random
@@ -119,6 +119,8 @@ def random_case(seed, satisfiable=False, k=None, witness_seed=None):
     else:
         cs.set_minimum_degree(rnd.choice((5, 6)) if with_lookup else rnd.choice((3, 4, 5, 6)))
     k_draw = rnd.randint(5, 9)                          # (always drawn: the stream must not depend on the arguments)
+    if os.environ.get("H2_FUZZ_KMAX"):                  # larger circuits: multi-workgroup scans, two-pass transforms
+        k_draw = 5 + (k_draw - 5 + seed) % (int(os.environ["H2_FUZZ_KMAX"]) - 4)
     k = k_draw if k is None else k                      # `k` given: the caller's size, raised if the circuit needs more
     while (1 << k) < cs.minimum_rows() + 8:
         k += 1
