@@ -87,12 +87,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # H2_BENCH_BACKEND=gloo: a dry run of the multi-rank flow on ONE GPU (every rank on cuda:0; RCCL refuses two ranks on one
+    # device) -- the barriers, the reductions of the timings and one proof over the ranks, not a measurement
+    backend = os.environ.get("H2_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("H2_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     L = h2.lib()  # raises loudly if libhalo2_hip.so is missing: no fallback path
     dev = torch.device("cuda", local_rank)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
