@@ -400,39 +400,7 @@ __device__ __forceinline__ Fp<P> fp_mul2_dev(const Fp<P>& a, const Fp<P>& b, con
 template <class P>
 __device__ __forceinline__ Fp<P> fp_mul_wide_dev(const Fp<P>& a, const Fp<P>& b);  // a < 2^256, b canonical -> < 2p, unreduced
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
-#define H2_MAD_FREE_V(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y))
-#define H2_MAD_FREE_S(x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y))
-#define H2_MAD_SET_V(x, y)                                                                      \
-    do {                                                                                        \
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y));          \
-        asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(hi) : "s"(cy));                                 \
-    } while (0)
-#define H2_MAD_SET_S(x, y)                                                                      \
-    do {                                                                                        \
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y));          \
-        asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(hi) : "s"(cy));                                 \
-    } while (0)
-#define H2_MAD_ACC_V(x, y)                                                                      \
-    do {                                                                                        \
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "v"(y));          \
-        asm("v_addc_co_u32 %0, %1, %0, 0, %1" : "+v"(hi), "+s"(cy));                            \
-    } while (0)
-#define H2_MAD_ACC_S(x, y)                                                                      \
-    do {                                                                                        \
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=s"(cy) : "v"(x), "s"(y));          \
-        asm("v_addc_co_u32 %0, %1, %0, 0, %1" : "+v"(hi), "+s"(cy));                            \
-    } while (0)
-#define H2_SHIFT1() lo = (lo >> 32) | ((uint64_t)hi << 32)
-#define H2_SHIFT0() lo >>= 32
 #include "fp_mul_gen.hpp"
-#undef H2_MAD_FREE_V
-#undef H2_MAD_FREE_S
-#undef H2_MAD_SET_V
-#undef H2_MAD_SET_S
-#undef H2_MAD_ACC_V
-#undef H2_MAD_ACC_S
-#undef H2_SHIFT1
-#undef H2_SHIFT0
 #endif
 
 // Montgomery product a*b*R^-1 mod p, product scanning (FIPS) form.

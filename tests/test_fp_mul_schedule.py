@@ -86,6 +86,67 @@ def run(lines, p, ops, raw=False):
     return out - p if out >= p else out
 
 
+def run_lowered(lowered, p, ops, raw=False):
+    """the same schedule after gen.lower (what fp_mul_gen.hpp holds: inline-assembly blocks whose carries are consumed two
+    instructions behind their multiply-adds, out of three rotating carry registers): executed instruction by instruction,
+    with the hazard distance and the life of every carry register checked"""
+    mod = limbs(p)
+    inv = (-pow(p, -1, 1 << 32)) & M32
+    env = {k: limbs(v) for k, v in ops.items()}
+    if "a" in ops:
+        two_a = limbs(2 * ops["a"])
+        for k in range(2, 8):
+            env["d%d" % k] = two_a[k]
+        for j in range(7):
+            env["f%d" % j] = (limbs(ops["a"])[j + 1] << 1) & M32
+    m = {}
+    lo, hi, r = 0, 0, [0] * 8
+
+    def val(tok):
+        g = re.fullmatch(r"([abcd])\.l\[(\d)\]", tok)
+        if g:
+            return env[g.group(1)][int(g.group(2))]
+        g = re.fullmatch(r"P::MOD\[(\d)\]", tok)
+        if g:
+            return mod[int(g.group(1))]
+        return m[tok] if tok in m else env[tok]
+
+    for item in lowered:
+        if item[0] == "asm":
+            cy, written, clock = [None] * 3, [None] * 3, 0       # carry registers: value, clock of the write
+            for ins in item[1]:
+                if ins[0] == "mad":
+                    assert cy[ins[4]] is None or cy[ins[4]] == 0 or written[ins[4]] is None, "a pending carry was overwritten"
+                    sm = lo + val(ins[1]) * val(ins[2])
+                    cy[ins[4]], lo, written[ins[4]] = sm >> 64, sm & M64, clock
+                    clock += 1
+                elif ins[0] == "nop":
+                    clock += ins[1]
+                else:
+                    assert clock - written[ins[1]] - 1 >= gen.WAIT, "carry read too early"
+                    hi = cy[ins[1]] if ins[0] == "set" else (hi + cy[ins[1]]) & M32
+                    cy[ins[1]], written[ins[1]] = None, None
+                    clock += 1
+            assert all(c in (None, 0) for c in cy), "a carry was dropped at the end of a block"
+            continue
+        ln = item[1]
+        g = re.match(r"const uint32_t (m\d) = \(uint32_t\)lo \* P::INV;", ln)
+        if g:
+            m[g.group(1)] = ((lo & M32) * inv) & M32
+        elif re.match(r"r\.l\[(\d)\] = \(uint32_t\)lo;", ln):
+            r[int(ln[4])] = lo & M32
+        elif ln.startswith("lo = (lo >> 32) |"):
+            lo = (lo >> 32) | (hi << 32)
+        elif ln.startswith("lo >>= 32"):
+            lo >>= 32
+        else:
+            assert ln.startswith("//") or not ln, "unparsed line: " + ln
+    out = sum(x << (32 * i) for i, x in enumerate(r))
+    if raw:
+        return out
+    return out - p if out >= p else out
+
+
 def operands(p, rng, count):
     edge = [0, 1, p - 1, p, (1 << 254) - 1, (1 << 253), p - 2, (1 << 254) - (1 << 224)]
     for x in edge:
@@ -135,3 +196,29 @@ def test_wide_operand_schedule_of_the_lazy_ntt_domain(name):
         for b in (seconds if i < 9 else seconds[i % 7::7]):
             out = run(wide, p, {"a": a, "b": b}, raw=True)
             assert out < 2 * p and out % p == a * b * rinv % p, (hex(a), hex(b))
+
+
+@pytest.mark.parametrize("name", sorted(gen.FIELDS))
+def test_lowered_blocks_compute_what_the_schedules_do(name):
+    """gen.lower: every variant's assembly blocks against the line-by-line schedule"""
+    p = gen.FIELDS[name]
+    rng = random.Random(4)
+    variants = {"mul": {}, "square": {"square": True}, "dual": {"dual": True}, "wide": {"wide": True}}
+    for vname, kw in variants.items():
+        lines, _ = gen.schedule(p, **kw)
+        lowered = gen.lower(lines)
+        nops = sum(1 for it in lowered if it[0] == "asm" for ins in it[1] if ins[0] == "nop")
+        mads = sum(1 for it in lowered if it[0] == "asm" for ins in it[1] if ins[0] == "mad")
+        assert nops <= 40 and mads in (128, 100, 192), (vname, nops, mads)
+        pairs = list(operands(p, rng, 60))
+        for i, (a, b) in enumerate(pairs):
+            if vname == "square":
+                ops = {"a": a}
+            elif vname == "dual":
+                c, d = pairs[(5 * i + 1) % len(pairs)]
+                ops = {"a": a, "b": b, "c": c, "d": d}
+            elif vname == "wide":
+                ops = {"a": (a << 2 | 3) & ((1 << 256) - 1), "b": b % p}
+            else:
+                ops = {"a": a, "b": b}
+            assert run_lowered(lowered, p, ops, raw=True) == run(lines, p, ops, raw=True), (vname, i)

@@ -94,12 +94,136 @@ def schedule(p, square=False, dual=False, wide=False):
     return lines, stats
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Lowering of a logical schedule (the macro lines above, which tests/test_fp_mul_schedule.py executes with Python integers)
+# to inline-assembly BLOCKS.  One asm statement per instruction made the compiler put an `s_nop` behind almost every
+# multiply-add (it cannot see inside an asm statement and pads each one against the gfx940 "VALU writes an SGPR -> VALU
+# reads it" hazard): a third of all instructions of the arithmetic kernels were `s_nop`s -- invisible at four waves per SIMD,
+# where another wave issues meanwhile, but a wave that runs alone (the chains of dependent point additions in k_reduce /
+# k_finish, small transforms) issues one instruction per ~4.6 cycles whatever it is.  Inside a block the schedule keeps the
+# hazard distance itself: the carry of multiply-add k (an SGPR pair, three of them in rotation) is consumed -- v_cndmask for
+# SET, v_addc_co for ACC -- after multiply-add k + 2, i.e. WAIT instructions later; only the tail of a block needs `s_nop`s.
+# ---------------------------------------------------------------------------------------------------------------
+WAIT = 2            # wait states between a VALU that writes an SGPR and a VALU that reads it (LLVM: VALUWriteSGPRVALURead)
+MAX_OPERANDS = 30   # of one asm statement (clang's limit)
+import re as _re
+
+_MAD = _re.compile(r"H2_MAD_(FREE|SET|ACC)_([VS])\(([^,]+), ([^)]+)\);")
+
+
+def lower(lines):
+    """-> list of ("c", text) / ("asm", [instr]) with instr = ("mad", x, y, ycls, reg) / ("set", reg) / ("acc", reg) /
+    ("nop", wait states)"""
+    out, run = [], []
+
+    def flush():
+        """the multiply-adds collected so far become asm blocks of at most MAX_OPERANDS operands"""
+        nonlocal run
+        while run:
+            ops, take = set(), 0
+            for kind, cls, x, y in run:
+                new = ops | {x, y}
+                if len(new) + 5 > MAX_OPERANDS:          # + lo, hi, three carry registers
+                    break
+                ops, take = new, take + 1
+            assert take > 0
+            out.append(("asm", _schedule_block(run[:take])))
+            run = run[take:]
+
+    for ln in lines:
+        t = ln.strip()
+        g = _MAD.match(t)
+        if g:
+            run.append((g.group(1), g.group(2), g.group(3).strip(), g.group(4).strip()))
+            continue
+        flush()
+        if t.startswith("//") or not t:
+            out.append(("c", t))
+        elif t.startswith("H2_SHIFT1"):
+            out.append(("c", "lo = (lo >> 32) | ((uint64_t)hi << 32);"))
+        elif t.startswith("H2_SHIFT0"):
+            out.append(("c", "lo >>= 32;"))
+        else:
+            out.append(("c", t))
+    flush()
+    return out
+
+
+def _schedule_block(terms):
+    instrs, pending = [], []          # pending: (index of the producing instruction, kind, reg)
+    for k, (kind, cls, x, y) in enumerate(terms):
+        reg = k % 3
+        instrs.append(("mad", x, y, cls, reg))
+        if kind != "FREE":
+            pending.append((len(instrs) - 1, kind, reg))
+        # consume what is WAIT instructions old (and must go before its register comes round again)
+        while pending and len(instrs) - 1 - pending[0][0] >= WAIT:
+            _, kd, rg = pending.pop(0)
+            instrs.append(("set" if kd == "SET" else "acc", rg))
+    while pending:
+        at, kd, rg = pending.pop(0)
+        gap = len(instrs) - 1 - at
+        if gap < WAIT:
+            instrs.append(("nop", WAIT - gap))
+        instrs.append(("set" if kd == "SET" else "acc", rg))
+    # a register is never rewritten while its carry is pending, and every carry is consumed WAIT or more instructions
+    # (or wait states of s_nop) after its multiply-add
+    live, nmad, clock = {}, 0, 0
+    for ins in instrs:
+        if ins[0] == "mad":
+            assert ins[4] not in live, "carry register reused before its carry was consumed"
+            if terms[nmad][0] != "FREE":
+                live[ins[4]] = clock
+            nmad += 1
+            clock += 1
+        elif ins[0] == "nop":
+            clock += ins[1]
+        else:
+            assert clock - live.pop(ins[1]) - 1 >= WAIT, "carry consumed too early"
+            clock += 1
+    assert not live and nmad == len(terms)
+    return instrs
+
+
+def emit(lowered, indent="    "):
+    """C++ text of a lowered schedule"""
+    text = []
+    for item in lowered:
+        if item[0] == "c":
+            text.append(indent + item[1] if item[1] else "")
+            continue
+        names, inputs, body = {}, [], []
+
+        def operand(expr, cls):
+            key = (expr, cls)
+            if key not in names:
+                names[key] = "x%d" % len(names)
+                inputs.append('[%s] "%s"(%s)' % (names[key], "s" if cls == "S" else "v", expr))
+            return "%%[%s]" % names[key]
+
+        for ins in item[1]:
+            if ins[0] == "mad":
+                body.append("v_mad_u64_u32 %%[lo], %%[cy%d], %s, %s, %%[lo]" % (ins[4], operand(ins[1], "V"), operand(ins[2], ins[3])))
+            elif ins[0] == "set":
+                body.append("v_cndmask_b32 %%[hi], 0, 1, %%[cy%d]" % ins[1])
+            elif ins[0] == "acc":
+                body.append("v_addc_co_u32 %%[hi], %%[cy%d], %%[hi], 0, %%[cy%d]" % (ins[1], ins[1]))
+            else:
+                body.append("s_nop %d" % (ins[1] - 1))
+        assert len(inputs) + 5 <= MAX_OPERANDS
+        text.append(indent + "asm(" + ("\n" + indent + "    ").join('"%s\\n\\t"' % b for b in body))
+        text.append(indent + '    : [lo] "+v"(lo), [hi] "+v"(hi), [cy0] "=&s"(cy0), [cy1] "=&s"(cy1), [cy2] "=&s"(cy2)')
+        text.append(indent + "    : " + ", ".join(inputs) + ");")
+    return text
+
+
 def main():
     out = ["// fp_mul_gen.hpp -- GENERATED by tools/gen_fp_mul.py (do not edit): carry-aware product-scanning schedules of the",
            "// device Montgomery product for BN254 Fr and Fq.  Included by field.hpp inside namespace h2.",
-           "// FREE = bare v_mad_u64_u32 (the column sum provably fits 64 bits so far), SET = first term of a column that can",
-           "// carry (third word := carry), ACC = multiply-add + add-with-carry into the third word.  _V / _S: second factor in a",
-           "// VGPR / an SGPR (modulus limbs are wave-uniform constants).", ""]
+           "// A multiply-add whose column sum provably fits 64 bits so far is bare; the first term of a column that can carry sets the",
+           "// third word from its carry (v_cndmask), the later ones add theirs (v_addc_co).  One asm statement per run of",
+           "// multiply-adds: the carries sit in three rotating SGPR pairs and are consumed two instructions behind their producers",
+           "// (the gfx940 'VALU writes an SGPR -> VALU reads it' distance), so the compiler has nothing to pad (see `lower`).", ""]
     for name, p in FIELDS.items():
         lines, stats = schedule(p)
         out.append("// %s: %d bare multiply-adds, %d carry-setting, %d carry-accumulating (round 1: 2 + 126)"
@@ -108,10 +232,10 @@ def main():
         out.append("__device__ __forceinline__ Fp<%s> fp_mul_dev<%s>(const Fp<%s>& a, const Fp<%s>& b) {" % ((name,) * 4))
         out.append("    using P = %s;" % name)
         out.append("    Fp<P> r;")
-        out.append("    uint64_t lo = 0, cy;")
+        out.append("    uint64_t lo = 0, cy0, cy1, cy2;")
         out.append("    uint32_t hi = 0;")
-        out += lines
-        out.append("    (void)cy; (void)hi;")
+        out += emit(lower(lines))
+        out.append("    (void)cy0; (void)cy1; (void)cy2; (void)hi;")
         out.append("    return fp_reduce_once(r);")
         out.append("}")
         out.append("")
@@ -123,15 +247,15 @@ def main():
         out.append("__device__ __forceinline__ Fp<%s> fp_sqr_dev<%s>(const Fp<%s>& a) {" % ((name,) * 3))
         out.append("    using P = %s;" % name)
         out.append("    Fp<P> r;")
-        out.append("    uint64_t lo = 0, cy;")
+        out.append("    uint64_t lo = 0, cy0, cy1, cy2;")
         out.append("    uint32_t hi = 0;")
         out.append("    // limbs of 2a (a < 2^254) and, per row, the first tail limb with the bit that belongs to 2 a_j cleared")
         for k in range(2, 8):
             out.append("    const uint32_t d%d = __builtin_amdgcn_alignbit(a.l[%d], a.l[%d], 31);" % (k, k, k - 1))
         for j in range(7):
             out.append("    const uint32_t f%d = a.l[%d] << 1;" % (j, j + 1))
-        out += lines
-        out.append("    (void)cy; (void)hi;")
+        out += emit(lower(lines))
+        out.append("    (void)cy0; (void)cy1; (void)cy2; (void)hi;")
         out.append("    return fp_reduce_once(r);")
         out.append("}")
         out.append("")
@@ -143,10 +267,10 @@ def main():
         out.append("__device__ __forceinline__ Fp<%s> fp_mul2_dev<%s>(const Fp<%s>& a, const Fp<%s>& b, const Fp<%s>& c, const Fp<%s>& d) {" % ((name,) * 6))
         out.append("    using P = %s;" % name)
         out.append("    Fp<P> r;")
-        out.append("    uint64_t lo = 0, cy;")
+        out.append("    uint64_t lo = 0, cy0, cy1, cy2;")
         out.append("    uint32_t hi = 0;")
-        out += lines
-        out.append("    (void)cy; (void)hi;")
+        out += emit(lower(lines))
+        out.append("    (void)cy0; (void)cy1; (void)cy2; (void)hi;")
         out.append("    return fp_reduce_once(r);  // inputs < 2^254: (a b + c d) / 2^256 + p < 2^253 + p < 2 p")
         out.append("}")
         out.append("")
@@ -159,10 +283,10 @@ def main():
         out.append("__device__ __forceinline__ Fp<%s> fp_mul_wide_dev<%s>(const Fp<%s>& a, const Fp<%s>& b) {" % ((name,) * 4))
         out.append("    using P = %s;" % name)
         out.append("    Fp<P> r;")
-        out.append("    uint64_t lo = 0, cy;")
+        out.append("    uint64_t lo = 0, cy0, cy1, cy2;")
         out.append("    uint32_t hi = 0;")
-        out += lines
-        out.append("    (void)cy; (void)hi;")
+        out += emit(lower(lines))
+        out.append("    (void)cy0; (void)cy1; (void)cy2; (void)hi;")
         out.append("    return r;  // (a b + m p) / 2^256 < 2p: the word above r.l[7] is zero")
         out.append("}")
         out.append("")
