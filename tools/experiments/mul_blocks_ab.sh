@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B: the multiplier as one asm statement per instruction (old: tools/experiments/oldlib/libhalo2_hip.so) against
-# the assembly blocks of tools/gen_fp_mul.py's `lower` (new: the tree's library)
+# the assembly blocks of tools/gen_fp_mul.py's `lower` (new: the tree's library).  The old library: a copy of csrc/ with the
+# fp_mul_gen.hpp of commit 18add17, `make`, the .so into tools/experiments/oldlib/ (not kept in the tree).
 OLD=tools/experiments/oldlib
 for round in 1 2; do
   for lib in new old; do
