@@ -15,6 +15,9 @@ included, stays below 2^64: those terms are accumulated first with a bare v_mad_
 that can carry sets the third word from the carry bit (`H2_MAD_SET`, no zero initialisation), the rest are the usual pair
 (`H2_MAD_ACC`).  The bounds are recomputed here with Python integers and asserted, column by column.
 
+`schedule` returns that LOGICAL schedule as lines (`H2_MAD_FREE_V(a.l[0], b.l[1]);` ...: what tests/test_fp_mul_schedule.py
+executes with Python integers); `lower` + `emit` turn it into the inline-assembly blocks the header holds (see `lower`).
+
 Precondition of the generated code (same as the reference's `Fr` / `Fq` invariants): both inputs < 2^254.
 """
 import os
