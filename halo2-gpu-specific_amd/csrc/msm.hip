@@ -1048,7 +1048,8 @@ __global__ void __launch_bounds__(256) k_finish(const XYZZ* partials, const uint
 
 // The same fold with ONE LANE per bucket, for bucket counts that fill the chip many times over (2^21 buckets of a
 // shifted-base table at 2^24): there the fold is bound by throughput, and a quad spends four lanes on the latency of
-// one chain (2^24 over a table, batch of 8: 21.3 -> 20.9 ms per MSM; at 2^19 buckets the two forms tie, below the quads win).
+// one chain (2^24 over a table, batch of 8: 21.3 -> 20.9 ms per MSM; from 2^19 buckets the lanes win by 1-2 %, at 2^17 the two forms tie,
+// below the quads win).
 __global__ void __launch_bounds__(256) k_finish_lane(const XYZZ* partials, const uint32_t* starts, uint32_t nbt,
                                                      uint32_t log_s, XYZZ* buckets, uint32_t* heavy_list,
                                                      uint32_t* heavy_count) {
@@ -1774,7 +1775,9 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     else
         hipLaunchKernelGGL(k_acc_slice<4>, dim3((nslices + 255) / 256), dim3(256), 0, stream, d_bases,
                            (!fused && hot.on) ? hot.block_sums : (const Affine*)nullptr, sorted, starts, s.nbt, s.log_s, partials);
-    static const uint32_t lane_from = getenv("H2_MSM_FINISH_LANE_LOG") ? 1u << atoi(getenv("H2_MSM_FINISH_LANE_LOG")) : 1u << 21;
+    // one lane per bucket from 2^19 buckets on (round 3, same box: 2^22 windowed 6.75 -> 6.61 ms, over a table 5.91 -> 5.76-5.90,
+    // 2^24 windowed 23.9 -> 23.7; at 2^17 the forms tie, at 2^16 buckets the quads win by 4-7 %)
+    static const uint32_t lane_from = getenv("H2_MSM_FINISH_LANE_LOG") ? 1u << atoi(getenv("H2_MSM_FINISH_LANE_LOG")) : 1u << 19;
     if (s.nbt >= lane_from)
         hipLaunchKernelGGL(k_finish_lane, dim3((s.nbt + 255) / 256), dim3(256), 0, stream, partials, starts, s.nbt, s.log_s,
                            buckets, heavy + 1, heavy);
