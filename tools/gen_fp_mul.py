@@ -214,8 +214,17 @@ def emit(lowered, indent="    "):
             else:
                 body.append("s_nop %d" % (ins[1] - 1))
         assert len(inputs) + 5 <= MAX_OPERANDS
+        # the third word: not an operand of a block without carries; write-only (early clobber: it is written while inputs
+        # are still to be read) when the block's first carry SETS it -- the register allocator can then put it where the
+        # upper half of the NEXT column's accumulator will be, which saves a move per column; read-write otherwise
+        carries = [ins[0] for ins in item[1] if ins[0] in ("set", "acc")]
+        outs = ['[lo] "+v"(lo)']
+        if carries:
+            outs.append('[hi] "=&v"(hi)' if carries[0] == "set" else '[hi] "+v"(hi)')
+        used = sorted({ins[4] for ins in item[1] if ins[0] == "mad"})
+        outs += ['[cy%d] "=&s"(cy%d)' % (r, r) for r in used]
         text.append(indent + "asm(" + ("\n" + indent + "    ").join('"%s\\n\\t"' % b for b in body))
-        text.append(indent + '    : [lo] "+v"(lo), [hi] "+v"(hi), [cy0] "=&s"(cy0), [cy1] "=&s"(cy1), [cy2] "=&s"(cy2)')
+        text.append(indent + "    : " + ", ".join(outs))
         text.append(indent + "    : " + ", ".join(inputs) + ");")
     return text
 
