@@ -61,6 +61,59 @@ def jac_eq(p, q):
     return (x1 * z2 * z2 - x2 * z1 * z1) % Q_MOD == 0 and (y1 * z2 ** 3 - y2 * z1 ** 3) % Q_MOD == 0
 
 
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` with no launcher around it: this process -- which has NOT imported torch and never
+    touches the GPU -- starts N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), relays rank 0's JSON line as its own last stdout line and exits non-zero if any rank
+    does.  The reference splits over N_GPU devices inside one call (arithmetic.rs:413-440, plonk/prover.rs:56-74); here
+    that is one process per device.  Nothing is re-executed from a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    import threading
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs, lines = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "1")                 # as torch.distributed.run does
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line.rstrip("\n"))
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    grace = float(os.environ.get("H2_BENCH_RANK_GRACE_S", "30"))
+    failed_at, rc = None, 0
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.perf_counter()                    # a rank died: the others are waiting for it in a collective
+        if failed_at is not None and time.perf_counter() - failed_at > grace:
+            for p in procs:                                    # exactly the processes started above
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print("bench.py: rank %d exited with code %s" % (r, p.returncode), file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
+    for line in lines[:-1]:
+        print(line, file=sys.stderr)                           # anything rank 0 printed before its result line
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +132,10 @@ def main():
     ap.add_argument("--k24", type=int, default=1, help="1: also run the k = 24 legs (MSM 2^24, create_proof k = 24) the metric is quoted at")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: become one (before torch is imported or the GPU is touched)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
 
     import halo2_gpu_specific_amd as h2
@@ -92,6 +149,10 @@ def main():
     backend = os.environ.get("H2_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
+    elif torch.cuda.device_count() < max(world, local_rank + 1):
+        # one rank per GPU under RCCL: fail loudly instead of piling ranks onto one device or hanging in the rendezvous
+        sys.exit("bench.py: %d ranks under RCCL need %d GPUs, this node shows %d (H2_BENCH_BACKEND=gloo dry-runs the "
+                 "multi-rank flow on one GPU)" % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("H2_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path with one rank
@@ -486,11 +547,13 @@ def main():
                "workload": "circuits.wide(%d): %d advice columns, q * (a b c - d) per quad, %d logup range lookups of two columns each "
                            "into a 2^16-row table, equality on two columns, 2^%d rows, KZG/SHPLONK" % (quads, 4 * quads, quads // 2, pk_k)}
         proofs = {}
-        for mode in ("resident", "budgeted"):
+        # N > 1: ONE proof over all ranks (degree 5 -> 4 cosets over the ranks, every MSM range-split): a single "sharded" mode
+        modes = ("resident", "budgeted") if dist is None else ("sharded",)
+        for mode in modes:
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(dev)
-            D0 = prover.Device(local_rank)
-            if mode == "resident":
+            D0 = prover.Device(local_rank, force_collective=dist is not None)
+            if mode != "budgeted":
                 D = D0
             else:
                 dom = prover.Domain(pk_k, cs.degree())
@@ -508,11 +571,18 @@ def main():
             proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))      # warm-up
             proofs[mode] = proof
             D.sync()
+            barrier()
             p0 = time.perf_counter()
             for i in range(steps):
                 prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(2 + i))
             D.sync()
-            sec = (time.perf_counter() - p0) / steps
+            barrier()
+            sec = time.perf_counter() - p0
+            if dist is not None:
+                t = torch.tensor([sec], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sec = float(t[0].item())
+            sec /= steps
             phases = {}
             prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=phases)
             res[mode] = {
@@ -522,9 +592,40 @@ def main():
                 "library_memory_gib": round(L.h2_library_memory_bytes() / 2**30, 2),
                 "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof),
             }
+            if dist is not None:
+                res[mode]["sharding"] = prover.sharding_description(D)
+                res[mode]["scaling"] = "strong"
+            if mode == "resident":
+                # the same proof with the columns that fit 64 bits handed over COMPACT (8 bytes per cell over PCIe instead of
+                # 32, widened on the device: h2_dev_widen_u64) -- the same proof bytes
+                cadv = [np.ascontiguousarray(a[:, 0]) if not a[:, 1:].any() else a for a in adv]
+                ncompact = sum(1 for a in cadv if a.ndim == 1)
+                pinned = D.pinned_columns(ncompact, 1 << pk_k, compact=True)
+                it = iter(pinned)
+                for i, a in enumerate(cadv):
+                    if a.ndim == 1:
+                        dst = next(it)
+                        dst[:] = a
+                        cadv[i] = dst
+                cproof = prover.create_proof_with_shplonk(D, params, pk, cadv, ProverRng(1))
+                D.sync()
+                c0 = time.perf_counter()
+                for i in range(steps):
+                    prover.create_proof_with_shplonk(D, params, pk, cadv, ProverRng(2 + i))
+                D.sync()
+                cphases = {}
+                csec = (time.perf_counter() - c0) / steps
+                prover.create_proof_with_shplonk(D, params, pk, cadv, ProverRng(1), timings=cphases)
+                res["resident_compact_witness"] = {
+                    "seconds": csec, "compact_columns": ncompact, "same_proof_bytes": bool(cproof == proof),
+                    "phases_ms": {n: round(v * 1e3, 2) for n, v in cphases.items()},
+                    "what": "columns whose cells all fit 64 bits cross PCIe as 8 bytes per cell and are widened on the device",
+                }
+                assert cproof == proof, "the compact witness changed the proof"
+                del cadv, pinned
             if pk.coset is not None:
                 res[mode]["coset_table_rebuilds"] = pk.coset.misses
-            if mode == "resident" and rank == 0:
+            if mode != "budgeted" and rank == 0:
                 import ref_plonk as rp
 
                 vk = rp.Keys()
@@ -534,16 +635,10 @@ def main():
                 assert res["verified"], "the wide-circuit proof was rejected by the verifier"
             del pk, params, adv, fixed, D, D0
             L.h2_release_plans()
-        res["same_proof_bytes"] = proofs["resident"] == proofs["budgeted"]
-        assert res["same_proof_bytes"], "the memory-budgeted route changed the proof"
+        if dist is None:
+            res["same_proof_bytes"] = proofs["resident"] == proofs["budgeted"]
+            assert res["same_proof_bytes"], "the memory-budgeted route changed the proof"
         return res
-
-    if args.wide_k and world == 1:
-        try:
-            out["create_proof_wide"] = wide_leg(args.wide_k, args.wide_quads, 2)
-        except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
-            out["create_proof_wide"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        torch.cuda.empty_cache()
 
     # N > 1: the proof legs are ONE proof over all ranks -- collectives on the data path.  A rank that fails or stalls
     # there would leave the others waiting inside RCCL for good, and the line above would never be printed: a watchdog
@@ -566,6 +661,13 @@ def main():
             os._exit(2)
 
         threading.Thread(target=watchdog, daemon=True).start()
+
+    if args.wide_k:
+        try:
+            out["create_proof_wide"] = wide_leg(args.wide_k, args.wide_quads, 2)
+        except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
+            out["create_proof_wide"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
     for key, kk, steps in (("create_proof", args.prove_k, args.prove_steps), ("create_proof_k24", 24 if args.k24 else 0, 2)):
         if not kk or (key == "create_proof_k24" and args.prove_k == 24):

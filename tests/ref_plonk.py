@@ -234,6 +234,152 @@ class Domain:
         return out
 
 
+# ---- write_cs (helpers.rs:406-456) from the circuit classes below ---------------------------------------------------
+# The classes describe their gates / lookups / shuffles as closures over cell VALUES.  Calling a closure with the
+# symbolic cells below records the Expression tree halo2's operator overloading would build for the same formula
+# (plonk/circuit.rs: `a + b` -> Sum, `a - b` -> Sum(a, Negated(b)), `a * b` -> Product, `a * F` -> Scaled, `-a` -> Negated);
+# the serialisation of that tree follows Expression::store (helpers.rs:687-757) and write_cs field by field.  Nothing of
+# the product package is used: tests/test_plonk_host.py compares these bytes with formats.cs_store of the product-side
+# description of the same circuit -- two independent derivations of the verifying-key digest's preimage.
+class _Sym:
+    def __init__(self, node):
+        self.node = node
+
+    @staticmethod
+    def wrap(o):
+        return o if isinstance(o, _Sym) else _Sym(("const", o % R))
+
+    def __add__(self, o):
+        return _Sym(("sum", self.node, _Sym.wrap(o).node))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return _Sym(("sum", self.node, ("neg", _Sym.wrap(o).node)))
+
+    def __rsub__(self, o):                       # Expression::Constant(o) - self
+        return _Sym(("sum", _Sym.wrap(o).node, ("neg", self.node)))
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return _Sym(("scaled", self.node, o % R))
+        return _Sym(("prod", self.node, o.node))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return _Sym(("neg", self.node))
+
+    def __mod__(self, _):                        # the closures reduce modulo r as they go: the tree does not change
+        return self
+
+
+_ANY_CODE = {"advice": 0, "fixed": 1, "instance": 2}                   # plonk/circuit.rs:79-86
+_EXPR_CODE = {"const": 0, "fixed": 1, "advice": 2, "instance": 3, "neg": 4, "sum": 5, "prod": 6, "scaled": 7}   # helpers.rs:590-599
+
+
+def _le32(v):
+    return (v & 0xFFFFFFFF).to_bytes(4, "little")
+
+
+def _sym_cells(cs):
+    def cell(kind):
+        return lambda column, rotation: _Sym((kind, column, rotation))
+
+    return cell("advice"), cell("fixed"), cell("instance")
+
+
+def _store_expression(cs, node, out):
+    kind = node[0]
+    out.append(_le32(_EXPR_CODE[kind]))
+    if kind == "const":
+        out.append(node[1].to_bytes(32, "little"))
+    elif kind in ("fixed", "advice", "instance"):
+        queries = _cs_get(cs, kind + "_queries", [])
+        out += [_le32(queries.index((node[1], node[2]))), _le32(node[1]), _le32(node[2])]
+    elif kind == "neg":
+        _store_expression(cs, node[1], out)
+    elif kind in ("sum", "prod"):
+        _store_expression(cs, node[1], out)
+        _store_expression(cs, node[2], out)
+    else:
+        _store_expression(cs, node[1], out)
+        out.append(node[2].to_bytes(32, "little"))
+
+
+def _store_expressions(cs, syms, out):
+    out.append(_le32(len(syms)))
+    for e in syms:
+        _store_expression(cs, _Sym.wrap(e).node, out)
+
+
+def _first_use_cells(node, cells):
+    """(kind, column, rotation) of every query of an expression tree, each once, in depth-first order: this build's
+    convention for Gate::queried_cells (the reference records the order of the `meta.query_*` calls of the gate's
+    closure, which an expression tree does not carry)"""
+    if node[0] in ("fixed", "advice", "instance"):
+        if node not in cells:
+            cells.append(node)
+    elif node[0] != "const":
+        for child in node[1:]:
+            if isinstance(child, tuple):
+                _first_use_cells(child, cells)
+
+
+def write_cs(cs):
+    adv, fix, inst = _sym_cells(cs)
+    nadv = cs.num_advice
+    per_column = [sum(1 for c, _ in cs.advice_queries if c == i) for i in range(nadv)]
+    out = [_le32(nadv), _le32(_cs_get(cs, "num_instance", 0)), _le32(0), _le32(cs.num_fixed), _le32(nadv)]
+    out += [_le32(v) for v in per_column]
+    out += [_le32(0), _le32(0)]                                  # selector_map, constants: empty after compilation
+    for queries in (cs.advice_queries, _cs_get(cs, "instance_queries", []), cs.fixed_queries):
+        out.append(_le32(len(queries)))
+        for column, rotation in queries:
+            out += [_le32(column), _le32(rotation)]
+    out.append(_le32(len(cs.perm_columns)))
+    for kind, index in cs.perm_columns:
+        out += [_le32(index), _le32(_ANY_CODE[kind])]
+    lookups = _cs_get(cs, "lookups", [])
+    out.append(_le32(len(lookups)))
+    for lk in lookups:
+        out.append(_le32(len(lk["input_sets"])))
+        for st in lk["input_sets"]:
+            out.append(_le32(len(st)))
+            for inputs in st:
+                _store_expressions(cs, inputs(adv, fix, inst), out)
+        _store_expressions(cs, lk["table"](adv, fix, inst), out)
+    shuffles = _cs_get(cs, "shuffles", [])
+    out.append(_le32(len(shuffles)))
+    for group in shuffles:
+        out.append(_le32(len(group)))
+        for inputs, shuffle in group:
+            _store_expressions(cs, inputs(adv, fix, inst), out)
+            _store_expressions(cs, shuffle(adv, fix, inst), out)
+    checks = _cs_get(cs, "range_checks", [])
+    out.append(_le32(len(checks)))
+    for origin, sort, vmin, vmax, step in checks:
+        out += [_le32(origin), _le32(sort), _le32(vmin), _le32(vmax), _le32(step)]
+    out.append(_le32(0))                                         # named_advices
+    polys = _gates(cs, adv, fix, inst)
+    groups = _cs_get(cs, "gate_groups", None) or [1] * len(polys)        # polynomials per create_gate call
+    assert sum(groups) == len(polys)
+    out.append(_le32(len(groups)))
+    at = 0
+    for count in groups:
+        mine = [_Sym.wrap(p).node for p in polys[at:at + count]]
+        at += count
+        out.append(_le32(len(mine)))
+        cells = []
+        for node in mine:
+            _store_expression(cs, node, out)
+            _first_use_cells(node, cells)
+        out.append(_le32(len(cells)))
+        for kind, column, rotation in cells:
+            out += [_le32(column), _le32(_ANY_CODE[kind]), _le32(rotation)]
+    return b"".join(out)
+
+
 # ---- circuit description -------------------------------------------------------------------------------
 class MiniPlonk:
     """the commented-out circuit of examples/simple-example-2.rs:177-288: a*sa + b*sb + a*b*sm - c*sc"""
@@ -247,24 +393,15 @@ class MiniPlonk:
 
     @classmethod
     def cs_bytes(cls):
-        """canonical write_cs bytes of this circuit (its product-side twin through formats.cs_store): hashed into the
-        verifying-key digest"""
-        import product_circuits as pc
-        from halo2_gpu_specific_amd.formats import cs_store
-
-        make = {"mini-plonk": pc.mini_plonk_cs, "rot-gate": pc.rot_gate_cs, "lookup-shuffle": pc.lookup_shuffle_cs,
-                "lookup-api": pc.lookup_api_cs, "shuffle-api-group": pc.shuffle_api_group_cs}
-        if cls.name.startswith("wide-"):
-            return cs_store(pc.wide_cs(int(cls.name[5:])))
-        if cls.name.startswith("range-check-"):
-            return cs_store(pc.range_check_cs(*[int(v) for v in cls.name.split("-")[2:]]))
-        return cs_store(make[cls.name]())
+        """write_cs bytes of this circuit (helpers.rs:406-456), derived from THIS class alone (`write_cs` below): hashed
+        into the verifying-key digest"""
+        return write_cs(cls)
 
     @staticmethod
     def gates(adv, fix):
         a, b, c = adv(0, 0), adv(1, 0), adv(2, 0)
         sm, sa, sb, sc = fix(0, 0), fix(1, 0), fix(2, 0), fix(3, 0)
-        return [(a * sa + b * sb + a * b * sm - c * sc) % R]
+        return [(a * sa + b * sb + a * b * sm + c * sc * (-1)) % R]        # the formula of simple-example-2.rs:201
 
     @staticmethod
     def synthesize(k, a=5):
@@ -403,7 +540,9 @@ def wide_class(quads):
         @staticmethod
         def gates(adv, fix):
             q = fix(0, 0)
-            return [q * (adv(4 * i, 0) * adv(4 * i + 1, 0) % R * adv(4 * i + 2, 0) - adv(4 * i + 3, 0)) % R for i in range(quads)]
+            return [q * (adv(4 * i, 0) * adv(4 * i + 1, 0) % R * adv(4 * i + 2, 0) + adv(4 * i + 3, 0) * (-1)) % R for i in range(quads)]
+
+        gate_groups = [quads]                 # one create_gate call with a polynomial per quad
 
         lookups = [{"table": lambda adv, fix, inst: [fix(1, 0)],
                     "input_sets": [[lambda adv, fix, inst, l=l: [adv(8 * l, 0)], lambda adv, fix, inst, l=l: [adv(8 * l + 4, 0)]]]}
@@ -452,7 +591,7 @@ class LookupApi:
 
     @staticmethod
     def gates(adv, fix):
-        return [fix(0, 0) * (adv(0, 0) - adv(1, 0)) % R]
+        return [fix(0, 0) * (adv(0, 0) * 1 - adv(1, 0)) % R]          # examples/lookup_api.rs:66-71
 
     lookups = [
         {"table": lambda adv, fix, inst: [fix(0, 0) * adv(1, 0) % R, fix(1, 0) * adv(2, 0) % R],
@@ -530,10 +669,14 @@ def range_check_class(vmin, vmax, step):
         @staticmethod
         def gates(adv, fix):
             cur, nxt = adv(1, 0), adv(1, 1)
-            prod = 1
+            prod = None
             for i in range(step + 1):
-                prod = prod * (nxt - cur - (step - i)) % R
+                term = (nxt - cur - (step - i)) % R
+                prod = term if prod is None else prod * term % R
             return [fix(0, 0) * (vmin - cur) % R, fix(2, 0) * (vmax - cur) % R, (fix(1, 0) - fix(2, 0)) * prod % R]
+
+        range_checks = [(0, 1, vmin, vmax, step)]
+        gate_groups = [3]                     # one create_gate call with three polynomials (circuit.rs:1793-1818)
 
         shuffles = [[(lambda adv, fix, inst: [adv(0, 0)], lambda adv, fix, inst: [adv(1, 0)])]]
 
@@ -585,8 +728,8 @@ def permutation_mapping(ncols, n, copies):
 def vk_digest(cs, dom, fixed_commitments, perm_commitments):
     """stand-in for `format!("{:?}", vk.pinned())` (plonk.rs:91-109): same framing (u64 length, Blake2b-512 with
     the Halo2-Verify-Key personalisation, from_bytes_wide) over the domain, both moduli, the canonical write_cs bytes
-    of the constraint system (the product-side twin of this circuit class serialised by formats.cs_store: the digest
-    text is this build's own convention, so there is nothing independent to restate) and the commitments"""
+    of the constraint system (`write_cs` above, derived from the circuit class of this file alone: the digest's preimage is
+    not taken from the product) and the commitments"""
     cs_bytes = cs.cs_bytes()
     body = [b"halo2-hip-vk-v2", dom.k.to_bytes(4, "little"), dom.extended_k.to_bytes(4, "little"),
             dom.omega.to_bytes(32, "little"), R.to_bytes(32, "little"), Q.to_bytes(32, "little"),

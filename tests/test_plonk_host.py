@@ -533,6 +533,30 @@ def test_constraint_system_bytes_follow_write_cs():
     assert formats.cs_store(cs) == want
 
 
+def test_verifying_key_preimage_is_derived_twice():
+    """The constraint-system bytes hashed into the verifying-key digest, derived independently on both sides: the product
+    serialises its ConstraintSystem (formats.cs_store), the big-integer prover traces the value closures of its own
+    circuit classes into expression trees and serialises those (ref_plonk.write_cs, written from helpers.rs:406-456 /
+    :687-757) -- byte-equal for every circuit the proof tests use, and the hand-written layout of the test above pins
+    one of them to the reference's field order"""
+    import product_circuits as pc
+    from halo2_gpu_specific_amd import formats
+
+    pairs = [(pc.mini_plonk_cs(), rp.MiniPlonk), (pc.rot_gate_cs(), rp.RotGate), (pc.lookup_shuffle_cs(), rp.LookupShuffle),
+             (pc.lookup_api_cs(), rp.LookupApi), (pc.shuffle_api_group_cs(), rp.ShuffleApiGroup),
+             (pc.wide_cs(2), rp.wide_class(2)), (pc.wide_cs(16), rp.wide_class(16)),
+             (pc.range_check_cs(0, 0xFFFF, 2), rp.range_check_class(0, 0xFFFF, 2)),
+             (pc.range_check_cs(3, 40, 1), rp.range_check_class(3, 40, 1))]
+    for cs, ref in pairs:
+        assert formats.cs_store(cs) == rp.write_cs(ref), ref.name
+    # the tracer itself: the tree shapes of plonk/circuit.rs's operator overloading
+    a, f = rp._Sym(("advice", 0, 0)), rp._Sym(("fixed", 0, 0))
+    assert (a - f).node == ("sum", ("advice", 0, 0), ("neg", ("fixed", 0, 0)))
+    assert (a * 3 % rp.R).node == ("scaled", ("advice", 0, 0), 3) and (a * (-1)).node[2] == rp.R - 1
+    assert (7 - a).node == ("sum", ("const", 7), ("neg", ("advice", 0, 0)))
+    assert (a * f + 1).node == ("sum", ("prod", ("advice", 0, 0), ("fixed", 0, 0)), ("const", 1))
+
+
 @pytest.mark.parametrize("make", [circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs, circuits.range_check, lambda: circuits.wide(2)])
 def test_constraint_system_round_trip(make):
     from halo2_gpu_specific_amd import formats
