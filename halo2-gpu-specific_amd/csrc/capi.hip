@@ -166,14 +166,22 @@ int h2_dev_download(void* dst, const void* d_src, size_t bytes, void* stream) {
 // ------------------------------------------------------------------ library-held device memory
 int h2_release_plans(void) {
     return guarded([&] {
-        int prev = 0;
-        (void)hipGetDevice(&prev);
+        // the calling thread's current device is restored on every way out (a throw from H2_HIP included): later h2_dev_*
+        // calls of this thread must not find themselves on another device
+        struct RestoreDevice {
+            int prev = 0;
+            RestoreDevice() { (void)hipGetDevice(&prev); }
+            ~RestoreDevice() { (void)hipSetDevice(prev); }
+        } restore;
         for (DeviceCtx* ctx : existing_contexts()) {
-            std::lock_guard<std::mutex> g(ctx->mu);
+            std::vector<NttPlan*> gone;
+            {
+                std::lock_guard<std::mutex> g(ctx->mu);      // no transform of this context is between lookup and launch
+                ntt_detach_idle_plans(ctx, gone);
+            }
             H2_HIP(hipSetDevice(ctx->device));
-            ntt_release_plans(ctx);
+            ntt_free_plans(gone);                             // synchronises and frees with no lock held
         }
-        (void)hipSetDevice(prev);
         return (int)H2_OK;
     });
 }

@@ -96,7 +96,7 @@ struct DeviceLease {
             throw;
         }
         ctx->mu.lock();  // two pool slots may map onto one physical device (idx % devices.len())
-        hipSetDevice(ctx->device);
+        (void)hipSetDevice(ctx->device);
     }
     ~DeviceLease() {
         ctx->mu.unlock();

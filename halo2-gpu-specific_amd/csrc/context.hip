@@ -36,7 +36,7 @@ void* PinnedBuf::get(size_t bytes) {
     return ptr;
 }
 void DevBuf::release() {
-    if (ptr) hipFree(ptr);
+    if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
     cap = 0;
 }

@@ -451,7 +451,7 @@ int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
     std::map<const uint64_t*, const uint64_t*> up;  // host -> device
     std::vector<void*> owned;
     auto cleanup = [&] {
-        for (void* q : owned) hipFree(q);
+        for (void* q : owned) (void)hipFree(q);
     };
     try {
         auto dev_of = [&](const uint64_t* h) -> const uint64_t* {

@@ -473,34 +473,45 @@ static void free_plan(NttPlan* pl) {
     delete pl;
 }
 
+// Two steps so that no lock is held across the device-wide synchronisation: `ntt_detach_idle_plans` (under the caller's
+// ctx->mu) unhooks every plan nobody holds and returns their bytes; `ntt_free_plans` -- with NO lock held, the plans' device
+// current -- waits for the passes already launched against their tables and frees them.
+size_t ntt_detach_idle_plans(DeviceCtx* ctx, std::vector<NttPlan*>& gone) {
+    size_t bytes = 0;
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    for (auto it = ctx->plans.begin(); it != ctx->plans.end();) {
+        NttPlan* pl = it->second;
+        bool busy = pl->users.load() != 0;
+        for (auto& kv : pl->last_direct) busy = busy || kv.second.users != 0;
+        if (busy) {
+            ++it;
+            continue;
+        }
+        bytes += pl->table_bytes;
+        for (auto& kv : pl->last_direct) {
+            bytes += kv.second.bytes;
+            ctx->ntt_last_table_bytes -= kv.second.bytes;
+        }
+        bytes += pl->scaled_hi.size() * ((sizeof(Fr) << pl->log_n) >> LO_BITS);
+        gone.push_back(pl);
+        it = ctx->plans.erase(it);
+    }
+    return bytes;
+}
+
+void ntt_free_plans(std::vector<NttPlan*>& gone) {
+    if (gone.empty()) return;
+    // nobody can reach these plans any more; passes already launched against their tables finish first
+    hipError_t e = hipDeviceSynchronize();
+    for (NttPlan* pl : gone) free_plan(pl);
+    gone.clear();
+    H2_HIP(e);
+}
+
 size_t ntt_release_plans(DeviceCtx* ctx) {
     std::vector<NttPlan*> gone;
-    size_t bytes = 0;
-    {
-        std::lock_guard<std::mutex> g(g_tab_mu);
-        for (auto it = ctx->plans.begin(); it != ctx->plans.end();) {
-            NttPlan* pl = it->second;
-            bool busy = pl->users.load() != 0;
-            for (auto& kv : pl->last_direct) busy = busy || kv.second.users != 0;
-            if (busy) {
-                ++it;
-                continue;
-            }
-            bytes += pl->table_bytes;
-            for (auto& kv : pl->last_direct) {
-                bytes += kv.second.bytes;
-                ctx->ntt_last_table_bytes -= kv.second.bytes;
-            }
-            for (auto& kv : pl->scaled_hi) bytes += (sizeof(Fr) << pl->log_n) >> LO_BITS;
-            gone.push_back(pl);
-            it = ctx->plans.erase(it);
-        }
-    }
-    if (!gone.empty()) {
-        // nobody can reach these plans any more; passes already launched against their tables finish first
-        H2_HIP(hipDeviceSynchronize());
-        for (NttPlan* pl : gone) free_plan(pl);
-    }
+    size_t bytes = ntt_detach_idle_plans(ctx, gone);
+    ntt_free_plans(gone);
     return bytes;
 }
 
@@ -518,12 +529,17 @@ size_t ntt_plan_bytes(DeviceCtx* ctx) {
 
 // Makes room for `need` more bytes of last-pass tables on `ctx`: idle tables leave in least-recently-used order.
 // Returns false when the budget cannot hold `need` even then.  Call WITHOUT g_tab_mu.
-static bool last_table_make_room(DeviceCtx* ctx, size_t need) {
+// `allow_evict` = false: only room that is already free counts.  A table is an optimisation worth ONE product per element
+// per transform; evicting one costs a device-wide synchronisation and rebuilding the other a pass over n elements, so a
+// key only displaces resident tables once it has missed twice (a budget of one or two tables under a proof that cycles
+// through forward / inverse transforms and their divisors would otherwise rebuild a table on every call).
+static bool last_table_make_room(DeviceCtx* ctx, size_t need, bool allow_evict) {
     const size_t budget = ntt_table_budget(ctx);
     if (need > budget) return false;
     std::vector<Fr*> gone;
     {
         std::lock_guard<std::mutex> g(g_tab_mu);
+        if (!allow_evict) return ctx->ntt_last_table_bytes + need <= budget;
         while (ctx->ntt_last_table_bytes + need > budget) {
             NttPlan::LastTable* victim = nullptr;
             NttPlan* owner = nullptr;
@@ -713,6 +729,17 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         static const bool last_table = !(getenv("H2_NTT_LAST_TABLE") && atoi(getenv("H2_NTT_LAST_TABLE")) == 0);
         static const uint32_t last_table_max = getenv("H2_NTT_LAST_TABLE_MAX_LOG") ? (uint32_t)atoi(getenv("H2_NTT_LAST_TABLE_MAX_LOG")) : 26u;
         NttPlan::LastTable* used_table = nullptr;
+        // the pin is dropped when this pass has been launched -- or when anything on the way there throws (H2_HIP): a leaked
+        // pin would keep the table from ever being evicted and its plan from ever being released
+        struct Pin {
+            NttPlan::LastTable* t = nullptr;
+            ~Pin() {
+                if (t) {
+                    std::lock_guard<std::mutex> g(g_tab_mu);
+                    t->users--;
+                }
+            }
+        } pinned;
         if (last && p > 0 && last_table && L >= 18 && L <= last_table_max) {
             const bool scaled = a.hi_scaled != 0;
             std::string key;
@@ -730,11 +757,14 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                 it->second.last_use = ++g_tick;
                 return &it->second;
             };
+            bool may_evict = false;
             {
                 std::lock_guard<std::mutex> g(g_tab_mu);
                 used_table = pin();
+                if (!used_table) may_evict = ++pl->last_misses[key] >= 2;   // see last_table_make_room
             }
-            if (!used_table && last_table_make_room(ctx, bytes)) {
+            pinned.t = used_table;
+            if (!used_table && last_table_make_room(ctx, bytes, may_evict)) {
                 // built outside the lock (a table is 0.5 .. 2 GiB of powers); a second builder of the same table loses
                 Fr* tab = nullptr;
                 if (hipMalloc(&tab, bytes) != hipSuccess) {
@@ -756,10 +786,12 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
                         e.ptr = tab;
                         e.bytes = bytes;
                         ctx->ntt_last_table_bytes += bytes;
+                        pl->last_misses[key] = 0;  // evicted later, it has to miss twice again before it displaces others
                         used_table = pin();
                     }
                 }
                 if (loser) (void)hipFree(loser);
+                pinned.t = used_table;
             }
             if (used_table != nullptr) {
                 a.tw_direct = used_table->ptr;
@@ -808,10 +840,7 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             else
                 hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(ntiles), dim3(threads), lds, stream, a);
         }
-        if (used_table) {  // launched: an eviction from here on synchronises the device before it frees
-            std::lock_guard<std::mutex> g(g_tab_mu);
-            used_table->users--;
-        }
+        // (`pinned` unpins here: launched -- an eviction from here on synchronises the device before it frees)
         consumed += B;
     }
     H2_HIP(hipGetLastError());

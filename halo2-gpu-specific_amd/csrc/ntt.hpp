@@ -31,6 +31,7 @@ struct NttPlan {
         int users = 0;  // transforms between looking the table up and having launched the pass that reads it
     };
     std::map<std::string, LastTable> last_direct;
+    std::map<std::string, int> last_misses;  // lookups of a key that found no table (a key evicts others from its 2nd miss on)
     std::atomic<int> users{0};         // callers holding the plan (PlanRef): a plan in use is not released
     uint64_t last_use = 0;
 };
@@ -64,6 +65,8 @@ PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hi
 // frees every plan of `ctx` that no caller holds, with all its tables (synchronises the device first); call with
 // ctx->mu held.  Returns the bytes released.
 size_t ntt_release_plans(DeviceCtx* ctx);
+size_t ntt_detach_idle_plans(DeviceCtx* ctx, std::vector<NttPlan*>& gone);  // under ctx->mu
+void ntt_free_plans(std::vector<NttPlan*>& gone);                           // no lock held: synchronises, frees
 // bytes of device memory the plans of `ctx` hold (twiddle tables + last-pass tables); call with ctx->mu held
 size_t ntt_plan_bytes(DeviceCtx* ctx);
 // per-device budget of the optional last-pass tables: H2_NTT_TABLE_BUDGET (bytes; K / M / G suffixes) or

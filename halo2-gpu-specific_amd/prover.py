@@ -76,26 +76,29 @@ def parse_bytes(text):
     return int(float(t[:-1]) * mult) if mult else int(float(t))
 
 
-def footprint(cs, dom, cached_cosets=None):
+def footprint(cs, dom, cached_cosets=None, instances=1):
     """Device bytes of polynomial data a proof of this circuit holds at its peak, by residency mode:
     'extended' = every extended coset resident (the proving key's fixed / sigma / l tables for the life of the key, the
     witness-dependent ones during the quotient phase); 'cosets' = coefficient forms only, the extended domain visited
     one coset of the n-th roots of unity at a time with `cached_cosets` sets of proving-key tables retained.
+    `instances`: circuit instances proved together (plonk/prover.rs:206-232): every witness-dependent polynomial exists once
+    per instance, the proving key's once.
     A planning estimate (it decides the mode against H2_DEVICE_MEM_BUDGET), not an allocator."""
     n, en = dom.n, dom.extended_n
     chunk = max(cs.degree() - 2, 1)
     nsets = (len(cs.perm_columns) + chunk - 1) // chunk
     F, A, I, P = cs.num_fixed, cs.num_advice, cs.num_instance, len(cs.perm_columns)
     lk_sets = sum(len(sets) for _, _, sets in cs.lookups)
-    witness_polys = A + I + nsets + lk_sets + len(cs.lookups) + len(cs.shuffles)
+    witness_polys = (A + I + nsets + lk_sets + len(cs.lookups) + len(cs.shuffles)) * max(1, instances)
     key_polys = 2 * (F + P)                                   # Lagrange values and coefficient forms
     c = dom.quotient_poly_degree
     cached = c if cached_cosets is None else max(1, min(c, cached_cosets))
     # + random / h / scratch vectors, the c per-coset quotients, and the scratch of two commitments in flight (sorted digit
     # entries, slice partials, buckets: ~370 B per point each = 23 n-vectors' worth; k = 25 measured: 97 GiB at the peak)
     base = 32 * n * (key_polys + 2 * witness_polys + 4 + c + 23)
-    return {"extended": base + 32 * en * ((F + P + 3) + witness_polys + 2),
-            "cosets": base + 32 * n * ((F + P + 3) * cached + witness_polys + 3)}
+    # (the extended cosets of the witness exist for one instance at a time: the quotient is evaluated circuit by circuit)
+    return {"extended": base + 32 * en * ((F + P + 3) + witness_polys // max(1, instances) + 2),
+            "cosets": base + 32 * n * ((F + P + 3) * cached + witness_polys // max(1, instances) + 3)}
 
 
 class CosetTables:
@@ -339,9 +342,10 @@ class Device:
         shards, owned = coset_plan(c, self.group_size, self.group_rank)
         return c, shards, owned
 
-    def residency(self, cs, dom):
+    def residency(self, cs, dom, instances=1):
         """('extended', None) or ('cosets', keep): how the extended-domain phase of this circuit runs on ONE device under
-        the memory budget.  `keep` = cosets' worth of proving-key tables retained between uses."""
+        the memory budget.  `keep` = cosets' worth of proving-key tables retained between uses.  `instances`: circuit
+        instances in one proof (decided at keygen for one; create_proof_ext asks again when it is handed several)."""
         c = dom.quotient_poly_degree
         if self.eval_cache is not None:
             return "cosets", max(0, min(c, self.eval_cache))
@@ -353,16 +357,16 @@ class Device:
             free, _ = torch.cuda.mem_get_info(self.dev)
             held = self._scratch.numel() if self._scratch is not None else 0     # commitment scratch: reused, and counted
             budget = int(0.8 * (free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) + held))
-            if footprint(cs, dom)["extended"] <= budget:
+            if footprint(cs, dom, None, instances)["extended"] <= budget:
                 return "extended", None
-        elif footprint(cs, dom)["extended"] <= budget:
+        elif footprint(cs, dom, None, instances)["extended"] <= budget:
             return "extended", None
         for keep in range(c, 0, -1):
-            if footprint(cs, dom, keep)["cosets"] <= budget:
+            if footprint(cs, dom, keep, instances)["cosets"] <= budget:
                 return "cosets", keep
-        if footprint(cs, dom, 1)["cosets"] > budget * 1.5:
+        if footprint(cs, dom, 1, instances)["cosets"] > budget * 1.5:
             raise MemoryError("this circuit needs ~%.1f GiB of device memory even coset by coset; the budget is %.1f GiB"
-                              % (footprint(cs, dom, 1)["cosets"] / 2**30, budget / 2**30))
+                              % (footprint(cs, dom, 1, instances)["cosets"] / 2**30, budget / 2**30))
         return "cosets", 0
 
     def coeff_to_coset(self, poly, dom, j):
@@ -927,6 +931,18 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         one = D.eval_op(8, D.empty(size), c=1)                                 # H2_OP_CONSTANT
         return D.eval_op(4, one, one, tmp)                                     # H2_OP_SUB
 
+    def coset_tables(j):
+        l_last_j = D.coeff_to_coset(l_last_poly, dom, j)
+        return {
+            "fixed": [D.coeff_to_coset(t, dom, j) for t in pk.fixed_polys],
+            "sigma": [D.coeff_to_coset(t, dom, j) for t in pk.sigma_polys],
+            "l0": D.coeff_to_coset(l0_poly, dom, j), "l_last": l_last_j,
+            "l_active_row": active_row(l_last_j, D.coeff_to_coset(l_blind_poly, dom, j), n),
+        }
+
+    # kept with the key (three n-vectors behind the closure): a proof of SEVERAL circuit instances may not fit the
+    # residency decided here for one and then runs coset by coset from tables built on demand (create_proof_ext)
+    pk.coset_builder = coset_tables
     if plan is None:
         pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
         pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)
@@ -935,16 +951,6 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         # one proof over several ranks: only the cosets this rank evaluates, each an n-point table
         # (under a memory budget on one device: every coset, built on demand and retained up to `keep` of them)
         pk.l0 = pk.l_last = pk.l_active_row = None
-
-        def coset_tables(j):
-            l_last_j = D.coeff_to_coset(l_last_poly, dom, j)
-            return {
-                "fixed": [D.coeff_to_coset(t, dom, j) for t in pk.fixed_polys],
-                "sigma": [D.coeff_to_coset(t, dom, j) for t in pk.sigma_polys],
-                "l0": D.coeff_to_coset(l0_poly, dom, j), "l_last": l_last_j,
-                "l_active_row": active_row(l_last_j, D.coeff_to_coset(l_blind_poly, dom, j), n),
-            }
-
         pk.coset = CosetTables(coset_tables, plan[2], keep)
         if keep is None:                       # one proof over several ranks: this rank's cosets stay resident
             for j in plan[2]:
@@ -1112,8 +1118,18 @@ def complete_range_check_witness(cs, n, advice, first_unassigned=None):
         low = lambda c: c if c.ndim == 1 else c[:, 0]            # noqa: E731  (compact columns hold limb 0 only)
         values = np.array(range_check_assigner(vmin, vmax, step), dtype=np.uint64)
         lo = last_active + 1 - len(values)
-        if lo < 0 or (first_unassigned is not None and first_unassigned.get(origin, 0) > lo):
+        # the reference asserts first_unassigned_offset <= (the offset below the last planted cell) = lo - 1 (prover.rs:1731)
+        if lo < 1 or (first_unassigned is not None and first_unassigned.get(origin, 0) >= lo):
             raise ValueError("range check: the range does not fit the unused cells of its column")
+        if first_unassigned is None:
+            # synthesis did not say which cells it assigned: the cells about to be planted (and the spare one below them)
+            # must be untouched -- zero -- or already hold exactly the planted values (the same host columns proved again);
+            # a witness that uses them would otherwise be silently overwritten and a different statement proved
+            target = low(col)[lo:last_active + 1]
+            wide_clear = col.ndim == 1 or not col[lo - 1:last_active + 1, 1:].any()
+            planted = np.array_equal(target, values[::-1])
+            if not wide_clear or low(col)[lo - 1] != 0 or not (planted or not target.any()):
+                raise ValueError("range check: the witness already uses the cells the range is planted in")
         low(col)[lo:last_active + 1] = values[::-1]
         if col.ndim == 2:
             col[lo:last_active + 1, 1:] = 0
@@ -1136,7 +1152,8 @@ def create_proof_from_witness(device, params, pk, witness, rng, use_gwc=True, ti
     return create_proof_ext(device, params, pk, witness, rng, use_gwc, timings, instances, montgomery=True)
 
 
-def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=(), montgomery=False):
+def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, instances=(), montgomery=False,
+                     first_unassigned=None):
     """plonk/prover.rs:206-850.  advice: list of (n, 4) u64 columns, canonical integers (or Montgomery residues with
     montgomery=True); rows past the usable range are overwritten with blinding values; instances: one list of
     canonical integers per instance column; rng: a rng.ProverRng.  Returns the proof bytes.
@@ -1146,7 +1163,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     Several circuit instances in one proof (`circuits: &[ConcreteCircuit]`, prover.rs:206-232): pass `advice` as a list
     of such column lists and `instances` as the matching list of instance-column lists.  Every phase then runs circuit
     by circuit in the reference's order (instance commitments, advice commitments, theta, lookup multiplicities, beta /
-    gamma, permutation / lookup / shuffle products, y, ONE quotient over all circuits, x, evaluations, openings)."""
+    gamma, permutation / lookup / shuffle products, y, ONE quotient over all circuits, x, evaluations, openings).
+
+    `first_unassigned`: {advice column index: first row synthesis left unassigned} (one dict, or one per circuit instance) for
+    the range-checked columns -- what the reference's assignment tracking records (prover.rs:1706-1731); without it the
+    cells the range is planted in must be zero."""
     import time
 
     D, L = device, device.L
@@ -1178,9 +1199,21 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if cs.range_checks:
         if montgomery:
             raise ValueError("range-check witness completion needs canonical advice columns")
-        for a in advice_sets:                                 # prover.rs:1699-1783: plant the range, sort the companion
-            complete_range_check_witness(cs, n, a)
+        fu = first_unassigned if isinstance(first_unassigned, (list, tuple)) else [first_unassigned] * len(advice_sets)
+        for a, f in zip(advice_sets, fu):                     # prover.rs:1699-1783: plant the range, sort the companion
+            complete_range_check_witness(cs, n, a, f)
     advice = [col for a in advice_sets for col in a]          # circuit-major: the order every phase walks them in
+    # The residency of the key was decided at keygen for ONE circuit instance; advice, product and lookup polynomials scale
+    # with the number of instances.  A key judged 'extended' whose multi-instance proof does not fit runs this proof by the
+    # coset route, from tables built on demand out of the key's coefficient forms (same bytes).
+    coset_tabs = pk.coset
+    if ncirc > 1 and coset_tabs is None and D.group_size <= 1 and getattr(pk, "coset_builder", None) is not None:
+        mode, keep_ = D.residency(cs, dom, ncirc)
+        if mode == "cosets":
+            hit = pk.__dict__.get("_multi_coset")
+            if hit is None or hit.keep != keep_:
+                hit = pk._multi_coset = CosetTables(pk.coset_builder, range(dom.quotient_poly_degree), keep_)
+            coset_tabs = hit
 
     # ---- instance columns (prover.rs:85-162): zero-padded, committed, hashed but not written -------------------
     instance_dev_sets = []
@@ -1299,7 +1332,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # the transforms only take their time away (60.1 vs 60.2 ms, 210 vs 211)
     side_intt = None
     if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= 20 and D.group_size <= 1 and not D.force_collective):
-        side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and pk.coset is None)
+        side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and coset_tabs is None)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
     for C in circuits:
@@ -1463,10 +1496,10 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     g = pk.graph
     plan = D.coset_plan(dom)
     if D.group_size <= 1:                      # on one device the proving key decides which tables exist
-        if pk.coset is None:
+        if coset_tabs is None:
             plan = None
         else:
-            plan = (dom.quotient_poly_degree, 1, sorted(pk.coset))
+            plan = (dom.quotient_poly_degree, 1, sorted(coset_tabs))
     # Several circuits share one quotient: the reference keeps folding `value = value * y + term` from one circuit into
     # the next (plonk/evaluation.rs:839-1100), i.e. h = sum_i y^(T (N - 1 - i)) h_i with T terms per circuit and h_i the
     # fold of circuit i alone -- each circuit runs through the evaluator on its own and the results are combined.
@@ -1533,7 +1566,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         mine = {}
         for j in owned:
             g_j = ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD
-            h_j = evaluate_quotient(lambda t, j=j: D.coeff_to_coset(t, dom, j), pk.coset[j], dom.k, g_j, dom.omega, n)
+            h_j = evaluate_quotient(lambda t, j=j: D.coeff_to_coset(t, dom, j), coset_tabs[j], dom.k, g_j, dom.omega, n)
             D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
             mine[j] = D.coset_to_coeff(h_j, dom, j)
         # Everything after the quotient -- the un-mixing, the h pieces' commitments, the evaluations, the multiopen argument --
@@ -1549,7 +1582,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         unmix = coset_unmix_matrix(gammas, dom.quotient_poly_degree)
         pieces = [D.lincomb_range(D.empty(n), polys_j, row, n) for row in unmix]
         del polys_j, mine
-        pk.coset.trim()
+        coset_tabs.trim()
     mark("vanishing transforms")
     for P in D.msm_batch(pieces, params.g, n, 254):
         transcript.write_point(P)

@@ -151,6 +151,69 @@ EXPORT void oracle_random_g1(uint64_t seed, size_t n, g1_affine *out) {
 }
 
 /* ------------------------------------------------------------------ */
+/* Compressed points: what Params::{write, read} (poly/commitment.rs:241-294) and the transcript
+ * (transcript.rs:181-215) call `to_bytes` / `from_bytes` for.  Those live in pairing_bn256 (rev 30b052f, absent:
+ * PARITY UNPINNED at byte level); restated from the published encoding of that curve family: 32 bytes = x canonical
+ * little-endian, bit 7 of byte 31 = the parity of canonical y, the identity = 32 zero bytes; decoding takes
+ * y = (x^3 + 3)^((q+1)/4) (q = 3 mod 4), checks y^2 = x^3 + 3 and negates y when its parity differs from the flag. */
+/* ------------------------------------------------------------------ */
+EXPORT void oracle_points_compress(const g1_affine *pts, size_t n, uint8_t *out) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        uint8_t *b = out + 32 * i;
+        if (g1a_is_identity(&pts[i])) {
+            memset(b, 0, 32);
+            continue;
+        }
+        u256 x, y;
+        fq_to_repr(&x, &pts[i].x);
+        fq_to_repr(&y, &pts[i].y);
+        memcpy(b, x.l, 32); /* little-endian host */
+        b[31] |= (uint8_t)((y.l[0] & 1) << 7);
+    }
+}
+
+/* returns the number of encodings that are not curve points (their output slot is zeroed) */
+EXPORT size_t oracle_points_decompress(const uint8_t *in, size_t n, g1_affine *out) {
+    static const uint64_t E[4] = {0x4f082305b61f3f52ULL, 0x65e05aa45a1c72a3ULL, 0x6e14116da0605617ULL,
+                                  0x0c19139cb84c680aULL}; /* (q+1)/4 */
+    size_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *b = in + 32 * i;
+        u256 c, x, rhs, y, y2, yc, three;
+        memcpy(c.l, b, 32);
+        const unsigned flag = (unsigned)(c.l[3] >> 63);
+        c.l[3] &= 0x7fffffffffffffffULL;
+        memset(&out[i], 0, sizeof(g1_affine));
+        if (!(c.l[0] | c.l[1] | c.l[2] | c.l[3])) {
+            if (flag) bad++; /* x = 0 with the flag set is not an encoding of anything */
+            continue;
+        }
+        if (fq_geq_mod(c.l)) {
+            bad++;
+            continue;
+        }
+        fq_from_repr(&x, &c);
+        fq_from_u64(&three, 3);
+        fq_sqr(&rhs, &x);
+        fq_mul(&rhs, &rhs, &x);
+        fq_add(&rhs, &rhs, &three);
+        fq_pow(&y, &rhs, E);
+        fq_sqr(&y2, &y);
+        if (!fq_eq(&y2, &rhs)) {
+            bad++;
+            continue;
+        }
+        fq_to_repr(&yc, &y);
+        if ((unsigned)(yc.l[0] & 1) != flag) fq_neg(&y, &y);
+        out[i].x = x;
+        out[i].y = y;
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------ */
 /* MSM: arithmetic.rs:20-108 (multiexp_serial), :465-492 (best_multiexp) */
 /* ------------------------------------------------------------------ */
 

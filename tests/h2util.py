@@ -193,6 +193,10 @@ class Oracle:
         L.oracle_find_max_scalar_bits.restype = u32
         L.oracle_domain_new.restype = i32
         L.oracle_extended_to_coeff.restype = sz
+        L.oracle_points_compress.argtypes = [vp, sz, vp]
+        L.oracle_points_compress.restype = None
+        L.oracle_points_decompress.argtypes = [vp, sz, vp]
+        L.oracle_points_decompress.restype = sz
         self.threads = os.cpu_count() or 1
         # libgomp does not scale the rayon-shaped FFT recursion past ~32 threads (65 s per 2^24 transform on 256 hardware
         # threads against 1.6 s on 32: DESIGN.md section 5); the MSM restatement does scale
@@ -218,6 +222,20 @@ class Oracle:
         out = np.zeros((n, 8), dtype=np.uint64)
         self.lib.oracle_random_g1(seed, n, _ptr(out))
         return out
+
+    def points_compress(self, pts):
+        """(n, 8) affine Montgomery points -> (n, 32) uint8 encodings"""
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 8)
+        out = np.zeros((len(pts), 32), dtype=np.uint8)
+        self.lib.oracle_points_compress(_ptr(pts), len(pts), out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def points_decompress(self, raw):
+        """(n, 32) uint8 encodings -> ((n, 8) affine Montgomery points, number of invalid encodings)"""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros((len(raw), 8), dtype=np.uint64)
+        bad = self.lib.oracle_points_decompress(raw.ctypes.data_as(ctypes.c_void_p), len(raw), _ptr(out))
+        return out, int(bad)
 
     def best_fft(self, a, omega, log_n, threads=None):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()

@@ -82,11 +82,11 @@ def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
 
 
 @pytest.mark.timeout(2400)
-@pytest.mark.parametrize("k", [20, 22] + ([24] if os.environ.get("H2_TEST_CPU_PROVER_K24") == "1" else []))
+@pytest.mark.parametrize("k", [20, 22] + ([] if os.environ.get("H2_TEST_CPU_PROVER_K24") == "0" else [24]))
 def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k):
-    """configs[3] (k = 22) and, with H2_TEST_CPU_PROVER_K24=1, configs[4]'s size (k = 24: ~4 minutes of CPU work; the run
-    of this build is kept in profiles/r3_cpu_prover_parity.txt): the CPU side of k = 24 runs coset by coset (2 x 2^24
-    points instead of one 2^26-point extended domain per column: the same bytes, a quarter of the host memory)"""
+    """configs[3] (k = 22) and configs[4]'s size (k = 24: ~4 minutes of CPU work, part of the default run;
+    H2_TEST_CPU_PROVER_K24=0 skips it): the CPU side of k = 24 runs coset by coset (2 x 2^24 points instead of one
+    2^26-point extended domain per column: the same bytes, a quarter of the host memory)"""
     from halo2_gpu_specific_amd import circuits
 
     adv, fixed, copies = circuits.mini_plonk_synthesize(k)

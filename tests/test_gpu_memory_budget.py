@@ -95,9 +95,38 @@ def test_same_proof_bytes_under_a_memory_budget(oracle, device, which, k):
         prover.Device(mem_budget=fp["cosets"] // 4).residency(pk.cs, dom)
 
 
+def test_several_instances_switch_to_the_coset_route_when_they_do_not_fit(oracle, device):
+    """residency is decided at keygen for ONE circuit instance; a proof of several instances whose polynomials do not fit
+    the budget runs coset by coset from tables built on demand -- the same bytes as the unbudgeted device"""
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k, cs = 10, circuits.mini_plonk()
+    advs = [circuits.mini_plonk_synthesize(k, a=a)[0] for a in (5, 9, 11)]
+    _, fixed, copies = circuits.mini_plonk_synthesize(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    want = prover.create_proof_ext(device, params, pk, advs, ProverRng(4), False, instances=[(), (), ()])
+    dom = pk.domain
+    one, three = prover.footprint(cs, dom, None, 1), prover.footprint(cs, dom, None, 3)
+    assert three["extended"] > one["extended"] and three["cosets"] > one["cosets"]
+    D2 = prover.Device(mem_budget=one["extended"])
+    assert D2.residency(cs, dom) == ("extended", None) and D2.residency(cs, dom, 3)[0] == "cosets"
+    params2 = prover.Params(D2, k, params.g, params.g_lagrange)
+    pk2 = prover.keygen(D2, params2, cs, fixed, copies)
+    assert pk2.residency == "extended" and pk2.coset is None
+    assert prover.create_proof_ext(D2, params2, pk2, advs, ProverRng(4), False, instances=[(), (), ()]) == want
+    assert pk2._multi_coset.misses >= 1                      # the coset route ran
+    # one instance on the same key still takes the extended route
+    single = prover.create_proof_ext(device, params, pk, advs[0], ProverRng(5), False)
+    assert prover.create_proof_ext(D2, params2, pk2, advs[0], ProverRng(5), False) == single
+
+
 def test_library_tables_budget_lru_and_release(oracle):
     """last-pass twiddle tables (32 B x n each, transforms of >= 2^18 points): inside the budget, least recently used out
-    first, none with a zero budget, all gone after h2_release_plans -- and the same transform values throughout"""
+    first -- but only for a key that has missed twice (no eviction to build a table that may be used once: a small budget
+    under alternating transforms would rebuild a table per call) --, none with a zero budget, all gone after
+    h2_release_plans -- and the same transform values throughout"""
     from halo2_gpu_specific_amd import arithmetic as ar
 
     L = h2.lib()
@@ -124,10 +153,15 @@ def test_library_tables_budget_lru_and_release(oracle):
         L.h2_set_table_budget(tab(19))                                # room for either table, not for both
         run(18)
         assert L.h2_library_memory_bytes() - base >= tab(18)
-        run(19)                                                       # evicts the 2^18 table
+        run(19)                                # first miss of a key that would have to evict: it composes its twiddles instead
+        held = L.h2_library_memory_bytes() - base
+        assert tab(18) <= held < tab(19)
+        run(19)                                # second miss: now the 2^18 table leaves (least recently used) and 2^19 is built
         held = L.h2_library_memory_bytes() - base
         assert tab(19) <= held < tab(19) + tab(18)
-        run(18)                                                       # ... and back
+        run(18)                                # ... the same the other way round: one miss changes nothing,
+        assert tab(19) <= L.h2_library_memory_bytes() - base < tab(19) + tab(18)
+        run(18)                                # the second brings the table back
         held = L.h2_library_memory_bytes() - base
         assert tab(18) <= held < tab(19)
         L.h2_set_table_budget(tab(19) + tab(18))

@@ -606,6 +606,57 @@ def test_params_file_and_witness_file_round_trip(oracle, device, tmp_path):
     assert prover.create_proof_from_witness(device, back, pk, cols, ProverRng(6)) == want
 
 
+def test_device_point_codec_on_every_srs_point(oracle, device):
+    """N4 (poly/commitment.rs:241-294): h2_dev_points_compress over EVERY point of both tables of a k = 13 setup against
+    the big-integer encoder (ref_plonk.point_to_bytes on the oracle's normalised points: written independently of the
+    product's transcript.point_to_bytes) and against the C oracle's encoder; h2_dev_points_decompress of those bytes
+    against the oracle's square root (oracle_points_decompress), bit for bit; invalid encodings are refused"""
+    import torch
+
+    from halo2_gpu_specific_amd._lib import check
+    from h2util import arr_to_points
+
+    k = 13
+    n = 1 << k
+    params = srs(oracle, device, k)
+    for table in (params.g, params.g_lagrange):
+        pts = device.download(table).reshape(-1, 8)
+        with torch.cuda.stream(device.tstream):
+            out = torch.empty((n, 32), dtype=torch.uint8, device=device.dev)
+        check(device.L.h2_dev_points_compress(table.data_ptr(), n, out.data_ptr(), device.stream), "h2_dev_points_compress")
+        with torch.cuda.stream(device.tstream):
+            raw = out.cpu().numpy()
+        assert np.array_equal(raw, oracle.points_compress(pts))
+        ints = arr_to_points(pts)
+        assert [bytes(r) for r in raw] == [rp.point_to_bytes(None if P == (0, 0) else P) for P in ints]
+        want, bad = oracle.points_decompress(raw)
+        assert bad == 0 and np.array_equal(want, pts)
+        with torch.cuda.stream(device.tstream):
+            back = torch.empty((n, 8), dtype=torch.int64, device=device.dev)
+        check(device.L.h2_dev_points_decompress(out.data_ptr(), n, back.data_ptr(), device.stream), "h2_dev_points_decompress")
+        assert np.array_equal(device.download(back), want)
+    # random points of both parities plus the identity, and a batch with junk in it
+    pts = oracle.random_g1(91, 5000)
+    pts[17] = 0
+    raw = oracle.points_compress(pts)
+    with torch.cuda.stream(device.tstream):
+        d_raw = torch.from_numpy(raw).to(device.dev)
+        back = torch.empty((len(pts), 8), dtype=torch.int64, device=device.dev)
+    check(device.L.h2_dev_points_decompress(d_raw.data_ptr(), len(pts), back.data_ptr(), device.stream), "h2_dev_points_decompress")
+    assert np.array_equal(device.download(back), pts)
+    junk = raw.copy()
+    x = 1
+    from h2util import Q_MOD
+    while pow((x ** 3 + 3) % Q_MOD, (Q_MOD - 1) // 2, Q_MOD) == 1:
+        x += 1
+    junk[123] = np.frombuffer(x.to_bytes(32, "little"), dtype=np.uint8)
+    assert oracle.points_decompress(junk)[1] == 1
+    with torch.cuda.stream(device.tstream):
+        d_junk = torch.from_numpy(junk).to(device.dev)
+    rc = device.L.h2_dev_points_decompress(d_junk.data_ptr(), len(pts), back.data_ptr(), device.stream)
+    assert rc != 0, "an abscissa off the curve must be refused"
+
+
 def test_device_prover_reproduces_committed_proofs(oracle, device):
     """the committed proof fixtures (tests/golden/proof_kat.json, made by the big-integer prover): same bytes from the
     device prover"""

@@ -154,3 +154,34 @@ def test_random_generators_are_deterministic_and_valid(oracle):
     assert np.array_equal(p, oracle.random_g1(9, 32))
     for x, y in arr_to_points(p):
         assert (y * y - x * x * x - 3) % Q_MOD == 0
+
+
+def test_point_codec_against_the_big_integer_encoder(oracle):
+    """oracle_points_{compress, decompress} (the checker of the device codec) against ref_plonk.point_to_bytes /
+    point_from_bytes on random points, both parities, the identity, and invalid encodings"""
+    import ref_plonk as rp
+    from h2util import Q_MOD, arr_to_points, points_to_arr
+
+    pts = oracle.random_g1(77, 600)
+    ints = arr_to_points(pts)
+    ints[5] = (0, 0)                                   # the identity
+    pts = points_to_arr(ints)
+    raw = oracle.points_compress(pts)
+    want = [rp.point_to_bytes(None if P == (0, 0) else P) for P in ints]
+    assert [bytes(r) for r in raw] == want
+    assert {b[31] >> 7 for b in want} == {0, 1}        # both parities occur
+    back, bad = oracle.points_decompress(raw)
+    assert bad == 0 and np.array_equal(back, pts)
+    for i in (0, 1, 2, 5, 599):
+        P = rp.point_from_bytes(want[i])
+        assert (P or (0, 0)) == ints[i]
+    # not on the curve / non-canonical x / the flagged zero
+    x = 1
+    while pow((x ** 3 + 3) % Q_MOD, (Q_MOD - 1) // 2, Q_MOD) == 1:
+        x += 1
+    junk = np.zeros((3, 32), dtype=np.uint8)
+    junk[0] = np.frombuffer(x.to_bytes(32, "little"), dtype=np.uint8)
+    junk[1] = np.frombuffer((Q_MOD + 1).to_bytes(32, "little"), dtype=np.uint8)
+    junk[2, 31] = 0x80
+    out, bad = oracle.points_decompress(junk)
+    assert bad == 3 and not out.any()

@@ -659,6 +659,22 @@ def test_range_check_argument_front_end_and_witness_completion():
         prover.complete_range_check_witness(small, 1 << k, bad)
     with pytest.raises(ValueError):                         # the range does not fit the unused cells
         prover.complete_range_check_witness(small, 1 << k, [c.copy() for c in adv], first_unassigned={0: 120})
+    # the reference's assertion (prover.rs:1731): first_unassigned <= lo - 1 with lo the lowest planted row
+    usable = (1 << k) - 6
+    lo = usable - len(prover.range_check_assigner(0, vmax, step))
+    fresh = lambda: circuits.range_check_synthesize(k, vmin=0, vmax=vmax, count=60)[0]      # noqa: E731
+    prover.complete_range_check_witness(small, 1 << k, fresh(), first_unassigned={0: lo - 1})
+    with pytest.raises(ValueError):
+        prover.complete_range_check_witness(small, 1 << k, fresh(), first_unassigned={0: lo})
+    # without assignment tracking: completing twice is idempotent, a witness that uses a cell of the planted range is refused
+    again = [c.copy() for c in adv]
+    prover.complete_range_check_witness(small, 1 << k, again)
+    assert all(np.array_equal(a, b) for a, b in zip(again, adv))
+    for row in (lo - 1, lo, usable - 1):
+        used = fresh()
+        used[0][row, 0] = 7
+        with pytest.raises(ValueError, match="already uses"):
+            prover.complete_range_check_witness(small, 1 << k, used)
 
 
 def test_constraint_system_round_trip_random_circuits():
