@@ -60,6 +60,11 @@ SYMBOLS = {
     "h2_eval_op": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i32, _i32, _sz, _vp]),
     "h2_divide_by_vanishing_poly": (ctypes.c_int, [_vp, _sz, _vp, _sz]),
     "h2_dev_ntt": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    "h2_dev_coset_ntt": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "h2_dev_coset_intt": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "h2_dev_ntt_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _u32, _vp]),
+    "h2_dev_intt_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _vp, _u32, _vp]),
+    "h2_dev_coset_ntt_batch": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _u32, _vp, _vp, _vp]),
     "h2_dev_intt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "h2_dev_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "h2_dev_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),

@@ -455,6 +455,101 @@ int h2_dev_coeff_to_extended(const void* d_coeffs, void* d_out, void* d_tmp, uin
     });
 }
 
+int h2_dev_coset_ntt(const void* d_coeffs, void* d_out, void* d_tmp, uint32_t log_n, const uint64_t g[4],
+                     const uint64_t omega[4], void* stream) {
+    if (!d_coeffs || !d_out || !g || !omega) return bad("h2_dev_coset_ntt: null argument");
+    if (log_n > 28) return bad("log_n exceeds the 2-adicity of Fr (S = 28)");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        hipStream_t s = pick_stream(ctx, stream);
+        std::vector<uint32_t> bits;
+        ntt_split(log_n, bits);
+        if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
+        PlanRef pl = plan_locked(ctx, log_n, omega, s, false);
+        const Fr* tab = ntt_scale_table(pl.get(), fr_from_u64x4(g), nullptr, s);
+        ntt_run(ctx, pl.get(), (const Fr*)d_coeffs, (Fr*)d_out, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab, 1u);
+        return (int)H2_OK;
+    });
+}
+
+// Several vectors through one plan, up to 16 per launch: d_tmp = min(count, 16) x 2^log_n Fr, shared by the chunks.
+static int dev_ntt_batch_impl(const void* const* srcs, void* const* dsts, size_t count, void* d_tmp, uint32_t log_n,
+                              const uint64_t omega[4], const uint64_t* g, const uint64_t* divisor, uint32_t scale_mode,
+                              void* stream, const char* what) {
+    if (count == 0) return H2_OK;
+    if (!srcs || !dsts || !omega) return bad(what);
+    if (log_n > 28) return bad("log_n exceeds the 2-adicity of Fr (S = 28)");
+    for (size_t i = 0; i < count; i++)
+        if (!srcs[i] || !dsts[i]) return bad(what);
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        hipStream_t s = pick_stream(ctx, stream);
+        std::vector<uint32_t> bits;
+        ntt_split(log_n, bits);
+        if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
+        PlanRef pl = plan_locked(ctx, log_n, omega, s, false);
+        const Fr* tab = nullptr;
+        Fr d{};
+        Fr post3[3];
+        const Fr* post = nullptr;
+        if (divisor) d = fr_from_u64x4(divisor);
+        if (g) {
+            tab = ntt_scale_table(pl.get(), fr_from_u64x4(g), divisor ? &d : nullptr, s);
+        } else if (divisor) {
+            post3[0] = post3[1] = post3[2] = d;
+            post = post3;
+        }
+        const size_t n = (size_t)1 << log_n;
+        std::vector<const Fr*> in(count);
+        std::vector<Fr*> out(count), tmp(count);
+        for (size_t i = 0; i < count; i++) {
+            in[i] = (const Fr*)srcs[i];
+            out[i] = (Fr*)dsts[i];
+            tmp[i] = d_tmp ? (Fr*)d_tmp + (i % 16) * n : nullptr;
+        }
+        ntt_run_many(ctx, pl.get(), in.data(), out.data(), tmp.data(), count, (uint32_t)n, nullptr, post, s, tab,
+                     tab ? scale_mode : 0u);
+        return (int)H2_OK;
+    });
+}
+
+int h2_dev_ntt_batch(void* const* d_a, size_t count, void* d_tmp, const uint64_t omega[4], uint32_t log_n, void* stream) {
+    return dev_ntt_batch_impl((const void* const*)d_a, d_a, count, d_tmp, log_n, omega, nullptr, nullptr, 0, stream,
+                              "h2_dev_ntt_batch: null argument");
+}
+
+int h2_dev_intt_batch(void* const* d_a, size_t count, void* d_tmp, const uint64_t omega_inv[4], const uint64_t divisor[4],
+                      uint32_t log_n, void* stream) {
+    if (!divisor) return bad("h2_dev_intt_batch: null argument");
+    return dev_ntt_batch_impl((const void* const*)d_a, d_a, count, d_tmp, log_n, omega_inv, nullptr, divisor, 0, stream,
+                              "h2_dev_intt_batch: null argument");
+}
+
+int h2_dev_coset_ntt_batch(const void* const* d_coeffs, void* const* d_out, size_t count, void* d_tmp, uint32_t log_n,
+                           const uint64_t g[4], const uint64_t omega[4], void* stream) {
+    if (!g) return bad("h2_dev_coset_ntt_batch: null argument");
+    return dev_ntt_batch_impl(d_coeffs, d_out, count, d_tmp, log_n, omega, g, nullptr, 1u, stream,
+                              "h2_dev_coset_ntt_batch: null argument");
+}
+
+int h2_dev_coset_intt(void* d_a, void* d_tmp, uint32_t log_n, const uint64_t g_inv[4], const uint64_t omega_inv[4],
+                      const uint64_t divisor[4], void* stream) {
+    if (!d_a || !g_inv || !omega_inv || !divisor) return bad("h2_dev_coset_intt: null argument");
+    if (log_n > 28) return bad("log_n exceeds the 2-adicity of Fr (S = 28)");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        hipStream_t s = pick_stream(ctx, stream);
+        std::vector<uint32_t> bits;
+        ntt_split(log_n, bits);
+        if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
+        PlanRef pl = plan_locked(ctx, log_n, omega_inv, s, false);
+        const Fr d = fr_from_u64x4(divisor);
+        const Fr* tab = ntt_scale_table(pl.get(), fr_from_u64x4(g_inv), &d, s);
+        ntt_run(ctx, pl.get(), (const Fr*)d_a, (Fr*)d_a, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab, 2u);
+        return (int)H2_OK;
+    });
+}
+
 int h2_dev_extended_to_coeff(void* d_a, void* d_tmp, uint32_t extended_k, const uint64_t g_coset[4],
                              const uint64_t g_coset_inv[4], const uint64_t extended_omega_inv[4],
                              const uint64_t extended_ifft_divisor[4], void* stream) {

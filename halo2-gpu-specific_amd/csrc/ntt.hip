@@ -21,6 +21,7 @@
 //   * zero padding  (eval_fft_prepare, evaluation_gpu.rs:890-900; domain.rs:280)
 //   * zeta-power coset pre-scale (distribute_powers_zeta, domain.rs:382-398)
 //   * 1/n and zeta^-1 post-scale (domain.rs:404-409, :341)
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -28,7 +29,7 @@
 
 namespace h2 {
 
-static constexpr int NTT_MAX_B = 9;
+static constexpr int NTT_BATCH_MAX = 16;  // vectors per launch of a batched transform (pointers travel in the kernel arguments)
 static constexpr int LO_BITS = 12;  // two-level twiddle tables: w^e = lo[e & 4095] * hi[e >> 12]
 
 // ---------------------------------------------------------------- table generation
@@ -84,6 +85,18 @@ struct PassArgs {
     uint32_t prevB[4];    // their bit widths
     uint32_t prevT[4];    // their T_q logs
     uint32_t is_last, in_len, log_c;
+    // generic coset scale (coeff -> one coset of the extended domain and back): sc[i] = g^i = sc_lo[i & 4095] * sc_hi[i >> 12]
+    // (sc_hi also carries the iNTT divisor).  scale_mode 1: x[i] *= sc[i] on the first pass's load (the inter-pass twiddle
+    // path, which a first pass never uses, does it); 2: y[i] *= sc[i] on the final store
+    const Fr* sc_lo;
+    const Fr* sc_hi;
+    uint32_t scale_mode;
+    // several transforms of one plan in ONE launch (blockIdx.y picks the vector): a 2^20-point pass is 1024 tiles, one
+    // resident round of the chip in which every workgroup waits out its own load -> stages -> store chain; with the
+    // tiles of 8-16 vectors in the grid the rounds overlap (the columns of a wide witness on one coset)
+    uint32_t batch;
+    const Fr* in_b[NTT_BATCH_MAX];
+    Fr* out_b[NTT_BATCH_MAX];
     uint32_t zskip;  // first pass of a zero-padded transform: rows rho >= R >> zskip are zero (see the load loop)
     uint32_t radix4;  // stage loop: two stages per LDS round trip (four elements per lane), launched with R / 4 * C threads
 };
@@ -150,6 +163,8 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
     uint4* w_hi = w_lo + (R >> 1) + 1;
     const uint32_t nthreads = blockDim.x;  // == max(R/2 * C, 1)
     const uint32_t tid = threadIdx.x;
+    const Fr* const in_p = a.batch ? a.in_b[blockIdx.y] : a.in;   // (wave-uniform: scalar loads from the kernel arguments)
+    Fr* const out_p = a.batch ? a.out_b[blockIdx.y] : a.out;
     const uint32_t n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
 
     for (uint32_t i = tid; i < (R >> 1); i += nthreads) lds_put(w_lo, w_hi, i, fp_load(a.tw_bfly + i));
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
 #pragma unroll
         for (uint32_t q = 0; q < NE; q++) {
             x[q] = fp_zero<FrParams>();
-            if (live[q] && idx[q] < a.in_len) x[q] = fp_load(a.in + idx[q]);
+            if (live[q] && idx[q] < a.in_len) x[q] = fp_load(in_p + idx[q]);
         }
         if (a.has_pre3) {
 #pragma unroll
@@ -211,9 +226,10 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
                 if (m != 0) x[q] = tmul(x[q], w);
             }
         }
-        if (a.nprev != 0) {
+        const bool pre_scale = a.scale_mode == 1u && a.nprev == 0;
+        if (a.nprev != 0 || pre_scale) {
             // omega^(rho * S * K); a unit twiddle (rho = 0 or K = 0) multiplies like any other: the tables hold it
-            if (a.tw_direct != nullptr) {
+            if (a.tw_direct != nullptr && !pre_scale) {
 #pragma unroll
                 for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
                     Fr w[2];
@@ -223,7 +239,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
 #pragma unroll
                     for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], w[q]);
                 }
-            } else if (a.log_n <= LO_BITS) {
+            } else if (a.log_n <= LO_BITS && !pre_scale) {
 #pragma unroll
                 for (uint32_t q = 0; q < NE; q++) {
                     const uint32_t ex = (uint32_t)(((uint64_t)rho[q] * Kk[q]) << a.s_log) & n_mask;
@@ -231,14 +247,18 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
                 }
             } else {
                 // two at a time: 16 twiddle halves in flight next to the elements keeps the kernel within 128 VGPRs
+                // (the coset pre-scale of a first pass, g^idx from its own two-level table, runs through the same code)
+                const Fr* const two_lo = pre_scale ? a.sc_lo : a.tw_lo;
+                const Fr* const two_hi = pre_scale ? a.sc_hi : a.tw_hi;
 #pragma unroll
                 for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
                     Fr wl[2], wh[2];
 #pragma unroll
                     for (uint32_t q = 0; q < 2; q++) {
-                        const uint32_t ex = (uint32_t)(((uint64_t)rho[q0 + q] * Kk[q0 + q]) << a.s_log) & n_mask;
-                        wl[q] = fp_load(a.tw_lo + (ex & ((1u << LO_BITS) - 1)));
-                        wh[q] = fp_load(a.tw_hi + (ex >> LO_BITS));
+                        const uint32_t ex = pre_scale ? (idx[q0 + q] & n_mask)
+                                                      : ((uint32_t)(((uint64_t)rho[q0 + q] * Kk[q0 + q]) << a.s_log) & n_mask);
+                        wl[q] = fp_load(two_lo + (ex & ((1u << LO_BITS) - 1)));
+                        wh[q] = fp_load(two_hi + (ex >> LO_BITS));
                     }
 #pragma unroll
                     for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], fp_mul(wl[q], wh[q]));
@@ -379,7 +399,16 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
                 idx[q] = ((tile_id << log_c) + c) + (k << a.t_log);
             y[q] = lds_get(t_lo, t_hi, (k << log_c) + c);
         }
-        if (a.is_last && a.has_post3 && !a.hi_scaled) {
+        if (a.is_last && a.scale_mode == 2u) {
+            // one at a time: four results are live next to the two table halves and the product
+#pragma unroll
+            for (uint32_t q = 0; q < NE; q++) {
+                const uint32_t i = idx[q] & n_mask;
+                const Fr w = fp_mul(fp_load(a.sc_lo + (i & ((1u << LO_BITS) - 1))), fp_load(a.sc_hi + (i >> LO_BITS)));
+                if constexpr (LAZY) y[q] = fp_reduce_once(fp_mul_wide(y[q], w));
+                else y[q] = fp_mul(y[q], w);
+            }
+        } else if (a.is_last && a.has_post3 && !a.hi_scaled) {
 #pragma unroll
             for (uint32_t q = 0; q < NE; q++) {
                 const uint32_t m = idx[q] % 3;
@@ -397,7 +426,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
         }
 #pragma unroll
         for (uint32_t q = 0; q < NE; q++)
-            if (e0 + q * nthreads < total) fp_store(a.out + idx[q], y[q]);
+            if (e0 + q * nthreads < total) fp_store(out_p + idx[q], y[q]);
     }
 }
 
@@ -467,6 +496,8 @@ static void free_plan(NttPlan* pl) {
     for (const Fr* t : pl->tw_direct)
         if (t) (void)hipFree(const_cast<Fr*>(t));
     for (auto& kv : pl->scaled_hi)
+        if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : pl->scale_tabs)
         if (kv.second) (void)hipFree(kv.second);
     for (auto& kv : pl->last_direct)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -650,8 +681,64 @@ static void set_scale3(PassArgs& a, const Fr* pre3, const Fr* post3) {
     }
 }
 
+static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr* const* dsts, Fr* const* tmps, uint32_t cnt,
+                          uint32_t in_len, const Fr* pre3, const Fr* post3, hipStream_t stream, const Fr* scale_tab,
+                          uint32_t scale_mode);
+
+// The two-level table of g^i (i < 2^log_n) with `d` folded into the high level, cached with the plan: the coset transforms
+// of a proof use quotient_poly_degree generators per direction, again and again.
+const Fr* ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream) {
+    char kb[200];
+    int at = 0;
+    for (int l = 7; l >= 0; l--) at += snprintf(kb + at, sizeof kb - at, "%08x", g.l[l]);
+    kb[at++] = d ? '*' : '.';
+    if (d)
+        for (int l = 7; l >= 0; l--) at += snprintf(kb + at, sizeof kb - at, "%08x", d->l[l]);
+    const std::string key(kb, (size_t)at);
+    std::lock_guard<std::mutex> lk(pl->mu);
+    auto it = pl->scale_tabs.find(key);
+    if (it != pl->scale_tabs.end()) return it->second;
+    const uint32_t n = 1u << pl->log_n;
+    const uint32_t lo_count = n < (1u << LO_BITS) ? n : (1u << LO_BITS);
+    const uint32_t hi_count = pl->log_n > LO_BITS ? (n >> LO_BITS) : 1u;
+    Fr* tab = nullptr;
+    H2_HIP(hipMalloc(&tab, ((size_t)(1u << LO_BITS) + hi_count) * sizeof(Fr)));
+    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, tab, g, 1u, lo_count);
+    Fr* hi = tab + (1u << LO_BITS);
+    hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, g, 1u << LO_BITS, hi_count);
+    if (d) hipLaunchKernelGGL(k_scale_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, hi, *d, hi_count);
+    H2_HIP(hipGetLastError());
+    H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per generator)
+    pl->scale_tabs[key] = tab;
+    {
+        std::lock_guard<std::mutex> g2(g_tab_mu);
+        pl->table_bytes += ((size_t)(1u << LO_BITS) + hi_count) * sizeof(Fr);
+    }
+    return tab;
+}
+
 void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const Fr* pre3,
-             const Fr* post3, hipStream_t stream) {
+             const Fr* post3, hipStream_t stream, const Fr* scale_tab, uint32_t scale_mode) {
+    ntt_run_many(ctx, pl, &src, &dst, &tmp, 1, in_len, pre3, post3, stream, scale_tab, scale_mode);
+}
+
+// `count` transforms of one plan (same size, root, scales): chunks of NTT_BATCH_MAX vectors per launch.  tmps[i]: the
+// scratch of vector i (distinct per vector of a chunk; needed when the plan has >= 2 passes).
+void ntt_run_many(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr* const* dsts, Fr* const* tmps, size_t count,
+                  uint32_t in_len, const Fr* pre3, const Fr* post3, hipStream_t stream, const Fr* scale_tab,
+                  uint32_t scale_mode) {
+    for (size_t c0 = 0; c0 < count; c0 += NTT_BATCH_MAX) {
+        const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - c0);
+        ntt_run_chunk(ctx, pl, srcs + c0, dsts + c0, tmps + c0, cnt, in_len, pre3, post3, stream, scale_tab, scale_mode);
+    }
+}
+
+static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr* const* dsts, Fr* const* tmps, uint32_t cnt,
+                          uint32_t in_len, const Fr* pre3, const Fr* post3, hipStream_t stream, const Fr* scale_tab,
+                          uint32_t scale_mode) {
+    const Fr* const src = srcs[0];
+    Fr* const dst = dsts[0];
+    Fr* const tmp = tmps[0];
     const uint32_t L = pl->log_n;
     if (L == 0) {
         // n = 1: X[0] = x[0] (times post3[0])
@@ -659,7 +746,12 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         a.in = src; a.out = dst; a.tw_bfly = pl->tables; a.tw_lo = pl->tw_lo; a.tw_hi = pl->tw_hi;
         set_scale3(a, pre3, post3); a.log_n = 0; a.B = 0; a.s_log = 0; a.t_log = 0; a.nprev = 0;
         a.is_last = 1; a.in_len = in_len; a.log_c = 0;
-        hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(1), dim3(64), 4 * sizeof(Fr), stream, a);
+        a.sc_lo = scale_tab; a.sc_hi = scale_tab ? scale_tab + (1u << LO_BITS) : nullptr; a.scale_mode = scale_tab ? scale_mode : 0u;
+        if (cnt > 1) {
+            a.batch = cnt;
+            for (uint32_t i = 0; i < cnt; i++) { a.in_b[i] = srcs[i]; a.out_b[i] = dsts[i]; }
+        }
+        hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(1, cnt), dim3(64), 4 * sizeof(Fr), stream, a);
         H2_HIP(hipGetLastError());
         return;
     }
@@ -675,6 +767,14 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         const bool last = (p + 1 == P);
         a.in = (p == 0) ? src : work;
         a.out = last ? dst : work;
+        if (cnt > 1) {
+            a.batch = cnt;
+            for (uint32_t i = 0; i < cnt; i++) {
+                Fr* const work_i = (P >= 2) ? tmps[i] : nullptr;
+                a.in_b[i] = (p == 0) ? srcs[i] : work_i;
+                a.out_b[i] = last ? dsts[i] : work_i;
+            }
+        }
         a.tw_bfly = pl->tw_bfly[p];
         a.tw_lo = pl->tw_lo;
         a.tw_hi = pl->tw_hi;
@@ -693,6 +793,9 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
         }
         a.is_last = last ? 1 : 0;
         a.in_len = (p == 0) ? in_len : (1u << L);
+        a.sc_lo = scale_tab;
+        a.sc_hi = scale_tab ? scale_tab + (1u << LO_BITS) : nullptr;
+        a.scale_mode = (scale_tab && ((scale_mode == 1u && p == 0) || (scale_mode == 2u && last))) ? scale_mode : 0u;
         if (p == 0 && !last && in_len && in_len < (1u << L) && (in_len & (in_len - 1)) == 0 && getenv("H2_NTT_NO_ZSKIP") == nullptr) {
             uint32_t z = 0;
             while ((in_len << z) < (1u << L)) z++;  // padded by 2^z
@@ -832,13 +935,13 @@ void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint3
             // H2_NTT_LAZY=0 keeps canonical residues everywhere -- same output either way
             static const bool lazy = !(getenv("H2_NTT_LAZY") && atoi(getenv("H2_NTT_LAZY")) == 0);
             if (a.radix4 && lazy)
-                hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(ntiles), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else if (a.radix4)
-                hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(ntiles), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else if (lazy)
-                hipLaunchKernelGGL((k_ntt_pass<false, true>), dim3(ntiles), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL((k_ntt_pass<false, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else
-                hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(ntiles), dim3(threads), lds, stream, a);
+                hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
         }
         // (`pinned` unpins here: launched -- an eviction from here on synchronises the device before it frees)
         consumed += B;

@@ -19,6 +19,7 @@ struct NttPlan {
     size_t table_bytes = 0;            // of `tables` and the per-pass direct tables
     std::mutex mu;                     // guards scaled_hi, last_direct
     std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)
+    std::map<std::string, Fr*> scale_tabs; // (generator, divisor) -> two-level table of g^i (coset transforms): 4096 + n/4096 entries
     // the last pass's complete inter-pass twiddle set, w^(rho * K) at [(K << B_last) | rho] (2^log_n entries, streamed in
     // the order the pass loads its elements), keyed by the divisor folded into it ("" = none).  These are the large
     // optional tables (32 B x n each): they count against the per-device budget (ntt_table_budget) and the least
@@ -76,8 +77,15 @@ void ntt_set_table_budget(size_t bytes);
 // src (in_len valid elements, zero-extended to 2^log_n) -> dst; tmp = 2^log_n scratch (needed when
 // the plan has >= 2 passes).  pre3 / post3: nullable HOST pointers to 3 Fr each (passed by value
 // in the kernel arguments): x[i] *= pre3[i % 3] (i % 3 != 0) on load, y[i] *= post3[i % 3] on store.
+// scale_tab (ntt_scale_table) with scale_mode 1: x[i] *= g^i on the first pass's load; 2: y[i] *= g^i (* divisor) on the
+// final store -- the transforms between coefficients and ONE coset g H of a larger domain, without a separate scaling pass.
 void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const Fr* pre3,
-             const Fr* post3, hipStream_t stream);
+             const Fr* post3, hipStream_t stream, const Fr* scale_tab = nullptr, uint32_t scale_mode = 0);
+const Fr* ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream);
+// `count` transforms of one plan with the same scales, several vectors per launch; tmps[i] = scratch of vector i
+void ntt_run_many(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr* const* dsts, Fr* const* tmps, size_t count,
+                  uint32_t in_len, const Fr* pre3, const Fr* post3, hipStream_t stream, const Fr* scale_tab = nullptr,
+                  uint32_t scale_mode = 0);
 Fr fr_from_u64x4(const uint64_t v[4]);
 
 }  // namespace h2

@@ -371,21 +371,53 @@ class Device:
 
     def coeff_to_coset(self, poly, dom, j):
         """values of a coefficient vector (n entries) on coset j: a[t] *= g_j^t, then the n-point NTT -- coeff_to_extended
-        (poly/domain.rs:270-287) restricted to the extended indices c i + j"""
-        out = self.clone(poly[:dom.n])
+        (poly/domain.rs:270-287) restricted to the extended indices c i + j.  One fused transform (h2_dev_coset_ntt: the
+        powers of g_j are applied on the first pass's load): `poly` is read, not copied"""
+        out = self.empty(dom.n)
         g = dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD
-        check(self.L.h2_dev_distribute_powers(out.data_ptr(), dom.n, _fr(g), self.stream), "h2_dev_distribute_powers")
         tmp = self.empty(dom.n)
-        check(self.L.h2_dev_ntt(out.data_ptr(), tmp.data_ptr(), _fr(dom.omega), dom.k, self.stream), "h2_dev_ntt")
+        check(self.L.h2_dev_coset_ntt(poly.data_ptr(), out.data_ptr(), tmp.data_ptr(), dom.k, _fr(g), _fr(dom.omega),
+                                      self.stream), "h2_dev_coset_ntt")
         return out
 
+    def coeffs_to_coset(self, polys, dom, j):
+        """coeff_to_coset of several coefficient vectors: up to 16 transforms per launch (h2_dev_coset_ntt_batch) -- the
+        tiles of one 2^20-point pass do not fill the chip for long enough to hide their own latencies, those of a
+        dozen vectors do"""
+        count = len(polys)
+        if count == 0:
+            return []
+        if count == 1:
+            return [self.coeff_to_coset(polys[0], dom, j)]
+        outs = [self.empty(dom.n) for _ in polys]
+        tmp = self.empty(min(count, 16) * dom.n)
+        g = dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD
+        src = (_vp * count)(*[p.data_ptr() for p in polys])
+        dst = (_vp * count)(*[o.data_ptr() for o in outs])
+        check(self.L.h2_dev_coset_ntt_batch(src, dst, count, tmp.data_ptr(), dom.k, _fr(g), _fr(dom.omega), self.stream),
+              "h2_dev_coset_ntt_batch")
+        return outs
+
+    def intt_many(self, ts, dom):
+        """lagrange_to_coeff in place on several vectors, up to 16 per launch (h2_dev_intt_batch)"""
+        count = len(ts)
+        if count == 0:
+            return ts
+        if count == 1 or not hasattr(self.L, "h2_dev_intt_batch"):
+            return [self.intt(t, dom) for t in ts]
+        tmp = self.empty(min(count, 16) * dom.n)
+        ptrs = (_vp * count)(*[t.data_ptr() for t in ts])
+        check(self.L.h2_dev_intt_batch(ptrs, count, tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                       self.stream), "h2_dev_intt_batch")
+        return ts
+
     def coset_to_coeff(self, vals, dom, j):
-        """in place: the polynomial of degree < n that takes the values `vals` on coset j"""
+        """in place: the polynomial of degree < n that takes the values `vals` on coset j (the inverse transform with
+        1 / n and the powers of 1 / g_j fused into its last pass)"""
         tmp = self.empty(dom.n)
-        check(self.L.h2_dev_intt(vals.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
-                                 self.stream), "h2_dev_intt")
         g_inv = _inv(dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD)
-        check(self.L.h2_dev_distribute_powers(vals.data_ptr(), dom.n, _fr(g_inv), self.stream), "h2_dev_distribute_powers")
+        check(self.L.h2_dev_coset_intt(vals.data_ptr(), tmp.data_ptr(), dom.k, _fr(g_inv), _fr(dom.omega_inv),
+                                       _fr(dom.ifft_divisor), self.stream), "h2_dev_coset_intt")
         return vals
 
     # -- transforms -------------------------------------------------------------------------------------
@@ -932,12 +964,11 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         return D.eval_op(4, one, one, tmp)                                     # H2_OP_SUB
 
     def coset_tables(j):
-        l_last_j = D.coeff_to_coset(l_last_poly, dom, j)
+        nf, ns = len(pk.fixed_polys), len(pk.sigma_polys)
+        vals = D.coeffs_to_coset(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly, l_blind_poly], dom, j)
         return {
-            "fixed": [D.coeff_to_coset(t, dom, j) for t in pk.fixed_polys],
-            "sigma": [D.coeff_to_coset(t, dom, j) for t in pk.sigma_polys],
-            "l0": D.coeff_to_coset(l0_poly, dom, j), "l_last": l_last_j,
-            "l_active_row": active_row(l_last_j, D.coeff_to_coset(l_blind_poly, dom, j), n),
+            "fixed": vals[:nf], "sigma": vals[nf:nf + ns], "l0": vals[nf + ns], "l_last": vals[nf + ns + 1],
+            "l_active_row": active_row(vals[nf + ns + 1], vals[nf + ns + 2], n),
         }
 
     # kept with the key (three n-vectors behind the closure): a proof of SEVERAL circuit instances may not fit the
@@ -1272,7 +1303,16 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # columns are blinded, measured and committed in groups while later uploads are still in flight; small witnesses
     # (<= 256 MiB: already on the device by the time the random polynomial is committed) go as one group -- one
     # synchronisation and one pipelined / fused batch instead of several
+    # A WIDE witness (dozens of narrow columns) wants large groups: the columns of a group that share a bound are committed
+    # as one fused MSM -- one sort, finish and reduce for all of them, and those latency-bound tails cost a narrow column
+    # more than its accumulation -- so a group takes as many columns as cross PCIe in ~5 ms (256 MiB: 8 columns of 32-byte
+    # cells at 2^20 rows, 32 compact ones), while the later groups are still in flight.
     group = len(uploads) if len(uploads) * n * 32 <= (256 << 20) else max(1, min(4, len(uploads) // 3))
+    if len(uploads) >= 12:
+        cell = max((8 if (not D.torch.is_tensor(c) and c.ndim == 1) else 32) for c in advice)
+        group = max(group, min(len(uploads), (256 << 20) // (cell * n)))
+    if os.environ.get("H2_ADVICE_GROUP"):
+        group = int(os.environ["H2_ADVICE_GROUP"])
     group = max(group, 1)
     advice_dev = []
     for g0 in range(0, len(uploads), group):
@@ -1469,13 +1509,14 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         transcript.write_point(P)
     for z in all_z:
         D.gather_rows(z, n)                       # (one proof over several ranks: every rank computed its own rows)
+    D.intt_many([z for C in circuits for z in C["z"]] + [z for C in circuits for st in C["lookups"] for z in st["z"]] +
+                [st["m"] for C in circuits for st in C["lookups"]] + [z for C in circuits for z in C["shuffle_z"]], dom)
     for C in circuits:
-        C["z_polys"] = [D.intt(z, dom) for z in C["z"]]
+        C["z_polys"] = C["z"]                                       # (transformed in place, sixteen to a launch)
         for st in C["lookups"]:
-            st["z_polys"] = [D.intt(z, dom) for z in st["z"]]
-            st["m_poly"] = D.intt(st["m"], dom)
+            st["z_polys"], st["m_poly"] = st["z"], st["m"]
             del st["table"], st["inputs"]
-        C["shuffle_polys"] = [D.intt(z, dom) for z in C["shuffle_z"]]
+        C["shuffle_polys"] = C["shuffle_z"]
         del C["shuffles"]
     mark("permutation")
     transcript.write_point(random_commitment.result())
@@ -1492,7 +1533,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         del advice_dev
     else:
         for C in circuits:
-            C["advice_polys"] = [D.intt(t, dom) for t in C["advice"]]    # in place: the Lagrange values are not needed again
+            C["advice_polys"] = D.intt_many(C["advice"], dom)           # in place: the Lagrange values are not needed again
     g = pk.graph
     plan = D.coset_plan(dom)
     if D.group_size <= 1:                      # on one device the proving key decides which tables exist
@@ -1515,15 +1556,21 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         return total
 
     def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size):
-        """the fused evaluator over one evaluation domain: `points_of` maps a coefficient vector to its values there"""
+        """the fused evaluator over one evaluation domain: `points_of` maps a list of coefficient vectors to their values there"""
         lookups = C["lookups"]
         pre = C.get("advice_extended") if size == en else None    # already extended on the side stream (small proofs)
-        advice_cosets = pre if pre is not None else [points_of(t) for t in C["advice_polys"]]
-        instance_cosets = [points_of(t) for t in C["instance_polys"]]
-        z_cosets = [points_of(t) for t in C["z_polys"]]
-        lookup_z_cosets = [points_of(t) for st in lookups for t in st["z_polys"]]
-        lookup_m_cosets = [points_of(st["m_poly"]) for st in lookups]
-        shuffle_cosets = [points_of(t) for t in C["shuffle_polys"]]
+        # every coefficient vector of this circuit instance that the evaluator reads, taken to the evaluation domain as ONE
+        # list (the coset route transforms them sixteen to a launch)
+        groups = [[] if pre is not None else list(C["advice_polys"]), list(C["instance_polys"]), list(C["z_polys"]),
+                  [t for st in lookups for t in st["z_polys"]], [st["m_poly"] for st in lookups], list(C["shuffle_polys"])]
+        flat = points_of([t for grp in groups for t in grp])
+        cut, at = [], 0
+        for grp in groups:
+            cut.append(flat[at:at + len(grp)])
+            at += len(grp)
+        advice_cosets = pre if pre is not None else cut[0]
+        instance_cosets, z_cosets, lookup_z_cosets, lookup_m_cosets, shuffle_cosets = cut[1:]
+        del flat, cut
         mark("cosets")
         b = ev.Builder().build(
             k=dom.k, extended_k=k_domain, blinding_factors=bf, chunk_len=chunk,
@@ -1548,7 +1595,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         # ---- one device: the whole extended domain at once ------------------------------------------------------
         tables = {"fixed": pk.fixed_cosets, "sigma": pk.sigma_cosets, "l0": pk.l0, "l_last": pk.l_last,
                   "l_active_row": pk.l_active_row}
-        h = evaluate_quotient(lambda t: D.coeff_to_extended(t, dom), tables, ek, ZETA, dom.extended_omega, en)
+        h = evaluate_quotient(lambda ts: [D.coeff_to_extended(t, dom) for t in ts], tables, ek, ZETA, dom.extended_omega, en)
         # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
         check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
                                                 D.stream), "h2_dev_divide_by_vanishing_poly")
@@ -1566,7 +1613,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         mine = {}
         for j in owned:
             g_j = ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD
-            h_j = evaluate_quotient(lambda t, j=j: D.coeff_to_coset(t, dom, j), coset_tabs[j], dom.k, g_j, dom.omega, n)
+            h_j = evaluate_quotient(lambda ts, j=j: D.coeffs_to_coset(ts, dom, j), coset_tabs[j], dom.k, g_j, dom.omega, n)
             D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
             mine[j] = D.coset_to_coeff(h_j, dom, j)
         # Everything after the quotient -- the un-mixing, the h pieces' commitments, the evaluations, the multiopen argument --

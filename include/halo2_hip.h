@@ -334,6 +334,30 @@ int h2_stream_synchronize(void *stream);
 int h2_dev_upload(void *d_dst, const void *src, size_t bytes, void *stream);
 int h2_dev_download(void *dst, const void *d_src, size_t bytes, void *stream);
 
+/* One coset of a larger domain, without a separate scaling pass (the unit of the coset-by-coset quotient: multi-GPU proofs,
+ * memory-budgeted proofs, and circuits whose extended domain is more than (degree - 1) n points wide):
+ *   h2_dev_coset_ntt   out[i] = sum_t coeffs[t] g^t omega^(i t)  -- coeff_to_extended (poly/domain.rs:270-287) restricted to
+ *                      the points g omega^i; g^t is applied on the first pass's load from a cached two-level table.
+ *                      d_coeffs is left untouched unless d_out == d_coeffs.
+ *   h2_dev_coset_intt  in place: the coefficients of the polynomial of degree < n with the values d_a on g H;
+ *                      a[t] *= divisor * g_inv^t fused into the last pass's store (divisor = 1/n).
+ * Same values as h2_dev_distribute_powers + h2_dev_ntt / h2_dev_intt + h2_dev_distribute_powers. */
+int h2_dev_coset_ntt(const void *d_coeffs, void *d_out, void *d_tmp, uint32_t log_n, const uint64_t g[4],
+                     const uint64_t omega[4], void *stream);
+int h2_dev_coset_intt(void *d_a, void *d_tmp, uint32_t log_n, const uint64_t g_inv[4], const uint64_t omega_inv[4],
+                      const uint64_t divisor[4], void *stream);
+
+/* Several vectors through one transform plan, up to 16 per launch (the columns of a wide witness: plonk/prover.rs:643-646
+ * runs them as a par_iter).  A 2^20-point pass alone is one resident round of the chip, every workgroup waiting out its own
+ * load -> stages -> store chain; with the tiles of many vectors in one grid the rounds overlap.  d_a / d_coeffs / d_out:
+ * HOST arrays of `count` device pointers; d_tmp: min(count, 16) x 2^log_n Fr of scratch (NULL allowed for log_n <= 8).
+ * Same values as `count` calls of h2_dev_ntt / h2_dev_intt / h2_dev_coset_ntt. */
+int h2_dev_ntt_batch(void *const *d_a, size_t count, void *d_tmp, const uint64_t omega[4], uint32_t log_n, void *stream);
+int h2_dev_intt_batch(void *const *d_a, size_t count, void *d_tmp, const uint64_t omega_inv[4], const uint64_t divisor[4],
+                      uint32_t log_n, void *stream);
+int h2_dev_coset_ntt_batch(const void *const *d_coeffs, void *const *d_out, size_t count, void *d_tmp, uint32_t log_n,
+                           const uint64_t g[4], const uint64_t omega[4], void *stream);
+
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for
  * log_n <= 8).  Results land in d_a (in place from the caller's view).

@@ -89,6 +89,29 @@ class OracleLib:
         self.O.oracle_distribute_powers_zeta(a, 1 << ek, _a(g), _a(g_inv), 0, self.threads)
         return 0
 
+    def h2_dev_coset_ntt(self, a, out, tmp, k, g, omega, stream):
+        """coeff_to_extended (poly/domain.rs:270-287) restricted to one coset: a[t] g^t, then the n-point transform"""
+        if out != a:
+            ctypes.memmove(out, a, 32 << k)
+        self.O.oracle_distribute_powers(out, 1 << k, _a(g))
+        self.O.oracle_best_fft(out, _a(omega), k, self.fft_threads)
+        return 0
+
+    def h2_dev_coset_intt(self, a, tmp, k, g_inv, omega_inv, divisor, stream):
+        self.O.oracle_ifft(a, _a(omega_inv), k, _a(divisor), self.fft_threads)
+        self.O.oracle_distribute_powers(a, 1 << k, _a(g_inv))
+        return 0
+
+    def h2_dev_coset_ntt_batch(self, srcs, dsts, count, tmp, k, g, omega, stream):
+        for i in range(count):
+            self.h2_dev_coset_ntt(srcs[i], dsts[i], tmp, k, g, omega, stream)
+        return 0
+
+    def h2_dev_intt_batch(self, ptrs, count, tmp, omega_inv, divisor, k, stream):
+        for i in range(count):
+            self.h2_dev_intt(ptrs[i], tmp, omega_inv, divisor, k, stream)
+        return 0
+
     def h2_dev_distribute_powers(self, a, n, g, stream):
         self.O.oracle_distribute_powers(a, n, _a(g))
         return 0
@@ -267,7 +290,7 @@ class OracleDevice(P.Device):
     def pinned_columns(self, count, n):
         return [np.zeros((n, 4), dtype=np.uint64) for _ in range(count)]
 
-    def residency(self, cs, dom):
+    def residency(self, cs, dom, instances=1):
         if self.eval_cache is not None:
             return "cosets", max(0, min(dom.quotient_poly_degree, self.eval_cache))
         return "extended", None

@@ -662,3 +662,92 @@ def test_msm_randomised_shapes():
                          text=True, timeout=280, env=dict(os.environ, H2_MSM_FINISH_LANE_LOG="0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "all equal to the oracle" in out.stdout
+
+
+@pytest.mark.parametrize("k,j", [(0, 3), (1, 3), (3, 5), (5, 6), (8, 3), (9, 5), (11, 5), (12, 6), (13, 3), (16, 5), (18, 6), (20, 5)])
+def test_fused_coset_transforms_vs_oracle(oracle, k, j):
+    """h2_dev_coset_ntt / h2_dev_coset_intt (the powers of the coset generator fused into the first pass's load / the last
+    pass's store): the values of a coefficient vector on EVERY coset g_c H of the extended domain (g_c = zeta
+    extended_omega^c) are the entries c, c + 2^(extended_k - k), ... of the oracle's coeff_to_extended
+    (poly/domain.rs:270-287); the inverse returns the coefficients; out-of-place reads leave the source untouched and the
+    in-place form gives the same values"""
+    import torch
+
+    from h2util import R_MOD, from_mont
+    from halo2_gpu_specific_amd._lib import check
+
+    L = h2.lib()
+    d, _ = oracle.domain(j, k)
+    n, en = 1 << d.k, 1 << d.extended_k
+    c = en // n
+    coeffs = oracle.random_fr(4100 + k, n)
+    ext = oracle.coeff_to_extended(coeffs, d)
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(coeffs.view(np.int64)).to(dev)
+    keep = src.clone()
+    tmp = torch.empty_like(src)
+    zeta, w_ext = from_mont(d.fr("g_coset"))[0], from_mont(d.fr("extended_omega"))[0]
+    omega, omega_inv, n_inv = d.fr("omega"), d.fr("omega_inv"), d.fr("ifft_divisor")
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for cs in sorted({0, 1, c - 1, c // 2}):
+        g = zeta * pow(w_ext, cs, R_MOD) % R_MOD
+        out = torch.empty_like(src)
+        torch.cuda.synchronize()
+        check(L.h2_dev_coset_ntt(src.data_ptr(), out.data_ptr(), tmp.data_ptr(), k, vp(fr_mont(g)), vp(omega), None), "h2_dev_coset_ntt")
+        torch.cuda.synchronize()
+        assert torch.equal(src, keep)
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, ext[cs::c]), (k, j, cs)
+        inplace = src.clone()
+        torch.cuda.synchronize()            # (the library's default stream is not torch's)
+        check(L.h2_dev_coset_ntt(inplace.data_ptr(), inplace.data_ptr(), tmp.data_ptr(), k, vp(fr_mont(g)), vp(omega), None), "h2_dev_coset_ntt")
+        torch.cuda.synchronize()
+        assert torch.equal(inplace, out)
+        check(L.h2_dev_coset_intt(out.data_ptr(), tmp.data_ptr(), k, vp(fr_mont(pow(g, -1, R_MOD))), vp(omega_inv), vp(n_inv), None),
+              "h2_dev_coset_intt")
+        torch.cuda.synchronize()
+        assert torch.equal(out, keep), (k, j, cs)
+
+
+@pytest.mark.parametrize("k", [0, 4, 9, 13, 18, 20])
+def test_batched_transforms_equal_single_ones(oracle, k):
+    """h2_dev_ntt_batch / h2_dev_intt_batch / h2_dev_coset_ntt_batch (up to 16 vectors per launch, 19 here: two chunks, a
+    ragged one) against the oracle's transforms vector by vector"""
+    import torch
+
+    from h2util import R_MOD, from_mont
+    from halo2_gpu_specific_amd._lib import check
+
+    L = h2.lib()
+    count, n = 19, 1 << k
+    d, _ = oracle.domain(3, k)
+    dev = torch.device("cuda", 0)
+    cols = [oracle.random_fr(5200 + 31 * k + i, n) for i in range(count)]
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    omega, omega_inv, n_inv = d.fr("omega"), d.fr("omega_inv"), d.fr("ifft_divisor")
+    ts = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    tmp = torch.empty((16 * n, 4), dtype=torch.int64, device=dev)
+    ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])
+    torch.cuda.synchronize()
+    check(L.h2_dev_ntt_batch(ptrs, count, tmp.data_ptr(), vp(omega), k, None), "h2_dev_ntt_batch")
+    torch.cuda.synchronize()
+    fwd = [oracle.best_fft(c, omega, k, threads=8) for c in cols]
+    for t, want in zip(ts, fwd):
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), want)
+    check(L.h2_dev_intt_batch(ptrs, count, tmp.data_ptr(), vp(omega_inv), vp(n_inv), k, None), "h2_dev_intt_batch")
+    torch.cuda.synchronize()
+    for t, c in zip(ts, cols):
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), c)
+    # one coset of the extended domain, out of place
+    ext_c = 1 << (d.extended_k - d.k)
+    zeta, w_ext = from_mont(d.fr("g_coset"))[0], from_mont(d.fr("extended_omega"))[0]
+    cs = ext_c - 1
+    g = zeta * pow(w_ext, cs, R_MOD) % R_MOD
+    outs = [torch.empty_like(t) for t in ts]
+    optrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in outs])
+    torch.cuda.synchronize()
+    check(L.h2_dev_coset_ntt_batch(ptrs, optrs, count, tmp.data_ptr(), k, vp(fr_mont(g)), vp(omega), None), "h2_dev_coset_ntt_batch")
+    torch.cuda.synchronize()
+    for i in (0, 7, 15, 16, 18):
+        assert np.array_equal(outs[i].cpu().numpy().view(np.uint64), oracle.coeff_to_extended(cols[i], d)[cs::ext_c]), i
+        assert np.array_equal(ts[i].cpu().numpy().view(np.uint64), cols[i])
