@@ -513,8 +513,36 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pelapsed = float(t[0].item())
         peak_gib = torch.cuda.max_memory_allocated(dev) / 2**30
+        host_api = None
+        if dist is None and pk_k <= 22 and not os.environ.get("H2_BENCH_NO_HOST_API"):
+            # the LITERAL drop-in's data flow, measured: every polynomial a host vector, every vector operation one
+            # host-slice entry point (the calls integration/hip.rs binds; halo2-gpu-specific_amd/host_api.py), the SRS
+            # registered once -- a PCIe round trip per call.  Same SRS / witness / randomness: the same proof bytes.
+            from halo2_gpu_specific_amd import host_api as ha
+
+            H = ha.HostApiDevice(local_rank)
+            hparams = ha.params_like(H, params)
+            hpk = prover.keygen(H, hparams, circuits.mini_plonk(), fixed, copies)
+            hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))      # warm-up (device copies, tables)
+            H.L.calls.clear()
+            h0 = time.perf_counter()
+            hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))
+            hsec = time.perf_counter() - h0
+            hphases = {}
+            prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1), timings=hphases)
+            host_api = {
+                "seconds": hsec, "proof_bytes_equal": bool(hproof == proof), "ratio_to_resident": hsec / (pelapsed / steps),
+                "phases_ms": {n: round(v * 1e3, 2) for n, v in hphases.items()},
+                "calls": dict(sorted(H.L.calls.items())),
+                "what": "host vectors + one host-slice C-ABI call per vector operation (h2_ntt, h2_intt, h2_msm over the registered "
+                        "SRS, h2_evaluate_h_coeff, h2_extended_to_coeff, h2_lincomb, ...): what `--features hip` as patched executes; "
+                        "the passes the reference leaves to rayon run through host-slice entry points too (no CPU arithmetic here)",
+            }
+            assert hproof == proof, "the host-slice data flow changed the proof"
+            del hpk, hparams, H
         return {
             "k": pk_k,
+            "host_slice_api": host_api,
             "seconds": pelapsed / steps,
             # the reference times witness synthesis INSIDE create_proof (plonk/prover.rs:1525-1781); here it is a host
             # (numpy) pass outside `seconds`, reported next to it; keygen likewise

@@ -192,3 +192,136 @@ def shuffle_api_group_synthesize(k, input0=(1, 2, 4, 1), input1=(4, 1, 1, 2)):
     for f in fixed:
         f[:m, 0] = 1
     return adv, fixed, np.zeros((0, 4), dtype=np.int64)
+
+
+def lookup_api_set():
+    """`configure` of examples/lookup_api_set.rs:52-103: six advice columns, fixed s_0, s_1 and a table column; the gate
+    s_0 * (input_0 * 1 - input_1); six traced `lookup`s into the one table column (input_0, 2 input_1, input_2, 10 input_3,
+    input_4, input_5).  The chunking pass packs them as the example's comments say: set 0 = {input_0} (it shares its
+    polynomial with the table term), then {2 input_1, input_2}, {10 input_3, input_4}, {input_5} (degree 4)."""
+    cs = ConstraintSystem("lookup-api-set")
+    ins = [cs.advice_column() for _ in range(6)]
+    s0, s1 = cs.fixed_column(), cs.fixed_column()
+    table = cs.fixed_column()
+    del s1                                                           # allocated, never queried (as in the example)
+    cs.create_gate("", [cs.query_fixed(s0) * (cs.query_advice(ins[0]) * 1 - cs.query_advice(ins[1]))])
+    for i, scale in enumerate((None, 2, None, 10, None, None)):
+        q = cs.query_advice(ins[i])
+        cs.lookup("table%d" % i, [(q * scale if scale else q, cs.query_fixed(table))])
+    cs.chunk_lookups()
+    return cs
+
+
+def lookup_api_set_synthesize(k):
+    """`synthesize` of examples/lookup_api_set.rs:121-170: every input column holds 1 on row 0 and 3 on row 1, s_0 = 1 on
+    row 0, s_1 = 1 on row 1, the table column 0 .. 99"""
+    n = 1 << k
+    adv = [np.zeros((n, 4), dtype=np.uint64) for _ in range(6)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    for a in adv:
+        a[0, 0], a[1, 0] = 1, 3
+    fixed[0][0, 0], fixed[1][1, 0] = 1, 1
+    fixed[2][:100, 0] = np.arange(100, dtype=np.uint64)
+    return adv, fixed, np.zeros((0, 4), dtype=np.int64)
+
+
+def shuffle_api():
+    """`configure` of examples/shuffle_api.rs:47-84: advice input_0, input_1, shuffle_0, shuffle_1; fixed s_input,
+    s_shuffle; the gate s_input * (10 input_0 - input_1) and ONE traced `shuffle` of two pairs
+    (s_input input_j, s_shuffle shuffle_j) -- degree 2 + 2 = 4"""
+    cs = ConstraintSystem("shuffle-api")
+    in0, in1, sh0, sh1 = (cs.advice_column() for _ in range(4))
+    s_in, s_sh = cs.fixed_column(), cs.fixed_column()
+    cs.create_gate("", [cs.query_fixed(s_in) * (cs.query_advice(in0) * 10 - cs.query_advice(in1))])
+    q_in0, q_sh0, q_in1, q_sh1 = cs.query_advice(in0), cs.query_advice(sh0), cs.query_advice(in1), cs.query_advice(sh1)
+    f_in, f_sh = cs.query_fixed(s_in), cs.query_fixed(s_sh)
+    cs.shuffle("shuffle", [(f_in * q_in0, f_sh * q_sh0), (f_in * q_in1, f_sh * q_sh1)])
+    cs.chunk_shuffles()
+    return cs
+
+
+def shuffle_api_synthesize(k, input0=(1, 2, 4, 1), shuffle0=(4, 1, 1, 2)):
+    """`synthesize` of examples/shuffle_api.rs:129-166: input_1 = 10 input_0 and shuffle_1 = 10 shuffle_0 row by row, the
+    selectors 1 on those rows"""
+    n = 1 << k
+    adv = [np.zeros((n, 4), dtype=np.uint64) for _ in range(4)]
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
+    m = len(input0)
+    adv[0][:m, 0] = np.array(input0, dtype=np.uint64)
+    adv[1][:m, 0] = 10 * np.array(input0, dtype=np.uint64)
+    adv[2][:m, 0] = np.array(shuffle0, dtype=np.uint64)
+    adv[3][:m, 0] = 10 * np.array(shuffle0, dtype=np.uint64)
+    fixed[0][:m, 0] = 1
+    fixed[1][:m, 0] = 1
+    return adv, fixed, np.zeros((0, 4), dtype=np.int64)
+
+
+def shuffle_gates(width=4, theta=111, beta=222):
+    """`MyConfig::configure` of examples/shuffle.rs:50-107: a shuffle argument written out as GATES -- fixed q_shuffle,
+    q_first, q_last; advice original[W], shuffled[W] and a running product z with z(first) = z(last) = 1 and
+    z(X) (compress(original) + beta) = z(wX) (compress(shuffled) + beta), theta and beta being CONSTANTS of the circuit"""
+    from .circuit import Constant
+
+    cs = ConstraintSystem("shuffle-gates-%d-%d-%d" % (width, theta, beta))
+    q_shuffle, q_first, q_last = cs.fixed_column(), cs.fixed_column(), cs.fixed_column()
+    original = [cs.advice_column() for _ in range(width)]
+    shuffled = [cs.advice_column() for _ in range(width)]
+    z = cs.advice_column()
+    th, be = Constant(theta), Constant(beta)
+    cs.create_gate("z should start with 1", [cs.query_fixed(q_first) * (Constant(1) - cs.query_advice(z))])
+    cs.create_gate("z should end with 1", [cs.query_fixed(q_last) * (Constant(1) - cs.query_advice(z))])
+    qs = cs.query_fixed(q_shuffle)
+    orig = [cs.query_advice(c) for c in original]
+    shuf = [cs.query_advice(c) for c in shuffled]
+    z_cur, z_next = cs.query_advice(z), cs.query_advice(z, 1)
+
+    def compress(cells):
+        acc = cells[0]
+        for cell in cells[1:]:
+            acc = acc * th + cell
+        return acc
+
+    cs.create_gate("z should have valid transition", [qs * (z_cur * (compress(orig) + be) - z_next * (compress(shuf) + be))])
+    return cs
+
+
+def shuffle_gates_witness(k, width=4, height=32, theta=111, beta=222, seed=0x5348554646):
+    """the witness of examples/shuffle.rs:150-238 as canonical integers: `width` columns of `height` random field
+    elements (a seeded generator instead of OsRng), the same rows in another order (its Fisher-Yates walk), and the
+    running product z[0] = 1, z[i + 1] = z[i] (compress(original_i) + beta) / (compress(shuffled_i) + beta).
+    Returns (advice[2 W + 1], fixed[3]) as lists of n integers."""
+    import random
+
+    from .circuit import R_MOD
+
+    n = 1 << k
+    assert height + 1 <= n - 6
+    rnd = random.Random(seed)
+    original = [[rnd.randrange(R_MOD) for _ in range(height)] for _ in range(width)]
+    order = list(range(height))
+    for row in range(height - 1, 0, -1):
+        other = rnd.getrandbits(32) % row
+        order[row], order[other] = order[other], order[row]
+    shuffled = [[col[i] for i in order] for col in original]
+
+    def compress(cols, i):
+        acc = 0
+        for col in cols:
+            acc = (acc * theta + col[i]) % R_MOD
+        return acc
+
+    z = [1]
+    for i in range(height):
+        z.append(z[-1] * (compress(original, i) + beta) % R_MOD * pow((compress(shuffled, i) + beta) % R_MOD, -1, R_MOD) % R_MOD)
+    assert z[-1] == 1
+    pad = lambda col: col + [0] * (n - len(col))  # noqa: E731
+    adv = [pad(c) for c in original] + [pad(c) for c in shuffled] + [pad(z)]
+    fixed = [pad([1] * height), pad([1]), pad([0] * height + [1])]           # q_shuffle, q_first, q_last
+    return adv, fixed
+
+
+def shuffle_gates_synthesize(k, width=4, height=32, theta=111, beta=222, seed=0x5348554646):
+    """... as the prover's (n, 4) u64 columns.  Returns (advice, fixed, copies)."""
+    adv, fixed = shuffle_gates_witness(k, width, height, theta, beta, seed)
+    to_arr = lambda col: np.array([[(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for v in col], dtype=np.uint64)  # noqa: E731
+    return [to_arr(c) for c in adv], [to_arr(c) for c in fixed], np.zeros((0, 4), dtype=np.int64)

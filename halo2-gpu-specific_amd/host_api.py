@@ -1,0 +1,357 @@
+"""create_proof as the LITERAL drop-in executes it: every polynomial lives in HOST memory (the reference's `Vec<F>`,
+poly.rs:33-64; `Params { g, g_lagrange }`, poly/commitment.rs:23-29) and every vector operation is one call of a
+host-slice entry point of include/halo2_hip.h -- the calls `integration/hip.rs` binds for `--features hip`:
+`h2_ntt` / `h2_intt` (arithmetic.rs:495-534), `h2_msm` over a registered SRS (arithmetic.rs:334-367 + `register_params`),
+`h2_coeff_to_extended` / `h2_extended_to_coeff` / `h2_divide_by_vanishing_poly` (poly/domain.rs:270-373),
+`h2_evaluate_h_coeff` (plonk/evaluation.rs:1229-1241: coefficient forms in, extended values out), `h2_evaluate_h` with
+y := theta (evaluate_with_theta, :2330-2398), `h2_lincomb` (gwc/prover.rs:57-151) -- i.e. one PCIe round trip per call.
+
+This is a MEASUREMENT device (bench.py: `create_proof.host_slice_api`; INTEGRATION.md states the ratio to the
+device-resident flow), built from product code only: there is no CPU arithmetic in it.  The passes the reference leaves
+to rayon between its GPU calls (permutation terms, batch inversion, grand products / sums, Horner evaluations, Kate
+division, the SHPLONK folds) also go through host-slice entry points where the library has them (`h2_batch_invert`,
+`h2_prefix_product`, `h2_eval_polynomial`, `h2_kate_division`, `h2_eval_op`, `h2_lincomb`); the few without a host-slice
+twin (`STAGED` below) are staged through device memory by hand -- upload, `h2_dev_*`, download, synchronise: the same
+round trip -- and counted in `HostSliceLib.calls`.  The proof bytes are those of the resident prover.
+"""
+import ctypes
+
+import numpy as np
+
+from . import prover as P
+from ._lib import check, lib
+
+_vp = ctypes.c_void_p
+STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_terms", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity",
+          "h2_dev_random_fr", "h2_dev_distribute_powers")
+
+
+def _addr(x):
+    if x is None or isinstance(x, int):
+        return x
+    if isinstance(x, (ctypes.Array, ctypes.Structure)):
+        return ctypes.addressof(x)
+    return x
+
+
+def _bytes_at(addr, nbytes):
+    """a numpy view of host memory"""
+    return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
+
+
+class HostSliceLib:
+    """the entry points prover.py calls (h2_dev_* signatures), each forwarded to the host-slice entry point the Rust patch
+    binds; pointers are host addresses"""
+
+    def __init__(self, torch, dev):
+        self.R = lib()
+        self.torch, self.dev = torch, dev
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    # -- staging for the entry points without a host-slice twin -------------------------------------------------------
+    def _up(self, addr, nbytes):
+        t = self.torch.from_numpy(_bytes_at(addr, nbytes)).to(self.dev)
+        self.torch.cuda.synchronize(self.dev)      # torch's stream is not the library's: the operand has landed
+        return t
+
+    def _down(self, t, addr, nbytes):
+        _bytes_at(addr, nbytes)[:] = t.cpu().numpy()
+
+    def _sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    # -- transforms ----------------------------------------------------------------------------------------------------
+    def h2_dev_ntt(self, a, tmp, omega, k, stream):
+        self._count("h2_ntt")
+        return self.R.h2_ntt(a, _addr(omega), k)
+
+    def h2_dev_intt(self, a, tmp, omega_inv, divisor, k, stream):
+        self._count("h2_intt")
+        return self.R.h2_intt(a, _addr(omega_inv), _addr(divisor), k)
+
+    def h2_dev_intt_batch(self, ptrs, count, tmp, omega_inv, divisor, k, stream):
+        for i in range(count):
+            rc = self.h2_dev_intt(ptrs[i], None, omega_inv, divisor, k, stream)
+            if rc:
+                return rc
+        return 0
+
+    def h2_dev_coeff_to_extended(self, a, out, tmp, k, ek, g, g_inv, ext_omega, stream):
+        self._count("h2_coeff_to_extended")
+        return self.R.h2_coeff_to_extended(a, out, k, ek, _addr(g), _addr(g_inv), _addr(ext_omega))
+
+    def h2_dev_extended_to_coeff(self, a, tmp, ek, g, g_inv, ext_omega_inv, ext_divisor, stream):
+        self._count("h2_extended_to_coeff")
+        return self.R.h2_extended_to_coeff(a, a, 1 << ek, ek, _addr(g), _addr(g_inv), _addr(ext_omega_inv), _addr(ext_divisor))
+
+    def h2_dev_divide_by_vanishing_poly(self, a, size, t_evals, t_len, stream):
+        self._count("h2_divide_by_vanishing_poly")
+        return self.R.h2_divide_by_vanishing_poly(a, size, t_evals, t_len)
+
+    def h2_dev_distribute_powers(self, a, n, g, stream):
+        self._count("h2_dev_distribute_powers (staged)")
+        t = self._up(a, 32 * n)
+        rc = self.R.h2_dev_distribute_powers(t.data_ptr(), n, _addr(g), None)
+        self._sync()
+        self._down(t, a, 32 * n)
+        return rc
+
+    # -- commitments: the SRS is registered once (Params below), each call ships the scalars ----------------------------
+    def h2_msm_scratch_bytes(self, n, bits):
+        return 256
+
+    def h2_msm_batch_scratch_bytes(self, n, bits, count):
+        return 512
+
+    def h2_logup_scratch_bytes(self, n):
+        return self.R.h2_logup_scratch_bytes(n)
+
+    def h2_dev_msm(self, scalars, bases, n, max_bits, scratch, nbytes, out, stream):
+        self._count("h2_msm")
+        return self.R.h2_msm(scalars, bases, n, max_bits, _addr(out))
+
+    def h2_dev_msm_batch_ex(self, sp, bp, bits, count, n, scratch, nbytes, out, stream):
+        for i in range(count):
+            rc = self.h2_dev_msm(sp[i], bp[i], n, bits[i], None, 0, _addr(out) + 96 * i, stream)
+            if rc:
+                return rc
+        return 0
+
+    def h2_dev_bases_precompute_bytes(self, n, digits):
+        return 0
+
+    def h2_dev_bases_precompute(self, bases, n, digits, stream):
+        return 0
+
+    def h2_dev_bases_forget(self, bases):
+        return 0
+
+    def h2_set_table_budget(self, nbytes):
+        return self.R.h2_set_table_budget(nbytes)
+
+    # -- Montgomery form, elementwise, scans, Horner, division ---------------------------------------------------------
+    def h2_dev_batch_mont(self, a, n, stream):
+        self._count("h2_batch_mont")
+        return self.R.h2_batch_mont(a, n)
+
+    def h2_dev_batch_unmont(self, a, n, stream):
+        self._count("h2_batch_unmont")
+        return self.R.h2_batch_unmont(a, n)
+
+    def h2_dev_eval_op(self, op, res, l, r, l_rot, r_rot, size, c, stream):
+        self._count("h2_eval_op")
+        return self.R.h2_eval_op(op, res, l, r, l_rot, r_rot, size, _addr(c))
+
+    def h2_dev_lincomb(self, res, ptrs, coeffs, count, size, stream):
+        self._count("h2_lincomb")
+        return self.R.h2_lincomb(res, ptrs, coeffs, count, size)
+
+    def h2_dev_eval_polynomial(self, poly, n, point, out, stream):
+        self._count("h2_eval_polynomial")
+        return self.R.h2_eval_polynomial(poly, n, _addr(point), _addr(out))
+
+    def h2_dev_eval_polynomial_batch(self, ptrs, count, n, points, out, stream):
+        for i in range(count):
+            rc = self.h2_dev_eval_polynomial(ptrs[i], n, points + 32 * i, out + 32 * i, stream)
+            if rc:
+                return rc
+        return 0
+
+    def h2_dev_kate_division(self, a, n, b, q, stream):
+        self._count("h2_kate_division")
+        return self.R.h2_kate_division(a, n, _addr(b), q)
+
+    def h2_dev_prefix_product(self, f, n, init, z, stream):
+        self._count("h2_prefix_product")
+        return self.R.h2_prefix_product(f, n, _addr(init), z)
+
+    def h2_dev_batch_invert(self, a, tmp, n, stream):
+        self._count("h2_batch_invert")
+        return self.R.h2_batch_invert(a, n)
+
+    def h2_dev_prefix_sum(self, f, n, init, z, stream):
+        self._count("h2_dev_prefix_sum (staged)")
+        tf = self._up(f, 32 * (n - 1 if n else 0))
+        tz = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
+        rc = self.R.h2_dev_prefix_sum(tf.data_ptr(), n, _addr(init), tz.data_ptr(), None)
+        self._sync()
+        self._down(tz, z, 32 * n)
+        return rc
+
+    def h2_dev_permutation_terms(self, num, den, value, sigma, n, beta, gamma, delta_pow, omega, first, stream):
+        self._count("h2_dev_permutation_terms (staged)")
+        tn, td = self._up(num, 32 * n), self._up(den, 32 * n)
+        tv, ts = self._up(value, 32 * n), self._up(sigma, 32 * n)
+        rc = self.R.h2_dev_permutation_terms(tn.data_ptr(), td.data_ptr(), tv.data_ptr(), ts.data_ptr(), n, _addr(beta),
+                                             _addr(gamma), _addr(delta_pow), _addr(omega), first, None)
+        self._sync()
+        self._down(tn, num, 32 * n)
+        self._down(td, den, 32 * n)
+        return rc
+
+    def h2_dev_permutation_sigma(self, out, map_col, map_row, n, delta, omega, stream):
+        self._count("h2_dev_permutation_sigma (staged)")
+        to = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
+        mc, mr = self._up(map_col, 4 * n), self._up(map_row, 4 * n)
+        rc = self.R.h2_dev_permutation_sigma(to.data_ptr(), mc.data_ptr(), mr.data_ptr(), n, _addr(delta), _addr(omega), None)
+        self._sync()
+        self._down(to, out, 32 * n)
+        return rc
+
+    def h2_dev_logup_multiplicity(self, table, ptrs, n_inputs, usable, n, m, scratch, nbytes, stream):
+        self._count("h2_dev_logup_multiplicity (staged)")
+        tt = self._up(table, 32 * n)
+        ins = [self._up(ptrs[i], 32 * n) for i in range(n_inputs)]
+        tm = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
+        sc = self.torch.empty(max(nbytes, 256), dtype=self.torch.uint8, device=self.dev)
+        dptrs = (_vp * n_inputs)(*[t.data_ptr() for t in ins])
+        rc = self.R.h2_dev_logup_multiplicity(tt.data_ptr(), dptrs, n_inputs, usable, n, tm.data_ptr(), sc.data_ptr(), nbytes, None)
+        self._sync()
+        self._down(tm, m, 32 * n)
+        return rc
+
+    def h2_dev_random_fr(self, key, n, out, stream):
+        self._count("h2_dev_random_fr (staged)")
+        t = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
+        rc = self.R.h2_dev_random_fr(key, n, t.data_ptr(), None)
+        self._sync()
+        self._down(t, out, 32 * n)
+        return rc
+
+    # -- the quotient numerator ---------------------------------------------------------------------------------------
+    def h2_dev_evaluate_h(self, desc, out, stream):
+        self._count("h2_evaluate_h")
+        return self.R.h2_evaluate_h(desc, out)
+
+    def h2_evaluate_h_coeff(self, desc, out):
+        self._count("h2_evaluate_h_coeff")
+        return self.R.h2_evaluate_h_coeff(desc, out)
+
+
+class _NullStream:
+    cuda_stream = 0
+
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, *a):
+        pass
+
+    def wait_event(self, *a):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _HostCuda:
+    """the stream plumbing of prover.Device with host tensors: nothing is asynchronous (every entry point returns with
+    its result in host memory)"""
+    Stream = Event = _NullStream
+
+    def __init__(self, torch):
+        self._torch = torch
+
+    def stream(self, _):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def set_device(self, _):
+        pass
+
+    def __getattr__(self, name):
+        return getattr(self._torch.cuda, name)
+
+
+class _HostTorch:
+    def __init__(self, torch):
+        self._torch = torch
+        self.cuda = _HostCuda(torch)
+
+    def __getattr__(self, name):
+        return getattr(self._torch, name)
+
+
+class HostApiDevice(P.Device):
+    """prover.Device whose vectors are host tensors and whose library is `HostSliceLib` (see the module docstring).
+    `quotient_from_coeffs`: create_proof_ext hands the evaluator COEFFICIENT forms and makes one h2_evaluate_h_coeff
+    call per circuit instance, as `Evaluator::evaluate_h` under the cuda / hip feature does."""
+    quotient_from_coeffs = True
+
+    def __init__(self, device=0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("the host-slice API needs a HIP device behind it: there is no CPU path")
+        self.gpu = torch.device("cuda", device)
+        torch.cuda.set_device(self.gpu)
+        self.torch = _HostTorch(torch)
+        self.dev = torch.device("cpu")
+        self.L = HostSliceLib(torch, self.gpu)
+        self.tstream = self.copy_stream = _NullStream()
+        self.stream = None
+        self._scratch, self._pinned = None, {}
+        self.group, self.group_size, self.group_rank, self.force_collective = None, 1, 0, False
+        self.force_cosets, self.mem_budget, self.eval_cache = False, None, None
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        if a.ndim == 1:
+            wide = np.zeros((a.shape[0], 4), dtype=np.uint64)
+            wide[:, 0] = a
+            a = wide
+        return self.torch.from_numpy(a.copy().view(np.int64))
+
+    def upload_async(self, a):
+        return (self.clone(a) if self.torch.is_tensor(a) else self.upload(a)), None
+
+    def widen(self, small, stream=None):
+        out = self.torch.zeros((small.shape[0], 4), dtype=self.torch.int64)
+        out[:, 0] = small
+        return out
+
+    def pinned_columns(self, count, n, compact=False):
+        return [np.zeros((n,) if compact else (n, 4), dtype=np.uint64) for _ in range(count)]
+
+    def max_scalar_bits_many(self, cols, n):
+        return [P.max_scalar_bits(c[:n].numpy().view(np.uint64)) for c in cols]
+
+    def residency(self, cs, dom, instances=1):
+        return "extended", None
+
+    def msm_async(self, scalars, bases, n, max_bits=254):
+        import concurrent.futures
+
+        fut = concurrent.futures.Future()
+        fut.set_result(self.msm(scalars, bases, n, max_bits))
+        return fut
+
+    def intt_on_side_stream(self, cols, dom, extend=False):
+        out = [self.intt(self.clone(t), dom) for t in cols]
+        return out, None, _NullStream()
+
+    def sync(self):
+        pass
+
+
+def _unregister(R, ptrs):
+    for p in ptrs:
+        R.h2_bases_unregister(p)
+
+
+def params_like(device, params):
+    """`params` (tables of a HIP device) as the reference's Params: host vectors, registered with the library once
+    (crate::hip::register_params in the patch) -- one device copy + shifted-base table per process"""
+    import weakref
+
+    g, gl = params.g.cpu().contiguous(), params.g_lagrange.cpu().contiguous()
+    out = P.Params(device, params.k, g, gl, tables=False)
+    R = device.L.R
+    for t in (g, gl):
+        check(R.h2_bases_register(t.data_ptr(), params.n), "h2_bases_register")
+    weakref.finalize(out, _unregister, R, [g.data_ptr(), gl.data_ptr()]).atexit = False
+    return out

@@ -150,6 +150,82 @@ def allgather_rows(t, lo, hi, group=None, stream=None):
     return t
 
 
+# ---- whole columns dealt over the ranks: the witness-dependent inverse transforms (north_star's per-column NTT sharding) ---
+# An NTT does not split by row range, so the inverse transforms of a proof's advice / product / multiplicity columns are
+# dealt round-robin BY COLUMN: rank i mod P transforms column i (the rows of a range-computed column are gathered to that
+# rank only), and the coefficient vectors reach the other ranks by broadcasts that run on a second communicator and a
+# side stream, under whatever the compute stream does next (the lookup / permutation phases after the advice columns, the
+# advice columns' coset transforms after the product columns) instead of P copies of every transform.
+def gather_rows_to(t, lo, hi, dst, group=None, stream=None):
+    """`t`: an (n, 4) int64 device tensor of which every rank holds the rows [lo, hi) (n / world rows, rank order); on
+    return rank `dst` of the group holds every row (the other ranks' tensors are unchanged)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    m = t.shape[0] // world
+    assert t.shape[0] % world == 0 and hi - lo == m
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
+    with _on_stream(stream):
+        if _backend(group) == "nccl":
+            parts = [t[r * m:(r + 1) * m] for r in range(world)] if rank == dst else None
+            dist.gather(t[lo:hi].clone(), gather_list=parts, dst=gdst, group=group)
+            return t
+        mine = t[lo:hi].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, gather_list=parts, dst=gdst, group=group)
+        if rank == dst:
+            t.copy_(torch.cat(parts).to(t.device))
+    return t
+
+
+class _Arrival:
+    """columns on their way to this rank: `wait()` makes the compute stream wait for them (idempotent)"""
+
+    def __init__(self, works, stream):
+        self.works, self.stream = works, stream
+
+    def wait(self):
+        import torch
+
+        if self.works:
+            with torch.cuda.stream(self.stream):
+                for w in self.works:
+                    w.wait()                    # the current (compute) stream waits for the communicator's stream
+            self.works = []
+
+
+def broadcast_columns_begin(cols, owners, group=None, stream=None, side=None):
+    """cols[i] is complete on rank owners[i] once the work queued on `stream` has run; start completing it on every rank.
+    RCCL: asynchronous broadcasts on `group`'s communicator (a second one next to the default group's, so that the small
+    all-gathers of the commitments do not queue behind them), issued from the side stream behind an event on `stream`.
+    gloo: through host memory, done on return.  Returns an `_Arrival`."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    if _backend(group) != "nccl":
+        with _on_stream(stream):
+            for t, owner in zip(cols, owners):
+                buf = t.cpu()
+                dist.broadcast(buf, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+                if rank != owner:
+                    t.copy_(buf.to(t.device))
+        return _Arrival([], stream)
+    ready = torch.cuda.Event()
+    ready.record(stream)
+    works = []
+    with torch.cuda.stream(side if side is not None else stream):
+        if side is not None:
+            side.wait_event(ready)
+        for t, owner in zip(cols, owners):
+            if side is not None:
+                t.record_stream(side)
+            works.append(dist.broadcast(t, src=dist.get_global_rank(group, owner) if group is not None else owner,
+                                        group=group, async_op=True))
+    return _Arrival(works, stream)
+
+
 # ---- coset sharding of the extended-domain phase ---------------------------------------------------------------------
 def coset_plan(c, world, rank):
     """c cosets (the quotient_poly_degree = degree - 1 cosets that determine the quotient, prover.Device.coset_plan) over

@@ -174,8 +174,14 @@ class Device:
         self.eval_cache = eval_cache if eval_cache is not None else (int(env_cache) if env_cache not in (None, "") else None)
         import torch.distributed as dist
 
+        self.bulk_group = group
         if dist.is_available() and dist.is_initialized():
             self.group_size, self.group_rank = dist.get_world_size(group), dist.get_rank(group)
+            if self.group_size > 1 and group is None:
+                # a second communicator for the bulk column traffic (parallel.broadcast_columns_begin): collectives of one
+                # communicator run in issue order, and the 96-byte all-gathers of the commitments must not wait behind
+                # half a gigabyte of coefficients.  (Collective: every rank constructs its Device at the same point.)
+                self.bulk_group = dist.new_group()
 
     # -- memory -----------------------------------------------------------------------------------------
     def empty(self, n):
@@ -410,6 +416,36 @@ class Device:
         check(self.L.h2_dev_intt_batch(ptrs, count, tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
                                        self.stream), "h2_dev_intt_batch")
         return ts
+
+    def column_owner(self, i):
+        return i % self.group_size
+
+    def intt_columns_begin(self, cols, dom, complete=True, keep=False):
+        """lagrange_to_coeff of whole columns dealt round-robin over the ranks -- north_star's per-column NTT sharding
+        (plonk/prover.rs:643-646 runs them as a par_iter) -- instead of every rank transforming every column: rank
+        i mod P transforms column i and the coefficient vectors travel to the other ranks on the side stream
+        (parallel.broadcast_columns_begin).  `complete` False: every rank holds only its row range of the columns (they
+        were computed by ranges): the rows are gathered to the owner, not to everybody.  `keep`: the columns' Lagrange
+        values stay as they are and the result is a new list.  Returns (coefficient columns, arrival): `arrival.wait()`
+        before the compute stream reads them.  One device: plain transforms, arrival None."""
+        n = dom.n
+        if self.group_size <= 1:
+            out = [self.clone(t) for t in cols] if keep else list(cols)
+            return self.intt_many(out, dom), None
+        from .parallel import broadcast_columns_begin, gather_rows_to
+
+        owners = [self.column_owner(i) for i in range(len(cols))]
+        lo, hi = self.row_range(n)
+        if not complete and (lo, hi) != (0, n):
+            for t, owner in zip(cols, owners):
+                gather_rows_to(t, lo, hi, owner, group=self.group, stream=self.tstream)
+        if keep:
+            out = [self.clone(t) if owner == self.group_rank else self.empty(n) for t, owner in zip(cols, owners)]
+        else:
+            out = list(cols)
+        self.intt_many([t for t, owner in zip(out, owners) if owner == self.group_rank], dom)
+        arrival = broadcast_columns_begin(out, owners, group=self.bulk_group, stream=self.tstream, side=self.copy_stream)
+        return out, arrival
 
     def coset_to_coeff(self, vals, dom, j):
         """in place: the polynomial of degree < n that takes the values `vals` on coset j (the inverse transform with
@@ -974,6 +1010,7 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     # kept with the key (three n-vectors behind the closure): a proof of SEVERAL circuit instances may not fit the
     # residency decided here for one and then runs coset by coset from tables built on demand (create_proof_ext)
     pk.coset_builder = coset_tables
+    pk.l0_poly, pk.l_last_poly = l0_poly, l_last_poly     # (the cuda-shaped evaluator takes l0 / l_last as coefficient forms)
     if plan is None:
         pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
         pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)
@@ -1373,6 +1410,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     side_intt = None
     if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= 20 and D.group_size <= 1 and not D.force_collective):
         side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and coset_tabs is None)
+    # one proof over several ranks: the advice columns' inverse transforms are dealt by column now (a rank transforms every
+    # P-th column) and the coefficient vectors cross xGMI under the lookup / permutation phases that follow
+    advice_arrival = None
+    if D.group_size > 1:
+        advice_coeffs, advice_arrival = D.intt_columns_begin(advice_dev, dom, complete=True, keep=True)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
     for C in circuits:
@@ -1507,10 +1549,10 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254)
     for P in z_commitments:
         transcript.write_point(P)
-    for z in all_z:
-        D.gather_rows(z, n)                       # (one proof over several ranks: every rank computed its own rows)
-    D.intt_many([z for C in circuits for z in C["z"]] + [z for C in circuits for st in C["lookups"] for z in st["z"]] +
-                [st["m"] for C in circuits for st in C["lookups"]] + [z for C in circuits for z in C["shuffle_z"]], dom)
+    # (one proof over several ranks: every rank computed its own rows of the product columns; a column's rows go to the
+    # rank that transforms it, and the coefficient vectors travel while the advice columns are taken to their cosets)
+    _, z_arrival = D.intt_columns_begin(all_z, dom, complete=False)
+    _, m_arrival = D.intt_columns_begin([st["m"] for C in circuits for st in C["lookups"]], dom, complete=True)
     for C in circuits:
         C["z_polys"] = C["z"]                                       # (transformed in place, sixteen to a launch)
         for st in C["lookups"]:
@@ -1530,6 +1572,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             C["advice_polys"] = polys_[ci * nadv:(ci + 1) * nadv]
             C["advice_extended"] = ext_[ci * nadv:(ci + 1) * nadv] if ext_ is not None else None
             C["advice"] = None                                       # the Lagrange values are not needed again
+        del advice_dev
+    elif advice_arrival is not None:
+        for ci, C in enumerate(circuits):
+            C["advice_polys"] = advice_coeffs[ci * nadv:(ci + 1) * nadv]
+            C["advice"] = None
         del advice_dev
     else:
         for C in circuits:
@@ -1558,12 +1605,44 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size):
         """the fused evaluator over one evaluation domain: `points_of` maps a list of coefficient vectors to their values there"""
         lookups = C["lookups"]
+        if points_of is None:
+            # the cuda shape of Evaluator::evaluate_h (plonk/evaluation.rs:1229-1241): COEFFICIENT forms in, the extended
+            # values of the numerator out, one h2_evaluate_h_coeff call (host slices: halo2-gpu-specific_amd/host_api.py)
+            b = ev.Builder().build(
+                k=dom.k, extended_k=k_domain, blinding_factors=bf, chunk_len=chunk,
+                constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
+                calculations=g.calculations, value_parts=pk.value_parts, lookups=pk.lookup_calcs, shuffles=pk.shuffle_calcs,
+                fixed=[t.data_ptr() for t in pk.fixed_polys], advice=[t.data_ptr() for t in C["advice_polys"]],
+                instance=[t.data_ptr() for t in C["instance_polys"]],
+                l0=pk.l0_poly.data_ptr(), l_last=pk.l_last_poly.data_ptr(), l_active_row=tables["l_active_row"].data_ptr(),
+                perm_z=[t.data_ptr() for t in C["z_polys"]], perm_columns=[(_ANY[kd], i) for kd, i in cols],
+                perm_sigma=[t.data_ptr() for t in pk.sigma_polys],
+                lookup_z=[t.data_ptr() for st in lookups for t in st["z_polys"]],
+                lookup_m=[st["m_poly"].data_ptr() for st in lookups],
+                shuffle_z=[t.data_ptr() for t in C["shuffle_polys"]],
+                y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
+                delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
+                jit_function=_jit_function(pk))
+            out = D.empty(size)
+            check(L.h2_evaluate_h_coeff(ctypes.byref(b.desc), out.data_ptr()), "h2_evaluate_h_coeff")
+            mark("evaluate_h")
+            return out
         pre = C.get("advice_extended") if size == en else None    # already extended on the side stream (small proofs)
         # every coefficient vector of this circuit instance that the evaluator reads, taken to the evaluation domain as ONE
         # list (the coset route transforms them sixteen to a launch)
         groups = [[] if pre is not None else list(C["advice_polys"]), list(C["instance_polys"]), list(C["z_polys"]),
                   [t for st in lookups for t in st["z_polys"]], [st["m_poly"] for st in lookups], list(C["shuffle_polys"])]
-        flat = points_of([t for grp in groups for t in grp])
+        if advice_arrival is not None:
+            # the advice columns' coefficients have been travelling since the commit phase; the product columns' are still on
+            # their way: the advice columns go to the evaluation domain first
+            advice_arrival.wait()
+            first = points_of(groups[0])
+            for arrival in (z_arrival, m_arrival):
+                if arrival is not None:
+                    arrival.wait()
+            flat = first + points_of([t for grp in groups[1:] for t in grp])
+        else:
+            flat = points_of([t for grp in groups for t in grp])
         cut, at = [], 0
         for grp in groups:
             cut.append(flat[at:at + len(grp)])
@@ -1595,7 +1674,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         # ---- one device: the whole extended domain at once ------------------------------------------------------
         tables = {"fixed": pk.fixed_cosets, "sigma": pk.sigma_cosets, "l0": pk.l0, "l_last": pk.l_last,
                   "l_active_row": pk.l_active_row}
-        h = evaluate_quotient(lambda ts: [D.coeff_to_extended(t, dom) for t in ts], tables, ek, ZETA, dom.extended_omega, en)
+        from_coeffs = getattr(D, "quotient_from_coeffs", False)
+        h = evaluate_quotient(None if from_coeffs else (lambda ts: [D.coeff_to_extended(t, dom) for t in ts]), tables, ek, ZETA,
+                              dom.extended_omega, en)
         # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
         check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
                                                 D.stream), "h2_dev_divide_by_vanishing_poly")

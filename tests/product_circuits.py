@@ -24,6 +24,18 @@ def shuffle_api_group_cs():
     return circuits.shuffle_api_group()
 
 
+def lookup_api_set_cs():
+    return circuits.lookup_api_set()
+
+
+def shuffle_api_cs():
+    return circuits.shuffle_api()
+
+
+def shuffle_gates_cs(width=4, theta=111, beta=222):
+    return circuits.shuffle_gates(width, theta, beta)
+
+
 def rot_gate_cs():
     """the product-side description of ref_plonk.RotGate"""
     cs = hc.ConstraintSystem("rot-gate")

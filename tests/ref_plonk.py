@@ -651,6 +651,131 @@ class ShuffleApiGroup:
         return adv, fixed, []
 
 
+class LookupApiSet:
+    """the big-integer twin of circuits.lookup_api_set (examples/lookup_api_set.rs): six advice inputs; fixed s_0, s_1,
+    table; ONE logup argument into the table column whose six traced lookups the chunking pass packs into four input
+    sets: {input_0}, {2 input_1, input_2}, {10 input_3, input_4}, {input_5}"""
+    num_advice, num_fixed = 6, 3
+    advice_queries = [(c, 0) for c in range(6)]
+    fixed_queries = [(0, 0), (2, 0)]                 # s_0 (gate), table; s_1 is allocated and never queried
+    perm_columns = []
+    degree = 4
+    blinding_factors = 5
+    name = "lookup-api-set"
+    cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
+
+    @staticmethod
+    def gates(adv, fix):
+        return [fix(0, 0) * (adv(0, 0) * 1 - adv(1, 0)) % R]          # examples/lookup_api_set.rs:58-63
+
+    lookups = [
+        {"table": lambda adv, fix, inst: [fix(2, 0)],
+         "input_sets": [[lambda adv, fix, inst: [adv(0, 0)]],
+                        [lambda adv, fix, inst: [adv(1, 0) * 2 % R], lambda adv, fix, inst: [adv(2, 0)]],
+                        [lambda adv, fix, inst: [adv(3, 0) * 10 % R], lambda adv, fix, inst: [adv(4, 0)]],
+                        [lambda adv, fix, inst: [adv(5, 0)]]]},
+    ]
+
+    @staticmethod
+    def synthesize(k):
+        n = 1 << k
+        adv = [[0] * n for _ in range(6)]
+        fixed = [[0] * n for _ in range(3)]
+        for a in adv:
+            a[0], a[1] = 1, 3
+        fixed[0][0], fixed[1][1] = 1, 1
+        for i in range(100):
+            fixed[2][i] = i
+        return adv, fixed, []
+
+
+class ShuffleApi:
+    """the big-integer twin of circuits.shuffle_api (examples/shuffle_api.rs): advice input_0, input_1, shuffle_0,
+    shuffle_1; fixed s_input, s_shuffle; one shuffle unit of two (input, shuffle) pairs"""
+    num_advice, num_fixed = 4, 2
+    advice_queries = [(0, 0), (1, 0), (2, 0), (3, 0)]
+    fixed_queries = [(0, 0), (1, 0)]
+    perm_columns = []
+    degree = 4
+    blinding_factors = 5
+    name = "shuffle-api"
+    cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
+
+    @staticmethod
+    def gates(adv, fix):
+        return [fix(0, 0) * (adv(0, 0) * 10 - adv(1, 0)) % R]         # examples/shuffle_api.rs:59-64
+
+    shuffles = [[(lambda adv, fix, inst: [fix(0, 0) * adv(0, 0) % R, fix(0, 0) * adv(1, 0) % R],
+                  lambda adv, fix, inst: [fix(1, 0) * adv(2, 0) % R, fix(1, 0) * adv(3, 0) % R])]]
+
+    @staticmethod
+    def synthesize(k, input0=(1, 2, 4, 1), shuffle0=(4, 1, 1, 2)):
+        n = 1 << k
+        adv = [[0] * n for _ in range(4)]
+        fixed = [[0] * n for _ in range(2)]
+        for i, (a, b) in enumerate(zip(input0, shuffle0)):
+            adv[0][i], adv[1][i], adv[2][i], adv[3][i] = a, 10 * a, b, 10 * b
+            fixed[0][i] = fixed[1][i] = 1
+        return adv, fixed, []
+
+
+def _const_like(x, v):
+    """Expression::Constant(v) next to the cell `x`: an integer among integers, a constant node among traced cells"""
+    return _Sym(("const", v % R)) if isinstance(x, _Sym) else v % R
+
+
+def shuffle_gates_class(width=4, theta=111, beta=222):
+    """the big-integer twin of circuits.shuffle_gates (examples/shuffle.rs): the shuffle written as three gates over a
+    running-product advice column; fixed q_shuffle, q_first, q_last; advice original[W], shuffled[W], z"""
+
+    class ShuffleGates:
+        num_advice, num_fixed = 2 * width + 1, 3
+        advice_queries = [(2 * width, 0)] + [(c, 0) for c in range(2 * width)] + [(2 * width, 1)]
+        fixed_queries = [(1, 0), (2, 0), (0, 0)]
+        perm_columns = []
+        degree = 3
+        blinding_factors = 5
+        name = "shuffle-gates-%d-%d-%d" % (width, theta, beta)
+        cs_bytes = classmethod(MiniPlonk.cs_bytes.__func__)
+
+        @staticmethod
+        def gates(adv, fix):
+            z, z_next = adv(2 * width, 0), adv(2 * width, 1)
+            one, th, be = _const_like(z, 1), _const_like(z, theta), _const_like(z, beta)
+
+            def compress(first):
+                acc = adv(first, 0)
+                for c in range(first + 1, first + width):
+                    acc = (acc * th + adv(c, 0)) % R
+                return acc
+
+            return [fix(1, 0) * (one - z) % R, fix(2, 0) * (one - z) % R,
+                    fix(0, 0) * (z * (compress(0) + be) - z_next * (compress(width) + be)) % R]
+
+        @staticmethod
+        def synthesize(k, height=32, seed=0x5348554646):
+            """the same seeded walk as circuits.shuffle_gates_witness, restated here"""
+            import random
+
+            n = 1 << k
+            rnd = random.Random(seed)
+            original = [[rnd.randrange(R) for _ in range(height)] for _ in range(width)]
+            order = list(range(height))
+            for row in range(height - 1, 0, -1):
+                other = rnd.getrandbits(32) % row
+                order[row], order[other] = order[other], order[row]
+            shuffled = [[col[i] for i in order] for col in original]
+            fold = lambda cols, i: sum(col[i] * pow(theta, len(cols) - 1 - j, R) for j, col in enumerate(cols)) % R  # noqa: E731
+            z = [1]
+            for i in range(height):
+                z.append(z[-1] * (fold(original, i) + beta) * inv((fold(shuffled, i) + beta) % R) % R)
+            pad = lambda col: col + [0] * (n - len(col))  # noqa: E731
+            return ([pad(c) for c in original] + [pad(c) for c in shuffled] + [pad(z)],
+                    [pad([1] * height), pad([1]), pad([0] * height + [1])], [])
+
+    return ShuffleGates
+
+
 def range_check_class(vmin, vmax, step):
     """the big-integer twin of halo2-gpu-specific_amd.circuits.range_check (examples/range-check.rs; the gate and the
     shuffle of `advice_column_range`, plonk/circuit.rs:1769-1826): advice origin (0) and sort (1); fixed l_0, l_active,

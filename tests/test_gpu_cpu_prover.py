@@ -172,6 +172,9 @@ def test_random_circuits_device_bytes_equal_cpu_bytes(device):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import prover_fuzz
 
+    # the fixed part of the corpus: the reference's live examples (simple-example-2, range-check, lookup_api, lookup_api_set,
+    # shuffle, shuffle_api, shuffle_api_group) with their own witnesses, by the extended route and both coset routes
+    assert len(prover_fuzz.run_examples(device)) == 7
     for seed in range(1, 17):
         prover_fuzz.run_case(device, seed)
     # satisfied circuits (every gate sel (E - d) with d set to E, copies that hold): the quotient is a polynomial, so the

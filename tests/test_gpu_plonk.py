@@ -505,6 +505,75 @@ dist.destroy_process_group()
     assert bytes.fromhex(line.split()[1]) == want
 
 
+def test_rccl_collective_shapes_on_one_rank(tmp_path):
+    """every RCCL-only code path of parallel.py (the in-place all_gather_into_tensor of allgather_rows, the scatter of
+    scatter_cosets, gather_rows_to, the asynchronous broadcasts of broadcast_columns_begin on a second communicator and a
+    side stream, the device-side fold, the small all-gathers / all-reduces) under a ONE-rank RCCL group, each at least
+    twice and with the view sizes a larger world would use: a mis-sized view or a wrong stream order fails here, on one
+    GPU, not on eight"""
+    import subprocess
+    import sys
+
+    from h2util import ROOT
+
+    script = tmp_path / "worker.py"
+    script.write_text(r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.init()
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from halo2_gpu_specific_amd import parallel, prover
+D = prover.Device(0, force_collective=True)
+bulk = dist.new_group()
+dev, stream, side = D.dev, D.tstream, D.copy_stream
+g = torch.Generator(device=dev); g.manual_seed(5)
+for rep in range(3):
+    n = 1 << (10 + rep)
+    with torch.cuda.stream(stream):
+        t = torch.randint(-2**62, 2**62, (n, 4), dtype=torch.int64, device=dev, generator=g)
+        want = t.clone()
+    parallel.allgather_rows(t, 0, n, stream=stream)
+    parallel.gather_rows_to(t, 0, n, 0, stream=stream)
+    stream.synchronize()
+    assert torch.equal(t, want), "allgather_rows / gather_rows_to"
+    cols = [t, want.clone(), want.clone()]
+    arrival = parallel.broadcast_columns_begin(cols, [0, 0, 0], group=bulk, stream=stream, side=side)
+    arrival.wait(); arrival.wait()
+    stream.synchronize()
+    assert all(torch.equal(c, want) for c in cols), "broadcast_columns_begin"
+    mine = {j: want.clone() + j for j in range(3)}
+    got = parallel.scatter_cosets(mine, 3, 1, 0, n, stream=stream)
+    stream.synchronize()
+    assert all(torch.equal(got[j], want + j) for j in range(3)), "scatter_cosets"
+    got = parallel.exchange_cosets(mine, 3, 1, stream=stream)
+    stream.synchronize()
+    assert all(torch.equal(got[j], want + j) for j in range(3)), "exchange_cosets"
+    assert parallel.allreduce_max([3, 254, rep], device=dev) == [3, 254, rep]
+    vals = [(1 << 200) + rep, 7, 0]
+    assert parallel.allgather_scalars(vals, device=dev) == [vals]
+    pts = np.zeros((2, 12), dtype=np.uint64); pts[:, 4] = 1          # two identities (0 : 1 : 0) in canonical limbs ...
+    out = parallel.allgather_fold_many(pts, device=dev, stream=stream)
+    assert out.shape == (2, 12) and not out[:, 8:].any()               # ... fold to the identity (z = 0)
+# the sharded inverse transforms of a proof, through Device: one rank owns every column
+dom = prover.Domain(12, 3)
+with torch.cuda.stream(stream):
+    cols = [torch.randint(0, 2**60, (dom.n, 4), dtype=torch.int64, device=dev, generator=g) for _ in range(3)]
+    for c in cols: c[:, 1:] = 0
+    want = [D.intt(c.clone(), dom) for c in cols]
+D.group_size = 1                                   # (row_range of a one-rank group is the whole vector either way)
+out, arrival = D.intt_columns_begin(cols, dom, complete=True, keep=True)
+assert arrival is None
+stream.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(out, want))
+sys.stdout.write("COLLECTIVES OK\n")
+dist.destroy_process_group()
+""" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and "COLLECTIVES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
 @pytest.mark.parametrize("k", [5, 8])
 def test_lookup_shuffle_instance_proof_bytes(oracle, device, k):
     """instance column + logup lookups (two input sets, a duplicated table row) + a shuffle group, end to end:

@@ -7,7 +7,12 @@ twin's verifier, and a CircuitData file carrying the argument rebuilds the same 
 
 examples/lookup_api.rs and examples/shuffle_api_group.rs -- the traced `lookup` / `lookup_any` / `shuffle` front end with
 the chunking passes (plonk/logup.rs:73-153, plonk/shuffle.rs:57-103): bytes equal to the twins at k = 6 / 7, accepted at
-the examples' k = 10."""
+the examples' k = 10.
+
+examples/lookup_api_set.rs (six lookups into one table, packed into four input sets), examples/shuffle_api.rs (one
+shuffle of two expression pairs under selectors) and examples/shuffle.rs (a shuffle written as three gates over a
+running-product advice column, constants theta / beta in the gate): bytes equal to the twins at k = 6 / 7, accepted at the
+examples' own k (10, 10 and 8)."""
 import numpy as np
 import pytest
 
@@ -137,3 +142,47 @@ def test_lookup_api_and_shuffle_api_group_examples(oracle, device, which, k):
         bad[2][1, 0] = 77
         with pytest.raises(Exception):
             prover.create_proof_with_shplonk(device, params, pk, bad, ProverRng(1))
+
+
+@pytest.mark.parametrize("which,k", [("lookup-api-set", 7), ("shuffle-api", 6), ("shuffle-gates", 6),
+                                     ("lookup-api-set", 10), ("shuffle-api", 10), ("shuffle-gates", 8)])
+def test_lookup_api_set_shuffle_api_and_shuffle_examples(oracle, device, which, k):
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    W, make, syn = {"lookup-api-set": (rp.LookupApiSet, circuits.lookup_api_set, circuits.lookup_api_set_synthesize),
+                    "shuffle-api": (rp.ShuffleApi, circuits.shuffle_api, circuits.shuffle_api_synthesize),
+                    "shuffle-gates": (rp.shuffle_gates_class(), circuits.shuffle_gates, circuits.shuffle_gates_synthesize)}[which]
+    cs = make()
+    assert cs.degree() == W.degree and cs.advice_queries == W.advice_queries and cs.fixed_queries == W.fixed_queries
+    adv, fixed, copies = syn(k)
+    params = srs(oracle, device, k)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    if k <= 7:
+        radv, rfixed, rcopies = W.synthesize(k)
+        rpk = rp.keygen(W, k, S_TRAPDOOR, rfixed, rcopies)
+        assert pk.transcript_repr == rpk.transcript_repr and pk.fixed_commitments == rpk.fixed_commitments
+        for seed, use_gwc in ((1, False), (2, True)):
+            proof = prover.create_proof_ext(device, params, pk, adv, ProverRng(seed), use_gwc)
+            want = rp.create_proof(rpk, radv, ProverRng(seed), use_gwc=use_gwc)
+            first = next((i for i in range(min(len(proof), len(want))) if proof[i] != want[i]), None)
+            assert len(proof) == len(want) and first is None, "differs from the big-integer prover at byte %s" % first
+            assert rp.verify_proof(rpk, proof, use_gwc=use_gwc)
+    else:
+        vk = rp.Keys()
+        vk.cs, vk.dom, vk.s = W, rp.Domain(k, cs.degree()), S_TRAPDOOR
+        vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
+        assert rp.verify_proof(vk, prover.create_proof_with_shplonk(device, params, pk, adv, ProverRng(5)))
+        assert rp.verify_proof(vk, prover.create_proof(device, params, pk, adv, ProverRng(6)), use_gwc=True)
+    bad = [c.copy() for c in adv]
+    if which == "lookup-api-set":                 # 10 * 11 is not in the table
+        bad[3][1, 0] = 11
+        with pytest.raises(Exception):
+            prover.create_proof_with_shplonk(device, params, pk, bad, ProverRng(1))
+    elif which == "shuffle-api":                  # not a permutation: the product does not close
+        bad[2][0, 0] = 5
+        with pytest.raises(ValueError):
+            prover.create_proof_with_shplonk(device, params, pk, bad, ProverRng(1))
+    elif k <= 7:                                  # a shuffled cell changed: the proof is made, and rejected
+        bad[5][3, 0] += np.uint64(1)
+        assert not rp.verify_proof(rpk, prover.create_proof_with_shplonk(device, params, pk, bad, ProverRng(1)))

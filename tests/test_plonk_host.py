@@ -113,6 +113,46 @@ def test_big_integer_prover_is_accepted(cs, k):
             pass
 
 
+@pytest.mark.parametrize("which", ["lookup-api-set", "shuffle-api", "shuffle-gates"])
+def test_remaining_reference_examples_on_the_big_integer_prover(which):
+    """examples/lookup_api_set.rs, shuffle_api.rs and shuffle.rs: the product-side descriptions go through the traced
+    front end and its chunking passes to the shapes the twins state, the witnesses agree, and the twins' proofs are
+    accepted -- and rejected once a witness value breaks the argument"""
+    from h2util import arr_to_ints
+
+    if which == "lookup-api-set":
+        cs, W, k = circuits.lookup_api_set(), rp.LookupApiSet, 7
+        adv, fixed, _ = circuits.lookup_api_set_synthesize(k)
+        assert [len(st) for st in cs.lookups[0][2]] == [1, 2, 2, 1] and len(cs.lookups) == 1    # the example's "set 0 .. 3"
+    elif which == "shuffle-api":
+        cs, W, k = circuits.shuffle_api(), rp.ShuffleApi, 6
+        adv, fixed, _ = circuits.shuffle_api_synthesize(k)
+        assert [len(g) for g in cs.shuffles] == [1] and len(cs.shuffles[0][0][1]) == 2
+    else:
+        cs, W, k = circuits.shuffle_gates(), rp.shuffle_gates_class(), 6
+        adv, fixed, _ = circuits.shuffle_gates_synthesize(k)
+        assert not cs.lookups and not cs.shuffles and len(cs.gates) == 3
+    assert cs.degree() == W.degree and cs.blinding_factors() == W.blinding_factors
+    assert cs.advice_queries == W.advice_queries and cs.fixed_queries == W.fixed_queries and cs.perm_columns == W.perm_columns
+    radv, rfixed, rcopies = W.synthesize(k)
+    assert [arr_to_ints(c) for c in adv] == radv and [arr_to_ints(c) for c in fixed] == rfixed
+    pk = rp.keygen(W, k, S_TRAPDOOR, rfixed, rcopies)
+    for gwc in (False, True):
+        assert rp.verify_proof(pk, rp.create_proof(pk, radv, ProverRng(3), use_gwc=gwc), use_gwc=gwc)
+    bad = [c[:] for c in radv]
+    if which == "lookup-api-set":
+        bad[3][1] = 11                                   # 10 * 11 is not in the table 0 .. 99
+        with pytest.raises(Exception):
+            rp.create_proof(pk, bad, ProverRng(3))
+    elif which == "shuffle-api":
+        bad[2][0] = 5                                    # no longer a permutation of the inputs
+        with pytest.raises(Exception):
+            rp.create_proof(pk, bad, ProverRng(3))
+    else:
+        bad[5][3] = (bad[5][3] + 1) % rp.R              # a shuffled cell changed: the transition gate fails on that row
+        assert not rp.verify_proof(pk, rp.create_proof(pk, bad, ProverRng(3)))
+
+
 def _second_lookup_shuffle_witness(k):
     """the LookupShuffle witness with another public input (w[0] = instance[0][0] = 43)"""
     adv, fixed, copies, inst = rp.LookupShuffle.synthesize(k)
@@ -546,7 +586,9 @@ def test_verifying_key_preimage_is_derived_twice():
              (pc.lookup_api_cs(), rp.LookupApi), (pc.shuffle_api_group_cs(), rp.ShuffleApiGroup),
              (pc.wide_cs(2), rp.wide_class(2)), (pc.wide_cs(16), rp.wide_class(16)),
              (pc.range_check_cs(0, 0xFFFF, 2), rp.range_check_class(0, 0xFFFF, 2)),
-             (pc.range_check_cs(3, 40, 1), rp.range_check_class(3, 40, 1))]
+             (pc.range_check_cs(3, 40, 1), rp.range_check_class(3, 40, 1)),
+             (pc.lookup_api_set_cs(), rp.LookupApiSet), (pc.shuffle_api_cs(), rp.ShuffleApi),
+             (pc.shuffle_gates_cs(), rp.shuffle_gates_class()), (pc.shuffle_gates_cs(3, 7, 9), rp.shuffle_gates_class(3, 7, 9))]
     for cs, ref in pairs:
         assert formats.cs_store(cs) == rp.write_cs(ref), ref.name
     # the tracer itself: the tree shapes of plonk/circuit.rs's operator overloading

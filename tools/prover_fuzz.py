@@ -177,11 +177,37 @@ def random_case(seed, satisfiable=False, k=None, witness_seed=None):
 def run_case(device, seed, cache={}, satisfiable=False):
     """one random circuit on the device and on the CPU; returns a description, raises on a mismatch.  `satisfiable`: also
     by the coset routes of the device (every coset at once, and coset by coset with no table set retained)"""
+    return compare(device, random_case(seed, satisfiable), seed, cache, satisfiable)
+
+
+def reference_examples():
+    """The fixed part of the corpus: every live example of the reference that runs create_proof, at small sizes, with the
+    example's own witness -- (name, (cs, k, advice, fixed, copies, instances)).  All satisfied: `compare` also takes them
+    through the coset routes of the device."""
+    from halo2_gpu_specific_amd import circuits as c
+
+    yield "simple-example-2 (mini-PLONK)", (c.mini_plonk(), 7) + tuple(c.mini_plonk_synthesize(7)) + ((),)
+    yield "range-check", (c.range_check(0, 61, 4), 8) + tuple(c.range_check_synthesize(8, vmin=0, vmax=61, count=150)) + ((),)
+    yield "lookup_api", (c.lookup_api(), 7) + tuple(c.lookup_api_synthesize(7)) + ((),)
+    yield "lookup_api_set", (c.lookup_api_set(), 8) + tuple(c.lookup_api_set_synthesize(8)) + ((),)
+    yield "shuffle_api", (c.shuffle_api(), 6) + tuple(c.shuffle_api_synthesize(6)) + ((),)
+    yield "shuffle_api_group", (c.shuffle_api_group(), 7) + tuple(c.shuffle_api_group_synthesize(7)) + ((),)
+    yield "shuffle (gates)", (c.shuffle_gates(), 7) + tuple(c.shuffle_gates_synthesize(7)) + ((),)
+
+
+def run_examples(device, cache={}):
+    out = []
+    for i, (name, case) in enumerate(reference_examples()):
+        out.append("%s -- %s" % (name, compare(device, case, 9000 + i, cache, satisfiable=True, several=False)))
+    return out
+
+
+def compare(device, case, seed, cache={}, satisfiable=False, several=True):
     import oracle_prover as op
     from halo2_gpu_specific_amd import prover
     from halo2_gpu_specific_amd.rng import ProverRng
 
-    cs, k, advice, fixed, copies, instances = random_case(seed, satisfiable)
+    cs, k, advice, fixed, copies, instances = case
     if k not in cache:
         params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
         cpu = op.OracleDevice(threads=4)
@@ -210,7 +236,7 @@ def run_case(device, seed, cache={}, satisfiable=False):
             first = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
             raise AssertionError("seed %d (%s): proof differs at byte %d of %d / %d" % (
                 seed, "gwc" if use_gwc else "shplonk", first, len(got), len(want)))
-    if not satisfiable and seed % 4 == 0:
+    if several and not satisfiable and seed % 4 == 0:
         # several circuit instances in one proof (plonk/prover.rs:206-232): two more witnesses of the same circuit
         advs, insts = [advice], [instances]
         for ws in (1, 2):
@@ -240,6 +266,8 @@ def main():
     satisfiable = len(sys.argv) > 3 and sys.argv[3] == "satisfiable"
     device = prover.Device()
     t_end, done = time.time() + seconds, 0
+    for line in run_examples(device):
+        print(line, flush=True)
     while time.time() < t_end:
         print(run_case(device, seed, satisfiable=satisfiable), flush=True)
         seed += 1
