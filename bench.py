@@ -520,26 +520,29 @@ def main():
             # registered once -- a PCIe round trip per call.  Same SRS / witness / randomness: the same proof bytes.
             from halo2_gpu_specific_amd import host_api as ha
 
-            H = ha.HostApiDevice(local_rank)
-            hparams = ha.params_like(H, params)
-            hpk = prover.keygen(H, hparams, circuits.mini_plonk(), fixed, copies)
-            hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))      # warm-up (device copies, tables)
-            H.L.calls.clear()
-            h0 = time.perf_counter()
-            hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))
-            hsec = time.perf_counter() - h0
-            hphases = {}
-            prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1), timings=hphases)
-            host_api = {
-                "seconds": hsec, "proof_bytes_equal": bool(hproof == proof), "ratio_to_resident": hsec / (pelapsed / steps),
-                "phases_ms": {n: round(v * 1e3, 2) for n, v in hphases.items()},
-                "calls": dict(sorted(H.L.calls.items())),
-                "what": "host vectors + one host-slice C-ABI call per vector operation (h2_ntt, h2_intt, h2_msm over the registered "
-                        "SRS, h2_evaluate_h_coeff, h2_extended_to_coeff, h2_lincomb, ...): what `--features hip` as patched executes; "
-                        "the passes the reference leaves to rayon run through host-slice entry points too (no CPU arithmetic here)",
-            }
-            assert hproof == proof, "the host-slice data flow changed the proof"
-            del hpk, hparams, H
+            host_api = {"what": "host vectors + one host-slice C-ABI call per vector operation (h2_ntt, h2_intt, h2_msm over the "
+                                "registered SRS, h2_evaluate_h_coeff, h2_extended_to_coeff, h2_lincomb, ...): what `--features hip` as "
+                                "patched executes; the passes the reference leaves to rayon run through host-slice entry points too "
+                                "(no CPU arithmetic here).  `pageable`: the vectors in ordinary memory (a Rust Vec); `pinned`: in "
+                                "page-locked memory (an allocator over h2_host_alloc_pinned): the same calls, DMA transfers"}
+            for mode in ("pageable", "pinned"):
+                H = ha.HostApiDevice(local_rank, pinned=(mode == "pinned"))
+                hparams = ha.params_like(H, params)
+                hpk = prover.keygen(H, hparams, circuits.mini_plonk(), fixed, copies)
+                hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))      # warm-up (device copies, tables)
+                H.L.calls.clear()
+                h0 = time.perf_counter()
+                hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))
+                hsec = time.perf_counter() - h0
+                calls = dict(sorted(H.L.calls.items()))
+                hphases = {}
+                prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1), timings=hphases)
+                host_api[mode] = {
+                    "seconds": hsec, "proof_bytes_equal": bool(hproof == proof), "ratio_to_resident": hsec / (pelapsed / steps),
+                    "phases_ms": {n: round(v * 1e3, 2) for n, v in hphases.items()}, "calls_per_proof": calls,
+                }
+                assert hproof == proof, "the host-slice data flow changed the proof"
+                del hpk, hparams, H
         return {
             "k": pk_k,
             "host_slice_api": host_api,

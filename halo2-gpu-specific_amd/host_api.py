@@ -282,7 +282,10 @@ class HostApiDevice(P.Device):
     call per circuit instance, as `Evaluator::evaluate_h` under the cuda / hip feature does."""
     quotient_from_coeffs = True
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, pinned=False):
+        """`pinned`: every host vector lives in page-locked memory (a Rust-side allocator over h2_host_alloc_pinned for
+        `Polynomial::values`): the same calls, but their transfers are DMA instead of staged pageable copies"""
+        self.pinned = pinned
         import torch
 
         if not torch.cuda.is_available():
@@ -298,19 +301,33 @@ class HostApiDevice(P.Device):
         self.group, self.group_size, self.group_rank, self.force_collective = None, 1, 0, False
         self.force_cosets, self.mem_budget, self.eval_cache = False, None, None
 
+    def _pin(self, t):
+        return t.pin_memory() if self.pinned else t
+
+    def empty(self, n):
+        return self.torch.empty((n, 4), dtype=self.torch.int64, pin_memory=self.pinned)
+
+    def zeros(self, n):
+        return self.torch.zeros((n, 4), dtype=self.torch.int64, pin_memory=self.pinned)
+
+    def clone(self, t):
+        out = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=self.pinned)
+        out.copy_(t)
+        return out
+
     def upload(self, a):
         a = np.ascontiguousarray(a)
         if a.ndim == 1:
             wide = np.zeros((a.shape[0], 4), dtype=np.uint64)
             wide[:, 0] = a
             a = wide
-        return self.torch.from_numpy(a.copy().view(np.int64))
+        return self.clone(self.torch.from_numpy(a.view(np.int64)))
 
     def upload_async(self, a):
         return (self.clone(a) if self.torch.is_tensor(a) else self.upload(a)), None
 
     def widen(self, small, stream=None):
-        out = self.torch.zeros((small.shape[0], 4), dtype=self.torch.int64)
+        out = self.zeros(small.shape[0])
         out[:, 0] = small
         return out
 
@@ -348,7 +365,7 @@ def params_like(device, params):
     (crate::hip::register_params in the patch) -- one device copy + shifted-base table per process"""
     import weakref
 
-    g, gl = params.g.cpu().contiguous(), params.g_lagrange.cpu().contiguous()
+    g, gl = device._pin(params.g.cpu().contiguous()), device._pin(params.g_lagrange.cpu().contiguous())
     out = P.Params(device, params.k, g, gl, tables=False)
     R = device.L.R
     for t in (g, gl):

@@ -16,6 +16,7 @@ REF = "/root/reference"
 PATCH = os.path.join(ROOT, "integration", "halo2_proofs_hip.patch")
 HIP_RS = os.path.join(ROOT, "integration", "hip.rs")
 EVAL_HIP_RS = os.path.join(ROOT, "integration", "evaluation_hip.rs")
+RESIDENT_RS = os.path.join(ROOT, "integration", "hip_resident.rs")
 needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "halo2_proofs")), reason="the reference tree is not on this machine")
 
 
@@ -38,6 +39,9 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert res.returncode == 0, res.stderr
     # the new module is the committed shim, byte for byte, and the feature is wired
     assert (tmp_path / "halo2_proofs/src/hip.rs").read_text() == open(HIP_RS).read()
+    # round 4: the device-resident containers (DevicePolynomial / DeviceParams / DeviceColumns) as a second module
+    assert (tmp_path / "halo2_proofs/src/hip_resident.rs").read_text() == open(RESIDENT_RS).read()
+    assert '#[cfg(feature = "hip")]\npub mod hip_resident;' in (tmp_path / "halo2_proofs/src/lib.rs").read_text()
     assert "hip = []" in (tmp_path / "halo2_proofs/Cargo.toml").read_text()
     arith = (tmp_path / "halo2_proofs/src/arithmetic.rs").read_text()
     for fn in ("gpu_multiexp_single_gpu_with_bound", "gpu_multiexp_bound", "gpu_multiexp_bound_and_fft", "gpu_fft", "gpu_ifft"):
@@ -78,19 +82,22 @@ def test_patch_is_what_the_generator_emits(tmp_path):
 
 
 def test_shim_declares_only_exported_symbols_with_the_header_arity():
-    """every `pub fn h2_*` of hip.rs exists in include/halo2_hip.h with the same number of parameters and is exported by
-    the built library"""
+    """every `pub fn h2_*` of hip.rs and hip_resident.rs exists in include/halo2_hip.h with the same number of parameters
+    and is exported by the built library"""
     import halo2_gpu_specific_amd as h2
 
     L = h2.lib()
     header = open(os.path.join(ROOT, "include", "halo2_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    rs = open(HIP_RS).read()
-    block = rs[rs.index('extern "C" {'):]
-    block = block[:block.index("\n}\n")]
-    block = re.sub(r"//[^\n]*", "", block)
-    decls = re.findall(r"pub fn (h2_\w+)\s*\((.*?)\)\s*(?:->\s*[\w\s\*]+)?;", block, flags=re.S)
-    assert len(decls) >= 19
+    decls = []
+    for path, least in ((HIP_RS, 19), (RESIDENT_RS, 25)):
+        rs = open(path).read()
+        block = rs[rs.index('extern "C" {'):]
+        block = block[:block.index("\n}\n")]
+        block = re.sub(r"//[^\n]*", "", block)
+        found = re.findall(r"pub fn (h2_\w+)\s*\((.*?)\)\s*(?:->\s*[\w\s\*]+)?;", block, flags=re.S)
+        assert len(found) >= least, (path, len(found))
+        decls += found
     for name, params in decls:
         assert hasattr(L, name), name
         m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, header, flags=re.S)

@@ -29,7 +29,8 @@ FILES = ["halo2_proofs/Cargo.toml", "halo2_proofs/build.rs", "halo2_proofs/src/l
          "halo2_proofs/src/plonk/permutation/keygen.rs", "halo2_proofs/src/plonk/permutation/prover.rs",
          "halo2_proofs/src/plonk/prover.rs", "halo2_proofs/src/plonk/evaluation.rs",
          "halo2_proofs/src/poly/multiopen/gwc/prover.rs"]
-NEW_FILES = {"halo2_proofs/src/hip.rs": "hip.rs", "halo2_proofs/src/plonk/evaluation_hip.rs": "evaluation_hip.rs"}
+NEW_FILES = {"halo2_proofs/src/hip.rs": "hip.rs", "halo2_proofs/src/plonk/evaluation_hip.rs": "evaluation_hip.rs",
+             "halo2_proofs/src/hip_resident.rs": "hip_resident.rs"}
 
 HIP_FUNCTIONS = '''#[cfg(feature = "hip")]
 pub fn gpu_multiexp_single_gpu_with_bound<C: CurveAffine>(
@@ -337,7 +338,7 @@ def edit(rel, text):
     if rel.endswith("build.rs"):
         return replace_once(text, "fn main() {\n", "fn main() {\n" + BUILD_RS, "build.rs main")
     if rel.endswith("lib.rs"):
-        return replace_once(text, "pub mod arithmetic;\n", 'pub mod arithmetic;\n#[cfg(feature = "hip")]\npub mod hip;\n', "mod arithmetic")
+        return replace_once(text, "pub mod arithmetic;\n", 'pub mod arithmetic;\n#[cfg(feature = "hip")]\npub mod hip;\n#[cfg(feature = "hip")]\npub mod hip_resident;\n', "mod arithmetic")
     if rel.endswith("arithmetic.rs"):
         text = replace_once(text, "pub fn best_multiexp_gpu_cond<", HIP_FUNCTIONS + "pub fn best_multiexp_gpu_cond<", "best_multiexp_gpu_cond")
         # the two dispatchers: best_multiexp_gpu_cond (:442-458) and best_fft (:546-554)
