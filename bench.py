@@ -468,6 +468,24 @@ def main():
                 out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
 
+    def evalh_roofline(pk, phases_s):
+        """evaluate_h against both of its rooflines (algorithmic bytes = 32 * (distinct columns read + 1) *
+        2^extended_k; products per row from the generated program): the phase's synchronised wall time, descriptor staging
+        included"""
+        st = getattr(pk, "evalh_stats", None)
+        if not st or not phases_s.get("evaluate_h") or pk.coset is not None:
+            return None
+        size, t = pk.domain.extended_n, phases_s["evaluate_h"]
+        alg = 32 * (st["vectors_read"] + 1) * size
+        muls = st["products_per_row"] * size / t
+        return {"bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": alg, "distinct_vectors_read": st["vectors_read"], "seconds": t,
+                "kernel": "h2_evalh_jit" + (" (gates + permutation / lookup / shuffle terms in one kernel)" if st["fused"] else
+                                            " + k_evalh_perm / k_evalh_lookup / k_evalh_shuffle"),
+                "alu": {"products_per_row": st["products_per_row"], "achieved_mul_per_s": muls, "peak_mul_per_s": MUL_HW_BOUND,
+                        "frac": muls / MUL_HW_BOUND, "frac_of_multiplier_in_a_loop": muls / MUL_MEASURED},
+                "limiter": "integer VALU: the field products of the gate and argument terms, not HBM"}
+
     # ---------------------------------------------------------------- create_proof legs (configs[3] k = 22; configs[4]'s k = 24)
     def prove_leg(pk_k, steps, verify):
         from halo2_gpu_specific_amd import circuits, prover
@@ -557,6 +575,7 @@ def main():
             "proof_bytes": len(proof),
             "verified": verified,
             "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
+            "evaluate_h": {"roofline": evalh_roofline(pk, phases)},
             "steps": steps,
             "peak_device_memory_gib": round(peak_gib, 1),
             "srs_shifted_base_tables_gib": round(params.table_bytes / 2**30, 1),   # library memory, not in the peak above
@@ -622,6 +641,7 @@ def main():
                 "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                 "library_memory_gib": round(L.h2_library_memory_bytes() / 2**30, 2),
                 "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof),
+                "evaluate_h": {"roofline": evalh_roofline(pk, phases)},
             }
             if dist is not None:
                 res[mode]["sharding"] = prover.sharding_description(D)

@@ -286,13 +286,18 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     }
     size_t need = 4096 + d->n_constants * 32 + d->n_rotations * 4 + (d->n_calculations + n_lookup_calcs + 2 * d->n_shuffles) * sizeof(h2_calculation) +
                   d->n_value_parts * sizeof(h2_value_source) + d->n_lookups * 4 +
-                  ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + n_lookup_z) * 8 + 64 * 16;
+                  ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + n_lookup_z +
+                   d->n_lookups + d->n_shuffles) * 8 + 64 * 16;
     // ---- work space: interpreter intermediates + lookup / shuffle compressed expressions
     const unsigned blocks = 256 * 8, threads = 256;
     const size_t nthreads = (size_t)blocks * threads;
     size_t inter_bytes = d->jit_function ? 256 : (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
-    size_t lk_bytes = (n_lookup_calcs ? n_lookup_calcs : 1) * size * sizeof(Fr);
-    size_t sh_bytes = (d->n_shuffles ? 2 * (size_t)d->n_shuffles : 1) * size * sizeof(Fr);
+    // a generated kernel that folds the lookup / shuffle terms itself keeps their compressed expressions in registers
+    const uint32_t covers = d->jit_function ? d->jit_covers : 0u;
+    size_t lk_bytes = ((covers & H2_JIT_LOOKUPS) || !n_lookup_calcs ? 1 : n_lookup_calcs) * size * sizeof(Fr);
+    size_t sh_bytes = ((covers & H2_JIT_SHUFFLES) || !d->n_shuffles ? 1 : 2 * (size_t)d->n_shuffles) * size * sizeof(Fr);
+    if (lk_bytes == size * sizeof(Fr) && ((covers & H2_JIT_LOOKUPS) || !n_lookup_calcs)) lk_bytes = 256;
+    if (sh_bytes == size * sizeof(Fr) && ((covers & H2_JIT_SHUFFLES) || !d->n_shuffles)) sh_bytes = 256;
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t total = align(need) + align(inter_bytes) + align(lk_bytes) + align(sh_bytes);
     char* block = (char*)ctx->evalh_scratch.get(total);
@@ -328,6 +333,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     }
     const Fr* const* d_perm_cols = (const Fr* const*)ar.put(cols.data(), cols.size());
     const Fr* const* d_lookup_z = (const Fr* const*)ar.put(d->lookup_z, n_lookup_z);
+    const Fr* const* d_lookup_m = (const Fr* const*)ar.put(d->lookup_m, d->n_lookups);
+    const Fr* const* d_shuffle_z = (const Fr* const*)ar.put(d->shuffle_z, d->n_shuffles);
     if (ar.off > need) {
         set_last_error("h2_evaluate_h: internal staging overflow");
         return H2_ERR_INVALID;
@@ -346,9 +353,31 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     p.gamma = fr_from_u64x4(d->gamma);
     p.theta = fr_from_u64x4(d->theta);
 
+    const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
+    PlanRef pl;  // the power tables of extended_omega: pinned until the kernels that read them are launched
+    if (d->n_perm_sets) {
+        if (have_lock) {
+            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+        } else {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+        }
+    }
     if (d->jit_function != nullptr) {
         // the program as generated straight-line code (evalh_jit.hpp): same outputs, intermediates in registers
         JitArgs ja{};
+        ja.perm_z = d_perm_z;
+        ja.perm_sigma = d_perm_sigma;
+        ja.l0 = (const Fr*)d->l0;
+        ja.l_last = (const Fr*)d->l_last;
+        ja.l_active_row = (const Fr*)d->l_active_row;
+        ja.tw_lo = d->n_perm_sets ? pl->tw_lo : nullptr;
+        ja.tw_hi = d->n_perm_sets ? pl->tw_hi : nullptr;
+        ja.lookup_z = d_lookup_z;
+        ja.lookup_m = d_lookup_m;
+        ja.shuffle_z = d_shuffle_z;
+        ja.delta = fr_from_u64x4(d->delta);
+        ja.delta_start = fp_mul(p.beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
         ja.constants = p.constants;
         ja.fixed = p.fixed;
         ja.advice = p.advice;
@@ -370,16 +399,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
     }
 
-    const int32_t last_rotation = -((int32_t)d->blinding_factors + 1);
     unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
-    if (d->n_perm_sets) {
-        PlanRef pl;  // pinned until the kernels that read its power tables are launched
-        if (have_lock) {
-            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
-        } else {
-            std::lock_guard<std::mutex> g(ctx->mu);
-            pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
-        }
+    if (d->n_perm_sets && !(covers & H2_JIT_PERMUTATION)) {
         PermArgs a{};
         a.values = d_values;
         a.perm_z = d_perm_z;
@@ -404,7 +425,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         hipLaunchKernelGGL(k_evalh_perm, dim3(eblocks), dim3(256), 0, stream, a);
     }
     size_t zoff = 0, slot = 0;
-    for (uint32_t lk = 0; lk < d->n_lookups; lk++) {
+    for (uint32_t lk = 0; lk < d->n_lookups && !(covers & H2_JIT_LOOKUPS); lk++) {
         LookupArgs a{};
         a.values = d_values;
         a.zs = d_lookup_z + zoff;
@@ -422,7 +443,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         zoff += d->lookup_sets[lk];
         slot += 1 + 2 * (size_t)d->lookup_sets[lk];
     }
-    for (uint32_t sh = 0; sh < d->n_shuffles; sh++) {
+    for (uint32_t sh = 0; sh < d->n_shuffles && !(covers & H2_JIT_SHUFFLES); sh++) {
         ShuffleArgs a{};
         a.values = d_values;
         a.z = (const Fr*)d->shuffle_z[sh];

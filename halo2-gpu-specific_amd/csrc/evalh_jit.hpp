@@ -22,6 +22,16 @@ struct JitArgs {
     Fr* sh_out;
     uint32_t extended_k, rot_scale;
     Fr y, beta, gamma, theta;
+    // for kernels that also fold the permutation / lookup / shuffle terms (h2_evalh_desc::jit_covers): the argument
+    // columns of evaluate_h (plonk/evaluation.rs:1004-1219) and the constants of k_evalh_perm
+    const Fr* const* perm_z;
+    const Fr* const* perm_sigma;
+    const Fr *l0, *l_last, *l_active_row;
+    const Fr *tw_lo, *tw_hi;          // extended_omega^i = tw_lo[i & 4095] * tw_hi[i >> 12] (tw_lo[i] alone up to 2^12 points)
+    const Fr* const* lookup_z;
+    const Fr* const* lookup_m;
+    const Fr* const* shuffle_z;
+    Fr delta, delta_start;            // DELTA, beta * ZETA
 };
 
 }  // namespace h2

@@ -9,6 +9,7 @@ from ._lib import check, lib
 VS_CONSTANT, VS_INTERMEDIATE, VS_FIXED, VS_ADVICE, VS_INSTANCE = range(5)
 CALC_ADD, CALC_SUB, CALC_MUL, CALC_NEGATE, CALC_LC_CHALLENGE, CALC_LC_THETA, CALC_ADD_CHALLENGE, CALC_STORE = range(8)
 CHALLENGE_BETA, CHALLENGE_GAMMA = 0, 1
+JIT_PERMUTATION, JIT_LOOKUPS, JIT_SHUFFLES = 1, 2, 4      # h2_evalh_desc::jit_covers
 ANY_ADVICE, ANY_FIXED, ANY_INSTANCE = 0, 1, 2
 
 _u32, _vp = ctypes.c_uint32, ctypes.c_void_p
@@ -43,7 +44,7 @@ class EvalHDesc(ctypes.Structure):
         ("shuffle_z", _vp),
         ("y", _fr), ("beta", _fr), ("gamma", _fr), ("theta", _fr),
         ("delta", _fr), ("zeta", _fr), ("extended_omega", _fr),
-        ("jit_function", _vp),
+        ("jit_function", _vp), ("jit_covers", _u32),
     ]
 
 
@@ -90,7 +91,7 @@ class Builder:
     def build(self, *, k, extended_k, blinding_factors, chunk_len, constants, rotations, calculations, value_parts,
               lookups=(), shuffles=(), fixed=(), advice=(), instance=(), l0=None, l_last=None, l_active_row=None,
               perm_z=(), perm_columns=(), perm_sigma=(), lookup_z=(), lookup_m=(), shuffle_z=(), y, beta, gamma, theta,
-              delta, zeta, extended_omega, jit_function=None):
+              delta, zeta, extended_omega, jit_function=None, jit_covers=0):
         """lookups: list of (table_calc, [product_calcs], [sum_calcs]); shuffles: list of (input_calc, shuffle_calc);
         perm_columns: list of (ANY_*, index)."""
         d = self.desc
@@ -123,6 +124,7 @@ class Builder:
         assert len(lookup_z) == sum(sets) and len(lookup_m) == len(sets) and len(shuffle_z) == len(shuffles)
         d.lookup_z, d.lookup_m, d.shuffle_z = self._ptrs(lookup_z), self._ptrs(lookup_m), self._ptrs(shuffle_z)
         d.jit_function = jit_function
+        d.jit_covers = jit_covers if jit_function else 0
         for name, val in (("y", y), ("beta", beta), ("gamma", gamma), ("theta", theta), ("delta", delta), ("zeta", zeta),
                           ("extended_omega", extended_omega)):
             setattr(d, name, _fr(*[int(x) for x in val]))

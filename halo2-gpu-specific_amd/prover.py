@@ -1034,8 +1034,12 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     # the same program as generated straight-line HIP (jit.py): None = keep the interpreter
     from . import jit
 
-    pk.evalh_code_object = jit.compile_program(pk.graph.rotations, pk.graph.calculations, pk.value_parts,
-                                               pk.lookup_calcs, pk.shuffle_calcs)
+    chunk_ = cs.degree() - 2
+    pk.evalh_code_object, pk.evalh_covers = jit.compile_program(
+        pk.graph.rotations, pk.graph.calculations, pk.value_parts, pk.lookup_calcs, pk.shuffle_calcs,
+        perm=dict(n_sets=(ncols + chunk_ - 1) // chunk_ if ncols else 0, chunk_len=chunk_,
+                  columns=[(_ANY[kd], i) for kd, i in cs.perm_columns], last_rotation=-(bf + 1)))
+    pk.evalh_stats = dict(jit.last_stats, fused=bool(pk.evalh_covers)) if pk.evalh_code_object else None
     pk.transcript_repr = (transcript_repr if transcript_repr is not None else
                           vk_digest(cs, dom, pk.fixed_commitments, pk.perm_commitments))
     D.sync()
@@ -1622,7 +1626,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 shuffle_z=[t.data_ptr() for t in C["shuffle_polys"]],
                 y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
                 delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
-                jit_function=_jit_function(pk))
+                jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0))
             out = D.empty(size)
             check(L.h2_evaluate_h_coeff(ctypes.byref(b.desc), out.data_ptr()), "h2_evaluate_h_coeff")
             mark("evaluate_h")
@@ -1664,7 +1668,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             shuffle_z=[t.data_ptr() for t in shuffle_cosets],
             y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
             delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
-            jit_function=_jit_function(pk))
+            jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0))
         out = D.empty(size)
         check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")
         mark("evaluate_h")

@@ -293,7 +293,11 @@ typedef struct {
     uint64_t delta[4], zeta[4], extended_omega[4]; /* FieldExt::DELTA, ::ZETA, domain.get_extended_omega() */
     /* optional: a kernel generated for exactly this program (h2_jit_load); NULL = the interpreter */
     const void *jit_function;
+    /* what else that kernel computes besides the gate program (it then folds those terms into `values` itself and the
+     * library skips its own kernels for them): H2_JIT_PERMUTATION | H2_JIT_LOOKUPS | H2_JIT_SHUFFLES; 0 = gates only */
+    uint32_t jit_covers;
 } h2_evalh_desc;
+enum { H2_JIT_PERMUTATION = 1, H2_JIT_LOOKUPS = 2, H2_JIT_SHUFFLES = 4 };
 
 /* Host buffers everywhere (descriptor and every pointer in it); values: 2^extended_k Fr out. */
 int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);

@@ -224,6 +224,7 @@ impl<C: CurveAffine> Evaluator<C> {
             zeta: hip::limbs(&C::Scalar::ZETA),
             extended_omega: hip::limbs(&domain.get_extended_omega()),
             jit_function: std::ptr::null(),
+            jit_covers: 0,
         };
         let values: Vec<C::ScalarExt> = hip::evaluate_h(&desc, true);
         Polynomial { values, _marker: PhantomData }
@@ -383,6 +384,7 @@ pub(in crate::plonk) fn evaluate_lc<F: FieldExt, B: Basis>(
         zeta: hip::limbs(&F::ZETA),
         extended_omega: hip::limbs(&omega),
         jit_function: std::ptr::null(),
+        jit_covers: 0,
     };
     hip::evaluate_h(&desc, false)
 }

@@ -54,6 +54,17 @@ def test_generated_kernel_matches_interpreter_and_oracle(oracle, seed, k, ek, kw
     assert path is not None, "hipcc could not build the generated kernel"
     b.desc.jit_function = jit.load(path)
     assert np.array_equal(ev.evaluate_h(b), want)
+    # ... and the whole of evaluate_h as one generated kernel: gate program + permutation / lookup / shuffle terms folded in
+    # registers (h2_evalh_desc::jit_covers), loads value-numbered and issued a group ahead
+    nsets = (len(kw["perm_columns"]) + kw["chunk_len"] - 1) // kw["chunk_len"] if kw["perm_columns"] else 0
+    fused, covers = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
+                                        perm=dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
+                                                  last_rotation=-(kw["blinding_factors"] + 1)))
+    assert fused is not None and fused != path
+    assert covers == ((ev.JIT_PERMUTATION if nsets else 0) | (ev.JIT_LOOKUPS if kw["lookups"] else 0) |
+                      (ev.JIT_SHUFFLES if kw["shuffles"] else 0))
+    b.desc.jit_function, b.desc.jit_covers = jit.load(fused), covers
+    assert np.array_equal(ev.evaluate_h(b), want)
 
 
 @pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),
