@@ -532,6 +532,22 @@ def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
         path = jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles)
         assert path and path.startswith(str(tmp_path)) and __import__("os").path.getsize(path) > 1000
         assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) == path   # cached
+        # the whole of evaluate_h as one kernel: every argument's terms folded in registers, ONE store, each distinct
+        # (column, rotation) loaded once per use window
+        cs = make()
+        chunk = cs.degree() - 2
+        nsets = (len(cs.perm_columns) + chunk - 1) // chunk if cs.perm_columns else 0
+        any_ = {"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}
+        perm = dict(n_sets=nsets, chunk_len=chunk, columns=[(any_[kd], i) for kd, i in cs.perm_columns], last_rotation=-6)
+        fsrc, covers = jit.generate_fused_source(g.rotations, g.calculations, parts, lookups, shuffles, perm)
+        assert fsrc.count("fp_store(") == 1 and "h2_evalh_fused" in fsrc and "lk_out" not in fsrc
+        assert covers == ((ev.JIT_PERMUTATION if nsets else 0) | (ev.JIT_LOOKUPS if lookups else 0) | (ev.JIT_SHUFFLES if shuffles else 0))
+        monkeypatch.setenv("H2_EVALH_FUSED", "1")
+        fpath, fcov = jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles, perm=perm)
+        assert fpath.endswith("_fused.hsaco") and fcov == covers and jit.last_stats["products_per_row"] > 0
+        monkeypatch.setenv("H2_EVALH_FUSED", "0")
+        assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles, perm=perm) == (path, 0)
+        monkeypatch.delenv("H2_EVALH_FUSED")
     monkeypatch.setenv("H2_EVALH_JIT", "0")
     assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) is None
 
