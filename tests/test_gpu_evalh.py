@@ -40,7 +40,7 @@ def test_evaluate_h_k20(oracle):
 @pytest.mark.parametrize("seed,k,ek,kwargs", [
     (1, 2, 3, {}), (2, 5, 7, {}), (4, 10, 12, {}), (6, 13, 13, {}), (7, 6, 8, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=3)),
     (8, 9, 11, dict(lookup_sets=(2,), n_shuffles=1, n_calcs=80)), (9, 16, 18, dict(n_calcs=60))])
-def test_generated_kernel_matches_interpreter_and_oracle(oracle, seed, k, ek, kwargs):
+def test_generated_kernel_matches_interpreter_and_oracle(oracle, monkeypatch, seed, k, ek, kwargs):
     """the gate program as generated straight-line HIP (jit.py -> hipcc --genco -> h2_jit_load -> desc.jit_function):
     every opcode, challenge powers, rotations, the lookup / shuffle result calculations -- same bits as the interpreter
     and as the CPU oracle"""
@@ -57,6 +57,7 @@ def test_generated_kernel_matches_interpreter_and_oracle(oracle, seed, k, ek, kw
     # ... and the whole of evaluate_h as one generated kernel: gate program + permutation / lookup / shuffle terms folded in
     # registers (h2_evalh_desc::jit_covers), loads value-numbered and issued a group ahead
     nsets = (len(kw["perm_columns"]) + kw["chunk_len"] - 1) // kw["chunk_len"] if kw["perm_columns"] else 0
+    monkeypatch.setenv("H2_EVALH_FUSED", "1")        # (by default only programs of up to 64 products per row are fused)
     fused, covers = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
                                         perm=dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
                                                   last_rotation=-(kw["blinding_factors"] + 1)))
