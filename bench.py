@@ -531,6 +531,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pelapsed = float(t[0].item())
         peak_gib = torch.cuda.max_memory_allocated(dev) / 2**30
+        # the same witness handed over COMPACT (every cell of this circuit fits 64 bits: 8 bytes per cell over PCIe instead of
+        # 32, widened on the device) -- the 32-byte form above is the reference's `Vec<Fr>`; same proof bytes
+        compact = None
+        if dist is None:
+            cadv = D.pinned_columns(len(adv), 1 << pk_k, compact=True)
+            for dst, src in zip(cadv, adv):
+                dst[:] = src[:, 0]
+            cproof = prover.create_proof_with_shplonk(D, params, pk, cadv, ProverRng(1))
+            D.sync()
+            c0 = time.perf_counter()
+            for i in range(steps):
+                prover.create_proof_with_shplonk(D, params, pk, cadv, ProverRng(2 + i))
+            D.sync()
+            compact = {"seconds": (time.perf_counter() - c0) / steps, "same_proof_bytes": bool(cproof == proof)}
+            assert cproof == proof, "the compact witness changed the proof"
+            del cadv
         host_api = None
         if dist is None and pk_k <= 22 and not os.environ.get("H2_BENCH_NO_HOST_API"):
             # the LITERAL drop-in's data flow, measured: every polynomial a host vector, every vector operation one
@@ -563,6 +579,7 @@ def main():
                 del hpk, hparams, H
         return {
             "k": pk_k,
+            "compact_witness": compact,
             "host_slice_api": host_api,
             "seconds": pelapsed / steps,
             # the reference times witness synthesis INSIDE create_proof (plonk/prover.rs:1525-1781); here it is a host
