@@ -65,6 +65,7 @@ SYMBOLS = {
     "h2_dev_ntt_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _u32, _vp]),
     "h2_dev_intt_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _vp, _u32, _vp]),
     "h2_dev_coset_ntt_batch": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _u32, _vp, _vp, _vp]),
+    "h2_dev_coeff_to_extended_batch": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "h2_dev_intt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "h2_dev_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "h2_dev_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),

@@ -475,7 +475,7 @@ int h2_dev_coset_ntt(const void* d_coeffs, void* d_out, void* d_tmp, uint32_t lo
 // Several vectors through one plan, up to 16 per launch: d_tmp = min(count, 16) x 2^log_n Fr, shared by the chunks.
 static int dev_ntt_batch_impl(const void* const* srcs, void* const* dsts, size_t count, void* d_tmp, uint32_t log_n,
                               const uint64_t omega[4], const uint64_t* g, const uint64_t* divisor, uint32_t scale_mode,
-                              void* stream, const char* what) {
+                              void* stream, const char* what, uint32_t in_log = 0xffffffffu, const Fr* pre3 = nullptr) {
     if (count == 0) return H2_OK;
     if (!srcs || !dsts || !omega) return bad(what);
     if (log_n > 28) return bad("log_n exceeds the 2-adicity of Fr (S = 28)");
@@ -507,7 +507,8 @@ static int dev_ntt_batch_impl(const void* const* srcs, void* const* dsts, size_t
             out[i] = (Fr*)dsts[i];
             tmp[i] = d_tmp ? (Fr*)d_tmp + (i % 16) * n : nullptr;
         }
-        ntt_run_many(ctx, pl.get(), in.data(), out.data(), tmp.data(), count, (uint32_t)n, nullptr, post, s, tab,
+        const uint32_t in_len = in_log == 0xffffffffu ? (uint32_t)n : (1u << in_log);   // shorter: zero-extended (coeff_to_extended)
+        ntt_run_many(ctx, pl.get(), in.data(), out.data(), tmp.data(), count, in_len, pre3, post, s, tab,
                      tab ? scale_mode : 0u);
         return (int)H2_OK;
     });
@@ -523,6 +524,16 @@ int h2_dev_intt_batch(void* const* d_a, size_t count, void* d_tmp, const uint64_
     if (!divisor) return bad("h2_dev_intt_batch: null argument");
     return dev_ntt_batch_impl((const void* const*)d_a, d_a, count, d_tmp, log_n, omega_inv, nullptr, divisor, 0, stream,
                               "h2_dev_intt_batch: null argument");
+}
+
+int h2_dev_coeff_to_extended_batch(const void* const* d_coeffs, void* const* d_out, size_t count, void* d_tmp, uint32_t k,
+                                   uint32_t extended_k, const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                                   const uint64_t extended_omega[4], void* stream) {
+    if (!g_coset || !g_coset_inv) return bad("h2_dev_coeff_to_extended_batch: null argument");
+    if (extended_k < k) return bad("h2_dev_coeff_to_extended_batch: extended_k < k");
+    const Fr pre3[3] = {fr_from_u64x4(g_coset), fr_from_u64x4(g_coset), fr_from_u64x4(g_coset_inv)};
+    return dev_ntt_batch_impl(d_coeffs, d_out, count, d_tmp, extended_k, extended_omega, nullptr, nullptr, 0, stream,
+                              "h2_dev_coeff_to_extended_batch: null argument", k, pre3);
 }
 
 int h2_dev_coset_ntt_batch(const void* const* d_coeffs, void* const* d_out, size_t count, void* d_tmp, uint32_t log_n,

@@ -79,6 +79,13 @@ class HostSliceLib:
                 return rc
         return 0
 
+    def h2_dev_coeff_to_extended_batch(self, srcs, dsts, count, tmp, k, ek, g, g_inv, ext_omega, stream):
+        for i in range(count):
+            rc = self.h2_dev_coeff_to_extended(srcs[i], dsts[i], None, k, ek, g, g_inv, ext_omega, stream)
+            if rc:
+                return rc
+        return 0
+
     def h2_dev_coeff_to_extended(self, a, out, tmp, k, ek, g, g_inv, ext_omega, stream):
         self._count("h2_coeff_to_extended")
         return self.R.h2_coeff_to_extended(a, out, k, ek, _addr(g), _addr(g_inv), _addr(ext_omega))

@@ -479,24 +479,26 @@ class Device:
         side.wait_event(ready)
         out = []
         with self.torch.cuda.stream(side):
-            for t in cols:
-                c = t.clone()
-                tmp = self.torch.empty_like(c)
-                check(self.L.h2_dev_intt(c.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
-                                         _vp(side.cuda_stream)), "h2_dev_intt")
+            sptr = _vp(side.cuda_stream)
+            out = [t.clone() for t in cols]
+            if len(out) >= 2 and hasattr(self.L, "h2_dev_intt_batch"):
+                tmp = self.torch.empty((min(len(out), 16) * dom.n, 4), dtype=self.torch.int64, device=self.dev)
+                ptrs = (_vp * len(out))(*[c.data_ptr() for c in out])
+                check(self.L.h2_dev_intt_batch(ptrs, len(out), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                               sptr), "h2_dev_intt_batch")
+                tmp.record_stream(self.tstream)
+            else:
+                for c in out:
+                    tmp = self.torch.empty_like(c)
+                    check(self.L.h2_dev_intt(c.data_ptr(), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                             sptr), "h2_dev_intt")
+            for c in out:
                 c.record_stream(self.tstream)
-                out.append(c)
             ext = None
             if extend:
-                ext = []
-                for c in out:
-                    e = self.torch.empty((dom.extended_n, 4), dtype=self.torch.int64, device=self.dev)
-                    tmp = self.torch.empty_like(e)
-                    check(self.L.h2_dev_coeff_to_extended(c.data_ptr(), e.data_ptr(), tmp.data_ptr(), dom.k, dom.extended_k,
-                                                          _fr(dom.g_coset), _fr(dom.g_coset_inv), _fr(dom.extended_omega),
-                                                          _vp(side.cuda_stream)), "h2_dev_coeff_to_extended")
+                ext = self.coeffs_to_extended(out, dom, stream=sptr)
+                for e in ext:
                     e.record_stream(self.tstream)
-                    ext.append(e)
             done = self.torch.cuda.Event()
             done.record(side)
         return out, ext, done
@@ -508,6 +510,27 @@ class Device:
                                               _fr(dom.g_coset), _fr(dom.g_coset_inv), _fr(dom.extended_omega),
                                               self.stream), "h2_dev_coeff_to_extended")
         return out
+
+    def coeffs_to_extended(self, ts, dom, stream=None):
+        """coeff_to_extended of several coefficient vectors: up to 16 per launch while the extended domain is small enough
+        for that to matter (<= 2^23 points: a pass over one vector does not keep the chip busy; the scratch is 16 extended
+        vectors), one by one above"""
+        count = len(ts)
+        if count < 2 or dom.extended_k > 23 or not hasattr(self.L, "h2_dev_coeff_to_extended_batch"):
+            return [self.coeff_to_extended(t, dom) for t in ts]
+        import contextlib
+
+        torch = self.torch
+        # (allocations belong to the stream they are made under: the caller's side stream, or the compute stream)
+        with (torch.cuda.stream(self.tstream) if stream is None else contextlib.nullcontext()):
+            outs = [torch.empty((dom.extended_n, 4), dtype=torch.int64, device=self.dev) for _ in ts]
+            tmp = torch.empty((min(count, 16) * dom.extended_n, 4), dtype=torch.int64, device=self.dev)
+        src = (_vp * count)(*[t.data_ptr() for t in ts])
+        dst = (_vp * count)(*[o.data_ptr() for o in outs])
+        check(self.L.h2_dev_coeff_to_extended_batch(src, dst, count, tmp.data_ptr(), dom.k, dom.extended_k, _fr(dom.g_coset),
+                                                    _fr(dom.g_coset_inv), _fr(dom.extended_omega),
+                                                    self.stream if stream is None else stream), "h2_dev_coeff_to_extended_batch")
+        return outs
 
     def extended_to_coeff(self, t, dom):
         tmp = self.empty(dom.extended_n)
@@ -1312,6 +1335,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # column over PCIe -- exactly the range its share of the commitment needs -- and the ranks complete each other's
     # columns over xGMI afterwards (parallel.allgather_rows): 1 / P of the witness per PCIe link instead of all of it.
     sharded_upload = D.group_size > 1 and n % D.group_size == 0 and n // D.group_size > bf + 1
+    # ... every rank needs every row of an advice column only where something reads whole Lagrange columns: the
+    # theta-compressions of lookups and shuffles (replicated).  Without them (mini-PLONK) a rank keeps its own rows -- all the
+    # permutation terms of its range read -- and a column's rows follow their OWNER for the inverse transform
+    # (Device.intt_columns_begin with complete = False): 1 / P of the all-gather's traffic.
+    whole_advice_rows = bool(cs.lookups or cs.shuffles) or not sharded_upload
     lo_r, hi_r = 0, n
     if sharded_upload:
         from .parallel import allgather_rows, allreduce_max, msm_split_range
@@ -1396,7 +1424,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 points_[i] = g1_add_affine(a_, b_)
         for P in points_:
             transcript.write_point(P)
-        if sharded_upload:
+        if sharded_upload and whole_advice_rows:
             for t in cols_:
                 allgather_rows(t, lo_r, hi_r, group=D.group, stream=D.tstream)
         advice_dev += cols_
@@ -1418,7 +1446,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # P-th column) and the coefficient vectors cross xGMI under the lookup / permutation phases that follow
     advice_arrival = None
     if D.group_size > 1:
-        advice_coeffs, advice_arrival = D.intt_columns_begin(advice_dev, dom, complete=True, keep=True)
+        advice_coeffs, advice_arrival = D.intt_columns_begin(advice_dev, dom, complete=whole_advice_rows, keep=True)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
     for C in circuits:
@@ -1679,7 +1707,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         tables = {"fixed": pk.fixed_cosets, "sigma": pk.sigma_cosets, "l0": pk.l0, "l_last": pk.l_last,
                   "l_active_row": pk.l_active_row}
         from_coeffs = getattr(D, "quotient_from_coeffs", False)
-        h = evaluate_quotient(None if from_coeffs else (lambda ts: [D.coeff_to_extended(t, dom) for t in ts]), tables, ek, ZETA,
+        h = evaluate_quotient(None if from_coeffs else (lambda ts: D.coeffs_to_extended(ts, dom)), tables, ek, ZETA,
                               dom.extended_omega, en)
         # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
         check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),

@@ -361,6 +361,11 @@ int h2_dev_intt_batch(void *const *d_a, size_t count, void *d_tmp, const uint64_
                       uint32_t log_n, void *stream);
 int h2_dev_coset_ntt_batch(const void *const *d_coeffs, void *const *d_out, size_t count, void *d_tmp, uint32_t log_n,
                            const uint64_t g[4], const uint64_t omega[4], void *stream);
+/* `count` coefficient vectors of 2^k elements to the extended domain (h2_dev_coeff_to_extended each); d_out[i] != d_coeffs[i];
+ * d_tmp: min(count, 16) x 2^extended_k Fr. */
+int h2_dev_coeff_to_extended_batch(const void *const *d_coeffs, void *const *d_out, size_t count, void *d_tmp, uint32_t k,
+                                   uint32_t extended_k, const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                                   const uint64_t extended_omega[4], void *stream);
 
 /* ---- device-resident entry points ---------------------------------------------------------- */
 /* Same semantics on HIP device pointers.  d_tmp: scratch of 2^log_n Fr (may be NULL for

@@ -107,6 +107,11 @@ class OracleLib:
             self.h2_dev_coset_ntt(srcs[i], dsts[i], tmp, k, g, omega, stream)
         return 0
 
+    def h2_dev_coeff_to_extended_batch(self, srcs, dsts, count, tmp, k, ek, g, g_inv, ext_omega, stream):
+        for i in range(count):
+            self.h2_dev_coeff_to_extended(srcs[i], dsts[i], tmp, k, ek, g, g_inv, ext_omega, stream)
+        return 0
+
     def h2_dev_intt_batch(self, ptrs, count, tmp, omega_inv, divisor, k, stream):
         for i in range(count):
             self.h2_dev_intt(ptrs[i], tmp, omega_inv, divisor, k, stream)

@@ -751,3 +751,15 @@ def test_batched_transforms_equal_single_ones(oracle, k):
     for i in (0, 7, 15, 16, 18):
         assert np.array_equal(outs[i].cpu().numpy().view(np.uint64), oracle.coeff_to_extended(cols[i], d)[cs::ext_c]), i
         assert np.array_equal(ts[i].cpu().numpy().view(np.uint64), cols[i])
+    # the whole extended domain, zero-padded and zeta-scaled in the first pass: h2_dev_coeff_to_extended_batch
+    if k <= 18:
+        en = 1 << d.extended_k
+        exts = [torch.empty((en, 4), dtype=torch.int64, device=dev) for _ in ts]
+        etmp = torch.empty((16 * en, 4), dtype=torch.int64, device=dev)
+        eptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in exts])
+        torch.cuda.synchronize()
+        check(L.h2_dev_coeff_to_extended_batch(ptrs, eptrs, count, etmp.data_ptr(), d.k, d.extended_k, vp(d.fr("g_coset")),
+                                               vp(d.fr("g_coset_inv")), vp(d.fr("extended_omega")), None), "h2_dev_coeff_to_extended_batch")
+        torch.cuda.synchronize()
+        for i in (0, 15, 16, 18):
+            assert np.array_equal(exts[i].cpu().numpy().view(np.uint64), oracle.coeff_to_extended(cols[i], d)), i
