@@ -39,6 +39,7 @@ struct EvalhProgram {  // everything the kernels need, device pointers
     const Fr* const* instance;
     uint32_t n_calcs, n_value_parts, n_lookups, n_shuffles;
     uint32_t extended_k, rot_scale;
+    size_t row_begin, row_end;   // rows to evaluate
     Fr y, beta, gamma, theta;
 };
 
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) k_evalh_expr(EvalhProgram p, Fr* inter, F
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr* my = inter + t;
-    for (size_t idx = t; idx < size; idx += nthreads) {
+    for (size_t idx = p.row_begin + t; idx < p.row_end; idx += nthreads) {
         Interp in{p, my, nthreads, idx};
         for (uint32_t i = 0; i < p.n_calcs; i++) {
             Fr r = in.eval(p.calcs[i]);
@@ -125,6 +126,7 @@ struct PermArgs {
     const Fr *tw_lo, *tw_hi;      // extended_omega^i tables (NTT plan)
     uint32_t n_sets, n_columns, chunk_len, extended_k, rot_scale;
     int32_t last_rotation;
+    size_t row_begin, row_end;
     Fr y, beta, gamma, delta, delta_start;  // delta_start = beta * ZETA
 };
 
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) k_evalh_perm(PermArgs a) {
     const size_t size = (size_t)1 << a.extended_k;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const Fr one = fp_one<FrParams>();
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+    for (size_t idx = a.row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.row_end; idx += stride) {
         const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
         const size_t r_last = rot_idx(idx, a.last_rotation, a.rot_scale, a.extended_k);
         Fr value = fp_load(a.values + idx);
@@ -182,13 +184,14 @@ struct LookupArgs {
     const Fr *l0, *l_last, *l_active_row;
     uint32_t sets_len, extended_k, rot_scale;
     int32_t last_rotation;
+    size_t row_begin, row_end;
     Fr y;
 };
 
 __global__ void __launch_bounds__(256) k_evalh_lookup(LookupArgs a) {
     const size_t size = (size_t)1 << a.extended_k;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+    for (size_t idx = a.row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.row_end; idx += stride) {
         const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
         const size_t r_last = rot_idx(idx, a.last_rotation, a.rot_scale, a.extended_k);
         Fr value = fp_load(a.values + idx);
@@ -224,6 +227,7 @@ struct ShuffleArgs {
     const Fr *input, *shuffle;
     const Fr *l0, *l_last, *l_active_row;
     uint32_t extended_k, rot_scale;
+    size_t row_begin, row_end;
     Fr y;
 };
 
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(256) k_evalh_shuffle(ShuffleArgs a) {
     const size_t size = (size_t)1 << a.extended_k;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const Fr one = fp_one<FrParams>();
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < size; idx += stride) {
+    for (size_t idx = a.row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.row_end; idx += stride) {
         const size_t r_next = rot_idx(idx, 1, a.rot_scale, a.extended_k);
         Fr value = fp_load(a.values + idx);
         const Fr z = fp_load(a.z + idx);
@@ -277,6 +281,12 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     }
     const size_t size = (size_t)1 << d->extended_k;
     const uint32_t rot_scale = 1u << (d->extended_k - d->k);
+    if ((size_t)d->row_begin + d->row_count > size) {
+        set_last_error("h2_evaluate_h: row range outside the domain");
+        return H2_ERR_INVALID;
+    }
+    const size_t row_begin = d->row_count ? d->row_begin : 0, row_end = d->row_count ? (size_t)d->row_begin + d->row_count : size;
+    const size_t rows = row_end - row_begin;
 
     // ---- stage the program and pointer tables (a few KB) into one device block
     size_t n_lookup_calcs = 0, n_lookup_z = 0;
@@ -348,6 +358,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     p.n_shuffles = d->n_shuffles;
     p.extended_k = d->extended_k;
     p.rot_scale = rot_scale;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
     p.y = fr_from_u64x4(d->y);
     p.beta = fr_from_u64x4(d->beta);
     p.gamma = fr_from_u64x4(d->gamma);
@@ -378,6 +390,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         ja.shuffle_z = d_shuffle_z;
         ja.delta = fr_from_u64x4(d->delta);
         ja.delta_start = fp_mul(p.beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
+        ja.row_begin = row_begin;
+        ja.row_end = row_end;
         ja.constants = p.constants;
         ja.fixed = p.fixed;
         ja.advice = p.advice;
@@ -393,15 +407,17 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         ja.theta = p.theta;
         void* kargs[] = {&ja};
         // one grid over the whole domain (poly.hip grid_for: neighbouring DRAM pages instead of all of them at once)
-        const unsigned jblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
+        const unsigned jblocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
         H2_HIP(hipModuleLaunchKernel((hipFunction_t)d->jit_function, jblocks, 1, 1, 256, 1, 1, 0, stream, kargs, nullptr));
     } else {
         hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
     }
 
-    unsigned eblocks = (unsigned)std::min<size_t>((size + 255) / 256, 0x7fffffffu);
+    unsigned eblocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
     if (d->n_perm_sets && !(covers & H2_JIT_PERMUTATION)) {
         PermArgs a{};
+        a.row_begin = row_begin;
+        a.row_end = row_end;
         a.values = d_values;
         a.perm_z = d_perm_z;
         a.perm_cols = d_perm_cols;
@@ -427,6 +443,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     size_t zoff = 0, slot = 0;
     for (uint32_t lk = 0; lk < d->n_lookups && !(covers & H2_JIT_LOOKUPS); lk++) {
         LookupArgs a{};
+        a.row_begin = row_begin;
+        a.row_end = row_end;
         a.values = d_values;
         a.zs = d_lookup_z + zoff;
         a.m = (const Fr*)d->lookup_m[lk];
@@ -445,6 +463,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     }
     for (uint32_t sh = 0; sh < d->n_shuffles && !(covers & H2_JIT_SHUFFLES); sh++) {
         ShuffleArgs a{};
+        a.row_begin = row_begin;
+        a.row_end = row_end;
         a.values = d_values;
         a.z = (const Fr*)d->shuffle_z[sh];
         a.input = d_sh + (size_t)(2 * sh) * size;
@@ -466,6 +486,10 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
 int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
     if (!d || !values) {
         set_last_error("h2_evaluate_h: null argument");
+        return H2_ERR_INVALID;
+    }
+    if (d->row_count) {
+        set_last_error("h2_evaluate_h: a row range is for the device entry point (h2_dev_evaluate_h)");
         return H2_ERR_INVALID;
     }
     const size_t size = (size_t)1 << d->extended_k, bytes = size * sizeof(Fr);
@@ -549,6 +573,10 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
     }
     if (d->extended_k < d->k || d->extended_k > 28) {
         set_last_error("h2_evaluate_h_coeff: bad k / extended_k");
+        return H2_ERR_INVALID;
+    }
+    if (d->row_count) {
+        set_last_error("h2_evaluate_h_coeff: a row range is for the device entry point (h2_dev_evaluate_h)");
         return H2_ERR_INVALID;
     }
     const uint32_t log_c = d->extended_k - d->k, c = 1u << log_c;

@@ -32,6 +32,7 @@ struct JitArgs {
     const Fr* const* lookup_m;
     const Fr* const* shuffle_z;
     Fr delta, delta_start;            // DELTA, beta * ZETA
+    size_t row_begin, row_end;        // the rows to evaluate (h2_evalh_desc::row_begin / row_count; the whole domain by default)
 };
 
 }  // namespace h2

@@ -44,7 +44,7 @@ class EvalHDesc(ctypes.Structure):
         ("shuffle_z", _vp),
         ("y", _fr), ("beta", _fr), ("gamma", _fr), ("theta", _fr),
         ("delta", _fr), ("zeta", _fr), ("extended_omega", _fr),
-        ("jit_function", _vp), ("jit_covers", _u32),
+        ("jit_function", _vp), ("jit_covers", _u32), ("row_begin", _u32), ("row_count", _u32),
     ]
 
 
@@ -91,7 +91,7 @@ class Builder:
     def build(self, *, k, extended_k, blinding_factors, chunk_len, constants, rotations, calculations, value_parts,
               lookups=(), shuffles=(), fixed=(), advice=(), instance=(), l0=None, l_last=None, l_active_row=None,
               perm_z=(), perm_columns=(), perm_sigma=(), lookup_z=(), lookup_m=(), shuffle_z=(), y, beta, gamma, theta,
-              delta, zeta, extended_omega, jit_function=None, jit_covers=0):
+              delta, zeta, extended_omega, jit_function=None, jit_covers=0, row_begin=0, row_count=0):
         """lookups: list of (table_calc, [product_calcs], [sum_calcs]); shuffles: list of (input_calc, shuffle_calc);
         perm_columns: list of (ANY_*, index)."""
         d = self.desc
@@ -125,6 +125,7 @@ class Builder:
         d.lookup_z, d.lookup_m, d.shuffle_z = self._ptrs(lookup_z), self._ptrs(lookup_m), self._ptrs(shuffle_z)
         d.jit_function = jit_function
         d.jit_covers = jit_covers if jit_function else 0
+        d.row_begin, d.row_count = row_begin, row_count
         for name, val in (("y", y), ("beta", beta), ("gamma", gamma), ("theta", theta), ("delta", delta), ("zeta", zeta),
                           ("extended_omega", extended_omega)):
             setattr(d, name, _fr(*[int(x) for x in val]))

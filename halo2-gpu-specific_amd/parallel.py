@@ -277,6 +277,59 @@ def exchange_cosets(mine, c, shards, group=None, stream=None):
     return out
 
 
+# ---- several ranks per coset: columns dealt for the transforms, rows dealt for the evaluator --------------------------------
+# With P ranks and c < P cosets (P a multiple of c) the G = P / c ranks that share coset j used to do the same work G times
+# over.  Instead member g of the coset's rank group takes EVERY G-th column to the coset (n-point coset transforms), the
+# members exchange row slices -- member g receives the rows [g n / G - halo, (g + 1) n / G + halo) of every column, the halo
+# being the rotations the evaluator reads -- and each evaluates the quotient on its n / G rows (h2_evalh_desc::row_begin /
+# row_count); the rows of the quotient are all-gathered inside the group for the inverse transform.
+def slice_rows(n, G, g, halo_lo, halo_hi, device):
+    """indices (modulo n) of the rows member g of a G-member coset group evaluates, with the halo the rotations reach"""
+    import torch
+
+    m = n // G
+    return torch.arange(g * m - halo_lo, (g + 1) * m + halo_hi, device=device, dtype=torch.int64) % n
+
+
+def exchange_row_slices(columns, owners, n, G, g, halo_lo, halo_hi, group=None, stream=None):
+    """`columns[i]`: an (n, 4) device tensor, complete on member owners[i] of the group (any content elsewhere).  On return
+    every member holds, in every column, the rows `slice_rows(n, G, g, ...)` of ITS slice (its own columns stay complete).
+    RCCL: one all-to-all over xGMI; gloo: one scatter per member through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    device = columns[0].device
+    rows = {m: slice_rows(n, G, m, halo_lo, halo_hi, device) for m in range(G)}
+    per = rows[0].shape[0]
+    mine = [i for i, o in enumerate(owners) if o == g]
+    theirs = {m: [i for i, o in enumerate(owners) if o == m] for m in range(G)}
+    with _on_stream(stream):
+        send = [torch.cat([columns[i].index_select(0, rows[m]) for i in mine]) if mine and m != g else
+                torch.empty((0, 4), dtype=columns[0].dtype, device=device) for m in range(G)]
+        recv = [torch.empty((per * len(theirs[m]) if m != g else 0, 4), dtype=columns[0].dtype, device=device) for m in range(G)]
+        if _backend(group) == "nccl":
+            dist.all_to_all(recv, send, group=group)
+        else:
+            for src in range(G):
+                if not theirs[src]:                  # a member without columns (fewer columns than members) sends nothing
+                    continue
+                gsrc = dist.get_global_rank(group, src) if group is not None else src
+                if src == g:
+                    parts = [t.cpu() for t in send]
+                    parts[g] = torch.zeros((per * len(mine), 4), dtype=columns[0].dtype)   # (gloo scatters equal sizes)
+                    dist.scatter(torch.empty_like(parts[g]), scatter_list=parts, src=gsrc, group=group)
+                else:
+                    buf = torch.empty((recv[src].shape[0], 4), dtype=columns[0].dtype)
+                    dist.scatter(buf, scatter_list=None, src=gsrc, group=group)
+                    recv[src] = buf.to(device)
+        for m in range(G):
+            if m == g:
+                continue
+            for k_, i in enumerate(theirs[m]):
+                columns[i].index_copy_(0, rows[g], recv[m][k_ * per:(k_ + 1) * per])
+    return columns
+
+
 # ---- index-range sharding of the O(n) passes (DESIGN.md section 6 (c)) --------------------------------------------------
 # Every rank holds the same full-size vectors and works on the rows / coefficients [lo, hi) of its contiguous range (the
 # range its share of every range-split MSM consumes).  Elementwise passes and linear combinations need nothing else; the

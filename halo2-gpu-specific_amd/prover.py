@@ -420,6 +420,40 @@ class Device:
     def column_owner(self, i):
         return i % self.group_size
 
+    def coset_rank_group(self, c):
+        """(group, members G, this rank's member index) of the ranks that share this rank's coset when the P ranks are a
+        multiple G >= 2 of the c cosets (rank r evaluates coset r mod c; its group is {j, j + c, j + 2 c, ...}), else None.
+        Creating the groups is collective: every rank creates all c of them, in order, the first time a circuit with c
+        cosets is proved (cached)."""
+        P = self.group_size
+        if P <= 1 or c < 1 or P % c or P // c < 2 or self.group is not None or os.environ.get("H2_COSET_GROUPS") == "0":
+            return None
+        cache = self.__dict__.setdefault("_coset_groups", {})
+        if c not in cache:
+            import torch.distributed as dist
+
+            G = P // c
+            groups = [dist.new_group(ranks=[j + c * m for m in range(G)]) for j in range(c)]
+            cache[c] = (groups[self.group_rank % c], G, self.group_rank // c)
+        return cache[c]
+
+    def coeffs_to_coset_rows(self, polys, dom, j, sub, halo):
+        """the values of `polys` on coset j where THIS member of the coset's rank group needs them: member g transforms
+        every G-th column (batched coset transforms) and the members exchange row slices (parallel.exchange_row_slices);
+        returns full-size vectors valid on this member's rows and their halo"""
+        from .parallel import exchange_row_slices
+
+        group, G, g = sub
+        count = len(polys)
+        if count == 0:
+            return []
+        owners = [i % G for i in range(count)]
+        done = self.coeffs_to_coset([p for p, o in zip(polys, owners) if o == g], dom, j)
+        it = iter(done)
+        cols = [next(it) if o == g else self.empty(dom.n) for o in owners]
+        exchange_row_slices(cols, owners, dom.n, G, g, halo[0], halo[1], group=group, stream=self.tstream)
+        return cols
+
     def intt_columns_begin(self, cols, dom, complete=True, keep=False):
         """lagrange_to_coeff of whole columns dealt round-robin over the ranks -- north_star's per-column NTT sharding
         (plonk/prover.rs:643-646 runs them as a par_iter) -- instead of every rank transforming every column: rank
@@ -1627,14 +1661,19 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                          sum(2 * len(st["z_polys"]) + 1 for st in circuits[0]["lookups"]) + 3 * len(circuits[0]["shuffle_polys"]))
     y_step = pow(y, terms_per_circuit, R_MOD)
 
-    def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size):
+    def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size, rows=None):
+        """`rows` = (first, count): only these rows of the domain are evaluated (and valid in the result)"""
         total = None
+        lo_, cnt_ = rows if rows is not None else (0, size)
         for C in circuits:
-            h_c = evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size)
-            total = h_c if total is None else D.eval_op(5, total, total, h_c, c=y_step)     # H2_OP_LCTHETA: l * c + r
+            h_c = evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows)
+            if total is None:
+                total = h_c
+            else:                                                                           # H2_OP_LCTHETA: l * c + r
+                D.eval_op(5, total[lo_:lo_ + cnt_], total[lo_:lo_ + cnt_], h_c[lo_:lo_ + cnt_], c=y_step, size=cnt_)
         return total
 
-    def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size):
+    def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows=None):
         """the fused evaluator over one evaluation domain: `points_of` maps a list of coefficient vectors to their values there"""
         lookups = C["lookups"]
         if points_of is None:
@@ -1696,7 +1735,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             shuffle_z=[t.data_ptr() for t in shuffle_cosets],
             y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
             delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
-            jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0))
+            jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0),
+            row_begin=rows[0] if rows is not None else 0, row_count=rows[1] if rows is not None else 0)
         out = D.empty(size)
         check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")
         mark("evaluate_h")
@@ -1724,10 +1764,28 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
         c, shards, owned = plan
         mine = {}
+        # More ranks than cosets (a multiple G of them): the G ranks of a coset share its work instead of repeating it --
+        # every G-th column's coset transform each, row slices exchanged, the evaluator on n / G rows each, the quotient's
+        # rows all-gathered inside the group (parallel.exchange_row_slices)
+        sub = D.coset_rank_group(c)
+        used_rots = list(g.rotations) + ([0, 1, last_rot] if (nsets or circuits[0]["lookups"] or circuits[0]["shuffle_polys"]) else [0])
+        halo = (max(0, -min(used_rots)), max(0, max(used_rots)))
+        if sub is not None and (n % sub[1] or n // sub[1] <= halo[0] + halo[1] + 1):
+            sub = None
         for j in owned:
             g_j = ZETA * pow(dom.extended_omega, j, R_MOD) % R_MOD
-            h_j = evaluate_quotient(lambda ts, j=j: D.coeffs_to_coset(ts, dom, j), coset_tabs[j], dom.k, g_j, dom.omega, n)
-            D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
+            if sub is None:
+                h_j = evaluate_quotient(lambda ts, j=j: D.coeffs_to_coset(ts, dom, j), coset_tabs[j], dom.k, g_j, dom.omega, n)
+                D.eval_op(0, h_j, h_j, c=dom.t_evaluations[j % len(dom.t_evaluations)])      # H2_OP_MUL_C: / (gamma_j - 1)
+            else:
+                from .parallel import allgather_rows
+
+                m_g = n // sub[1]
+                lo_g = sub[2] * m_g
+                h_j = evaluate_quotient(lambda ts, j=j: D.coeffs_to_coset_rows(ts, dom, j, sub, halo), coset_tabs[j], dom.k, g_j,
+                                        dom.omega, n, rows=(lo_g, m_g))
+                D.eval_op(0, h_j[lo_g:lo_g + m_g], h_j[lo_g:lo_g + m_g], c=dom.t_evaluations[j % len(dom.t_evaluations)], size=m_g)
+                allgather_rows(h_j, lo_g, lo_g + m_g, group=sub[0], stream=D.tstream)
             mine[j] = D.coset_to_coeff(h_j, dom, j)
         # Everything after the quotient -- the un-mixing, the h pieces' commitments, the evaluations, the multiopen argument --
         # works on coefficient RANGES (Device.row_range): a rank needs only its own n / P coefficients of every coset

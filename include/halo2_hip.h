@@ -296,6 +296,11 @@ typedef struct {
     /* what else that kernel computes besides the gate program (it then folds those terms into `values` itself and the
      * library skips its own kernels for them): H2_JIT_PERMUTATION | H2_JIT_LOOKUPS | H2_JIT_SHUFFLES; 0 = gates only */
     uint32_t jit_covers;
+    /* rows of the domain to evaluate: `values[row_begin .. row_begin + row_count)` are written, nothing else (row_count = 0:
+     * the whole domain).  Column values are still read at rotated indices modulo the domain, so the rows
+     * [row_begin - (blinding_factors + 1) * rot_scale ..., row_begin + row_count + max rotation * rot_scale) of every column
+     * must be valid.  For callers that split one evaluation over several devices by row range. */
+    uint32_t row_begin, row_count;
 } h2_evalh_desc;
 enum { H2_JIT_PERMUTATION = 1, H2_JIT_LOOKUPS = 2, H2_JIT_SHUFFLES = 4 };
 

@@ -225,6 +225,8 @@ impl<C: CurveAffine> Evaluator<C> {
             extended_omega: hip::limbs(&domain.get_extended_omega()),
             jit_function: std::ptr::null(),
             jit_covers: 0,
+            row_begin: 0,
+            row_count: 0,
         };
         let values: Vec<C::ScalarExt> = hip::evaluate_h(&desc, true);
         Polynomial { values, _marker: PhantomData }
@@ -385,6 +387,8 @@ pub(in crate::plonk) fn evaluate_lc<F: FieldExt, B: Basis>(
         extended_omega: hip::limbs(&omega),
         jit_function: std::ptr::null(),
         jit_covers: 0,
+        row_begin: 0,
+        row_count: 0,
     };
     hip::evaluate_h(&desc, false)
 }

@@ -120,6 +120,8 @@ pub struct H2EvalhDesc {
     pub extended_omega: [u64; 4],
     pub jit_function: *const c_void,
     pub jit_covers: u32,
+    pub row_begin: u32,
+    pub row_count: u32,
 }
 
 /// (field, byte offset) of `h2_evalh_desc` on the LP64 ABI both sides are built for; checked against the C header by
@@ -169,8 +171,10 @@ pub const H2_EVALH_DESC_OFFSETS: &[(&str, usize)] = &[
     ("extended_omega", 448),
     ("jit_function", 480),
     ("jit_covers", 488),
+    ("row_begin", 492),
+    ("row_count", 496),
 ];
-pub const H2_EVALH_DESC_SIZE: usize = 496;
+pub const H2_EVALH_DESC_SIZE: usize = 504;
 pub const H2_VALUE_SOURCE_SIZE: usize = 12;
 pub const H2_CALCULATION_SIZE: usize = 36;
 

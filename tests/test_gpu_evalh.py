@@ -114,3 +114,56 @@ def test_host_lincomb(oracle):
     ptrs = (ctypes.c_void_p * count)(*[p.ctypes.data for p in polys])
     assert h2.lib().h2_lincomb(res.ctypes.data, ptrs, coeffs.ctypes.data, count, n) == 0
     assert np.array_equal(res, want)
+
+
+@pytest.mark.parametrize("seed,k,ek", [(41, 6, 8), (42, 10, 12), (43, 13, 14)])
+def test_row_ranges_of_the_device_evaluator(oracle, monkeypatch, seed, k, ek):
+    """h2_evalh_desc::row_begin / row_count (one evaluation split over several devices by row range): the interpreter, the
+    generated gate kernel with the library's argument kernels, and the fused generated kernel write exactly the rows asked
+    for -- the oracle's values there, the buffer untouched elsewhere -- for ranges at the start, across the wrap of the
+    rotations, a single row and the whole domain"""
+    import ctypes
+
+    import torch
+
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import jit
+    from halo2_gpu_specific_amd._lib import check
+
+    kw = random_case(seed, k, ek, oracle, n_calcs=30, lookup_sets=(1, 2), n_shuffles=1)
+    want = oracle_evaluate_h(oracle, ev.Builder().build(**kw))
+    size = 1 << ek
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)  # noqa: E731
+    names = ("fixed", "advice", "instance", "perm_z", "perm_sigma", "lookup_z", "lookup_m", "shuffle_z")
+    tensors = {name: [up(c) for c in kw[name]] for name in names}
+    singles = {name: up(kw[name]) for name in ("l0", "l_last", "l_active_row")}
+    dkw = dict(kw)
+    for name in names:
+        dkw[name] = [t.data_ptr() for t in tensors[name]]
+    for name in singles:
+        dkw[name] = singles[name].data_ptr()
+    nsets = (len(kw["perm_columns"]) + kw["chunk_len"] - 1) // kw["chunk_len"]
+    path = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"])
+    monkeypatch.setenv("H2_EVALH_FUSED", "1")
+    fused, covers = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
+                                        perm=dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
+                                                  last_rotation=-(kw["blinding_factors"] + 1)))
+    L = h2.lib()
+    sentinel = 0x5A5A5A5A5A5A5A5A
+    for fn, cov in ((None, 0), (jit.load(path), 0), (jit.load(fused), covers)):
+        for lo, cnt in ((0, size // 4), (size - 5, 5), (size // 2 - 3, 1), (7, size - 7), (0, 0)):
+            b = ev.Builder().build(**dkw, jit_function=fn, jit_covers=cov, row_begin=lo, row_count=cnt)
+            out = torch.full((size, 4), sentinel, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), None), "h2_dev_evaluate_h")
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+            hi = lo + cnt if cnt else size
+            lo_ = lo if cnt else 0
+            assert np.array_equal(got[lo_:hi], want[lo_:hi]), (fn is not None, cov, lo, cnt)
+            rest = np.concatenate([got[:lo_], got[hi:]])
+            assert (rest == np.uint64(sentinel)).all(), "rows outside the range were written"
+    # the host-buffer entry points take no row range
+    bad = ev.Builder().build(**kw, row_begin=0, row_count=4)
+    assert L.h2_evaluate_h(ctypes.byref(bad.desc), np.zeros((size, 4), dtype=np.uint64).ctypes.data) != 0

@@ -296,7 +296,8 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
 @pytest.mark.parametrize("world,which,k", [(2, "mini", 10), (2, "mini", 17), (4, "mini", 12), (8, "mini", 10), (2, "lookup", 9),
                                            (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8),
                                            (2, "fuzz:201", 8), (4, "fuzz:202", 8), (3, "fuzz:203", 8), (2, "fuzz:204", 9),
-                                           (4, "fuzz:205", 9), (8, "fuzz:206", 9)])
+                                           (4, "fuzz:205", 9), (8, "fuzz:206", 9), (8, "wide", 9), (8, "mini", 12),
+                                           (8, "fuzz:207", 9), (4, "fuzz:208", 10)])
 def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
     """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
@@ -305,7 +306,9 @@ def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp
     Kate division.  Every rank must emit the single-device proof, for the mini-PLONK circuit, the lookup + shuffle +
     instance circuit (degree 6: 5 cosets over 2 or 4 ranks), the wide circuit (degree 5, eight grand sums) and random
     satisfied circuits (tools/prover_fuzz.py: gates with rotations -2 .. 2 reaching across the ranks' row ranges, lookups
-    with two input sets, shuffles, instance columns)."""
+    with two input sets, shuffles, instance columns).  With more ranks than cosets (8 or 4 ranks over the 2 cosets of
+    mini-PLONK, 8 over the 4 of the wide circuit) the ranks of a coset deal its columns for the coset transforms, exchange row
+    slices with the rotations' halo and evaluate the quotient on a row range each (parallel.exchange_row_slices)."""
     import subprocess
     import sys
 

@@ -182,3 +182,75 @@ def test_range_sharded_scans_division_evaluation_world2(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert "OK %d" % rank in out
+
+
+COLUMN_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from halo2_gpu_specific_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+gen = torch.Generator(); gen.manual_seed(77)                      # every rank draws the same reference data
+n, ncols = 96 * world, 5
+ref = [torch.randint(-2**62, 2**62, (n, 4), dtype=torch.int64, generator=gen) for _ in range(ncols)]
+lo, hi = parallel.msm_split_range(n, world, rank)
+# ---- rows computed by ranges go to the column's owner only (parallel.gather_rows_to)
+for i, full in enumerate(ref):
+    owner = i %% world
+    t = torch.zeros_like(full); t[lo:hi] = full[lo:hi]
+    parallel.gather_rows_to(t, lo, hi, owner)
+    if rank == owner:
+        assert torch.equal(t, full), ("gather_rows_to", i)
+    else:
+        assert torch.equal(t[lo:hi], full[lo:hi]) and not t[:lo].any() and not t[hi:].any()
+# ---- whole columns from their owners to everybody (parallel.broadcast_columns_begin; gloo: complete on return)
+cols = [full.clone() if i %% world == rank else torch.zeros_like(full) for i, full in enumerate(ref)]
+arrival = parallel.broadcast_columns_begin(cols, [i %% world for i in range(ncols)])
+arrival.wait()
+assert all(torch.equal(a, b) for a, b in zip(cols, ref)), "broadcast_columns_begin"
+# ---- the ranks of one coset: columns dealt for the transforms, row slices (with the rotations' halo, wrapping around the
+# domain) exchanged so that every member holds ITS rows of EVERY column (parallel.exchange_row_slices)
+G, g = world, rank
+for ncol, halo in ((5, (6, 1)), (2, (0, 0)), (7, (3, 2))):        # 2 columns over 3 members: one member owns none
+    owners = [i %% G for i in range(ncol)]
+    data = [torch.randint(-2**62, 2**62, (n, 4), dtype=torch.int64, generator=gen) for _ in range(ncol)]
+    mine = [d.clone() if o == g else torch.full_like(d, -7) for d, o in zip(data, owners)]
+    parallel.exchange_row_slices(mine, owners, n, G, g, halo[0], halo[1])
+    rows = parallel.slice_rows(n, G, g, halo[0], halo[1], torch.device("cpu"))
+    assert rows.shape[0] == n // G + halo[0] + halo[1] and int(rows[0]) == (g * (n // G) - halo[0]) %% n
+    for i, (got, want, o) in enumerate(zip(mine, data, owners)):
+        assert torch.equal(got[rows], want[rows]), ("exchange_row_slices", ncol, i)
+        if o == g:
+            assert torch.equal(got, want)
+        else:
+            other = torch.ones(n, dtype=torch.bool); other[rows] = False
+            assert (got[other] == -7).all(), "rows outside the slice were written"
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def _run_workers(tmp_path, text, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(text % {"root": ROOT})
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "OK %d" % rank in out
+
+
+def test_columns_dealt_over_the_ranks_world2_and_world3(tmp_path):
+    """round 4's exchanges: the rows of a range-computed column gathered to its owner, whole coefficient columns broadcast from
+    their owners, and -- inside the rank group of one coset -- row slices with the evaluator's halo, including the wrap around
+    the domain and a member that owns no column; two and three gloo ranks"""
+    _run_workers(tmp_path, COLUMN_WORKER, 2)
+    _run_workers(tmp_path, COLUMN_WORKER, 3)
