@@ -440,6 +440,9 @@ pk = prover.keygen(D, params, cs, fixed, copies)
 # the O(n) passes really are range-sharded (a world that does not divide 2^k keeps them replicated: uneven MSM ranges only)
 assert (D.row_range(1 << k) != (0, 1 << k)) == ((1 << k) %% dist.get_world_size() == 0)
 proof = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), False, instances=inst)
+# more ranks than cosets (a multiple of them): the ranks of a coset really shared its work (coset rank groups)
+c_, w_ = pk.domain.quotient_poly_degree, dist.get_world_size()
+assert bool(getattr(D, "_coset_groups", {})) == (w_ %% c_ == 0 and w_ // c_ >= 2), (c_, w_)
 sys.stdout.write("PROOF " + proof.hex() + "\n")
 gwc = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), True, instances=inst)
 sys.stdout.write("GWC " + gwc.hex() + "\n")
@@ -552,6 +555,12 @@ for rep in range(3):
     got = parallel.exchange_cosets(mine, 3, 1, stream=stream)
     stream.synchronize()
     assert all(torch.equal(got[j], want + j) for j in range(3)), "exchange_cosets"
+    # the coset rank group's row-slice exchange (all-to-all under RCCL): one member keeps its columns, nothing moves
+    for _ in range(2):
+        keep = [want.clone(), want.clone() + 1]
+        parallel.exchange_row_slices(keep, [0, 0], n, 1, 0, 6, 1, stream=stream)
+        stream.synchronize()
+        assert torch.equal(keep[0], want) and torch.equal(keep[1], want + 1), "exchange_row_slices"
     assert parallel.allreduce_max([3, 254, rep], device=dev) == [3, 254, rep]
     vals = [(1 << 200) + rep, 7, 0]
     assert parallel.allgather_scalars(vals, device=dev) == [vals]
