@@ -812,8 +812,10 @@ def sharding_description(device):
             "coset of the n-th roots of unity, the per-coset quotients scattered as coefficient ranges; the O(n) passes of the "
             "permutation / lookup / shuffle products (terms, batch inversion, prefix scans), the evaluations and the multiopen "
             "argument (linear combinations, Kate divisions) on the rank's row / coefficient range, one field element per rank "
-            "exchanged per scan / division / evaluation batch; witness-dependent inverse transforms replicated"
-            % device.group_size)
+            "exchanged per scan / division / evaluation batch; witness-dependent inverse transforms dealt by column (rows to "
+            "the owner, coefficient vectors broadcast on a second communicator and a side stream); with more ranks than cosets "
+            "the ranks of a coset deal its columns for the coset transforms, exchange row slices and evaluate the quotient by "
+            "row range" % device.group_size)
 
 
 def _forget_tables(L, ptrs):
