@@ -911,6 +911,24 @@ int h2_dev_prefix_sum(const void* d_f, size_t n, const uint64_t init[4], void* d
 
 size_t h2_logup_scratch_bytes(size_t n) { return logup_scratch_bytes(n); }
 
+int h2_dev_logup_counts(const void* d_table, const void* const* d_inputs, size_t n_inputs, size_t usable_rows, size_t n,
+                        size_t row_begin, size_t row_end, void* d_counts, void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (!d_table || !d_counts || !d_scratch || (n_inputs && !d_inputs)) return bad("h2_dev_logup_counts: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return logup_counts_launch((const Fr*)d_table, (const Fr* const*)d_inputs, n_inputs, usable_rows, n, row_begin, row_end,
+                                   (uint32_t*)d_counts, d_scratch, scratch_bytes, pick_stream(ctx, stream));
+    });
+}
+
+int h2_dev_logup_emit(const void* d_counts, size_t usable_rows, size_t n, void* d_m, void* stream) {
+    if (!d_counts || !d_m) return bad("h2_dev_logup_emit: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        return logup_emit_launch((const uint32_t*)d_counts, usable_rows, n, (Fr*)d_m, pick_stream(ctx, stream));
+    });
+}
+
 int h2_dev_logup_multiplicity(const void* d_table, const void* const* d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void* d_m, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!d_table || !d_m || !d_scratch || (n_inputs && !d_inputs)) return bad("h2_dev_logup_multiplicity: null argument");

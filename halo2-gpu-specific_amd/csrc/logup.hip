@@ -50,9 +50,9 @@ __global__ void __launch_bounds__(256) k_logup_build(const Fr* table, uint32_t u
 
 // One lane per (input column, row).  count[row hit] += 1, aggregated over the lanes of a wave that hit the row of
 // the first active lane (two rounds), the rest individually.
-__global__ void __launch_bounds__(256) k_logup_count(const Fr* table, const Fr* input, uint32_t usable, uint32_t mask,
-                                                     const uint32_t* slots, uint32_t* count, uint32_t* miss) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_logup_count(const Fr* table, const Fr* input, uint32_t first, uint32_t usable,
+                                                     uint32_t mask, const uint32_t* slots, uint32_t* count, uint32_t* miss) {
+    uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;   // rows [first, usable) of the input column
     bool valid = i < usable;
     uint32_t hit = SLOT_EMPTY;
     if (valid) {
@@ -125,7 +125,7 @@ int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size
     if (usable) {
         hipLaunchKernelGGL(k_logup_build, dim3(blocks), dim3(256), 0, stream, d_table, (uint32_t)usable, mask, slots);
         for (size_t j = 0; j < n_inputs; j++)
-            hipLaunchKernelGGL(k_logup_count, dim3(blocks), dim3(256), 0, stream, d_table, d_inputs[j], (uint32_t)usable,
+            hipLaunchKernelGGL(k_logup_count, dim3(blocks), dim3(256), 0, stream, d_table, d_inputs[j], 0u, (uint32_t)usable,
                                mask, slots, count, miss);
     }
     hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, (uint32_t)usable, n,
@@ -138,6 +138,46 @@ int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size
         set_last_error("logup: " + std::to_string(h_miss) + " input value(s) are missing from the table");
         return H2_ERR_INVALID;
     }
+    return H2_OK;
+}
+
+// The same counting restricted to the input rows [row_begin, row_end) -- one rank's share when the rows of a proof are dealt
+// over several devices -- with the RAW counters out (n u32, then the number of input values missing from the table): integer
+// counts are an RCCL reduction (sum), field elements are not; logup_emit_launch turns the summed counters into m(X).
+int logup_counts_launch(const Fr* d_table, const Fr* const* d_inputs, size_t n_inputs, size_t usable, size_t n, size_t row_begin,
+                        size_t row_end, uint32_t* d_counts, void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+    if (usable > n || n >= 0x7fffffffu || row_begin > row_end || row_end > n) {
+        set_last_error("h2_dev_logup_counts: bad sizes");
+        return H2_ERR_INVALID;
+    }
+    if (scratch_bytes < logup_scratch_bytes(n)) {
+        set_last_error("h2_dev_logup_counts: scratch too small (h2_logup_scratch_bytes)");
+        return H2_ERR_INVALID;
+    }
+    const uint32_t cap = table_capacity(usable), mask = cap - 1;
+    uint32_t* slots = (uint32_t*)d_scratch;
+    H2_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, stream));
+    H2_HIP(hipMemsetAsync(d_counts, 0, (n + 1) * 4, stream));
+    const size_t last = row_end < usable ? row_end : usable;
+    if (usable) {
+        hipLaunchKernelGGL(k_logup_build, dim3((unsigned)((usable + 255) / 256)), dim3(256), 0, stream, d_table, (uint32_t)usable,
+                           mask, slots);
+        if (row_begin < last)
+            for (size_t j = 0; j < n_inputs; j++)
+                hipLaunchKernelGGL(k_logup_count, dim3((unsigned)((last - row_begin + 255) / 256)), dim3(256), 0, stream, d_table,
+                                   d_inputs[j], (uint32_t)row_begin, (uint32_t)last, mask, slots, d_counts, d_counts + n);
+    }
+    H2_HIP(hipGetLastError());
+    return H2_OK;
+}
+
+int logup_emit_launch(const uint32_t* d_counts, size_t usable, size_t n, Fr* d_m, hipStream_t stream) {
+    if (usable > n || n >= 0x7fffffffu) {
+        set_last_error("h2_dev_logup_emit: bad sizes");
+        return H2_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_counts, (uint32_t)usable, n, d_m);
+    H2_HIP(hipGetLastError());
     return H2_OK;
 }
 

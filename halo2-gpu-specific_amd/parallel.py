@@ -131,6 +131,22 @@ def allreduce_max(values, group=None, device=None):
     return [int(v) for v in t.cpu().tolist()]
 
 
+def allreduce_counts(counts, group=None, stream=None):
+    """`counts`: an int32 device tensor of n + 1 counters (h2_dev_logup_counts: credits per table row, then the number of input
+    values this rank could not find); summed over the ranks in place -- integer addition IS an RCCL reduction, unlike field
+    addition -- and the total of the last counter returned (the same on every rank, so that all of them raise or none)."""
+    import torch.distributed as dist
+
+    with _on_stream(stream):
+        if _backend(group) == "nccl":
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        else:
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            counts.copy_(host.to(counts.device))
+        return int(counts[-1].item())
+
+
 def allgather_rows(t, lo, hi, group=None, stream=None):
     """`t`: an (n, 4) int64 device tensor of which this rank holds the rows [lo, hi) (n / world rows, rank order); on
     return every rank holds every row.  RCCL: one in-place all-gather over xGMI; gloo: through host memory."""

@@ -815,7 +815,7 @@ def sharding_description(device):
             "exchanged per scan / division / evaluation batch; witness-dependent inverse transforms dealt by column (rows to "
             "the owner, coefficient vectors broadcast on a second communicator and a side stream); with more ranks than cosets "
             "the ranks of a coset deal its columns for the coset transforms, exchange row slices and evaluate the quotient by "
-            "row range" % device.group_size)
+            "row range; lookup inputs compressed by rows, multiplicities all-reduced as integer counts" % device.group_size)
 
 
 def _forget_tables(L, ptrs):
@@ -1184,11 +1184,12 @@ def create_proof_with_shplonk(device, params, pk, advice, rng, timings=None, ins
 _ANY = {"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}
 
 
-def _compress(D, dom, program, theta, fixed, advice, instance):
+def _compress(D, dom, program, theta, fixed, advice, instance, rows=None):
     """evaluate_with_theta (plonk/evaluation.rs:2330-2398): the theta-compression of an expression list over the
     n-point Lagrange domain = the evaluator program with y := theta and extended_k := k.  The descriptor of a program
     is built once per device and re-bound to the columns / theta of each call (building it costs ~0.1 ms of host time,
-    a k = 18 proof compresses eight expression lists)."""
+    a k = 18 proof compresses eight expression lists).  `rows` = (first, count): only these rows are computed (one rank's
+    share of a proof dealt by rows); the result is a full-size vector valid there."""
     g, parts = program
     cache = D.__dict__.setdefault("_compress_descs", {})
     pointers = dict(fixed=[t.data_ptr() for t in fixed], advice=[t.data_ptr() for t in advice],
@@ -1196,6 +1197,7 @@ def _compress(D, dom, program, theta, fixed, advice, instance):
     hit = cache.get((id(program), dom.k))
     if hit is not None and hit[0] is program:
         b = hit[1].rebind(y=fr_to_mont_limbs(theta), theta=fr_to_mont_limbs(theta), **pointers)
+        b.desc.row_begin, b.desc.row_count = rows if rows is not None else (0, 0)
     else:
         zero = fr_to_mont_limbs(0)
         b = ev.Builder().build(
@@ -1203,7 +1205,8 @@ def _compress(D, dom, program, theta, fixed, advice, instance):
             constants=np.array([fr_to_mont_limbs(c) for c in g.constants], dtype=np.uint64), rotations=g.rotations,
             calculations=g.calculations, value_parts=parts,
             y=fr_to_mont_limbs(theta), beta=zero, gamma=zero, theta=fr_to_mont_limbs(theta),
-            delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.omega), **pointers)
+            delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(ZETA), extended_omega=fr_to_mont_limbs(dom.omega),
+            row_begin=rows[0] if rows is not None else 0, row_count=rows[1] if rows is not None else 0, **pointers)
         cache[(id(program), dom.k)] = (program, b)
     out = D.empty(dom.n)
     check(D.L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h (compress)")
@@ -1485,24 +1488,42 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         advice_coeffs, advice_arrival = D.intt_columns_begin(advice_dev, dom, complete=whole_advice_rows, keep=True)
 
     # ---- lookups: theta-compressed inputs / table, multiplicities (logup/prover.rs:63-240) ---------------------
+    # One proof over several ranks with the rows dealt (Device.row_range): the compressed INPUT expressions are needed on this
+    # rank's rows only (the grand sums below read them there), and the multiplicities are integer counts -- an RCCL reduction:
+    # every rank counts the hits of its own input rows in the (whole, replicated) compressed table, the counters are summed by
+    # ONE all-reduce per lookup and become field elements afterwards.  The shuffles' expressions likewise: rows only.
+    lo_c, hi_c = D.row_range(n)
+    rows_c = None if (lo_c, hi_c) == (0, n) else (lo_c, hi_c - lo_c)
     for C in circuits:
-        def compress(program, C=C):
-            return _compress(D, dom, program, theta, pk.fixed_values, C["advice"], C["instance"])
+        def compress(program, C=C, rows=None):
+            return _compress(D, dom, program, theta, pk.fixed_values, C["advice"], C["instance"], rows)
 
         C["lookups"] = []
         for table_prog, set_progs in pk.lookup_programs:
-            st = {"table": compress(table_prog), "inputs": [[compress(pr) for pr in progs] for progs in set_progs]}
+            st = {"table": compress(table_prog), "inputs": [[compress(pr, rows=rows_c) for pr in progs] for progs in set_progs]}
             flat = [c for cols_ in st["inputs"] for c in cols_]
             m = D.empty(n)
             nbytes = L.h2_logup_scratch_bytes(n)
             ptrs = (_vp * len(flat))(*[c.data_ptr() for c in flat])
-            check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
-                                              D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
+            if rows_c is None:
+                check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
+                                                  D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
+            else:
+                from .parallel import allreduce_counts
+
+                with D.torch.cuda.stream(D.tstream):
+                    counts = D.torch.empty(n + 1, dtype=D.torch.int32, device=D.dev)
+                check(L.h2_dev_logup_counts(st["table"].data_ptr(), ptrs, len(flat), usable, n, lo_c, hi_c, counts.data_ptr(),
+                                            D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_counts")
+                missing = allreduce_counts(counts, group=D.group, stream=D.tstream)
+                if missing:
+                    raise ValueError("logup: %d input value(s) are missing from the table" % missing)
+                check(L.h2_dev_logup_emit(counts.data_ptr(), usable, n, m.data_ptr(), D.stream), "h2_dev_logup_emit")
             D.set_rows(m, usable, [rng.u16() for _ in range(usable, n)])
             st["m"], st["m_bits"] = m, max(16, (usable * len(flat)).bit_length())
             C["lookups"].append(st)
         # ---- shuffles: compressed expressions (shuffle/prover.rs:40-80) ------------------------------------------
-        C["shuffles"] = [[(compress(ip), compress(sp)) for ip, sp in group] for group in pk.shuffle_programs]
+        C["shuffles"] = [[(compress(ip, rows=rows_c), compress(sp, rows=rows_c)) for ip, sp in group] for group in pk.shuffle_programs]
     all_lookups = [st for C in circuits for st in C["lookups"]]
     if all_lookups:
         for P in D.msm_batch([st["m"] for st in all_lookups], params.g_lagrange, n, max(st["m_bits"] for st in all_lookups)):

@@ -216,6 +216,14 @@ int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d
 size_t h2_logup_scratch_bytes(size_t n);
 int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
+/* The same counting restricted to the input rows [row_begin, row_end) -- one device's share when the rows of a proof are dealt
+ * over several devices -- with the RAW counters out: d_counts = n + 1 u32 (credits per table row, then the number of input
+ * values missing from the table).  Integer counts are an RCCL reduction (sum), field elements are not: the ranks all-reduce
+ * d_counts, check the last word and turn the first n into the field elements of m(X) with h2_dev_logup_emit (rows >=
+ * usable_rows zero).  Asynchronous on `stream`; same scratch as above. */
+int h2_dev_logup_counts(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows, size_t n,
+                        size_t row_begin, size_t row_end, void *d_counts, void *d_scratch, size_t scratch_bytes, void *stream);
+int h2_dev_logup_emit(const void *d_counts, size_t usable_rows, size_t n, void *d_m, void *stream);
 
 /* Fixed-base multiplication, the work of Params::unsafe_setup (poly/commitment.rs:56-124: g[i] = [s^i] G,
  * g_lagrange[i] = [l_i(s)] G, one variable-base multiplication per point under `parallelize` there):

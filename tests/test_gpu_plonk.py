@@ -511,6 +511,64 @@ dist.destroy_process_group()
     assert bytes.fromhex(line.split()[1]) == want
 
 
+def test_logup_counts_by_row_ranges_sum_to_the_multiplicities(oracle, device):
+    """h2_dev_logup_counts over the row ranges of 1, 2, 4 and 8 ranks, the raw counters summed (what the ranks' all-reduce
+    does) and h2_dev_logup_emit: the field elements h2_dev_logup_multiplicity gives for the whole columns (itself checked
+    against the oracle's multiplicities in the proof tests); a value missing from the table is counted in the last word"""
+    import ctypes
+
+    import torch
+
+    from halo2_gpu_specific_amd._lib import check
+    from halo2_gpu_specific_amd import parallel
+
+    L, dev = device.L, device.dev
+    n, usable = 1 << 12, (1 << 12) - 6
+    rng = np.random.default_rng(3)
+    table = np.zeros((n, 4), dtype=np.uint64)
+    table[:300, 0] = np.arange(300) * 7 + 1            # 300 distinct values, then padding zeros (a duplicated value)
+    ins = []
+    for _ in range(3):
+        col = np.zeros((n, 4), dtype=np.uint64)
+        col[:usable, 0] = table[rng.integers(0, 400, size=usable), 0]
+        ins.append(col)
+    up = lambda a: torch.from_numpy(a.view(np.int64)).to(dev)  # noqa: E731
+    d_table, d_ins = up(table), [up(c) for c in ins]
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in d_ins])
+    nbytes = L.h2_logup_scratch_bytes(n)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    want = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    check(L.h2_dev_logup_multiplicity(d_table.data_ptr(), ptrs, 3, usable, n, want.data_ptr(), scratch.data_ptr(), nbytes, None),
+          "h2_dev_logup_multiplicity")
+    for world in (1, 2, 4, 8):
+        total = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        for rank in range(world):
+            lo, hi = parallel.msm_split_range(n, world, rank)
+            part = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            check(L.h2_dev_logup_counts(d_table.data_ptr(), ptrs, 3, usable, n, lo, hi, part.data_ptr(), scratch.data_ptr(), nbytes,
+                                        None), "h2_dev_logup_counts")
+            torch.cuda.synchronize()
+            total += part
+        assert int(total[-1]) == 0 and int(total[:n].sum()) == 3 * usable
+        got = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        check(L.h2_dev_logup_emit(total.data_ptr(), usable, n, got.data_ptr(), None), "h2_dev_logup_emit")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), world
+    bad = ins[1].copy()
+    bad[77, 0] = 5                                      # not a table value
+    d_bad = up(bad)
+    ptrs2 = (ctypes.c_void_p * 1)(d_bad.data_ptr())
+    part = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    check(L.h2_dev_logup_counts(d_table.data_ptr(), ptrs2, 1, usable, n, 0, 128, part.data_ptr(), scratch.data_ptr(), nbytes, None),
+          "h2_dev_logup_counts")
+    torch.cuda.synchronize()
+    assert int(part[-1]) == 1 and int(part[:n].sum()) == 127
+
+
 def test_rccl_collective_shapes_on_one_rank(tmp_path):
     """every RCCL-only code path of parallel.py (the in-place all_gather_into_tensor of allgather_rows, the scatter of
     scatter_cosets, gather_rows_to, the asynchronous broadcasts of broadcast_columns_begin on a second communicator and a
@@ -561,6 +619,9 @@ for rep in range(3):
         parallel.exchange_row_slices(keep, [0, 0], n, 1, 0, 6, 1, stream=stream)
         stream.synchronize()
         assert torch.equal(keep[0], want) and torch.equal(keep[1], want + 1), "exchange_row_slices"
+    with torch.cuda.stream(stream):
+        cnt = torch.arange(n + 1, dtype=torch.int32, device=dev); cnt[-1] = 0
+    assert parallel.allreduce_counts(cnt, stream=stream) == 0 and int(cnt[5]) == 5
     assert parallel.allreduce_max([3, 254, rep], device=dev) == [3, 254, rep]
     vals = [(1 << 200) + rep, 7, 0]
     assert parallel.allgather_scalars(vals, device=dev) == [vals]
