@@ -131,7 +131,6 @@ struct PermArgs {
 };
 
 __global__ void __launch_bounds__(256) k_evalh_perm(PermArgs a) {
-    const size_t size = (size_t)1 << a.extended_k;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const Fr one = fp_one<FrParams>();
     for (size_t idx = a.row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.row_end; idx += stride) {
@@ -232,7 +231,6 @@ struct ShuffleArgs {
 };
 
 __global__ void __launch_bounds__(256) k_evalh_shuffle(ShuffleArgs a) {
-    const size_t size = (size_t)1 << a.extended_k;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const Fr one = fp_one<FrParams>();
     for (size_t idx = a.row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.row_end; idx += stride) {
@@ -627,7 +625,7 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
         }
         Fr* d_values = (Fr*)dmalloc(ebytes);
         Fr* d_values_j = (Fr*)dmalloc(nbytes);
-        Fr* d_tmp = (Fr*)dmalloc(nbytes);
+        Fr* d_tmp = (Fr*)dmalloc(16 * nbytes);   // scratch of a batch of transforms
         // omega = extended_omega^c generates the n-th roots of unity
         const Fr w_ext = fr_from_u64x4(d->extended_omega), zeta = fr_from_u64x4(d->zeta);
         Fr omega = w_ext;
@@ -639,16 +637,19 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
         Fr g = zeta;  // g_0
         for (uint32_t j = 0; j < c; j++) {
             for (int i = 0; i < 4; i++) g_u[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
-            for (auto& kv : cols) {
-                Fr* dc = kv.second.first;
-                Fr* dv = kv.second.second;
-                H2_HIP(hipMemcpyAsync(dv, dc, nbytes, hipMemcpyDeviceToDevice, stream));
-                int rc = distribute_powers_launch(dv, n, g_u, stream);
-                if (rc != H2_OK) {
-                    cleanup();
-                    return rc;
+            {
+                // every column to coset j in batched, fused coset transforms (ntt.hip: g_j^t applied in the first pass's load,
+                // sixteen vectors per launch): no copy, no separate scaling pass
+                std::vector<const Fr*> srcs;
+                std::vector<Fr*> dsts, tmps;
+                for (auto& kv : cols) {
+                    srcs.push_back(kv.second.first);
+                    dsts.push_back(kv.second.second);
+                    tmps.push_back(d_tmp + (tmps.size() % 16) * n);
                 }
-                ntt_run(ctx, pl.get(), dv, dv, d_tmp, (uint32_t)n, nullptr, nullptr, stream);
+                const Fr* tab = ntt_scale_table(pl.get(), g, nullptr, stream);
+                ntt_run_many(ctx, pl.get(), srcs.data(), dsts.data(), tmps.data(), srcs.size(), (uint32_t)n, nullptr, nullptr,
+                             stream, tab, 1u);
             }
             if (d_active) hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);
             h2_evalh_desc dd = *d;
