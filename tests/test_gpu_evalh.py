@@ -66,6 +66,12 @@ def test_generated_kernel_matches_interpreter_and_oracle(oracle, monkeypatch, se
                       (ev.JIT_SHUFFLES if kw["shuffles"] else 0))
     b.desc.jit_function, b.desc.jit_covers = jit.load(fused), covers
     assert np.array_equal(ev.evaluate_h(b), want)
+    # ... and the gate program alone under that generator's load scheduling (what a program too wide to fuse gets)
+    gsrc, _ = jit.generate_fused_source(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
+                                        dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
+                                             last_rotation=-(kw["blinding_factors"] + 1)), fold_args=False)
+    b.desc.jit_function, b.desc.jit_covers = jit.load(jit.compile_source(gsrc, "_fused")), 0
+    assert np.array_equal(ev.evaluate_h(b), want)
 
 
 @pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),

@@ -548,6 +548,11 @@ def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
         monkeypatch.setenv("H2_EVALH_FUSED", "0")
         assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles, perm=perm) == (path, 0)
         monkeypatch.delenv("H2_EVALH_FUSED")
+        # the gate program alone under the new load scheduling (what a program too wide to fuse gets): the lookup / shuffle
+        # expressions are stored for the library's argument kernels
+        gsrc, gcov = jit.generate_fused_source(g.rotations, g.calculations, parts, lookups, shuffles, perm, fold_args=False)
+        assert gcov == 0 and gsrc.count("fp_store(a.values") == 1
+        assert gsrc.count("a.lk_out") == sum(1 + 2 * len(p) for _, p, _ in lookups) and gsrc.count("a.sh_out") == 2 * len(shuffles)
     monkeypatch.setenv("H2_EVALH_JIT", "0")
     assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) is None
 
