@@ -67,13 +67,14 @@ ref = out.clone()
 streams_fused = cs.num_fixed + cs.num_advice + 3 + nsets + ncols + nlz + len(lm) + 1
 print("%s 2^%d: gate kernel + library argument kernels %.3f ms" % (which, ek, t_base))
 # the gate program alone under the new load scheduling (the library's argument kernels behind it)
-for grp, ahead, gap in [(6, 6, 30), (8, 8, 30), (10, 6, 20), (4, 4, 16)]:
-    jit._GROUP, jit._MAX_AHEAD, jit._GAP = grp, ahead, gap
+for grp, ahead, gap, sb in [(6, 6, 30, True), (10, 6, 20, True), (6, 6, 30, False), (10, 6, 20, False), (16, 8, 30, False)]:
+    jit._GROUP, jit._MAX_AHEAD, jit._GAP, jit._STMT_BARRIER = grp, ahead, gap, sb
     src, _ = jit.generate_fused_source(g.rotations, g.calculations, parts, lk, sh, perm, fold_args=False)
     b = build(jit.load(jit.compile_source(src, "_fused")), 0)
     t = run(b)
-    print("  gates only, loads a group ahead (group=%d ahead=%d gap=%d) + library argument kernels: %.3f ms  same=%s" % (
-        grp, ahead, gap, t, torch.equal(out, ref)))
+    print("  gates only, loads a group ahead (group=%d ahead=%d gap=%d stmt barriers=%s) + library argument kernels: %.3f ms  same=%s" % (
+        grp, ahead, gap, sb, t, torch.equal(out, ref)))
+jit._STMT_BARRIER = True
 os.environ["H2_EVALH_FUSED"] = "1"
 sweep = [(6, 6, 30)] if len(sys.argv) > 3 and sys.argv[3] == "single" else [(6, 6, 30), (6, 4, 30), (4, 4, 16), (8, 8, 30), (6, 3, 12), (10, 6, 20), (6, 10, 60)]
 for grp, ahead, gap in sweep:
