@@ -625,7 +625,9 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
         }
         Fr* d_values = (Fr*)dmalloc(ebytes);
         Fr* d_values_j = (Fr*)dmalloc(nbytes);
-        Fr* d_tmp = (Fr*)dmalloc(16 * nbytes);   // scratch of a batch of transforms
+        // scratch of a batch of transforms: up to 16 vectors per launch, fewer when that would pass 1 GiB
+        const size_t batch_width = std::max<size_t>(1, std::min<size_t>(16, ((size_t)1 << 30) / nbytes));
+        Fr* d_tmp = (Fr*)dmalloc(batch_width * nbytes);
         // omega = extended_omega^c generates the n-th roots of unity
         const Fr w_ext = fr_from_u64x4(d->extended_omega), zeta = fr_from_u64x4(d->zeta);
         Fr omega = w_ext;
@@ -645,11 +647,12 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
                 for (auto& kv : cols) {
                     srcs.push_back(kv.second.first);
                     dsts.push_back(kv.second.second);
-                    tmps.push_back(d_tmp + (tmps.size() % 16) * n);
+                    tmps.push_back(d_tmp + (tmps.size() % batch_width) * n);
                 }
                 const Fr* tab = ntt_scale_table(pl.get(), g, nullptr, stream);
-                ntt_run_many(ctx, pl.get(), srcs.data(), dsts.data(), tmps.data(), srcs.size(), (uint32_t)n, nullptr, nullptr,
-                             stream, tab, 1u);
+                for (size_t at = 0; at < srcs.size(); at += batch_width)   // (a chunk's scratch slots are distinct)
+                    ntt_run_many(ctx, pl.get(), srcs.data() + at, dsts.data() + at, tmps.data() + at,
+                                 std::min(batch_width, srcs.size() - at), (uint32_t)n, nullptr, nullptr, stream, tab, 1u);
             }
             if (d_active) hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);
             h2_evalh_desc dd = *d;

@@ -386,6 +386,12 @@ class Device:
                                       self.stream), "h2_dev_coset_ntt")
         return out
 
+    @staticmethod
+    def _batch_width(points, cap_bytes=1 << 30):
+        """vectors per batched-transform call: up to 16, fewer when their scratch (one vector each) would pass `cap_bytes` --
+        large transforms fill the chip on their own, and the scratch must stay small next to a memory budget"""
+        return max(1, min(16, cap_bytes // (32 * points)))
+
     def coeffs_to_coset(self, polys, dom, j):
         """coeff_to_coset of several coefficient vectors: up to 16 transforms per launch (h2_dev_coset_ntt_batch) -- the
         tiles of one 2^20-point pass do not fill the chip for long enough to hide their own latencies, those of a
@@ -396,12 +402,15 @@ class Device:
         if count == 1:
             return [self.coeff_to_coset(polys[0], dom, j)]
         outs = [self.empty(dom.n) for _ in polys]
-        tmp = self.empty(min(count, 16) * dom.n)
+        width = self._batch_width(dom.n)
+        tmp = self.empty(min(count, width) * dom.n)
         g = dom.g_coset * pow(dom.extended_omega, j, R_MOD) % R_MOD
-        src = (_vp * count)(*[p.data_ptr() for p in polys])
-        dst = (_vp * count)(*[o.data_ptr() for o in outs])
-        check(self.L.h2_dev_coset_ntt_batch(src, dst, count, tmp.data_ptr(), dom.k, _fr(g), _fr(dom.omega), self.stream),
-              "h2_dev_coset_ntt_batch")
+        for at in range(0, count, width):
+            part = min(width, count - at)
+            src = (_vp * part)(*[p.data_ptr() for p in polys[at:at + part]])
+            dst = (_vp * part)(*[o.data_ptr() for o in outs[at:at + part]])
+            check(self.L.h2_dev_coset_ntt_batch(src, dst, part, tmp.data_ptr(), dom.k, _fr(g), _fr(dom.omega), self.stream),
+                  "h2_dev_coset_ntt_batch")
         return outs
 
     def intt_many(self, ts, dom):
@@ -411,10 +420,13 @@ class Device:
             return ts
         if count == 1 or not hasattr(self.L, "h2_dev_intt_batch"):
             return [self.intt(t, dom) for t in ts]
-        tmp = self.empty(min(count, 16) * dom.n)
-        ptrs = (_vp * count)(*[t.data_ptr() for t in ts])
-        check(self.L.h2_dev_intt_batch(ptrs, count, tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
-                                       self.stream), "h2_dev_intt_batch")
+        width = self._batch_width(dom.n)
+        tmp = self.empty(min(count, width) * dom.n)
+        for at in range(0, count, width):
+            part = min(width, count - at)
+            ptrs = (_vp * part)(*[t.data_ptr() for t in ts[at:at + part]])
+            check(self.L.h2_dev_intt_batch(ptrs, part, tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
+                                           self.stream), "h2_dev_intt_batch")
         return ts
 
     def column_owner(self, i):
@@ -516,10 +528,13 @@ class Device:
             sptr = _vp(side.cuda_stream)
             out = [t.clone() for t in cols]
             if len(out) >= 2 and hasattr(self.L, "h2_dev_intt_batch"):
-                tmp = self.torch.empty((min(len(out), 16) * dom.n, 4), dtype=self.torch.int64, device=self.dev)
-                ptrs = (_vp * len(out))(*[c.data_ptr() for c in out])
-                check(self.L.h2_dev_intt_batch(ptrs, len(out), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k,
-                                               sptr), "h2_dev_intt_batch")
+                width = self._batch_width(dom.n)
+                tmp = self.torch.empty((min(len(out), width) * dom.n, 4), dtype=self.torch.int64, device=self.dev)
+                for at in range(0, len(out), width):
+                    part = out[at:at + width]
+                    ptrs = (_vp * len(part))(*[c.data_ptr() for c in part])
+                    check(self.L.h2_dev_intt_batch(ptrs, len(part), tmp.data_ptr(), _fr(dom.omega_inv), _fr(dom.ifft_divisor),
+                                                   dom.k, sptr), "h2_dev_intt_batch")
                 tmp.record_stream(self.tstream)
             else:
                 for c in out:
@@ -556,14 +571,17 @@ class Device:
 
         torch = self.torch
         # (allocations belong to the stream they are made under: the caller's side stream, or the compute stream)
+        width = self._batch_width(dom.extended_n, 2 << 30)
         with (torch.cuda.stream(self.tstream) if stream is None else contextlib.nullcontext()):
             outs = [torch.empty((dom.extended_n, 4), dtype=torch.int64, device=self.dev) for _ in ts]
-            tmp = torch.empty((min(count, 16) * dom.extended_n, 4), dtype=torch.int64, device=self.dev)
-        src = (_vp * count)(*[t.data_ptr() for t in ts])
-        dst = (_vp * count)(*[o.data_ptr() for o in outs])
-        check(self.L.h2_dev_coeff_to_extended_batch(src, dst, count, tmp.data_ptr(), dom.k, dom.extended_k, _fr(dom.g_coset),
-                                                    _fr(dom.g_coset_inv), _fr(dom.extended_omega),
-                                                    self.stream if stream is None else stream), "h2_dev_coeff_to_extended_batch")
+            tmp = torch.empty((min(count, width) * dom.extended_n, 4), dtype=torch.int64, device=self.dev)
+        for at in range(0, count, width):
+            part = min(width, count - at)
+            src = (_vp * part)(*[t.data_ptr() for t in ts[at:at + part]])
+            dst = (_vp * part)(*[o.data_ptr() for o in outs[at:at + part]])
+            check(self.L.h2_dev_coeff_to_extended_batch(src, dst, part, tmp.data_ptr(), dom.k, dom.extended_k, _fr(dom.g_coset),
+                                                        _fr(dom.g_coset_inv), _fr(dom.extended_omega),
+                                                        self.stream if stream is None else stream), "h2_dev_coeff_to_extended_batch")
         return outs
 
     def extended_to_coeff(self, t, dom):
