@@ -1209,6 +1209,12 @@ def _compress(D, dom, program, theta, fixed, advice, instance, rows=None):
     a k = 18 proof compresses eight expression lists).  `rows` = (first, count): only these rows are computed (one rank's
     share of a proof dealt by rows); the result is a full-size vector valid there."""
     g, parts = program
+    # the pure-column fast path of the reference (plonk/evaluation.rs:2266-2276): ONE expression that is a plain query at the
+    # current rotation compresses to the column itself -- no kernel, no copy (the callers only read the result; an advice column
+    # keeps its Lagrange values until the quotient phase turns it into coefficients, after every lookup pass has consumed them)
+    if len(parts) == 1 and not g.calculations and parts[0].kind in (ev.VS_FIXED, ev.VS_ADVICE, ev.VS_INSTANCE) and \
+            g.rotations[parts[0].rot] == 0 and os.environ.get("H2_COMPRESS_PURE", "1") != "0":
+        return {ev.VS_FIXED: fixed, ev.VS_ADVICE: advice, ev.VS_INSTANCE: instance}[parts[0].kind][parts[0].index]
     cache = D.__dict__.setdefault("_compress_descs", {})
     pointers = dict(fixed=[t.data_ptr() for t in fixed], advice=[t.data_ptr() for t in advice],
                     instance=[t.data_ptr() for t in instance])
