@@ -195,9 +195,15 @@ size_t h2_library_memory_bytes(void) {
     size_t total = 0;
     int rc = guarded([&] {
         DeviceCtx* ctx = current_ctx();
-        std::lock_guard<std::mutex> g(ctx->mu);
-        total = ntt_plan_bytes(ctx) + msm_library_bytes(ctx) + ctx->buf_a.cap + ctx->buf_b.cap + ctx->buf_c.cap +
-                ctx->buf_d.cap + ctx->msm_scratch.cap + ctx->evalh_scratch.cap;
+        {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            total = ntt_plan_bytes(ctx) + msm_library_bytes(ctx);          // shared by the host-API slots of the device
+        }
+        for (DeviceCtx* c : existing_contexts()) {                        // ... plus every slot's own buffers
+            if (c->device != ctx->device) continue;
+            std::lock_guard<std::mutex> g(c->mu);
+            total += c->buf_a.cap + c->buf_b.cap + c->buf_c.cap + c->buf_d.cap + c->msm_scratch.cap + c->evalh_scratch.cap;
+        }
         return (int)H2_OK;
     });
     return rc == H2_OK ? total : 0;

@@ -62,25 +62,44 @@ struct ResidentCopy {
     uint64_t gen = 0;
 };
 
+// What the host-API slots of ONE physical device share: the transform plans (twiddle tables), the device copies of
+// registered SRS ranges (1 GiB + a 12 GiB table at k = 24: never per slot) and their accounting.
+struct DeviceShared {
+    std::mutex mu;                     // guards `resident` (a lookup may upload an SRS) and plan creation across the slots
+    std::map<const void*, ResidentCopy> resident;  // registered host base ranges -> device copies (msm.hip)
+    std::map<std::string, NttPlan*> plans;
+    size_t ntt_last_table_bytes = 0;   // of the optional last-pass tables (ntt.hip; guarded by ntt.hip's table mutex)
+};
+
+// One host-API SLOT of a device: its own streams, staging buffers and scratch, so that two host-slice calls on one device
+// -- the reference's entry points are invoked concurrently from rayon workers (plonk/prover.rs:293-299, 731-737) --
+// overlap one call's transfers with the other's kernels (H2_HOST_SLOTS, default 2; the reference runs one operation per
+// device at a time, arithmetic.rs:314-331).  The h2_dev_* entry points use slot 0's context of the current device for
+// plans only.
 struct DeviceCtx {
     int device = -1;
+    int slot = 0;
     hipStream_t stream = nullptr;      // compute stream for host-API calls
     hipStream_t copy_stream = nullptr; // H2D/D2H overlap
     hipStream_t aux_stream[2] = {nullptr, nullptr};  // third / fourth lane of the batched-MSM pipeline
-    std::mutex mu;                     // one in-flight host-API op per device
+    std::mutex mu;                     // one in-flight host-API op per slot
     DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
     DevBuf msm_scratch;
     DevBuf evalh_scratch;
     PinnedBuf pinned;
-    std::map<const void*, ResidentCopy> resident;  // registered host base ranges -> device copies (msm.hip)
-    std::map<std::string, NttPlan*> plans;
-    size_t ntt_last_table_bytes = 0;   // of the optional last-pass tables (ntt.hip; guarded by ntt.hip's table mutex)
+    DeviceShared* shared;
+    std::map<const void*, ResidentCopy>& resident;
+    std::map<std::string, NttPlan*>& plans;
+    size_t& ntt_last_table_bytes;
     hipDeviceProp_t prop;
+    explicit DeviceCtx(DeviceShared* s)
+        : shared(s), resident(s->resident), plans(s->plans), ntt_last_table_bytes(s->ntt_last_table_bytes) {}
 };
 
 // Device pool (HALO2_PROOFS_N_GPU honoured, prover.rs:57-70).
 int device_count();
-DeviceCtx* ctx_for(int device);  // creates on first use; throws HipError
+DeviceCtx* ctx_for(int device);        // slot 0 of a physical device (the h2_dev_* entry points); creates on first use; throws HipError
+DeviceCtx* ctx_for_entry(int entry);   // pool entry (acquire_device) -> its device's slot context
 std::vector<DeviceCtx*> existing_contexts();  // the contexts created so far
 int acquire_device();            // blocking free-list, arithmetic.rs:314-321
 void release_device(int idx);    // arithmetic.rs:324-331
@@ -90,7 +109,7 @@ struct DeviceLease {
     DeviceCtx* ctx;
     DeviceLease() : idx(acquire_device()), ctx(nullptr) {
         try {
-            ctx = ctx_for(idx);
+            ctx = ctx_for_entry(idx);
         } catch (...) {
             release_device(idx);
             throw;

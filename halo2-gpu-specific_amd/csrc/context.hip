@@ -45,10 +45,12 @@ namespace {
 struct Pool {
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<int> free_list;  // GPU_LOCK: Vec of free device indices
-    std::vector<DeviceCtx*> ctxs;
+    std::vector<int> free_list;  // GPU_LOCK: Vec of free pool entries: device index + n_gpu * slot
+    std::vector<DeviceCtx*> ctxs;        // [physical device * slots + slot]
+    std::vector<DeviceShared*> shared;   // per physical device
     int n_gpu = -1;  // pool size (N_GPU)
     int n_visible = 0;
+    int slots = 2;   // host-API slots per pool entry (H2_HOST_SLOTS)
     bool inited = false;
 
     void init() {
@@ -64,8 +66,15 @@ struct Pool {
             if (v > 0) n_gpu = v;
         }
         if (cnt == 0) n_gpu = 0;
-        for (int i = n_gpu - 1; i >= 0; i--) free_list.push_back(i);
-        ctxs.assign(cnt > 0 ? cnt : 0, nullptr);
+        if (const char* env = std::getenv("H2_HOST_SLOTS")) {
+            int v = std::atoi(env);
+            if (v >= 1 && v <= 4) slots = v;
+        }
+        // handed out from the back: every device's first slot before any second one
+        for (int sub = slots - 1; sub >= 0; sub--)
+            for (int i = n_gpu - 1; i >= 0; i--) free_list.push_back(i + n_gpu * sub);
+        ctxs.assign(cnt > 0 ? (size_t)cnt * slots : 0, nullptr);
+        shared.assign(cnt > 0 ? cnt : 0, nullptr);
         inited = true;
     }
 };
@@ -82,23 +91,47 @@ int device_count() {
     return p.n_gpu;
 }
 
-DeviceCtx* ctx_for(int idx) {
+static DeviceCtx* ctx_at(int dev, int sub);
+
+DeviceCtx* ctx_for(int device) {
+    Pool& p = pool();
+    {
+        std::lock_guard<std::mutex> g(p.mu);
+        p.init();
+        if (p.n_visible == 0) throw HipError{hipErrorNoDevice, "no HIP device visible", __FILE__, __LINE__};
+    }
+    return ctx_at(device % p.n_visible, 0);
+}
+
+DeviceCtx* ctx_for_entry(int entry) {
+    Pool& p = pool();
+    {
+        std::lock_guard<std::mutex> g(p.mu);
+        p.init();
+        if (p.n_visible == 0) throw HipError{hipErrorNoDevice, "no HIP device visible", __FILE__, __LINE__};
+    }
+    // pool entry = device index + n_gpu * slot; device indices wrap modulo the visible devices (arithmetic.rs:355)
+    const int per = p.n_gpu > 0 ? p.n_gpu : 1;
+    return ctx_at((entry % per) % p.n_visible, (entry / per) % p.slots);
+}
+
+static DeviceCtx* ctx_at(int dev, int sub) {
     Pool& p = pool();
     std::lock_guard<std::mutex> g(p.mu);
-    p.init();
-    if (p.n_visible == 0) throw HipError{hipErrorNoDevice, "no HIP device visible", __FILE__, __LINE__};
-    int dev = idx % p.n_visible;
-    if (!p.ctxs[dev]) {
-        DeviceCtx* c = new DeviceCtx();
+    const size_t at = (size_t)dev * p.slots + sub;
+    if (!p.ctxs[at]) {
+        if (!p.shared[dev]) p.shared[dev] = new DeviceShared();
+        DeviceCtx* c = new DeviceCtx(p.shared[dev]);
         c->device = dev;
+        c->slot = sub;
         H2_HIP(hipSetDevice(dev));
         H2_HIP(hipGetDeviceProperties(&c->prop, dev));
         H2_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         H2_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) H2_HIP(hipStreamCreateWithFlags(&c->aux_stream[k], hipStreamNonBlocking));
-        p.ctxs[dev] = c;
+        p.ctxs[at] = c;
     }
-    return p.ctxs[dev];
+    return p.ctxs[at];
 }
 
 std::vector<DeviceCtx*> existing_contexts() {

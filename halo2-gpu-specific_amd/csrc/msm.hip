@@ -1520,6 +1520,7 @@ size_t msm_library_bytes(DeviceCtx* ctx) {
         for (const auto& kv : g_tables)
             bytes += (size_t)kv.second.D * kv.second.n * sizeof(Affine) + (kv.second.blocks ? kv.second.n / BLOCK_ROWS * sizeof(Affine) : 0);
     }
+    std::lock_guard<std::mutex> g2(ctx->shared->mu);
     for (const auto& kv : ctx->resident) bytes += kv.second.len * sizeof(Affine);
     return bytes;
 }
@@ -2153,16 +2154,24 @@ int bases_unregister(const uint64_t* bases) {
         g_registered.erase(bases);
         ++g_reg_gen;
     }
-    // free the device copies now, on every context (under its lock: a host-buffer MSM holds it until its result is
-    // back, so nothing in flight reads the copy); a context that never runs another MSM would keep them otherwise
-    for (DeviceCtx* ctx : existing_contexts()) {
-        std::lock_guard<std::mutex> g(ctx->mu);
-        auto it = ctx->resident.find((const void*)bases);
-        if (it != ctx->resident.end()) {
-            bases_forget((const uint64_t*)it->second.ptr);
-            (void)hipFree(it->second.ptr);
-            ctx->resident.erase(it);
+    // free the device copies now, on every device (under the locks of ALL its host-API slots: a host-buffer MSM holds its
+    // slot's lock until its result is back, so nothing in flight reads the copy; then the shared map's own lock); a device
+    // that never runs another MSM would keep them otherwise
+    std::map<DeviceShared*, std::vector<DeviceCtx*>> by_device;
+    for (DeviceCtx* ctx : existing_contexts()) by_device[ctx->shared].push_back(ctx);
+    for (auto& dv : by_device) {
+        std::sort(dv.second.begin(), dv.second.end(), [](DeviceCtx* a, DeviceCtx* b) { return a->slot < b->slot; });
+        for (DeviceCtx* ctx : dv.second) ctx->mu.lock();
+        {
+            std::lock_guard<std::mutex> g(dv.first->mu);
+            auto it = dv.first->resident.find((const void*)bases);
+            if (it != dv.first->resident.end()) {
+                bases_forget((const uint64_t*)it->second.ptr);
+                (void)hipFree(it->second.ptr);
+                dv.first->resident.erase(it);
+            }
         }
+        for (DeviceCtx* ctx : dv.second) ctx->mu.unlock();
     }
     return H2_OK;
 }
@@ -2173,6 +2182,9 @@ int bases_unregister(const uint64_t* bases) {
 static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size_t n) {
     const uint64_t* key = nullptr;
     Registration reg{0, 0};
+    // the device copies are shared by the host-API slots of the device: one slot uploads (and tabulates) an SRS, the other
+    // waits here and finds it complete
+    std::lock_guard<std::mutex> shared_lock(ctx->shared->mu);
     {
         std::lock_guard<std::mutex> g(g_reg_mu);
         // drop device copies whose registration is gone or was replaced
@@ -2215,6 +2227,7 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
                 (void)hipGetLastError();  // clear the sticky error; no table for this copy
             }
         }
+        H2_HIP(hipStreamSynchronize(ctx->stream));  // complete before another slot (another stream) can find it
     }
     return (const Affine*)rit->second.ptr + (bases - key) / 8;
 }

@@ -663,6 +663,15 @@ PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hi
     // written.  Once per (log_n, omega) for the life of the process.
     H2_HIP(hipStreamSynchronize(stream));
     std::lock_guard<std::mutex> g(g_tab_mu);
+    auto raced = ctx->plans.find(key);
+    if (raced != ctx->plans.end()) {
+        // another host-API slot of this device built the same plan meanwhile: keep the published one (this one's tables are
+        // complete and nobody else has seen them: freed at once)
+        free_plan(pl);
+        raced->second->users.fetch_add(1);
+        raced->second->last_use = ++g_tick;
+        return PlanRef(raced->second);
+    }
     pl->users.fetch_add(1);
     pl->last_use = ++g_tick;
     ctx->plans[key] = pl;

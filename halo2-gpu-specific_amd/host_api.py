@@ -43,13 +43,27 @@ class HostSliceLib:
     """the entry points prover.py calls (h2_dev_* signatures), each forwarded to the host-slice entry point the Rust patch
     binds; pointers are host addresses"""
 
-    def __init__(self, torch, dev):
+    def __init__(self, torch, dev, workers=4):
+        import concurrent.futures
+
         self.R = lib()
         self.torch, self.dev = torch, dev
         self.calls = {}
+        # the reference runs its per-column loops as rayon par_iters (commitments plonk/prover.rs:293-299, inverse transforms
+        # :643-646, evaluations :731-737): the calls of such a loop are issued from a few threads here too, and the library's
+        # two host-API slots per device overlap one call's transfers with another's kernels
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers) if workers > 1 else None
+
+    def _each(self, fn, items):
+        """fn(item) for every item, from the worker threads when there are any; the first non-zero status wins"""
+        if self.pool is None or len(items) < 2:
+            rcs = [fn(it) for it in items]
+        else:
+            rcs = list(self.pool.map(fn, items))
+        return next((rc for rc in rcs if rc), 0)
 
     def _count(self, name):
-        self.calls[name] = self.calls.get(name, 0) + 1
+        self.calls[name] = self.calls.get(name, 0) + 1      # (dict updates of the worker threads: GIL-atomic enough for a tally)
 
     # -- staging for the entry points without a host-slice twin -------------------------------------------------------
     def _up(self, addr, nbytes):
@@ -73,18 +87,11 @@ class HostSliceLib:
         return self.R.h2_intt(a, _addr(omega_inv), _addr(divisor), k)
 
     def h2_dev_intt_batch(self, ptrs, count, tmp, omega_inv, divisor, k, stream):
-        for i in range(count):
-            rc = self.h2_dev_intt(ptrs[i], None, omega_inv, divisor, k, stream)
-            if rc:
-                return rc
-        return 0
+        return self._each(lambda i: self.h2_dev_intt(ptrs[i], None, omega_inv, divisor, k, stream), list(range(count)))
 
     def h2_dev_coeff_to_extended_batch(self, srcs, dsts, count, tmp, k, ek, g, g_inv, ext_omega, stream):
-        for i in range(count):
-            rc = self.h2_dev_coeff_to_extended(srcs[i], dsts[i], None, k, ek, g, g_inv, ext_omega, stream)
-            if rc:
-                return rc
-        return 0
+        return self._each(lambda i: self.h2_dev_coeff_to_extended(srcs[i], dsts[i], None, k, ek, g, g_inv, ext_omega, stream),
+                          list(range(count)))
 
     def h2_dev_coeff_to_extended(self, a, out, tmp, k, ek, g, g_inv, ext_omega, stream):
         self._count("h2_coeff_to_extended")
@@ -121,11 +128,8 @@ class HostSliceLib:
         return self.R.h2_msm(scalars, bases, n, max_bits, _addr(out))
 
     def h2_dev_msm_batch_ex(self, sp, bp, bits, count, n, scratch, nbytes, out, stream):
-        for i in range(count):
-            rc = self.h2_dev_msm(sp[i], bp[i], n, bits[i], None, 0, _addr(out) + 96 * i, stream)
-            if rc:
-                return rc
-        return 0
+        return self._each(lambda i: self.h2_dev_msm(sp[i], bp[i], n, bits[i], None, 0, _addr(out) + 96 * i, stream),
+                          list(range(count)))
 
     def h2_dev_bases_precompute_bytes(self, n, digits):
         return 0
@@ -161,11 +165,8 @@ class HostSliceLib:
         return self.R.h2_eval_polynomial(poly, n, _addr(point), _addr(out))
 
     def h2_dev_eval_polynomial_batch(self, ptrs, count, n, points, out, stream):
-        for i in range(count):
-            rc = self.h2_dev_eval_polynomial(ptrs[i], n, points + 32 * i, out + 32 * i, stream)
-            if rc:
-                return rc
-        return 0
+        return self._each(lambda i: self.h2_dev_eval_polynomial(ptrs[i], n, points + 32 * i, out + 32 * i, stream),
+                          list(range(count)))
 
     def h2_dev_kate_division(self, a, n, b, q, stream):
         self._count("h2_kate_division")
@@ -289,10 +290,12 @@ class HostApiDevice(P.Device):
     call per circuit instance, as `Evaluator::evaluate_h` under the cuda / hip feature does."""
     quotient_from_coeffs = True
 
-    def __init__(self, device=0, pinned=False):
+    def __init__(self, device=0, pinned=False, workers=4):
         """`pinned`: every host vector lives in page-locked memory (a Rust-side allocator over h2_host_alloc_pinned for
-        `Polynomial::values`): the same calls, but their transfers are DMA instead of staged pageable copies"""
+        `Polynomial::values`): the same calls, but their transfers are DMA instead of staged pageable copies.  `workers`:
+        threads that issue the calls of a per-column loop (the reference's rayon par_iters); 1 = strictly sequential"""
         self.pinned = pinned
+        self.workers = workers
         import torch
 
         if not torch.cuda.is_available():
@@ -301,7 +304,7 @@ class HostApiDevice(P.Device):
         torch.cuda.set_device(self.gpu)
         self.torch = _HostTorch(torch)
         self.dev = torch.device("cpu")
-        self.L = HostSliceLib(torch, self.gpu)
+        self.L = HostSliceLib(torch, self.gpu, self.workers)
         self.tstream = self.copy_stream = _NullStream()
         self.stream = None
         self._scratch, self._pinned = None, {}

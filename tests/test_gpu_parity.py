@@ -763,3 +763,70 @@ def test_batched_transforms_equal_single_ones(oracle, k):
         torch.cuda.synchronize()
         for i in (0, 15, 16, 18):
             assert np.array_equal(exts[i].cpu().numpy().view(np.uint64), oracle.coeff_to_extended(cols[i], d)), i
+
+
+@pytest.mark.parametrize("slots", [1, 2, 3])
+def test_concurrent_host_slice_callers_over_the_host_api_slots(tmp_path, slots):
+    """Two (or three) host-API slots per device (H2_HOST_SLOTS): concurrent host-slice callers -- the reference's entry
+    points are invoked from rayon workers -- overlap one call's transfers with another's kernels.  Six threads mix
+    transforms that share plans and last-pass tables (2^18), MSMs over ONE registered SRS (its device copy and table shared by
+    the slots), coset extensions and Horner evaluations; every result equals the one the same call gives alone."""
+    import subprocess
+    import sys
+
+    from h2util import ROOT as REPO
+
+    script = tmp_path / "worker.py"
+    script.write_text(r"""
+import os, sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch
+torch.cuda.init()
+import halo2_gpu_specific_amd as h2
+from halo2_gpu_specific_amd import arithmetic as ar
+from h2util import R_MOD, fr_mont
+L = h2.lib()
+ROOT_W = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+rng = np.random.default_rng(9)
+def vec(n):
+    return rng.integers(0, 2**62, size=(n, 4), dtype=np.uint64)
+log_n, m = 18, 1 << 16
+w = fr_mont(pow(ROOT_W, 1 << (28 - log_n), R_MOD))
+w_inv, n_inv = fr_mont(pow(pow(ROOT_W, 1 << (28 - log_n), R_MOD), -1, R_MOD)), fr_mont(pow(1 << log_n, -1, R_MOD))
+d_pts = torch.empty((m, 8), dtype=torch.int64, device="cuda")
+L.h2_dev_random_points(11, m, d_pts.data_ptr(), None); L.h2_synchronize()
+pts = d_pts.cpu().numpy().view(np.uint64)
+assert L.h2_bases_register(pts.ctypes.data, m) == 0
+xs = [vec(1 << log_n) for _ in range(6)]
+ss = [vec(m) for _ in range(6)]
+point = fr_mont(123456789)
+def job(i):
+    if i %% 3 == 0:
+        return ("ntt", ar.best_fft(xs[i].copy(), w, log_n), ar.gpu_ifft(xs[i].copy(), w_inv, log_n, n_inv))
+    if i %% 3 == 1:
+        return ("msm", ar.gpu_multiexp_single_gpu_with_bound(ss[i], pts, 254), ar.gpu_multiexp_single_gpu_with_bound(ss[i][:m // 2], pts[:m // 2], 64))
+    return ("eval", ar.eval_polynomial(xs[i], point), ar.best_fft(xs[i].copy(), w, log_n))
+alone = [job(i) for i in range(6)]
+errors, got = [], [None] * 6
+def worker(i):
+    try:
+        for _ in range(3):
+            got[i] = job(i)
+    except Exception as e:
+        errors.append((i, repr(e)))
+ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errors, errors
+def same(a, b):
+    if a[0] == "msm":      # Jacobian representations may differ with the summation order: compare the group elements
+        from bench import jac_eq
+        return all(jac_eq(p, q) for p, q in zip(a[1:], b[1:]))
+    return all(np.array_equal(p, q) for p, q in zip(a[1:], b[1:]))
+assert all(same(a, b) for a, b in zip(alone, got)), "a concurrent call differs from the same call alone"
+assert L.h2_bases_unregister(pts.ctypes.data) == 0
+assert L.h2_release_plans() == 0
+print("SLOTS OK")
+""" % (REPO, REPO))
+    res = subprocess.run([sys.executable, str(script)], env=dict(os.environ, H2_HOST_SLOTS=str(slots)), capture_output=True,
+                         text=True, timeout=280, cwd=REPO)
+    assert res.returncode == 0 and "SLOTS OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -48,3 +48,33 @@ sc = rng.integers(0, 2**62, size=(n, 4), dtype=np.uint64)
 t("h2_msm 2^20 (scalars + bases uploaded)", lambda: ar.gpu_multiexp_single_gpu_with_bound(sc, pts, 254))
 L.h2_bases_register(pts.ctypes.data, n)
 t("h2_msm 2^20 (bases registered / resident)", lambda: ar.gpu_multiexp_single_gpu_with_bound(sc, pts, 254))
+
+
+# ---- concurrent callers (the reference's entry points are invoked from rayon workers): T threads, each its own vectors; with
+# two host-API slots per device (H2_HOST_SLOTS, default 2) one call's transfers overlap another's kernels
+import threading  # noqa: E402
+
+
+def concurrent(name, make_call, threads, reps=6):
+    calls = [make_call(i) for i in range(threads)]
+    for c in calls:
+        c()
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=lambda c=c: [c() for _ in range(reps)]) for c in calls]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    dt = time.perf_counter() - t0
+    print("%-58s %8.2f ms per call  (%d threads)" % (name, dt / (threads * reps) * 1e3, threads))
+
+
+log_n = 22
+w22 = mont(pow(ROOT, 1 << (28 - log_n), R))
+arrs = [rng.integers(0, 2**62, size=(1 << log_n, 4), dtype=np.uint64) for _ in range(4)]
+scs = [rng.integers(0, 2**62, size=(n, 4), dtype=np.uint64) for _ in range(4)]
+print("H2_HOST_SLOTS =", os.environ.get("H2_HOST_SLOTS", "2 (default)"))
+for T in (1, 2, 4):
+    concurrent("h2_ntt 2^22, concurrent callers", lambda i: (lambda: ar.best_fft(arrs[i], w22, log_n)), T)
+for T in (1, 2, 4):
+    concurrent("h2_msm 2^20 (registered bases), concurrent callers", lambda i: (lambda: ar.gpu_multiexp_single_gpu_with_bound(scs[i], pts, 254)), T)
