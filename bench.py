@@ -166,6 +166,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def leg_failed(key, e):
+        """a secondary leg raised: recorded in the line (the primary NTT metric is still printed) and reported on stderr with
+        the rank.  With N > 1 the legs are sequences of collectives that every rank must walk in step -- a rank that left one
+        early would pair its next barrier with the others' current one -- so there the run ends here, non-zero (the launcher
+        stops the other ranks and reports which one failed)."""
+        import traceback
+
+        sys.stderr.write("bench.py: rank %d: leg %s failed: %s: %s\n%s" % (rank, key, type(e).__name__, e, traceback.format_exc()))
+        sys.stderr.flush()
+        if world > 1:
+            if rank == 0:
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print(json.dumps(out), flush=True)
+            os._exit(3)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -198,6 +214,9 @@ def main():
             torch.cuda.synchronize()
 
     ref_head = a[:64].clone()
+    # torch generated `a` on ITS current stream; the library runs on the stream it is handed (NULL = its own, non-blocking:
+    # not ordered with torch's default stream): everything above is complete before the first transform starts
+    torch.cuda.synchronize()
     spin(ntt_step)
     for _ in range(args.warmup):
         ntt_step()
@@ -320,6 +339,7 @@ def main():
             sc = torch.randint(-(2**63), 2**63 - 1, (mn, 4), dtype=torch.int64, device=dev, generator=g)
             sc[:, 3] &= 0x1FFFFFFFFFFFFFFF
             cols.append(sc)
+        torch.cuda.synchronize()                # torch's stream produced the columns; the library's streams consume them
         sbytes = L.h2_msm_scratch_bytes(mn, 254)
         scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
         res = np.zeros(12, dtype=np.uint64)
@@ -465,7 +485,7 @@ def main():
             try:
                 out[key] = dict(workload=what, **msm_leg(mlog, msteps, mbatch))
             except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
-                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out[key] = leg_failed(key, e)
             torch.cuda.empty_cache()
 
     def evalh_roofline(pk, phases_s):
@@ -734,7 +754,7 @@ def main():
         try:
             out["create_proof_wide"] = wide_leg(args.wide_k, args.wide_quads, 2)
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
-            out["create_proof_wide"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["create_proof_wide"] = leg_failed("create_proof_wide", e)
         torch.cuda.empty_cache()
 
     for key, kk, steps in (("create_proof", args.prove_k, args.prove_steps), ("create_proof_k24", 24 if args.k24 else 0, 2)):
@@ -746,7 +766,7 @@ def main():
                                "witness in pinned host memory, SRS / proving key resident in HBM" % (3 if kk != 24 else 4, kk))
             out[key] = leg
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
-            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out[key] = leg_failed(key, e)
         torch.cuda.empty_cache()
     if watchdog_done is not None:
         watchdog_done.set()

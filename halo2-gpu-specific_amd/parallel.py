@@ -46,6 +46,18 @@ def g1_sum(points):
     return out
 
 
+def _empty_like(t):
+    """an uninitialised vector of which only a part will be written (poisoned under H2_POISON_EMPTY=1, prover.POISON_EMPTY)"""
+    import os
+
+    import torch
+
+    out = torch.empty_like(t)
+    if os.environ.get("H2_POISON_EMPTY") == "1":
+        out.fill_(-1)
+    return out
+
+
 def _backend(group):
     import torch.distributed as dist
 
@@ -283,7 +295,7 @@ def exchange_cosets(mine, c, shards, group=None, stream=None):
     with _on_stream(stream):
         for j in range(c):
             src = j % shards
-            t = mine[j] if (j in mine and rank == src) else torch.empty_like(template)
+            t = mine[j] if (j in mine and rank == src) else _empty_like(template)
             if j in mine and rank != src:
                 out.append(mine[j])             # a replica of the shard already holds it; still take part in the broadcast
             buf = t.cpu() if staged else t
@@ -315,11 +327,13 @@ def exchange_row_slices(columns, owners, n, G, g, halo_lo, halo_hi, group=None, 
     import torch.distributed as dist
 
     device = columns[0].device
-    rows = {m: slice_rows(n, G, m, halo_lo, halo_hi, device) for m in range(G)}
-    per = rows[0].shape[0]
+    per = n // G + halo_lo + halo_hi
     mine = [i for i, o in enumerate(owners) if o == g]
     theirs = {m: [i for i, o in enumerate(owners) if o == m] for m in range(G)}
     with _on_stream(stream):
+        # (the index vectors are built by kernels too: on THIS stream -- torch's default stream and a stream created with
+        # torch.cuda.Stream() do not order each other, and an index_select that overtakes its own indices reads garbage rows)
+        rows = {m: slice_rows(n, G, m, halo_lo, halo_hi, device) for m in range(G)}
         send = [torch.cat([columns[i].index_select(0, rows[m]) for i in mine]) if mine and m != g else
                 torch.empty((0, 4), dtype=columns[0].dtype, device=device) for m in range(G)]
         recv = [torch.empty((per * len(theirs[m]) if m != g else 0, 4), dtype=columns[0].dtype, device=device) for m in range(G)]
@@ -425,7 +439,7 @@ def scatter_cosets(mine, c, shards, lo, hi, group=None, stream=None):
     with _on_stream(stream):
         for j in range(c):
             src = j % shards
-            full = mine[j] if j in mine else torch.empty_like(template)
+            full = mine[j] if j in mine else _empty_like(template)
             recv = full[lo:hi]
             if rank == src:
                 parts = [full[r * (n // world):(r + 1) * (n // world)] for r in range(world)]

@@ -34,6 +34,13 @@ _vp = ctypes.c_void_p
 _FR = ctypes.c_uint64 * 4
 
 
+# H2_POISON_EMPTY=1 (tests): every "uninitialised" vector starts as all-ones words -- not even a field element -- so a pass
+# that reads rows nobody wrote (a partially valid vector of the multi-rank paths: only a row range, a row slice and its halo)
+# changes the proof on every run instead of only when the allocator hands back dirty memory
+POISON_EMPTY = os.environ.get("H2_POISON_EMPTY") == "1"
+TRACE_TRANSCRIPT = os.environ.get("H2_TRACE_TRANSCRIPT") == "1"     # create_proof prints a hash of the proof stream per phase
+
+
 def _fr(v):
     """canonical integer -> Montgomery limbs for the C ABI"""
     return _FR(*fr_to_mont_limbs(v % R_MOD))
@@ -186,7 +193,10 @@ class Device:
     # -- memory -----------------------------------------------------------------------------------------
     def empty(self, n):
         with self.torch.cuda.stream(self.tstream):
-            return self.torch.empty((n, 4), dtype=self.torch.int64, device=self.dev)
+            t = self.torch.empty((n, 4), dtype=self.torch.int64, device=self.dev)
+            if POISON_EMPTY:
+                t.fill_(-1)
+            return t
 
     def zeros(self, n):
         with self.torch.cuda.stream(self.tstream):
@@ -1340,6 +1350,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         if timings is not None:
             D.sync()
             marks.append((name, time.perf_counter()))
+        if TRACE_TRANSCRIPT:                 # where two runs (or two ranks) of one proof part ways: the transcript after a phase
+            import sys
+
+            sys.stderr.write("h2 trace: rank %d after %s: %s (%d bytes)\n" % (
+                D.group_rank, name, hashlib.sha256(bytes(transcript.writer)).hexdigest()[:12], len(transcript.writer)))
 
     transcript = Blake2bWrite()
     transcript.common_scalar(pk.transcript_repr)

@@ -146,6 +146,7 @@ def test_compact_and_resident_witness_columns_give_the_same_bytes(device):
     assert prover.create_proof_ext(device, params, pk, mixed, ProverRng(9), True) == gwc
     # the widening on its own: every value, a ragged length
     src = torch.randint(-(2**63), 2**63 - 1, (100003,), dtype=torch.int64, device=device.dev)
+    torch.cuda.synchronize()                       # generated on torch's stream, consumed on the device's own
     wide = device.widen(src)
     device.sync()
     assert torch.equal(wide[:, 0], src) and not wide[:, 1:].any()

@@ -297,7 +297,7 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
                                            (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8),
                                            (2, "fuzz:201", 8), (4, "fuzz:202", 8), (3, "fuzz:203", 8), (2, "fuzz:204", 9),
                                            (4, "fuzz:205", 9), (8, "fuzz:206", 9), (8, "wide", 9), (8, "mini", 12),
-                                           (8, "fuzz:207", 9), (4, "fuzz:208", 10)])
+                                           (8, "fuzz:207", 9), (4, "fuzz:208", 10), (8, "wide16", 10), (8, "wide16", 12)])
 def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
     """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
@@ -328,14 +328,23 @@ def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     for tag, proof in (("PROOF", want[0]), ("GWC", want[1])):
         got = [l.split()[1] for l in res.stdout.splitlines() if l.startswith(tag + " ")]
-        assert len(got) == world and all(bytes.fromhex(h) == proof for h in got), tag
+        assert len(got) == world and all(_same_proof(h, proof) for h in got), tag
     secure = [l.split()[1] for l in res.stdout.splitlines() if l.startswith("SECURE ")]
-    assert len(secure) == world and len(set(secure)) == 1 and secure[0] != want[0].hex()
+    assert len(secure) == world and len(set(secure)) == 1 and not _same_proof(secure[0], want[0])
     if which == "mini":
         vk = rp.Keys()
         vk.cs, vk.dom, vk.s = rp.MiniPlonk, rp.Domain(k, 3), S_TRAPDOOR
         vk.fixed_commitments, vk.perm_commitments, vk.transcript_repr = pk.fixed_commitments, pk.perm_commitments, pk.transcript_repr
         assert rp.verify_proof(vk, bytes.fromhex(secure[0]))
+
+
+def _same_proof(text, proof):
+    """a worker's line against the expected bytes: hex for short proofs, "sha256:<digest>" for long ones (_WORKER.emit)"""
+    import hashlib
+
+    if text.startswith("sha256:"):
+        return text[7:] == hashlib.sha256(proof).hexdigest()
+    return bytes.fromhex(text) == proof
 
 
 def _multi_rank_case(which, k):
@@ -345,9 +354,10 @@ def _multi_rank_case(which, k):
     if which == "mini":
         adv, fixed, copies = circuits.mini_plonk_synthesize(k)
         return circuits.mini_plonk(), adv, fixed, copies, []
-    if which == "wide":
-        adv, fixed, copies = circuits.wide_synthesize(k, 4)
-        return circuits.wide(4), adv, fixed, copies, []
+    if which.startswith("wide"):                       # "wide": 4 quads (16 columns, 2 lookups); "wide16": the bench's 64 columns
+        quads = int(which[4:] or 4)
+        adv, fixed, copies = circuits.wide_synthesize(k, quads)
+        return circuits.wide(quads), adv, fixed, copies, []
     if which.startswith("fuzz:"):                      # a random satisfied circuit of tools/prover_fuzz.py
         import sys
 
@@ -439,17 +449,44 @@ cs, adv, fixed, copies, inst = _multi_rank_case(which, k)
 pk = prover.keygen(D, params, cs, fixed, copies)
 # the O(n) passes really are range-sharded (a world that does not divide 2^k keeps them replicated: uneven MSM ranges only)
 assert (D.row_range(1 << k) != (0, 1 << k)) == ((1 << k) %% dist.get_world_size() == 0)
+# A stream-order check: a background thread keeps torch's DEFAULT stream busy (one 30 ms sleep kernel always queued) for as long
+# as the proofs run.  Everything of a proof runs on the device's own streams (created with torch.cuda.Stream(): not ordered with
+# the default stream), so a tensor that some helper builds on the default stream by mistake -- an index vector, a mask -- is
+# not there yet when the proof's stream reads it, and the proof comes out wrong HERE instead of only when eight processes
+# contend for one GPU (parallel.exchange_row_slices once built its row indices that way).
+import threading
+_stall = {"on": True}
+def _keep_default_stream_busy():
+    torch.cuda.set_device(local)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); torch.cuda._sleep(20_000_000); b.record(); b.synchronize()
+    cycles = int(0.03 * 20_000_000 / max(a.elapsed_time(b) * 1e-3, 1e-6))
+    done = torch.cuda.Event()
+    while _stall["on"]:
+        torch.cuda._sleep(cycles); done.record(); done.synchronize()
+_staller = threading.Thread(target=_keep_default_stream_busy, daemon=True)
+if os.environ.get("H2_TEST_STALL", "1") != "0":
+    _staller.start()
+import hashlib
+def emit(tag, data):
+    # one write() of at most PIPE_BUF bytes is atomic on the pipe the ranks share: a long proof goes out as its hash
+    text = data.hex() if len(data) <= 1500 else "sha256:" + hashlib.sha256(data).hexdigest()
+    os.write(1, (tag + " " + text + "\n").encode())
 proof = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), False, instances=inst)
 # more ranks than cosets (a multiple of them): the ranks of a coset really shared its work (coset rank groups)
 c_, w_ = pk.domain.quotient_poly_degree, dist.get_world_size()
 assert bool(getattr(D, "_coset_groups", {})) == (w_ %% c_ == 0 and w_ // c_ >= 2), (c_, w_)
-sys.stdout.write("PROOF " + proof.hex() + "\n")
+emit("PROOF", proof)
 gwc = prover.create_proof_ext(D, params, pk, adv, ProverRng(9), True, instances=inst)
-sys.stdout.write("GWC " + gwc.hex() + "\n")
+emit("GWC", gwc)
 # OS-entropy blinding: rank 0's key is broadcast (ProverRng.shared), so the ranks still agree on every byte
 secure = prover.create_proof_ext(D, params, pk, adv, ProverRng(), False, instances=inst)
-sys.stdout.write("SECURE " + secure.hex() + "\n")
+emit("SECURE", secure)
 sys.stdout.flush()
+_stall["on"] = False
+if _staller.is_alive():
+    _staller.join()
+torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()
 """
