@@ -65,6 +65,7 @@ def test_lincomb(oracle):
     d_polys = [torch.from_numpy(p.view(np.int64)).to(dev) for p in polys]
     res = torch.zeros((size, 4), dtype=torch.int64, device=dev)
     ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_polys])
+    torch.cuda.synchronize()          # torch's stream filled `res`; the library's own stream (NULL) writes it next
     assert L.h2_dev_lincomb(res.data_ptr(), ptrs, coeffs.ctypes.data, count, size, None) == 0
     torch.cuda.synchronize()
     h2.lib().h2_synchronize()
