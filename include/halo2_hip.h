@@ -20,7 +20,9 @@
  *                 Rust shim panics on non-zero.
  *   threading     every function may be called concurrently from any thread (rayon workers);
  *                 host-buffer calls take a device from the blocking pool sized by
- *                 HALO2_PROOFS_N_GPU (plonk/prover.rs:56-74; arithmetic.rs:314-331).
+ *                 HALO2_PROOFS_N_GPU (plonk/prover.rs:56-74; arithmetic.rs:314-331).  A device serves
+ *                 H2_HOST_SLOTS (default 2, 1..4) such calls at a time, each on its own stream and staging, so that
+ *                 one caller's transfers overlap another's kernels; 1 = the reference's one operation per device.
  *   h2_dev_*      operate on HIP device pointers on the caller's stream (void* = hipStream_t,
  *                 NULL = the library's stream for the current device) and do not synchronise.
  *                 NULL does NOT mean HIP's legacy default stream: the library's stream is non-blocking, so work

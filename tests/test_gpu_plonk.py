@@ -297,7 +297,7 @@ def test_coset_path_reproduces_the_proof(oracle, device, which, k):
                                            (4, "lookup", 8), (4, "wide", 9), (3, "mini", 10), (3, "lookup", 8),
                                            (2, "fuzz:201", 8), (4, "fuzz:202", 8), (3, "fuzz:203", 8), (2, "fuzz:204", 9),
                                            (4, "fuzz:205", 9), (8, "fuzz:206", 9), (8, "wide", 9), (8, "mini", 12),
-                                           (8, "fuzz:207", 9), (4, "fuzz:208", 10), (8, "wide16", 10), (8, "wide16", 12)])
+                                           (8, "fuzz:207", 9), (4, "fuzz:208", 10), (8, "wide16", 10)])
 def test_gloo_ranks_on_one_gpu_prove_the_single_device_bytes(oracle, device, tmp_path, world, which, k):
     """config 5's data flow with 2 / 4 / 8 ranks (here processes sharing cuda:0 over gloo; RCCL refuses two ranks on one
     device): every MSM range-split + all-gather + fold; the extended domain split by coset, the per-coset quotients
