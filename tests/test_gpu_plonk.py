@@ -429,6 +429,32 @@ def test_two_rank_rccl_proof_equals_single_device_proof(oracle, device, tmp_path
     assert len(proofs) == 2 and all(bytes.fromhex(h) == want for h in proofs)
 
 
+# A stream-order check shared by the worker scripts below: a background thread keeps torch's DEFAULT stream busy (one 30 ms sleep
+# kernel always queued) for as long as the proofs run.  Everything of a proof runs on the device's own streams (created with
+# torch.cuda.Stream(): not ordered with the default stream), so a tensor that some helper builds on the default stream by mistake
+# -- an index vector, a mask -- is not there yet when the proof's stream reads it, and the proof comes out wrong HERE instead of
+# only when eight processes contend for one GPU (parallel.exchange_row_slices once built its row indices that way).
+_STALLER = r"""
+import threading
+_stall = {"on": True, "device": torch.cuda.current_device()}
+def _keep_default_stream_busy():
+    torch.cuda.set_device(_stall["device"])
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); torch.cuda._sleep(20_000_000); b.record(); b.synchronize()
+    cycles = int(0.03 * 20_000_000 / max(a.elapsed_time(b) * 1e-3, 1e-6))
+    done = torch.cuda.Event()
+    while _stall["on"]:
+        torch.cuda._sleep(cycles); done.record(); done.synchronize()
+_staller = threading.Thread(target=_keep_default_stream_busy, daemon=True)
+if os.environ.get("H2_TEST_STALL", "1") != "0":
+    _staller.start()
+def stop_staller():
+    _stall["on"] = False
+    if _staller.is_alive():
+        _staller.join()
+    torch.cuda.synchronize()
+"""
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, %r)
@@ -452,24 +478,7 @@ cs, adv, fixed, copies, inst = _multi_rank_case(which, k)
 pk = prover.keygen(D, params, cs, fixed, copies)
 # the O(n) passes really are range-sharded (a world that does not divide 2^k keeps them replicated: uneven MSM ranges only)
 assert (D.row_range(1 << k) != (0, 1 << k)) == ((1 << k) %% dist.get_world_size() == 0)
-# A stream-order check: a background thread keeps torch's DEFAULT stream busy (one 30 ms sleep kernel always queued) for as long
-# as the proofs run.  Everything of a proof runs on the device's own streams (created with torch.cuda.Stream(): not ordered with
-# the default stream), so a tensor that some helper builds on the default stream by mistake -- an index vector, a mask -- is
-# not there yet when the proof's stream reads it, and the proof comes out wrong HERE instead of only when eight processes
-# contend for one GPU (parallel.exchange_row_slices once built its row indices that way).
-import threading
-_stall = {"on": True}
-def _keep_default_stream_busy():
-    torch.cuda.set_device(local)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); torch.cuda._sleep(20_000_000); b.record(); b.synchronize()
-    cycles = int(0.03 * 20_000_000 / max(a.elapsed_time(b) * 1e-3, 1e-6))
-    done = torch.cuda.Event()
-    while _stall["on"]:
-        torch.cuda._sleep(cycles); done.record(); done.synchronize()
-_staller = threading.Thread(target=_keep_default_stream_busy, daemon=True)
-if os.environ.get("H2_TEST_STALL", "1") != "0":
-    _staller.start()
+__STALLER__
 import hashlib
 def emit(tag, data):
     # one write() of at most PIPE_BUF bytes is atomic on the pipe the ranks share: a long proof goes out as its hash
@@ -486,13 +495,10 @@ emit("GWC", gwc)
 secure = prover.create_proof_ext(D, params, pk, adv, ProverRng(), False, instances=inst)
 emit("SECURE", secure)
 sys.stdout.flush()
-_stall["on"] = False
-if _staller.is_alive():
-    _staller.join()
-torch.cuda.synchronize()
+stop_staller()
 dist.barrier()
 dist.destroy_process_group()
-"""
+""".replace("__STALLER__", _STALLER)
 
 
 def _free_port():
@@ -531,14 +537,16 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 from halo2_gpu_specific_amd import circuits, prover
 from halo2_gpu_specific_amd.rng import ProverRng
 D = prover.Device(0, force_collective=True)
+__STALLER__
 k = %d
 params = prover.Params(D, k, np.load(%r), np.load(%r))
 adv, fixed, copies = circuits.mini_plonk_synthesize(k)
 pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
 proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(9))
 sys.stdout.write("PROOF " + proof.hex() + "\n")
+stop_staller()
 dist.destroy_process_group()
-""" % (ROOT, k, str(g_path), str(gl_path)))
+""".replace("__STALLER__", _STALLER) % (ROOT, k, str(g_path), str(gl_path)))
     import socket
 
     with socket.socket() as sock:
@@ -629,6 +637,7 @@ torch.cuda.init()
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from halo2_gpu_specific_amd import parallel, prover
 D = prover.Device(0, force_collective=True)
+__STALLER__
 bulk = dist.new_group()
 dev, stream, side = D.dev, D.tstream, D.copy_stream
 g = torch.Generator(device=dev); g.manual_seed(5)
@@ -680,8 +689,9 @@ assert arrival is None
 stream.synchronize()
 assert all(torch.equal(a, b) for a, b in zip(out, want))
 sys.stdout.write("COLLECTIVES OK\n")
+stop_staller()
 dist.destroy_process_group()
-""" % ROOT)
+""".replace("__STALLER__", _STALLER) % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0 and "COLLECTIVES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
