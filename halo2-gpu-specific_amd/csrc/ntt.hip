@@ -149,19 +149,23 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const 
 
 // LAZY: the lazy domain of field.hpp -- values below 4p in LDS and between the passes, products by fp_mul_wide (no final
 // subtraction), bare additions; canonical residues come back at the last pass's store.  Same field elements, same output.
-template <bool RADIX4, bool LAZY>
+// FB != 0: the pass geometry as compile-time constants (B = FB bits, 4 columns per tile, no zero-padding skip, RADIX4 lanes):
+// the stage loop unrolls with constant strides, the LDS planes sit at immediate offsets and the loops over a tile collapse to
+// one iteration -- the same instructions on the same operands minus most of the index arithmetic.  FB = 0: everything from `a`.
+template <bool RADIX4, bool LAZY, uint32_t FB = 0>
 __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
     // x * w for a canonical twiddle w: canonical arithmetic, or any x < 2^256 -> a value below 2p
     auto tmul = [](const Fr& x, const Fr& w) -> Fr {
         if constexpr (LAZY) return fp_mul_wide(x, w);
         else return fp_mul(x, w);
     };
-    const uint32_t B = a.B, R = 1u << B, log_c = a.log_c, C = 1u << log_c;
+    const uint32_t B = FB ? FB : a.B, R = 1u << B, log_c = FB ? 2u : a.log_c, C = 1u << log_c;
+    const uint32_t zskip = FB ? 0u : a.zskip;
     uint4* t_lo = h2_smem;                  // R*C low halves
     uint4* t_hi = t_lo + (R << log_c);      // R*C high halves
     uint4* w_lo = t_hi + (R << log_c);      // R/2 butterfly twiddles, low / high halves
     uint4* w_hi = w_lo + (R >> 1) + 1;
-    const uint32_t nthreads = blockDim.x;  // == max(R/2 * C, 1)
+    const uint32_t nthreads = FB ? ((RADIX4 ? (R >> 2) : (R >> 1)) << log_c) : blockDim.x;  // == max(R/2 * C, 1) (RADIX4: half)
     const uint32_t tid = threadIdx.x;
     const Fr* const in_p = a.batch ? a.in_b[blockIdx.y] : a.in;   // (wave-uniform: scalar loads from the kernel arguments)
     Fr* const out_p = a.batch ? a.out_b[blockIdx.y] : a.out;
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
             // Zero padding by 2^z (coeff_to_extended): the rows rho >= R >> z of the first pass are zero, so its first z
             // stages are butterflies (u, 0) -> (u, u) whatever the twiddle: each loaded element is written to the 2^z rows
             // those stages would copy it to (the low z bits of the bit-reversed row index) and the stage loop starts at z.
-            live[q] = e < total && !(a.zskip && rho[q] >= (R >> a.zskip));
+            live[q] = e < total && !(zskip && rho[q] >= (R >> zskip));
         }
 #pragma unroll
         for (uint32_t q = 0; q < NE; q++) {
@@ -271,9 +275,9 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
             const uint32_t e = e0 + q * nthreads;
             const uint32_t r_q = a.is_last ? (e & (R - 1)) : ((e >> log_c) & (R - 1));
             const uint32_t c_q = a.is_last ? ((e >> B) & (C - 1)) : (e & (C - 1));
-            if (e >= total || (a.zskip && r_q >= (R >> a.zskip))) continue;
-            if (a.zskip) {
-                for (uint32_t m = 0; m < (1u << a.zskip); m++) lds_put(t_lo, t_hi, ((bitrev(r_q, B) | m) << log_c) + c_q, x[q]);
+            if (e >= total || (zskip && r_q >= (R >> zskip))) continue;
+            if (zskip) {
+                for (uint32_t m = 0; m < (1u << zskip); m++) lds_put(t_lo, t_hi, ((bitrev(r_q, B) | m) << log_c) + c_q, x[q]);
             } else {
                 lds_put(t_lo, t_hi, (bitrev(r_q, B) << log_c) + c_q, x[q]);
             }
@@ -286,11 +290,11 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
     // twiddle, index r = p mod h, for both) and the two stage-(s+1) butterflies (indices r and r + h) in registers and
     // writes the four rows back: half the LDS instructions, address arithmetic and barriers of the stage-by-stage loop,
     // the same products on the same operands.
-    uint32_t s0 = a.zskip;
+    uint32_t s0 = zskip;
     if constexpr (RADIX4) {
         const uint32_t nunits = total >> 2;
-        for (; s0 + 1 < B; s0 += 2) {
-            const uint32_t s = s0, h = 1u << s;
+        auto round4 = [&](const uint32_t s) __attribute__((always_inline)) {
+            const uint32_t h = 1u << s;
             const uint32_t log_per = (B - 2 + log_c) - s;  // units that share one r: 2^log_per
             const bool by_r = s != 0 && log_per >= 6 && (nthreads & 63) == 0;
             for (uint32_t t = tid; t < nunits; t += nthreads) {
@@ -346,6 +350,13 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
                 }
             }
             __syncthreads();
+        };
+        if constexpr (FB != 0) {
+#pragma unroll
+            for (uint32_t s = 0; s + 1 < FB; s += 2) round4(s);
+            s0 = FB & ~1u;
+        } else {
+            for (; s0 + 1 < B; s0 += 2) round4(s0);
         }
     }
     const uint32_t nbf = total >> 1;
@@ -943,7 +954,11 @@ static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr
             // the lazy domain (field.hpp: values below 4p between load and store, products without their final subtraction);
             // H2_NTT_LAZY=0 keeps canonical residues everywhere -- same output either way
             static const bool lazy = !(getenv("H2_NTT_LAZY") && atoi(getenv("H2_NTT_LAZY")) == 0);
-            if (a.radix4 && lazy)
+            // the common pass -- 8 bits, tiles of 4 columns, nothing skipped -- has its geometry compiled in (H2_NTT_FIXED=0: generic)
+            static const bool fixed = !(getenv("H2_NTT_FIXED") && atoi(getenv("H2_NTT_FIXED")) == 0);
+            if (fixed && a.radix4 && lazy && B == 8 && log_c == 2 && a.zskip == 0 && threads == 256)
+                hipLaunchKernelGGL((k_ntt_pass<true, true, 8>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
+            else if (a.radix4 && lazy)
                 hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else if (a.radix4)
                 hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
