@@ -500,9 +500,9 @@ def main():
         muls = st["products_per_row"] * size / t
         return {"bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes": alg, "distinct_vectors_read": st["vectors_read"], "seconds": t,
-                "kernel": ("h2_evalh_fused (gates + permutation / lookup / shuffle terms in one generated kernel)" if st["fused"] else
-                           "h2_evalh_jit + k_evalh_perm / k_evalh_lookup / k_evalh_shuffle"),
-                "alu": {"products_per_row": st["products_per_row"], "achieved_mul_per_s": muls, "peak_mul_per_s": MUL_HW_BOUND,
+                "kernel": "h2_evalh_gen x %d (gates + permutation / lookup / shuffle terms, generated by the library: csrc/evalh_gen.cpp)" % st["stages"],
+                "alu": {"products_per_row": st["products_per_row"], "products_per_row_as_written": st["reference_products_per_row"],
+                        "max_registers": st["max_registers"], "achieved_mul_per_s": muls, "peak_mul_per_s": MUL_HW_BOUND,
                         "frac": muls / MUL_HW_BOUND, "frac_of_multiplier_in_a_loop": muls / MUL_MEASURED},
                 "limiter": "integer VALU: the field products of the gate and argument terms, not HBM"}
 

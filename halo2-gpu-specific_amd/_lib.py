@@ -108,7 +108,10 @@ SYMBOLS = {
     "h2_dev_fixed_base_mul": (ctypes.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "h2_dev_points_decompress": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_points_compress": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
-    "h2_jit_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _vp]),
+    "h2_evalh_prepare": (ctypes.c_int, [_vp, _vp]),
+    "h2_evalh_compile": (ctypes.c_int, [_vp, _vp]),
+    "h2_evalh_source": (ctypes.c_int, [_vp, _u32, _vp, _sz, _vp]),
+    "h2_evalh_generated_launches": (ctypes.c_uint64, []),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_evaluate_h_coeff": (ctypes.c_int, [_vp, _vp]),
     "h2_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz]),

@@ -945,18 +945,48 @@ int h2_dev_logup_multiplicity(const void* d_table, const void* const* d_inputs, 
     });
 }
 
-int h2_jit_load(const char* code_object_path, const char* kernel_name, const void** function_out) {
-    if (!code_object_path || !kernel_name || !function_out) return bad("h2_jit_load: null argument");
+// ------------------------------------------------------------------ evaluate_h: the generated form
+int h2_evalh_prepare(const h2_evalh_desc* desc, h2_evalh_info* info) {
+    if (!desc) return bad("h2_evalh_prepare: null argument");
     return guarded([&] {
         current_ctx();  // the device of this thread is initialised
-        hipModule_t mod = nullptr;
-        H2_HIP(hipModuleLoad(&mod, code_object_path));
-        hipFunction_t fn = nullptr;
-        H2_HIP(hipModuleGetFunction(&fn, mod, kernel_name));
-        *function_out = (const void*)fn;
+        int cached = 0;
+        const EvalhPlan* plan = evalh_plan_get(desc, &cached);
+        if (!plan) return bad("h2_evalh_prepare: no generated kernels for this program (H2_EVALH_JIT=0, hipRTC unavailable or a rejected program: see stderr)");
+        if (info) {
+            evalh_plan_info(plan, info);
+            info->from_cache = (uint32_t)cached;
+        }
         return (int)H2_OK;
     });
 }
+
+int h2_evalh_compile(const h2_evalh_desc* desc, h2_evalh_info* info) {
+    if (!desc) return bad("h2_evalh_compile: null argument");
+    return guarded([&] {
+        evgen::Generated g = evgen::compile(desc, evgen::Options::from_env());
+        if (info) evalh_gen_info(g, info);
+        return (int)H2_OK;
+    });
+}
+
+int h2_evalh_source(const h2_evalh_desc* desc, uint32_t stage, char* buf, size_t cap, size_t* len) {
+    if (!desc || !len || (cap && !buf)) return bad("h2_evalh_source: null argument");
+    return guarded([&] {
+        evgen::Generated g = evgen::generate(desc, evgen::Options::from_env());
+        if (stage >= g.stages.size()) return bad("h2_evalh_source: no such stage");
+        const std::string& src = g.stages[stage].source;
+        *len = src.size();
+        if (cap) {
+            const size_t n = std::min(cap - 1, src.size());
+            memcpy(buf, src.data(), n);
+            buf[n] = 0;
+        }
+        return (int)H2_OK;
+    });
+}
+
+uint64_t h2_evalh_generated_launches(void) { return evalh_generated_launches(); }
 
 // ------------------------------------------------------------------ evaluate_h
 int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {

@@ -13,14 +13,19 @@
 //   k_evalh_shuffle  shuffle terms (:1197-1219; cuda eval_h_shuffles, :1935-1952)
 // Intermediates of the interpreter live in a [calculation][thread] global array (coalesced, L2-resident);
 // the program itself is read with wave-uniform (scalar) loads, so there is no divergence.
+// These four kernels are the fallback: a program is normally run as kernels GENERATED for it (evalh_gen.cpp: straight-line
+// code, intermediates in registers, all terms in one or a few launches), built by hipRTC on first use -- `EvalhPlan` below.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "common.hpp"
 #include "evalh.hpp"
-#include "evalh_jit.hpp"
+#include "evalh_gen.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
 
@@ -245,6 +250,233 @@ __global__ void __launch_bounds__(256) k_evalh_shuffle(ShuffleArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------- generated kernels: plans per (program, device)
+struct EvalhPlan {
+    evgen::Generated gen;               // stage metadata (sources and code objects dropped after loading)
+    std::vector<hipModule_t> modules;
+    std::vector<hipFunction_t> functions;
+    int device = -1;
+    bool uses_omega = false;
+    int from_cache = 0;                 // 0 compiled now, 2 from the disk cache (1 = memory is decided by the caller)
+};
+
+namespace {
+struct PlanKey {
+    uint64_t h[2];
+    int device;
+    bool operator<(const PlanKey& o) const {
+        if (h[0] != o.h[0]) return h[0] < o.h[0];
+        if (h[1] != o.h[1]) return h[1] < o.h[1];
+        return device < o.device;
+    }
+};
+std::mutex g_plan_mu;
+std::map<PlanKey, std::unique_ptr<EvalhPlan>> g_plans;   // a null entry: generation failed for this program (said once)
+std::atomic<uint64_t> g_generated_launches{0};
+
+// in-memory identity of a program: two multiply-xorshift lanes over the same bytes program_hash covers (the SHA-256 is
+// for the file name on disk, where a collision would load foreign code; here it would at worst pick the wrong cached plan
+// of THIS process's own programs, at 2^-128)
+struct FastHash {
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0xc2b2ae3d27d4eb4full;
+    void word(uint64_t w) {
+        a = (a ^ w) * 0xff51afd7ed558ccdull;
+        a ^= a >> 32;
+        b = (b + w) * 0x9fb21c651e98df25ull;
+        b ^= b >> 29;
+    }
+    void bytes(const void* p, size_t n) {
+        const uint8_t* q = (const uint8_t*)p;
+        word(n);
+        for (; n >= 8; n -= 8, q += 8) {
+            uint64_t w;
+            memcpy(&w, q, 8);
+            word(w);
+        }
+        uint64_t w = 0;
+        memcpy(&w, q, n);
+        word(w);
+    }
+};
+
+PlanKey plan_key(const h2_evalh_desc* d, const evgen::Options& opt, int device) {
+    FastHash h;
+    const uint32_t o[] = {opt.group, opt.max_ahead, opt.gap, opt.inline_muls, opt.stage_products, opt.max_cols, opt.max_regs,
+                          (uint32_t)opt.factor, (uint32_t)opt.mul2, opt.waves, d->blinding_factors, d->chunk_len, d->n_fixed, d->n_advice,
+                          d->n_instance, d->n_perm_sets, d->n_perm_columns, d->n_lookups, d->n_shuffles};
+    h.bytes(o, sizeof o);
+    h.bytes(d->constants, (size_t)d->n_constants * 32);
+    h.bytes(d->rotations, (size_t)d->n_rotations * 4);
+    h.bytes(d->calculations, (size_t)d->n_calculations * sizeof(h2_calculation));
+    h.bytes(d->value_parts, (size_t)d->n_value_parts * sizeof(h2_value_source));
+    size_t n_lookup_calcs = 0;
+    for (uint32_t t = 0; t < d->n_lookups; t++) n_lookup_calcs += 1 + 2 * (size_t)d->lookup_sets[t];
+    h.bytes(d->lookup_sets, (size_t)d->n_lookups * 4);
+    h.bytes(d->lookup_calcs, n_lookup_calcs * sizeof(h2_calculation));
+    h.bytes(d->shuffle_calcs, 2 * (size_t)d->n_shuffles * sizeof(h2_calculation));
+    if (d->n_perm_sets) {
+        h.bytes(d->perm_col_type, (size_t)d->n_perm_columns * 4);
+        h.bytes(d->perm_col_index, (size_t)d->n_perm_columns * 4);
+    }
+    return PlanKey{{h.a, h.b}, device};
+}
+
+bool generation_enabled() {
+    const char* v = getenv("H2_EVALH_JIT");
+    return !(v && v[0] == '0');
+}
+}  // namespace
+
+const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached) {
+    if (cached) *cached = 0;
+    if (!generation_enabled()) return nullptr;
+    int device = 0;
+    H2_HIP(hipGetDevice(&device));
+    const evgen::Options opt = evgen::Options::from_env();
+    const PlanKey key = plan_key(d, opt, device);
+    // one builder at a time: two callers with the same new program would otherwise both compile it
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        if (cached) *cached = 1;
+        return it->second.get();
+    }
+    std::unique_ptr<EvalhPlan> plan;
+    try {
+        plan.reset(new EvalhPlan);
+        plan->gen = evgen::compile(d, opt);
+        plan->device = device;
+        plan->from_cache = plan->gen.from_disk ? 2 : 0;
+        for (evgen::Stage& st : plan->gen.stages) {
+            hipModule_t mod = nullptr;
+            H2_HIP(hipModuleLoadData(&mod, st.code.data()));
+            plan->modules.push_back(mod);
+            hipFunction_t fn = nullptr;
+            H2_HIP(hipModuleGetFunction(&fn, mod, evgen::KERNEL_NAME));
+            plan->functions.push_back(fn);
+            plan->uses_omega = plan->uses_omega || st.uses_omega;
+            // (st.code stays for the life of the plan: hipModuleLoadData does not copy the image -- freeing it here ended in
+            //  memory faults at the first launch)
+            std::string().swap(st.source);
+        }
+        if (cached) *cached = plan->from_cache;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "libhalo2_hip: evaluate_h runs on the interpreter kernels for this program: %s\n", e.what());
+        plan.reset();
+    } catch (const HipError& e) {
+        fprintf(stderr, "libhalo2_hip: evaluate_h runs on the interpreter kernels for this program: HIP error %d loading the generated code (%s)\n",
+                (int)e.code, e.expr);
+        plan.reset();
+    }
+    const EvalhPlan* out = plan.get();
+    g_plans[key] = std::move(plan);
+    return out;
+}
+
+void evalh_plan_info(const EvalhPlan* plan, h2_evalh_info* info) {
+    if (!info) return;
+    memset(info, 0, sizeof *info);
+    if (!plan) return;
+    evalh_gen_info(plan->gen, info);
+}
+
+void evalh_gen_info(const evgen::Generated& g, h2_evalh_info* info) {
+    memset(info, 0, sizeof *info);
+    info->stages = (uint32_t)g.stages.size();
+    info->terms = g.terms;
+    info->products_per_row = g.products_per_row;
+    info->reference_products_per_row = g.reference_products_per_row;
+    info->vectors_read = g.vectors_read;
+    for (const evgen::Stage& st : g.stages) {
+        info->max_registers = std::max(info->max_registers, st.vgprs + st.agprs);
+        info->scratch_bytes = std::max(info->scratch_bytes, st.scratch);
+    }
+    info->from_cache = g.from_disk ? 2 : 0;
+}
+
+uint64_t evalh_generated_launches() { return g_generated_launches.load(); }
+
+// Fills each stage's argument block (evalh_gen.hpp: fixed part, uniform scalars, column pointers) and launches it.
+static void evalh_plan_launch(const EvalhPlan* plan, const h2_evalh_desc* d, Fr* d_values, const Fr* tw_lo, const Fr* tw_hi,
+                              size_t row_begin, size_t row_end, hipStream_t stream) {
+    const Fr y = fr_from_u64x4(d->y), beta = fr_from_u64x4(d->beta), gamma = fr_from_u64x4(d->gamma), theta = fr_from_u64x4(d->theta);
+    const Fr delta = fr_from_u64x4(d->delta), delta_start = fp_mul(beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
+    size_t n_lookup_z = 0;
+    for (uint32_t t = 0; t < d->n_lookups; t++) n_lookup_z += d->lookup_sets[t];
+    const size_t rows = row_end - row_begin;
+    const unsigned blocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
+    std::vector<Fr> delta_pow;  // DELTA^j, grown on demand
+    for (size_t s = 0; s < plan->gen.stages.size(); s++) {
+        const evgen::Stage& st = plan->gen.stages[s];
+        const size_t ns = std::max<size_t>(st.scalars.size(), 1), nc = std::max<size_t>(st.cols.size(), 1);
+        const size_t bytes = evgen::ARGS_FIXED_BYTES + 32 * ns + 8 * nc;
+        alignas(16) unsigned char buf[4096];
+        if (bytes > sizeof buf) throw std::runtime_error("h2_evaluate_h: generated stage with oversized arguments");
+        memset(buf, 0, bytes);
+        struct Fixed {
+            Fr* values;
+            const Fr* tw_lo;
+            const Fr* tw_hi;
+            unsigned long long row_begin, row_end;
+            unsigned int extended_k, rot_scale;
+        } fx{d_values, tw_lo, tw_hi, (unsigned long long)row_begin, (unsigned long long)row_end, d->extended_k, 1u << (d->extended_k - d->k)};
+        static_assert(sizeof(Fixed) == evgen::ARGS_FIXED_BYTES, "argument layout");
+        memcpy(buf, &fx, sizeof fx);
+        Fr* sc = (Fr*)(buf + evgen::ARGS_FIXED_BYTES);
+        for (size_t i = 0; i < st.scalars.size(); i++) {
+            const evgen::ScalarRef& r = st.scalars[i];
+            switch (r.kind) {
+                case evgen::SC_ONE: sc[i] = fp_one<FrParams>(); break;
+                case evgen::SC_CONST: sc[i] = fr_from_u64x4(d->constants + 4 * (size_t)r.arg); break;
+                case evgen::SC_Y_POW: sc[i] = fp_pow_u32(y, r.arg); break;
+                case evgen::SC_BETA_POW: sc[i] = fp_pow_u32(beta, r.arg); break;
+                case evgen::SC_GAMMA_POW: sc[i] = fp_pow_u32(gamma, r.arg); break;
+                case evgen::SC_THETA: sc[i] = theta; break;
+                default: {  // SC_DELTA_TERM: beta ZETA DELTA^arg
+                    if (delta_pow.empty()) delta_pow.push_back(fp_one<FrParams>());
+                    while (delta_pow.size() <= r.arg) delta_pow.push_back(fp_mul(delta_pow.back(), delta));
+                    sc[i] = fp_mul(delta_start, delta_pow[r.arg]);
+                }
+            }
+        }
+        const void** cols = (const void**)(buf + evgen::ARGS_FIXED_BYTES + 32 * ns);
+        for (size_t i = 0; i < st.cols.size(); i++) {
+            const evgen::ColRef& c = st.cols[i];
+            const void* p = nullptr;
+            switch (c.table) {
+                case evgen::T_FIXED: p = c.index < d->n_fixed ? d->fixed[c.index] : nullptr; break;
+                case evgen::T_ADVICE: p = c.index < d->n_advice ? d->advice[c.index] : nullptr; break;
+                case evgen::T_INSTANCE: p = c.index < d->n_instance ? d->instance[c.index] : nullptr; break;
+                case evgen::T_PERM_Z: p = c.index < d->n_perm_sets ? d->perm_z[c.index] : nullptr; break;
+                case evgen::T_PERM_SIGMA: p = c.index < d->n_perm_columns ? d->perm_sigma[c.index] : nullptr; break;
+                case evgen::T_LOOKUP_Z: p = c.index < n_lookup_z ? d->lookup_z[c.index] : nullptr; break;
+                case evgen::T_LOOKUP_M: p = c.index < d->n_lookups ? d->lookup_m[c.index] : nullptr; break;
+                case evgen::T_SHUFFLE_Z: p = c.index < d->n_shuffles ? d->shuffle_z[c.index] : nullptr; break;
+                case evgen::T_L0: p = d->l0; break;
+                case evgen::T_L_LAST: p = d->l_last; break;
+                default: p = d->l_active_row;
+            }
+            if (!p) throw std::runtime_error("h2_evaluate_h: a column the program reads has a null pointer in the descriptor");
+            cols[i] = p;
+        }
+        static const bool debug = getenv("H2_JIT_DEBUG") != nullptr;
+        if (debug)
+            fprintf(stderr, "h2_evalh_gen stage %zu: %u blocks, rows [%zu, %zu), %zu scalars, %zu columns, %zu argument bytes, values %p\n", s,
+                    blocks, row_begin, row_end, st.scalars.size(), st.cols.size(), bytes, (void*)d_values);
+        if (getenv("H2_JIT_LAUNCH_EXTRA")) {
+            size_t arg_bytes = (bytes + 15) & ~(size_t)15;
+            void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
+            H2_HIP(hipModuleLaunchKernel(plan->functions[s], blocks, 1, 1, 256, 1, 1, 0, stream, nullptr, config));
+        } else {
+            void* kargs[] = {buf};  // the kernel's one parameter: the argument block by value (copied at the call)
+            H2_HIP(hipModuleLaunchKernel(plan->functions[s], blocks, 1, 1, 256, 1, 1, 0, stream, kargs, nullptr));
+        }
+        if (debug) H2_HIP(hipStreamSynchronize(stream));
+        g_generated_launches.fetch_add(1);
+    }
+}
+
 // ---------------------------------------------------------------- host driver
 namespace {
 struct Arena {  // bump allocator over one host staging block mirrored to one device block
@@ -286,7 +518,25 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     const size_t row_begin = d->row_count ? d->row_begin : 0, row_end = d->row_count ? (size_t)d->row_begin + d->row_count : size;
     const size_t rows = row_end - row_begin;
 
-    // ---- stage the program and pointer tables (a few KB) into one device block
+    // ---- the program as generated straight-line kernels (evalh_gen.cpp), unless switched off or unavailable
+    if (!(d->flags & H2_EVALH_INTERPRET)) {
+        if (const EvalhPlan* plan = evalh_plan_get(d, nullptr)) {
+            PlanRef pl;  // the power tables of extended_omega: pinned until the kernels that read them are launched
+            if (plan->uses_omega) {
+                if (have_lock) {
+                    pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+                } else {
+                    std::lock_guard<std::mutex> g(ctx->mu);
+                    pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
+                }
+            }
+            evalh_plan_launch(plan, d, d_values, plan->uses_omega ? pl->tw_lo : nullptr, plan->uses_omega ? pl->tw_hi : nullptr,
+                              row_begin, row_end, stream);
+            return H2_OK;
+        }
+    }
+
+    // ---- the interpreter: stage the program and pointer tables (a few KB) into one device block
     size_t n_lookup_calcs = 0, n_lookup_z = 0;
     for (uint32_t t = 0; t < d->n_lookups; t++) {
         n_lookup_calcs += 1 + 2 * (size_t)d->lookup_sets[t];
@@ -299,13 +549,9 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     // ---- work space: interpreter intermediates + lookup / shuffle compressed expressions
     const unsigned blocks = 256 * 8, threads = 256;
     const size_t nthreads = (size_t)blocks * threads;
-    size_t inter_bytes = d->jit_function ? 256 : (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
-    // a generated kernel that folds the lookup / shuffle terms itself keeps their compressed expressions in registers
-    const uint32_t covers = d->jit_function ? d->jit_covers : 0u;
-    size_t lk_bytes = ((covers & H2_JIT_LOOKUPS) || !n_lookup_calcs ? 1 : n_lookup_calcs) * size * sizeof(Fr);
-    size_t sh_bytes = ((covers & H2_JIT_SHUFFLES) || !d->n_shuffles ? 1 : 2 * (size_t)d->n_shuffles) * size * sizeof(Fr);
-    if (lk_bytes == size * sizeof(Fr) && ((covers & H2_JIT_LOOKUPS) || !n_lookup_calcs)) lk_bytes = 256;
-    if (sh_bytes == size * sizeof(Fr) && ((covers & H2_JIT_SHUFFLES) || !d->n_shuffles)) sh_bytes = 256;
+    size_t inter_bytes = (size_t)(d->n_calculations ? d->n_calculations : 1) * nthreads * sizeof(Fr);
+    size_t lk_bytes = n_lookup_calcs ? n_lookup_calcs * size * sizeof(Fr) : 256;
+    size_t sh_bytes = d->n_shuffles ? 2 * (size_t)d->n_shuffles * size * sizeof(Fr) : 256;
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t total = align(need) + align(inter_bytes) + align(lk_bytes) + align(sh_bytes);
     char* block = (char*)ctx->evalh_scratch.get(total);
@@ -341,8 +587,6 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
     }
     const Fr* const* d_perm_cols = (const Fr* const*)ar.put(cols.data(), cols.size());
     const Fr* const* d_lookup_z = (const Fr* const*)ar.put(d->lookup_z, n_lookup_z);
-    const Fr* const* d_lookup_m = (const Fr* const*)ar.put(d->lookup_m, d->n_lookups);
-    const Fr* const* d_shuffle_z = (const Fr* const*)ar.put(d->shuffle_z, d->n_shuffles);
     if (ar.off > need) {
         set_last_error("h2_evaluate_h: internal staging overflow");
         return H2_ERR_INVALID;
@@ -373,46 +617,12 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
             pl = ntt_get_plan(ctx, d->extended_k, d->extended_omega, stream);
         }
     }
-    if (d->jit_function != nullptr) {
-        // the program as generated straight-line code (evalh_jit.hpp): same outputs, intermediates in registers
-        JitArgs ja{};
-        ja.perm_z = d_perm_z;
-        ja.perm_sigma = d_perm_sigma;
-        ja.l0 = (const Fr*)d->l0;
-        ja.l_last = (const Fr*)d->l_last;
-        ja.l_active_row = (const Fr*)d->l_active_row;
-        ja.tw_lo = d->n_perm_sets ? pl->tw_lo : nullptr;
-        ja.tw_hi = d->n_perm_sets ? pl->tw_hi : nullptr;
-        ja.lookup_z = d_lookup_z;
-        ja.lookup_m = d_lookup_m;
-        ja.shuffle_z = d_shuffle_z;
-        ja.delta = fr_from_u64x4(d->delta);
-        ja.delta_start = fp_mul(p.beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
-        ja.row_begin = row_begin;
-        ja.row_end = row_end;
-        ja.constants = p.constants;
-        ja.fixed = p.fixed;
-        ja.advice = p.advice;
-        ja.instance = p.instance;
-        ja.values = d_values;
-        ja.lk_out = d_lk;
-        ja.sh_out = d_sh;
-        ja.extended_k = p.extended_k;
-        ja.rot_scale = p.rot_scale;
-        ja.y = p.y;
-        ja.beta = p.beta;
-        ja.gamma = p.gamma;
-        ja.theta = p.theta;
-        void* kargs[] = {&ja};
-        // one grid over the whole domain (poly.hip grid_for: neighbouring DRAM pages instead of all of them at once)
-        const unsigned jblocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
-        H2_HIP(hipModuleLaunchKernel((hipFunction_t)d->jit_function, jblocks, 1, 1, 256, 1, 1, 0, stream, kargs, nullptr));
-    } else {
+    {
         hipLaunchKernelGGL(k_evalh_expr, dim3(blocks), dim3(threads), 0, stream, p, d_inter, d_values, d_lk, d_sh);
     }
 
     unsigned eblocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
-    if (d->n_perm_sets && !(covers & H2_JIT_PERMUTATION)) {
+    if (d->n_perm_sets) {
         PermArgs a{};
         a.row_begin = row_begin;
         a.row_end = row_end;
@@ -439,7 +649,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         hipLaunchKernelGGL(k_evalh_perm, dim3(eblocks), dim3(256), 0, stream, a);
     }
     size_t zoff = 0, slot = 0;
-    for (uint32_t lk = 0; lk < d->n_lookups && !(covers & H2_JIT_LOOKUPS); lk++) {
+    for (uint32_t lk = 0; lk < d->n_lookups; lk++) {
         LookupArgs a{};
         a.row_begin = row_begin;
         a.row_end = row_end;
@@ -459,7 +669,7 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         zoff += d->lookup_sets[lk];
         slot += 1 + 2 * (size_t)d->lookup_sets[lk];
     }
-    for (uint32_t sh = 0; sh < d->n_shuffles && !(covers & H2_JIT_SHUFFLES); sh++) {
+    for (uint32_t sh = 0; sh < d->n_shuffles; sh++) {
         ShuffleArgs a{};
         a.row_begin = row_begin;
         a.row_end = row_end;

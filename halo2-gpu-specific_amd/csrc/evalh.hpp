@@ -1,6 +1,7 @@
 // evalh.hpp -- evaluate_h drivers (evalh.hip)
 #pragma once
 #include "common.hpp"
+#include "evalh_gen.hpp"
 
 namespace h2 {
 // column pointers inside `d` are device pointers; the descriptor and its program arrays are host memory
@@ -9,4 +10,14 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
 int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values);
 // host memory, columns as COEFFICIENT vectors of 2^k elements (l_active_row extended): the cuda evaluate_h's shape
 int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values);
+
+// ---- the generated form (evalh_gen.cpp builds it, evalh.hip loads and launches it)
+struct EvalhPlan;  // the loaded kernels of one program on one device
+// The plan for this descriptor's program on the CURRENT device: from the cache, or generated + compiled + loaded now
+// (*cached: 1 memory, 2 disk, 0 built now).  nullptr when generation is switched off (H2_EVALH_JIT=0) or unavailable (no
+// hipRTC, a compile failure: reported once on stderr) -- the interpreter kernels then run the program.
+const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached);
+void evalh_plan_info(const EvalhPlan* plan, h2_evalh_info* info);
+void evalh_gen_info(const evgen::Generated& g, h2_evalh_info* info);
+uint64_t evalh_generated_launches();
 }  // namespace h2

@@ -12,8 +12,19 @@
 // i.e. 1 multiply-add (half the issue rate of a 32-bit add: 12.4 vs 24.6 lanes/clk/SIMD, profiles/r1_ubench.txt) + at most 1 add-with-carry per 32x32 partial product (136 mads per
 // modular multiplication; measured chip ceiling 1.31e11 multiplications/s, profiles/r1_mulbench.txt).  No MFMA: there is no dense contraction here.
 #pragma once
+#ifdef __HIPCC_RTC__
+// hipRTC (the evaluate_h generator, evalh_gen.cpp, compiles this header from memory): the runtime header is built in and
+// there is no <stdint.h>
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long uint64_t;
+typedef int int32_t;
+typedef long int64_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace h2 {
 

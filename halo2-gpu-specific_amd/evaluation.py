@@ -9,7 +9,7 @@ from ._lib import check, lib
 VS_CONSTANT, VS_INTERMEDIATE, VS_FIXED, VS_ADVICE, VS_INSTANCE = range(5)
 CALC_ADD, CALC_SUB, CALC_MUL, CALC_NEGATE, CALC_LC_CHALLENGE, CALC_LC_THETA, CALC_ADD_CHALLENGE, CALC_STORE = range(8)
 CHALLENGE_BETA, CHALLENGE_GAMMA = 0, 1
-JIT_PERMUTATION, JIT_LOOKUPS, JIT_SHUFFLES = 1, 2, 4      # h2_evalh_desc::jit_covers
+EVALH_INTERPRET = 1                                        # h2_evalh_desc::flags
 ANY_ADVICE, ANY_FIXED, ANY_INSTANCE = 0, 1, 2
 
 _u32, _vp = ctypes.c_uint32, ctypes.c_void_p
@@ -44,7 +44,7 @@ class EvalHDesc(ctypes.Structure):
         ("shuffle_z", _vp),
         ("y", _fr), ("beta", _fr), ("gamma", _fr), ("theta", _fr),
         ("delta", _fr), ("zeta", _fr), ("extended_omega", _fr),
-        ("jit_function", _vp), ("jit_covers", _u32), ("row_begin", _u32), ("row_count", _u32),
+        ("reserved", _vp), ("flags", _u32), ("row_begin", _u32), ("row_count", _u32),
     ]
 
 
@@ -91,7 +91,7 @@ class Builder:
     def build(self, *, k, extended_k, blinding_factors, chunk_len, constants, rotations, calculations, value_parts,
               lookups=(), shuffles=(), fixed=(), advice=(), instance=(), l0=None, l_last=None, l_active_row=None,
               perm_z=(), perm_columns=(), perm_sigma=(), lookup_z=(), lookup_m=(), shuffle_z=(), y, beta, gamma, theta,
-              delta, zeta, extended_omega, jit_function=None, jit_covers=0, row_begin=0, row_count=0):
+              delta, zeta, extended_omega, flags=0, row_begin=0, row_count=0):
         """lookups: list of (table_calc, [product_calcs], [sum_calcs]); shuffles: list of (input_calc, shuffle_calc);
         perm_columns: list of (ANY_*, index)."""
         d = self.desc
@@ -123,8 +123,8 @@ class Builder:
         d.perm_sigma = self._ptrs(perm_sigma)
         assert len(lookup_z) == sum(sets) and len(lookup_m) == len(sets) and len(shuffle_z) == len(shuffles)
         d.lookup_z, d.lookup_m, d.shuffle_z = self._ptrs(lookup_z), self._ptrs(lookup_m), self._ptrs(shuffle_z)
-        d.jit_function = jit_function
-        d.jit_covers = jit_covers if jit_function else 0
+        d.reserved = None
+        d.flags = flags
         d.row_begin, d.row_count = row_begin, row_count
         for name, val in (("y", y), ("beta", beta), ("gamma", gamma), ("theta", theta), ("delta", delta), ("zeta", zeta),
                           ("extended_omega", extended_omega)):
@@ -146,6 +146,42 @@ def _rebind(self, *, fixed, advice, instance, y, theta):
 
 
 Builder.rebind = _rebind
+
+
+class EvalHInfo(ctypes.Structure):
+    """h2_evalh_info: what the library generated for a program"""
+    _fields_ = [("stages", _u32), ("terms", _u32), ("products_per_row", _u32), ("reference_products_per_row", _u32),
+                ("vectors_read", _u32), ("max_registers", _u32), ("scratch_bytes", _u32), ("from_cache", _u32)]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+def prepare(builder):
+    """h2_evalh_prepare: generate + compile + load the program's kernels on the current device (keygen time) -> dict"""
+    info = EvalHInfo()
+    check(lib().h2_evalh_prepare(ctypes.byref(builder.desc), ctypes.byref(info)), "h2_evalh_prepare")
+    return info.as_dict()
+
+
+def compile_only(builder):
+    """h2_evalh_compile: generate + hipRTC into the caches, no device needed -> dict"""
+    info = EvalHInfo()
+    check(lib().h2_evalh_compile(ctypes.byref(builder.desc), ctypes.byref(info)), "h2_evalh_compile")
+    return info.as_dict()
+
+
+def generated_source(builder, stage=0):
+    """h2_evalh_source: the HIP text of one stage"""
+    n = ctypes.c_size_t(0)
+    check(lib().h2_evalh_source(ctypes.byref(builder.desc), stage, None, 0, ctypes.byref(n)), "h2_evalh_source")
+    buf = ctypes.create_string_buffer(n.value + 1)
+    check(lib().h2_evalh_source(ctypes.byref(builder.desc), stage, buf, n.value + 1, ctypes.byref(n)), "h2_evalh_source")
+    return buf.value.decode()
+
+
+def generated_launches():
+    return int(lib().h2_evalh_generated_launches())
 
 
 def evaluate_h(builder):

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 from . import evaluation as ev
-from ._lib import check, lib
+from ._lib import H2Error, check, lib
 from .circuit import compile_compress, compile_evaluator
 from .transcript import (Blake2bWrite, R_MOD, fr_from_mont_limbs, fr_to_mont_limbs, g1_add_affine, jacobian_to_affine, jacobians_to_affine,
                          point_to_bytes)
@@ -562,12 +562,18 @@ class Device:
             done.record(side)
         return out, ext, done
 
-    def coeff_to_extended(self, t, dom, out=None):
-        out = out if out is not None else self.empty(dom.extended_n)
-        tmp = self.empty(dom.extended_n)
+    def coeff_to_extended(self, t, dom, out=None, stream=None):
+        """`stream`: a caller's side stream (a raw handle; the caller is inside its torch.cuda.stream context, so the buffers
+        made here belong to it) -- the launch must be on the stream the input was produced on, not on the compute stream"""
+        if stream is None:
+            out = out if out is not None else self.empty(dom.extended_n)
+            tmp = self.empty(dom.extended_n)
+        else:
+            out = out if out is not None else self.torch.empty((dom.extended_n, 4), dtype=self.torch.int64, device=self.dev)
+            tmp = self.torch.empty((dom.extended_n, 4), dtype=self.torch.int64, device=self.dev)
         check(self.L.h2_dev_coeff_to_extended(t.data_ptr(), out.data_ptr(), tmp.data_ptr(), dom.k, dom.extended_k,
                                               _fr(dom.g_coset), _fr(dom.g_coset_inv), _fr(dom.extended_omega),
-                                              self.stream), "h2_dev_coeff_to_extended")
+                                              self.stream if stream is None else stream), "h2_dev_coeff_to_extended")
         return out
 
     def coeffs_to_extended(self, ts, dom, stream=None):
@@ -576,7 +582,7 @@ class Device:
         vectors), one by one above"""
         count = len(ts)
         if count < 2 or dom.extended_k > 23 or not hasattr(self.L, "h2_dev_coeff_to_extended_batch"):
-            return [self.coeff_to_extended(t, dom) for t in ts]
+            return [self.coeff_to_extended(t, dom, stream=stream) for t in ts]
         import contextlib
 
         torch = self.torch
@@ -1027,6 +1033,26 @@ class ProvingKey:
     pass
 
 
+def program_descriptor(cs, k, extended_k, graph=None, value_parts=None, lookup_calcs=None, shuffle_calcs=None):
+    """the evaluate_h descriptor of a circuit's PROGRAM alone -- constants, rotations, calculations, value parts, lookup /
+    shuffle calculations, the permutation argument's shape; every column pointer null -- as h2_evalh_prepare /
+    h2_evalh_compile / h2_evalh_source take it"""
+    if graph is None:
+        graph, value_parts, lookup_calcs, shuffle_calcs = compile_evaluator(cs)
+    ncols, chunk = len(cs.perm_columns), cs.degree() - 2
+    nsets = (ncols + chunk - 1) // chunk if ncols else 0
+    zero = fr_to_mont_limbs(0)
+    nz = [len(sets) for _, _, sets in cs.lookups]
+    return ev.Builder().build(
+        k=k, extended_k=extended_k, blinding_factors=cs.blinding_factors(), chunk_len=chunk,
+        constants=np.array([fr_to_mont_limbs(c) for c in graph.constants], dtype=np.uint64), rotations=graph.rotations,
+        calculations=graph.calculations, value_parts=value_parts, lookups=lookup_calcs, shuffles=shuffle_calcs,
+        fixed=[0] * cs.num_fixed, advice=[0] * cs.num_advice, instance=[0] * cs.num_instance,
+        perm_z=[0] * nsets, perm_columns=[(_ANY[kd], i) for kd, i in cs.perm_columns], perm_sigma=[0] * ncols,
+        lookup_z=[0] * sum(nz), lookup_m=[0] * len(nz), shuffle_z=[0] * len(shuffle_calcs),
+        y=zero, beta=zero, gamma=zero, theta=zero, delta=zero, zeta=zero, extended_omega=zero)
+
+
 def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=False, transcript_repr=None):
     """keygen_vk + keygen_pk.  fixed: list of canonical (n, 4) u64 columns; copies: see permutation_mapping.
     `mapping` = (map_col, map_row) replaces `copies` and `fixed_montgomery` marks columns already in the in-memory
@@ -1118,15 +1144,18 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
                           for _, table, sets in cs.lookups]
     pk.shuffle_programs = [[(compile_compress(inp), compile_compress(shf)) for _, inp, shf in group]
                            for group in cs.shuffles]
-    # the same program as generated straight-line HIP (jit.py): None = keep the interpreter
-    from . import jit
+    # The library generates and compiles the program's kernels itself the first time a descriptor carries it
+    # (csrc/evalh_gen.cpp, hipRTC); doing that here moves the cost from the first proof to keygen and reports what was built.
+    # None = the interpreter kernels run (H2_EVALH_JIT=0, or no hipRTC on this machine).
+    pk.evalh_stats = None
+    if os.environ.get("H2_EVALH_JIT", "1") != "0":
+        try:
+            pk.evalh_stats = ev.prepare(program_descriptor(cs, dom.k, dom.extended_k, pk.graph, pk.value_parts, pk.lookup_calcs,
+                                                           pk.shuffle_calcs))
+        except H2Error as e:
+            import warnings
 
-    chunk_ = cs.degree() - 2
-    pk.evalh_code_object, pk.evalh_covers = jit.compile_program(
-        pk.graph.rotations, pk.graph.calculations, pk.value_parts, pk.lookup_calcs, pk.shuffle_calcs,
-        perm=dict(n_sets=(ncols + chunk_ - 1) // chunk_ if ncols else 0, chunk_len=chunk_,
-                  columns=[(_ANY[kd], i) for kd, i in cs.perm_columns], last_rotation=-(bf + 1)))
-    pk.evalh_stats = dict(jit.last_stats, fused=bool(pk.evalh_covers)) if pk.evalh_code_object else None
+            warnings.warn("evaluate_h keeps the interpreter kernels: %s" % e)
     pk.transcript_repr = (transcript_repr if transcript_repr is not None else
                           vk_digest(cs, dom, pk.fixed_commitments, pk.perm_commitments))
     D.sync()
@@ -1245,15 +1274,6 @@ def _compress(D, dom, program, theta, fixed, advice, instance, rows=None):
     out = D.empty(dom.n)
     check(D.L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h (compress)")
     return out
-
-
-def _jit_function(pk):
-    path = getattr(pk, "evalh_code_object", None)
-    if not path:
-        return None
-    from . import jit
-
-    return jit.load(path)
 
 
 def range_check_assigner(vmin, vmax, step):
@@ -1755,7 +1775,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 shuffle_z=[t.data_ptr() for t in C["shuffle_polys"]],
                 y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
                 delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
-                jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0))
+                flags=0 if pk.evalh_stats else ev.EVALH_INTERPRET)
             out = D.empty(size)
             check(L.h2_evaluate_h_coeff(ctypes.byref(b.desc), out.data_ptr()), "h2_evaluate_h_coeff")
             mark("evaluate_h")
@@ -1797,7 +1817,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             shuffle_z=[t.data_ptr() for t in shuffle_cosets],
             y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
             delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
-            jit_function=_jit_function(pk), jit_covers=getattr(pk, "evalh_covers", 0),
+            flags=0 if pk.evalh_stats else ev.EVALH_INTERPRET,
             row_begin=rows[0] if rows is not None else 0, row_count=rows[1] if rows is not None else 0)
         out = D.empty(size)
         check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")

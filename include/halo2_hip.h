@@ -301,18 +301,18 @@ typedef struct {
     /* challenges and field constants */
     uint64_t y[4], beta[4], gamma[4], theta[4];
     uint64_t delta[4], zeta[4], extended_omega[4]; /* FieldExt::DELTA, ::ZETA, domain.get_extended_omega() */
-    /* optional: a kernel generated for exactly this program (h2_jit_load); NULL = the interpreter */
-    const void *jit_function;
-    /* what else that kernel computes besides the gate program (it then folds those terms into `values` itself and the
-     * library skips its own kernels for them): H2_JIT_PERMUTATION | H2_JIT_LOOKUPS | H2_JIT_SHUFFLES; 0 = gates only */
-    uint32_t jit_covers;
+    /* must be NULL (the slot of round 4's caller-supplied kernel: the library now generates, compiles and caches the
+     * program's kernels itself, see h2_evalh_prepare) */
+    const void *reserved;
+    /* H2_EVALH_INTERPRET: run this call on the interpreter kernels even when generated ones exist (tests compare the two) */
+    uint32_t flags;
     /* rows of the domain to evaluate: `values[row_begin .. row_begin + row_count)` are written, nothing else (row_count = 0:
      * the whole domain).  Column values are still read at rotated indices modulo the domain, so the rows
      * [row_begin - (blinding_factors + 1) * rot_scale ..., row_begin + row_count + max rotation * rot_scale) of every column
      * must be valid.  For callers that split one evaluation over several devices by row range. */
     uint32_t row_begin, row_count;
 } h2_evalh_desc;
-enum { H2_JIT_PERMUTATION = 1, H2_JIT_LOOKUPS = 2, H2_JIT_SHUFFLES = 4 };
+enum { H2_EVALH_INTERPRET = 1 };
 
 /* Host buffers everywhere (descriptor and every pointer in it); values: 2^extended_k Fr out. */
 int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);
@@ -329,11 +329,37 @@ int h2_evaluate_h_coeff(const h2_evalh_desc *desc, uint64_t *values);
  * d_values: 2^extended_k Fr on the device.  Work space is taken from the library's arena. */
 int h2_dev_evaluate_h(const h2_evalh_desc *desc, void *d_values, void *stream);
 
-/* Loads a code object produced for one gate program (halo2-gpu-specific_amd/jit.py: straight-line HIP generated from the
- * `Calculation` list, compiled with `hipcc --genco`) on the current device and returns its kernel, to be passed as
- * h2_evalh_desc.jit_function.  The kernel must have been generated from the same constants / rotations / calculations /
- * value parts / lookup and shuffle calculations as the descriptor it is used with.  The module stays loaded. */
-int h2_jit_load(const char *code_object_path, const char *kernel_name, const void **function_out);
+/* The generated form of evaluate_h.  The cuda `Evaluator::evaluate_h` of the reference is self-contained in the host
+ * language (plonk/evaluation.rs:1229-1985, plonk/evaluation_gpu.rs:594-803); so is this: the first time a descriptor's
+ * program (constants, rotations, calculations, value parts, lookup / shuffle calculations, permutation shape) reaches one
+ * of the three entry points above, the library turns it into straight-line HIP -- intermediates in registers, every
+ * argument's terms folded in, terms that share a factor (l_0, l_last, l_active_row, a gate selector) summed before the
+ * factor multiplies them (exact field arithmetic: the same bits) -- compiles it with hipRTC for gfx950, keeps the code
+ * object in memory and in a private directory (H2_JIT_CACHE, default <tmp>/halo2_hip_jit_<uid>) under the hash of the
+ * program, and launches it for every later call with the same program.  H2_EVALH_JIT=0 (environment) or
+ * H2_EVALH_INTERPRET (per call) keeps the interpreter kernels; so does a machine without libhiprtc.so (one warning on
+ * stderr).  Both are HIP paths with identical results.
+ *
+ * h2_evalh_prepare  does that work ahead of the first proof -- at keygen -- for the CURRENT device (h2_set_device) and
+ *                   reports what was built; pointers to columns inside `desc` are not read.
+ * h2_evalh_compile  generates and compiles into the caches without touching a device (works on a machine without a GPU).
+ * h2_evalh_source   the generated source of stage `stage` (for inspection): copies up to `cap` bytes including the
+ *                   terminating NUL into `buf` and stores the full length (without NUL) in *len. */
+typedef struct {
+    uint32_t stages;                     /* kernels the program was cut into (1 unless it is too wide for one) */
+    uint32_t terms;                      /* y-folded terms of the numerator: value parts + argument terms */
+    uint32_t products_per_row;           /* field products the generated kernels spend per row */
+    uint32_t reference_products_per_row; /* ... and the formulas of evaluation.rs:875-1219 as written */
+    uint32_t vectors_read;               /* distinct column vectors read per row */
+    uint32_t max_registers;              /* VGPRs + AGPRs of the widest stage */
+    uint32_t scratch_bytes;              /* per-lane scratch of the worst stage (0 = no spills) */
+    uint32_t from_cache;                 /* 1 = memory, 2 = disk, 0 = compiled now */
+} h2_evalh_info;
+int h2_evalh_prepare(const h2_evalh_desc *desc, h2_evalh_info *info);
+int h2_evalh_compile(const h2_evalh_desc *desc, h2_evalh_info *info);
+int h2_evalh_source(const h2_evalh_desc *desc, uint32_t stage, char *buf, size_t cap, size_t *len);
+/* stages of generated kernels launched so far in this process (a test's proof that they, not the interpreter, ran) */
+uint64_t h2_evalh_generated_launches(void);
 
 /* ---- device memory and streams for hosts without a HIP binding of their own ------------------
  * The h2_dev_* entry points below take HIP device pointers and a HIP stream.  A host that already links HIP (or, like

@@ -223,8 +223,8 @@ impl<C: CurveAffine> Evaluator<C> {
             delta: hip::limbs(&C::Scalar::DELTA),
             zeta: hip::limbs(&C::Scalar::ZETA),
             extended_omega: hip::limbs(&domain.get_extended_omega()),
-            jit_function: std::ptr::null(),
-            jit_covers: 0,
+            reserved: std::ptr::null(),
+            flags: 0,
             row_begin: 0,
             row_count: 0,
         };
@@ -385,8 +385,8 @@ pub(in crate::plonk) fn evaluate_lc<F: FieldExt, B: Basis>(
         delta: hip::limbs(&F::DELTA),
         zeta: hip::limbs(&F::ZETA),
         extended_omega: hip::limbs(&omega),
-        jit_function: std::ptr::null(),
-        jit_covers: 0,
+        reserved: std::ptr::null(),
+        flags: 0,
         row_begin: 0,
         row_count: 0,
     };

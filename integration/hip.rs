@@ -118,10 +118,26 @@ pub struct H2EvalhDesc {
     pub delta: [u64; 4],
     pub zeta: [u64; 4],
     pub extended_omega: [u64; 4],
-    pub jit_function: *const c_void,
-    pub jit_covers: u32,
+    /// must be null: the library generates, compiles (hipRTC) and caches the program's kernels itself
+    pub reserved: *const c_void,
+    /// H2_EVALH_INTERPRET = 1 keeps the interpreter kernels for this call
+    pub flags: u32,
     pub row_begin: u32,
     pub row_count: u32,
+}
+
+/// `h2_evalh_info` (include/halo2_hip.h): what the library generated for a program
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct H2EvalhInfo {
+    pub stages: u32,
+    pub terms: u32,
+    pub products_per_row: u32,
+    pub reference_products_per_row: u32,
+    pub vectors_read: u32,
+    pub max_registers: u32,
+    pub scratch_bytes: u32,
+    pub from_cache: u32,
 }
 
 /// (field, byte offset) of `h2_evalh_desc` on the LP64 ABI both sides are built for; checked against the C header by
@@ -169,8 +185,8 @@ pub const H2_EVALH_DESC_OFFSETS: &[(&str, usize)] = &[
     ("delta", 384),
     ("zeta", 416),
     ("extended_omega", 448),
-    ("jit_function", 480),
-    ("jit_covers", 488),
+    ("reserved", 480),
+    ("flags", 488),
     ("row_begin", 492),
     ("row_count", 496),
 ];
@@ -250,6 +266,9 @@ extern "C" {
     // (the cuda shape, :1229-1241); evaluate_with_theta is h2_evaluate_h with y := theta, extended_k := k
     pub fn h2_evaluate_h(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
     pub fn h2_evaluate_h_coeff(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
+    // The library turns a descriptor's program into generated kernels (hipRTC, cached by program hash in memory and on
+    // disk) the first time it sees it; h2_evalh_prepare does that ahead of the first proof, e.g. from keygen_pk
+    pub fn h2_evalh_prepare(desc: *const H2EvalhDesc, info: *mut H2EvalhInfo) -> c_int;
     // resident SRS: Params::g / g_lagrange are uploaded once per device instead of once per MSM
     pub fn h2_bases_register(bases: *const u64, n: usize) -> c_int;
     pub fn h2_bases_unregister(bases: *const u64) -> c_int;
@@ -480,6 +499,20 @@ pub fn evaluate_h<F: Copy + Default>(desc: &H2EvalhDesc, from_coefficient_forms:
     };
     check(rc, "evaluate_h");
     values
+}
+
+/// Builds (or finds in the cache) the generated kernels of a descriptor's program on the current device, so that the first
+/// `evaluate_h` of a proof does not pay the hipRTC compile; column pointers inside `desc` are not read.  Optional: without
+/// it the first call does the same work.  Returns None when the library keeps the interpreter kernels (H2_EVALH_JIT=0,
+/// no libhiprtc.so).
+pub fn prepare_evaluate_h(desc: &H2EvalhDesc) -> Option<H2EvalhInfo> {
+    let mut info = H2EvalhInfo::default();
+    let rc = unsafe { h2_evalh_prepare(desc as *const H2EvalhDesc, &mut info as *mut H2EvalhInfo) };
+    if rc == 0 {
+        Some(info)
+    } else {
+        None
+    }
 }
 
 /// Called by `Params::unsafe_setup` / `Params::read` (poly/commitment.rs:56-124,256-294): later `commit*` calls whose

@@ -330,5 +330,5 @@ def keygen(device, params, cs, fixed, copies, **kw):
             del os.environ["H2_EVALH_JIT"]
         else:
             os.environ["H2_EVALH_JIT"] = prev
-    pk.evalh_code_object, pk.evalh_covers = None, 0
+    pk.evalh_stats = None
     return pk

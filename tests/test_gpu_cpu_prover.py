@@ -81,6 +81,43 @@ def test_device_proof_bytes_equal_cpu_proof_bytes(device, which, k):
         prove_both(device, cs, k, adv, fixed, copies, insts, modes=((3, False),), cpu_kw={"eval_cache": 0})
 
 
+def test_one_advice_column_proof_and_the_side_stream_extension(device):
+    """with ONE advice column (or an extended domain above 2^23) Device.coeffs_to_extended falls back to
+    the single-vector transform, which used to launch on the compute stream while the side stream was still producing its
+    input.  A one-column circuit's proof (k <= 20: the side-stream route) against the CPU run, and the fallback itself on the
+    side stream against the compute-stream result."""
+    import torch
+
+    from halo2_gpu_specific_amd import circuit as hc, prover
+
+    cs = hc.ConstraintSystem("one-column")
+    a, q = cs.advice_column(), cs.fixed_column()
+    cs.enable_equality(a)
+    qa = cs.query_advice(a)
+    cs.create_gate("boolean", [cs.query_fixed(q) * (qa * qa - qa)])
+    k = 12
+    n = 1 << k
+    rng = np.random.default_rng(5)
+    adv = [np.zeros((n, 4), dtype=np.uint64)]
+    adv[0][: n - 8, 0] = rng.integers(0, 2, n - 8)
+    adv[0][1, 0] = adv[0][0, 0]
+    fixed = [np.zeros((n, 4), dtype=np.uint64)]
+    fixed[0][: n - 8, 0] = 1
+    prove_both(device, cs, k, adv, fixed, [(0, 0, 0, 1)])
+    dom = prover.Domain(14, 4)
+    x = device.upload(rng.integers(0, 1 << 60, (dom.n, 4), dtype=np.int64).astype(np.uint64))      # below r: canonical
+    want = device.coeffs_to_extended([x], dom)[0]
+    device.sync()
+    side = torch.cuda.Stream(device=device.dev)
+    with torch.cuda.stream(side):
+        import ctypes
+
+        y = x.clone()                                       # produced on the side stream, as intt_on_side_stream's copies are
+        got = device.coeffs_to_extended([y], dom, stream=ctypes.c_void_p(side.cuda_stream))[0]
+    side.synchronize()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.timeout(2400)
 @pytest.mark.parametrize("k", [20, 22] + ([] if os.environ.get("H2_TEST_CPU_PROVER_K24") == "0" else [24]))
 def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k):

@@ -37,41 +37,60 @@ def test_evaluate_h_k20(oracle):
     assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
 
 
+GENERATOR_SETTINGS = [
+    {},                                   # the defaults: one stage, factors grouped
+    {"H2_JIT_FACTOR": "0"},               # the reference's own fold order (every term folded by y, factors multiplied per term)
+    {"H2_JIT_STAGE_PRODUCTS": "8"},       # cut into many stages that each add their share into `values`
+    {"H2_JIT_STAGE_PRODUCTS": "20", "H2_JIT_GROUP": "3", "H2_JIT_MAX_AHEAD": "2", "H2_JIT_GAP": "4"},
+    {"H2_JIT_INLINE_MULS": "1000"},       # the multiplier inlined at every product
+]
+
+
 @pytest.mark.parametrize("seed,k,ek,kwargs", [
     (1, 2, 3, {}), (2, 5, 7, {}), (4, 10, 12, {}), (6, 13, 13, {}), (7, 6, 8, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=3)),
     (8, 9, 11, dict(lookup_sets=(2,), n_shuffles=1, n_calcs=80)), (9, 16, 18, dict(n_calcs=60))])
-def test_generated_kernel_matches_interpreter_and_oracle(oracle, monkeypatch, seed, k, ek, kwargs):
-    """the gate program as generated straight-line HIP (jit.py -> hipcc --genco -> h2_jit_load -> desc.jit_function):
-    every opcode, challenge powers, rotations, the lookup / shuffle result calculations -- same bits as the interpreter
-    and as the CPU oracle"""
-    from halo2_gpu_specific_amd import jit
-
+def test_generated_kernels_match_interpreter_and_oracle(oracle, monkeypatch, tmp_path, seed, k, ek, kwargs):
+    """the program as straight-line HIP generated, compiled (hipRTC) and cached INSIDE the library (csrc/evalh_gen.cpp) the first
+    time its descriptor arrives -- nothing passed in, `reserved` NULL: every opcode, challenge powers, rotations, the lookup /
+    shuffle result calculations, the argument terms; grouped by factor or in the reference's fold order, in one stage or many --
+    same bits as the interpreter kernels (H2_EVALH_INTERPRET) and as the CPU oracle, and the generated kernels are what ran"""
+    monkeypatch.setenv("H2_JIT_CACHE", str(tmp_path))
     kw = random_case(seed, k, ek, oracle, **({"n_calcs": 40} | kwargs))
     b = ev.Builder().build(**kw)
     want = oracle_evaluate_h(oracle, b)
+    before = ev.generated_launches()
+    assert np.array_equal(ev.evaluate_h(ev.Builder().build(**kw, flags=ev.EVALH_INTERPRET)), want)
+    assert ev.generated_launches() == before, "H2_EVALH_INTERPRET must keep the interpreter kernels"
+    for env in GENERATOR_SETTINGS:
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
+        info = ev.prepare(b)
+        assert info["stages"] >= (2 if "H2_JIT_STAGE_PRODUCTS" in env and info["products_per_row"] > 40 else 1) and info["scratch_bytes"] == 0
+        before = ev.generated_launches()
+        assert np.array_equal(ev.evaluate_h(b), want), env
+        assert ev.generated_launches() == before + info["stages"], "the generated kernels did not run"
+        assert ev.prepare(b)["from_cache"] == 1
+        for name in env:
+            monkeypatch.delenv(name)
+    monkeypatch.setenv("H2_EVALH_JIT", "0")
+    before = ev.generated_launches()
     assert np.array_equal(ev.evaluate_h(b), want)
-    path = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"])
-    assert path is not None, "hipcc could not build the generated kernel"
-    b.desc.jit_function = jit.load(path)
-    assert np.array_equal(ev.evaluate_h(b), want)
-    # ... and the whole of evaluate_h as one generated kernel: gate program + permutation / lookup / shuffle terms folded in
-    # registers (h2_evalh_desc::jit_covers), loads value-numbered and issued a group ahead
-    nsets = (len(kw["perm_columns"]) + kw["chunk_len"] - 1) // kw["chunk_len"] if kw["perm_columns"] else 0
-    monkeypatch.setenv("H2_EVALH_FUSED", "1")        # (by default only programs of up to 64 products per row are fused)
-    fused, covers = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
-                                        perm=dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
-                                                  last_rotation=-(kw["blinding_factors"] + 1)))
-    assert fused is not None and fused != path
-    assert covers == ((ev.JIT_PERMUTATION if nsets else 0) | (ev.JIT_LOOKUPS if kw["lookups"] else 0) |
-                      (ev.JIT_SHUFFLES if kw["shuffles"] else 0))
-    b.desc.jit_function, b.desc.jit_covers = jit.load(fused), covers
-    assert np.array_equal(ev.evaluate_h(b), want)
-    # ... and the gate program alone under that generator's load scheduling (what a program too wide to fuse gets)
-    gsrc, _ = jit.generate_fused_source(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
-                                        dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
-                                             last_rotation=-(kw["blinding_factors"] + 1)), fold_args=False)
-    b.desc.jit_function, b.desc.jit_covers = jit.load(jit.compile_source(gsrc, "_fused")), 0
-    assert np.array_equal(ev.evaluate_h(b), want)
+    assert ev.generated_launches() == before
+
+
+def test_generated_kernels_disk_cache(oracle, monkeypatch, tmp_path):
+    """a second process (here: a second option set that hashes differently, then the same one again after the memory cache is
+    bypassed by a fresh hash) finds the code objects on disk: one file per program, written atomically, mode of a private dir"""
+    import os
+
+    monkeypatch.setenv("H2_JIT_CACHE", str(tmp_path))
+    kw = random_case(77, 6, 8, oracle, n_calcs=30)
+    b = ev.Builder().build(**kw)
+    info = ev.compile_only(b)
+    assert info["from_cache"] == 0 and len(os.listdir(tmp_path)) == 1
+    assert ev.compile_only(b)["from_cache"] == 2
+    assert ev.prepare(b)["from_cache"] == 2               # the first load on this device: from the file, no compile
+    assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
 
 
 @pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),
@@ -125,7 +144,7 @@ def test_host_lincomb(oracle):
 @pytest.mark.parametrize("seed,k,ek", [(41, 6, 8), (42, 10, 12), (43, 13, 14)])
 def test_row_ranges_of_the_device_evaluator(oracle, monkeypatch, seed, k, ek):
     """h2_evalh_desc::row_begin / row_count (one evaluation split over several devices by row range): the interpreter, the
-    generated gate kernel with the library's argument kernels, and the fused generated kernel write exactly the rows asked
+    generated kernel and its many-stage form (every stage after the first ADDS into `values`) write exactly the rows asked
     for -- the oracle's values there, the buffer untouched elsewhere -- for ranges at the start, across the wrap of the
     rotations, a single row and the whole domain"""
     import ctypes
@@ -133,7 +152,6 @@ def test_row_ranges_of_the_device_evaluator(oracle, monkeypatch, seed, k, ek):
     import torch
 
     import halo2_gpu_specific_amd as h2
-    from halo2_gpu_specific_amd import jit
     from halo2_gpu_specific_amd._lib import check
 
     kw = random_case(seed, k, ek, oracle, n_calcs=30, lookup_sets=(1, 2), n_shuffles=1)
@@ -149,17 +167,13 @@ def test_row_ranges_of_the_device_evaluator(oracle, monkeypatch, seed, k, ek):
         dkw[name] = [t.data_ptr() for t in tensors[name]]
     for name in singles:
         dkw[name] = singles[name].data_ptr()
-    nsets = (len(kw["perm_columns"]) + kw["chunk_len"] - 1) // kw["chunk_len"]
-    path = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"])
-    monkeypatch.setenv("H2_EVALH_FUSED", "1")
-    fused, covers = jit.compile_program(kw["rotations"], kw["calculations"], kw["value_parts"], kw["lookups"], kw["shuffles"],
-                                        perm=dict(n_sets=nsets, chunk_len=kw["chunk_len"], columns=kw["perm_columns"],
-                                                  last_rotation=-(kw["blinding_factors"] + 1)))
     L = h2.lib()
     sentinel = 0x5A5A5A5A5A5A5A5A
-    for fn, cov in ((None, 0), (jit.load(path), 0), (jit.load(fused), covers)):
+    for flags, env in ((ev.EVALH_INTERPRET, {}), (0, {}), (0, {"H2_JIT_STAGE_PRODUCTS": "10"})):
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
         for lo, cnt in ((0, size // 4), (size - 5, 5), (size // 2 - 3, 1), (7, size - 7), (0, 0)):
-            b = ev.Builder().build(**dkw, jit_function=fn, jit_covers=cov, row_begin=lo, row_count=cnt)
+            b = ev.Builder().build(**dkw, flags=flags, row_begin=lo, row_count=cnt)
             out = torch.full((size, 4), sentinel, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), None), "h2_dev_evaluate_h")
@@ -167,7 +181,7 @@ def test_row_ranges_of_the_device_evaluator(oracle, monkeypatch, seed, k, ek):
             got = out.cpu().numpy().view(np.uint64)
             hi = lo + cnt if cnt else size
             lo_ = lo if cnt else 0
-            assert np.array_equal(got[lo_:hi], want[lo_:hi]), (fn is not None, cov, lo, cnt)
+            assert np.array_equal(got[lo_:hi], want[lo_:hi]), (flags, env, lo, cnt)
             rest = np.concatenate([got[:lo_], got[hi:]])
             assert (rest == np.uint64(sentinel)).all(), "rows outside the range were written"
     # the host-buffer entry points take no row range

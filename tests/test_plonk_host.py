@@ -494,67 +494,56 @@ def test_big_integer_prover_reproduces_committed_proofs():
         assert rp.verify_proof(pk, bytes.fromhex(case["proof"]), use_gwc=gwc, instances=inst)
 
 
-def test_jit_cache_directory_must_be_private(tmp_path, monkeypatch):
-    """a cache directory that others can write to is not used (a planted code object would be loaded)"""
+def test_code_object_cache_directory_must_be_private(tmp_path, monkeypatch):
+    """a cache directory that others can write to is not used (a planted code object would be loaded into the
+    prover by hipModuleLoadData); the library makes its own, mode 0700"""
     import os
-    import warnings
 
-    from halo2_gpu_specific_amd import jit
+    from halo2_gpu_specific_amd import prover
 
+    b = prover.program_descriptor(circuits.mini_plonk(), 5, 7)
     good = tmp_path / "mine"
     monkeypatch.setenv("H2_JIT_CACHE", str(good))
-    assert jit.cache_dir() == str(good) and (os.stat(good).st_mode & 0o777) == 0o700
+    assert ev.compile_only(b)["from_cache"] == 0
+    assert (os.stat(good).st_mode & 0o777) == 0o700 and len(os.listdir(good)) == 1
+    assert ev.compile_only(b)["from_cache"] == 2
     shared = tmp_path / "shared"
     shared.mkdir()
     os.chmod(shared, 0o777)
     monkeypatch.setenv("H2_JIT_CACHE", str(shared))
-    monkeypatch.setattr(jit, "_private_dir", None)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        d = jit.cache_dir()
-    assert d != str(shared) and (os.stat(d).st_mode & 0o077) == 0 and w
+    assert ev.compile_only(b)["from_cache"] == 0         # not found: the shared directory is neither read nor written
+    assert os.listdir(shared) == []
 
 
-def test_generated_gate_kernels_compile_for_gfx950(tmp_path, monkeypatch):
-    """jit.py: the straight-line HIP generated from a gate program (all three test circuits, with their lookup and
-    shuffle result calculations) cross-compiles with hipcc; the Horner fold is interleaved with the calculations"""
-    import shutil
+def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
+    """csrc/evalh_gen.cpp behind the C ABI, no GPU needed: the straight-line HIP generated from a circuit's program (all three
+    test circuits, with their permutation / lookup / shuffle terms) goes through hipRTC for gfx950 without spills; one store
+    per stage; grouping by factor never spends more products than the reference's fold order; many-stage forms accumulate"""
+    from halo2_gpu_specific_amd import prover
 
-    from halo2_gpu_specific_amd import jit
-
-    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
-        pytest.skip("no hipcc")
     monkeypatch.setenv("H2_JIT_CACHE", str(tmp_path))
-    for make in (circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs):
-        g, parts, lookups, shuffles = hc.compile_evaluator(make())
-        src = jit.generate_source(g.rotations, g.calculations, parts, lookups, shuffles)
-        assert src.count("fp_store(a.values") == 1 and "h2_evalh_jit" in src
-        path = jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles)
-        assert path and path.startswith(str(tmp_path)) and __import__("os").path.getsize(path) > 1000
-        assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) == path   # cached
-        # the whole of evaluate_h as one kernel: every argument's terms folded in registers, ONE store, each distinct
-        # (column, rotation) loaded once per use window
-        cs = make()
-        chunk = cs.degree() - 2
-        nsets = (len(cs.perm_columns) + chunk - 1) // chunk if cs.perm_columns else 0
-        any_ = {"advice": ev.ANY_ADVICE, "fixed": ev.ANY_FIXED, "instance": ev.ANY_INSTANCE}
-        perm = dict(n_sets=nsets, chunk_len=chunk, columns=[(any_[kd], i) for kd, i in cs.perm_columns], last_rotation=-6)
-        fsrc, covers = jit.generate_fused_source(g.rotations, g.calculations, parts, lookups, shuffles, perm)
-        assert fsrc.count("fp_store(") == 1 and "h2_evalh_fused" in fsrc and "lk_out" not in fsrc
-        assert covers == ((ev.JIT_PERMUTATION if nsets else 0) | (ev.JIT_LOOKUPS if lookups else 0) | (ev.JIT_SHUFFLES if shuffles else 0))
-        monkeypatch.setenv("H2_EVALH_FUSED", "1")
-        fpath, fcov = jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles, perm=perm)
-        assert fpath.endswith("_fused.hsaco") and fcov == covers and jit.last_stats["products_per_row"] > 0
-        monkeypatch.setenv("H2_EVALH_FUSED", "0")
-        assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles, perm=perm) == (path, 0)
-        monkeypatch.delenv("H2_EVALH_FUSED")
-        # the gate program alone under the new load scheduling (what a program too wide to fuse gets): the lookup / shuffle
-        # expressions are stored for the library's argument kernels
-        gsrc, gcov = jit.generate_fused_source(g.rotations, g.calculations, parts, lookups, shuffles, perm, fold_args=False)
-        assert gcov == 0 and gsrc.count("fp_store(a.values") == 1
-        assert gsrc.count("a.lk_out") == sum(1 + 2 * len(p) for _, p, _ in lookups) and gsrc.count("a.sh_out") == 2 * len(shuffles)
-    monkeypatch.setenv("H2_EVALH_JIT", "0")
-    assert jit.compile_program(g.rotations, g.calculations, parts, lookups, shuffles) is None
+    for make in (circuits.mini_plonk, rot_gate_cs, lookup_shuffle_cs, lambda: circuits.wide(4)):
+        b = prover.program_descriptor(make(), 6, 8)
+        src = ev.generated_source(b)
+        assert src.count("fp_store(a.values") == 1 and "h2_evalh_gen" in src and "fp_load(a.values" not in src
+        info = ev.compile_only(b)
+        assert info["stages"] == 1 and info["scratch_bytes"] == 0 and 0 < info["max_registers"] <= 256
+        assert info["products_per_row"] <= info["reference_products_per_row"]
+        monkeypatch.setenv("H2_JIT_FACTOR", "0")
+        plain = ev.compile_only(b)
+        assert plain["products_per_row"] >= info["products_per_row"] and plain["terms"] == info["terms"]
+        monkeypatch.delenv("H2_JIT_FACTOR")
+        monkeypatch.setenv("H2_JIT_STAGE_PRODUCTS", "6")
+        staged = ev.compile_only(b)
+        if info["products_per_row"] > 12:
+            assert staged["stages"] > 1
+            assert "fp_add(fp_load(a.values + idx)" in ev.generated_source(b, 1)
+        monkeypatch.delenv("H2_JIT_STAGE_PRODUCTS")
+    # the wide circuit: 16 gates q (a b c - d) share their selector, the lookups' terms share l_0 / l_last / l_active_row
+    wide = ev.compile_only(prover.program_descriptor(circuits.wide(16), 6, 8))
+    assert wide["products_per_row"] <= 0.75 * wide["reference_products_per_row"]
+    with pytest.raises(Exception):
+        ev.generated_source(b, 99)
 
 
 # ---- CircuitData (plonk.rs:126-204, helpers.rs write_cs / read_cs) ------------------------------------------------

@@ -255,7 +255,7 @@ def compare(device, case, seed, cache={}, satisfiable=False, several=True):
             assert other == got, "seed %d: the coset route (%s) changed the proof" % (seed, kw)
     return "seed %d: k=%d degree=%d advice=%d fixed=%d gates=%d lookups=%d shuffles=%d jit=%s  %d bytes" % (
         seed, k, cs.degree(), cs.num_advice, cs.num_fixed, len(cs.gates), len(cs.lookups), len(cs.shuffles),
-        bool(pk.evalh_code_object), len(got))
+        bool(pk.evalh_stats), len(got))
 
 
 def main():
