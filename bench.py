@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--prove-steps", type=int, default=3)
     ap.add_argument("--wide-k", type=int, default=20, help="create_proof_wide leg: circuits.wide with 2^k rows (0 = skip)")
     ap.add_argument("--wide-quads", type=int, default=16, help="create_proof_wide: quads of advice columns (16 -> 64 columns)")
-    ap.add_argument("--cpu-prove-k", type=int, default=20, help="CPU create_proof baseline: mini-PLONK with 2^k rows on the host cores (0 = skip)")
+    ap.add_argument("--wide-k22", type=int, default=1, help="1: also run the wide circuit at 2^22 rows (the zkWasm size), resident mode only")
+    ap.add_argument("--cpu-prove-k", type=int, default=22, help="CPU create_proof baseline: mini-PLONK with 2^k rows on the host cores (0 = skip)")
     ap.add_argument("--k24", type=int, default=1, help="1: also run the k = 24 legs (MSM 2^24, create_proof k = 24) the metric is quoted at")
     args = ap.parse_args()
 
@@ -136,6 +137,11 @@ def main():
         # no launcher around this process: become one (before torch is imported or the GPU is touched)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # the CPU baseline's OpenMP teams sleep at their barriers instead of spinning (read when libgomp is loaded, i.e. before
+    # torch is imported): rayon's idle workers park; a spinning team of 256 on a box whose cgroup grants fewer CPUs took 4.7 s
+    # for a 2^20 transform in round 4's line
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     import torch
 
     import halo2_gpu_specific_amd as h2
@@ -475,6 +481,15 @@ def main():
         }
         return leg
 
+    # BASELINE.json's metric has three parts (create_proof seconds, MSM G1-adds/s, NTT Fr-ops/s, all at k = 24): `value` is the
+    # third; the other two, and the zkWasm-shaped legs, are repeated here inside `config` -- the part of the line every summary keeps
+    headline = out["config"].setdefault("headline", {"ntt_fr_ops_per_s_k%d" % log_n: value, "ntt_hbm_roofline_frac": achieved_gbs / HBM_PEAK_GBS})
+
+    def seconds_of(leg, *path):
+        for name in path:
+            leg = leg.get(name) if isinstance(leg, dict) else None
+        return leg
+
     if not args.no_msm:
         for key, mlog, msteps, mbatch, what in (
                 ("msm", args.msm_log_n, args.msm_steps, 8, "BASELINE configs[1]: 2^%d BN254 G1 MSM, uniform 254-bit scalars, resident in HBM" % args.msm_log_n),
@@ -487,6 +502,9 @@ def main():
             except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
                 out[key] = leg_failed(key, e)
             torch.cuda.empty_cache()
+            headline["%s_g1_adds_per_s" % key] = seconds_of(out[key], "over_shifted_base_table", "g1_adds_executed_per_s")
+            headline["%s_ms" % key] = seconds_of(out[key], "over_shifted_base_table", "ms_per_msm")
+            headline["%s_alu_roofline_frac" % key] = seconds_of(out[key], "alu_roofline", "frac")
 
     def evalh_roofline(pk, phases_s):
         """evaluate_h against both of its rooflines (algorithmic bytes = 32 * (distinct columns read + 1) *
@@ -622,7 +640,7 @@ def main():
     # ---------------------------------------------------------------- wide circuit (zkWasm-shaped): 64 advice columns, degree 5,
     # 8 logup range lookups -- with every extended coset resident, and under a memory budget that forces the coset-by-coset
     # route with the proving key's coset tables evicted and rebuilt (same proof bytes)
-    def wide_leg(pk_k, quads, steps):
+    def wide_leg(pk_k, quads, steps, only_resident=False):
         import hashlib
 
         from halo2_gpu_specific_amd import circuits, prover
@@ -636,6 +654,8 @@ def main():
         proofs = {}
         # N > 1: ONE proof over all ranks (degree 5 -> 4 cosets over the ranks, every MSM range-split): a single "sharded" mode
         modes = ("resident", "budgeted") if dist is None else ("sharded",)
+        if only_resident and dist is None:
+            modes = ("resident",)
         for mode in modes:
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(dev)
@@ -723,7 +743,7 @@ def main():
                 assert res["verified"], "the wide-circuit proof was rejected by the verifier"
             del pk, params, adv, fixed, D, D0
             L.h2_release_plans()
-        if dist is None:
+        if dist is None and "budgeted" in proofs:
             res["same_proof_bytes"] = proofs["resident"] == proofs["budgeted"]
             assert res["same_proof_bytes"], "the memory-budgeted route changed the proof"
         return res
@@ -756,6 +776,17 @@ def main():
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
             out["create_proof_wide"] = leg_failed("create_proof_wide", e)
         torch.cuda.empty_cache()
+        headline["create_proof_wide_k%d_seconds" % args.wide_k] = seconds_of(out["create_proof_wide"], "resident" if dist is None else "sharded", "seconds")
+        headline["create_proof_wide_k%d_compact_witness_seconds" % args.wide_k] = seconds_of(out["create_proof_wide"], "resident_compact_witness", "seconds")
+    if args.wide_k22 and args.wide_k != 22 and (dist is None or world >= 2):
+        # the zkWasm-sized leg: 64 advice columns x 2^22 rows (8 GiB of 32-byte cells; 2 GiB handed over compact)
+        try:
+            out["create_proof_wide_k22"] = wide_leg(22, args.wide_quads, 2, only_resident=True)
+        except Exception as e:  # noqa: BLE001
+            out["create_proof_wide_k22"] = leg_failed("create_proof_wide_k22", e)
+        torch.cuda.empty_cache()
+        headline["create_proof_wide_k22_seconds"] = seconds_of(out["create_proof_wide_k22"], "resident" if dist is None else "sharded", "seconds")
+        headline["create_proof_wide_k22_compact_witness_seconds"] = seconds_of(out["create_proof_wide_k22"], "resident_compact_witness", "seconds")
 
     for key, kk, steps in (("create_proof", args.prove_k, args.prove_steps), ("create_proof_k24", 24 if args.k24 else 0, 2)):
         if not kk or (key == "create_proof_k24" and args.prove_k == 24):
@@ -768,6 +799,8 @@ def main():
         except Exception as e:  # noqa: BLE001 - the primary (NTT) line must still be printed
             out[key] = leg_failed(key, e)
         torch.cuda.empty_cache()
+        headline["create_proof_k%d_seconds" % kk] = seconds_of(out[key], "seconds")
+        headline["create_proof_k%d_evaluate_h_alu_frac" % kk] = seconds_of(out[key], "evaluate_h", "roofline", "alu", "frac")
     if watchdog_done is not None:
         watchdog_done.set()
 
@@ -778,6 +811,20 @@ def main():
 
             oracle = Oracle.get()
             cores = os.cpu_count() or 1
+            # what this process may actually run on: its affinity mask and the cgroup's CPU quota (a container that shows
+            # 256 CPUs may be granted far fewer)
+            try:
+                affinity = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                affinity = cores
+            quota = None
+            try:
+                with open("/sys/fs/cgroup/cpu.max") as f:
+                    q, per = f.read().split()[:2]
+                    quota = None if q == "max" else float(q) / float(per)
+            except (OSError, ValueError):
+                pass
+            cores = max(1, min(cores, affinity))
             clog = log_n                       # the GPU's own size (2^24)
             wc = fr_limbs(pow(ROOT_OF_UNITY, 1 << (28 - clog), R_MOD))
             # team size: probed on a 2^20 transform (a fraction of a second each), then the full size is timed with the best
@@ -826,6 +873,8 @@ def main():
                 "unit": "Fr-ops/s",
                 "cores": best_th,
                 "host_threads_available": cores,
+                "cgroup_cpu_quota": quota,
+                "omp_wait_policy": os.environ.get("OMP_WAIT_POLICY"),
                 "kind": "port",
                 "sample": "oracle best_fft (C restatement of arithmetic.rs:556-705: serial bit reversal as the reference, the "
                 "butterflies of its recursion scheduled statically over the team) on one forward 2^%d NTT (the GPU's size), "
@@ -886,8 +935,8 @@ def main():
                     "kind": "port", "gpu_seconds_same_circuit": gpu_s, "proof_bytes_equal": bool(proof == want),
                     "sample": "one mini-PLONK create_proof (SHPLONK) at k = %d on the host cores: the host orchestration of prover.py "
                     "over the C oracle's loops (oracle/oracle.c; serial scans and Kate divisions as the reference), same SRS, "
-                    "witness and randomness as the device proof next to it; at the leg's own k = 22 / 24 the same comparison is "
-                    "tests/test_gpu_cpu_prover.py (24 s / 135 s of CPU on 32 threads)" % kc,
+                    "witness and randomness as the device proof next to it; at k = 24 the same comparison is "
+                    "tests/test_gpu_cpu_prover.py (135 s of CPU on 32 threads)" % kc,
                 }
         except Exception as e:  # noqa: BLE001 - the line must still be printed
             if "cpu_baseline" in out:

@@ -999,10 +999,7 @@ int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
 
 int h2_evaluate_h_coeff(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h_coeff: null argument");
-    return guarded([&] {
-        DeviceLease lease;
-        return evalh_host_coeffs(lease.ctx, desc, values);
-    });
+    return guarded([&] { return evalh_host_coeffs(desc, values); });
 }
 
 int h2_dev_evaluate_h(const h2_evalh_desc* desc, void* d_values, void* stream) {

@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -774,19 +775,12 @@ __global__ void __launch_bounds__(256) k_coset_scatter(const Fr* in, Fr* out, si
 // coset j by a[t] *= g_j^t and an n-point NTT, and the fused evaluator runs with extended_k := k, zeta := g_j,
 // extended_omega := omega -- on one coset a rotation is an index shift and nothing else changes.  Device memory is
 // (distinct columns) x 2 x 2^k x 32 B + two extended vectors: bounded by the circuit's width, not by width x 2^extended_k.
-int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
-    if (!d || !values) {
-        set_last_error("h2_evaluate_h_coeff: null argument");
-        return H2_ERR_INVALID;
-    }
-    if (d->extended_k < d->k || d->extended_k > 28) {
-        set_last_error("h2_evaluate_h_coeff: bad k / extended_k");
-        return H2_ERR_INVALID;
-    }
-    if (d->row_count) {
-        set_last_error("h2_evaluate_h_coeff: a row range is for the device entry point (h2_dev_evaluate_h)");
-        return H2_ERR_INVALID;
-    }
+//
+// One worker = one leased device running the cosets first, first + step, ...  With `whole` (the only worker) the values
+// are scattered to their stride-c positions on the device and come back in one transfer; otherwise each coset's n values
+// come back through the slot's pinned buffer and this thread writes them to values[c i + j] (the workers of the other
+// devices do the same for their cosets at the same time: disjoint 32-byte cells of the caller's vector).
+static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values, uint32_t first, uint32_t step, bool whole) {
     const uint32_t log_c = d->extended_k - d->k, c = 1u << log_c;
     const size_t n = (size_t)1 << d->k, size = (size_t)1 << d->extended_k;
     const size_t nbytes = n * sizeof(Fr), ebytes = size * sizeof(Fr);
@@ -828,12 +822,18 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
         add(d->l_last);
         Fr* d_active = nullptr;
         Fr* d_active_j = nullptr;
-        if (d->l_active_row) {
-            d_active = (Fr*)dmalloc(ebytes);
-            d_active_j = (Fr*)dmalloc(nbytes);
-            H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+        Fr* d_values = nullptr;
+        Fr* stage = nullptr;  // pinned, n elements: one coset of l_active_row on its way in, one coset of values on its way out
+        if (d->l_active_row) d_active_j = (Fr*)dmalloc(nbytes);
+        if (whole) {
+            if (d->l_active_row) {
+                d_active = (Fr*)dmalloc(ebytes);
+                H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+            }
+            d_values = (Fr*)dmalloc(ebytes);
+        } else {
+            stage = (Fr*)ctx->pinned.get(nbytes);
         }
-        Fr* d_values = (Fr*)dmalloc(ebytes);
         Fr* d_values_j = (Fr*)dmalloc(nbytes);
         // scratch of a batch of transforms: up to 16 vectors per launch, fewer when that would pass 1 GiB
         const size_t batch_width = std::max<size_t>(1, std::min<size_t>(16, ((size_t)1 << 30) / nbytes));
@@ -846,8 +846,10 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
         for (int i = 0; i < 4; i++) omega_u[i] = (uint64_t)omega.l[2 * i] | ((uint64_t)omega.l[2 * i + 1] << 32);
         PlanRef pl = ntt_get_plan(ctx, d->k, omega_u, stream);  // the caller holds ctx->mu (DeviceLease)
         const unsigned nblocks = (unsigned)((n + 255) / 256);
-        Fr g = zeta;  // g_0
-        for (uint32_t j = 0; j < c; j++) {
+        const Fr w_step = fp_pow_u32(w_ext, step);
+        Fr g = fp_mul(zeta, fp_pow_u32(w_ext, first));  // g_first
+        const Fr* active_host = (const Fr*)d->l_active_row;
+        for (uint32_t j = first; j < c; j += step) {
             for (int i = 0; i < 4; i++) g_u[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
             {
                 // every column to coset j in batched, fused coset transforms (ntt.hip: g_j^t applied in the first pass's load,
@@ -864,7 +866,12 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
                     ntt_run_many(ctx, pl.get(), srcs.data() + at, dsts.data() + at, tmps.data() + at,
                                  std::min(batch_width, srcs.size() - at), (uint32_t)n, nullptr, nullptr, stream, tab, 1u);
             }
-            if (d_active) hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);
+            if (d_active) {
+                hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);
+            } else if (active_host) {
+                for (size_t i = 0; i < n; i++) stage[i] = active_host[(i << log_c) | j];
+                H2_HIP(hipMemcpyAsync(d_active_j, stage, nbytes, hipMemcpyHostToDevice, stream));
+            }
             h2_evalh_desc dd = *d;
             dd.extended_k = d->k;
             for (int i = 0; i < 4; i++) {
@@ -894,18 +901,71 @@ int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) 
                 cleanup();
                 return rc;
             }
-            hipLaunchKernelGGL(k_coset_scatter, dim3(nblocks), dim3(256), 0, stream, d_values_j, d_values, n, log_c, j);
-            g = fp_mul(g, w_ext);
+            if (whole) {
+                hipLaunchKernelGGL(k_coset_scatter, dim3(nblocks), dim3(256), 0, stream, d_values_j, d_values, n, log_c, j);
+            } else {
+                H2_HIP(hipMemcpyAsync(stage, d_values_j, nbytes, hipMemcpyDeviceToHost, stream));
+                H2_HIP(hipStreamSynchronize(stream));
+                Fr* out = (Fr*)values;
+                for (size_t i = 0; i < n; i++) out[(i << log_c) | j] = stage[i];
+            }
+            g = fp_mul(g, w_step);
         }
         H2_HIP(hipGetLastError());
-        H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
+        if (whole) H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
         H2_HIP(hipStreamSynchronize(stream));
         cleanup();
         return H2_OK;
     } catch (...) {
+        (void)hipStreamSynchronize(stream);
         cleanup();
         throw;
     }
+}
+
+// The reference's cuda evaluate_h deals its gates / lookups / shuffles over the N_GPU devices of the process inside the one
+// call (plonk/evaluation.rs:326-333,1262-1275,1513-1520,1830-1837: `group_expr_len`, one thread per GPU).  Here the unit is a
+// coset of the extended domain -- the work per coset is the same and nothing is exchanged between cosets: P = min(pool
+// size, cosets) threads lease a device each (acquire_gpu, arithmetic.rs:314-321), upload the coefficient vectors once per
+// device and take the cosets p, p + P, ...; with one device (or one coset) the caller's thread does it all.
+int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values) {
+    if (!d || !values) {
+        set_last_error("h2_evaluate_h_coeff: null argument");
+        return H2_ERR_INVALID;
+    }
+    if (d->extended_k < d->k || d->extended_k > 28) {
+        set_last_error("h2_evaluate_h_coeff: bad k / extended_k");
+        return H2_ERR_INVALID;
+    }
+    if (d->row_count) {
+        set_last_error("h2_evaluate_h_coeff: a row range is for the device entry point (h2_dev_evaluate_h)");
+        return H2_ERR_INVALID;
+    }
+    const uint32_t c = 1u << (d->extended_k - d->k);
+    const uint32_t workers = (uint32_t)std::max(1, std::min<int>(device_count(), (int)c));
+    if (workers <= 1) {
+        DeviceLease lease;
+        return evalh_coeffs_worker(lease.ctx, d, values, 0, 1, true);
+    }
+    std::vector<int> rcs(workers, H2_OK);
+    std::vector<std::string> errs(workers);
+    std::vector<std::thread> th;
+    for (uint32_t p = 0; p < workers; p++) {
+        th.emplace_back([&, p] {
+            rcs[p] = guarded([&] {
+                DeviceLease lease;
+                return evalh_coeffs_worker(lease.ctx, d, values, p, workers, false);
+            });
+            if (rcs[p] != H2_OK) errs[p] = get_last_error();
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t p = 0; p < workers; p++)
+        if (rcs[p] != H2_OK) {
+            set_last_error(errs[p]);
+            return rcs[p];
+        }
+    return H2_OK;
 }
 
 }  // namespace h2

@@ -8,8 +8,9 @@ namespace h2 {
 int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream_t stream, bool have_lock);
 // everything in host memory
 int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values);
-// host memory, columns as COEFFICIENT vectors of 2^k elements (l_active_row extended): the cuda evaluate_h's shape
-int evalh_host_coeffs(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values);
+// host memory, columns as COEFFICIENT vectors of 2^k elements (l_active_row extended): the cuda evaluate_h's shape; leases
+// its devices itself -- the cosets of the extended domain are dealt over the pool (HALO2_PROOFS_N_GPU)
+int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values);
 
 // ---- the generated form (evalh_gen.cpp builds it, evalh.hip loads and launches it)
 struct EvalhPlan;  // the loaded kernels of one program on one device
