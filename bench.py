@@ -96,7 +96,15 @@ def launch_ranks(n, argv):
         if failed_at is None and any(c not in (None, 0) for c in codes):
             failed_at = time.perf_counter()                    # a rank died: the others are waiting for it in a collective
         if failed_at is not None and time.perf_counter() - failed_at > grace:
+            # SIGTERM first: rank 0's signal thread (main: `partial_line_on_sigterm`) prints what it has measured -- the
+            # primary NTT metric is complete long before the proof legs -- and exits; SIGKILL for what is left 5 s later
             for p in procs:                                    # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.perf_counter() + 5.0
+            while time.perf_counter() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            for p in procs:
                 if p.poll() is None:
                     p.kill()
         time.sleep(0.05)
@@ -137,6 +145,14 @@ def main():
         # no launcher around this process: become one (before torch is imported or the GPU is touched)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1:
+        # SIGTERM (our launcher or torchrun stopping the ranks after another rank failed) is taken by a dedicated thread:
+        # blocked here, before any other thread exists, so that every thread inherits the mask; the main thread may be
+        # inside an RCCL call that never returns and could not run a Python signal handler
+        import signal
+
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
     # the CPU baseline's OpenMP teams sleep at their barriers instead of spinning (read when libgomp is loaded, i.e. before
     # torch is imported): rayon's idle workers park; a spinning team of 256 on a box whose cgroup grants fewer CPUs took 4.7 s
     # for a 2^20 transform in round 4's line
@@ -187,6 +203,26 @@ def main():
                 print(json.dumps(out), flush=True)
             os._exit(3)
         return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    partial = {}                                  # rank 0's result line so far, for the SIGTERM thread below
+
+    def partial_line_on_sigterm():
+        import signal
+
+        signal.sigwait({signal.SIGTERM})
+        if rank == 0 and partial.get("out") is not None:
+            line = dict(partial["out"])
+            line["error"] = "stopped by SIGTERM before the run was complete (another rank failed or stalled): the legs present were measured"
+            try:
+                print(json.dumps(line), flush=True)
+            except Exception:  # noqa: BLE001 - a leg being written by the main thread at this instant
+                pass
+        os._exit(4)
+
+    if world > 1:
+        import threading
+
+        threading.Thread(target=partial_line_on_sigterm, daemon=True).start()
 
     def barrier():
         torch.cuda.synchronize()
@@ -481,6 +517,7 @@ def main():
         }
         return leg
 
+    partial["out"] = out
     # BASELINE.json's metric has three parts (create_proof seconds, MSM G1-adds/s, NTT Fr-ops/s, all at k = 24): `value` is the
     # third; the other two, and the zkWasm-shaped legs, are repeated here inside `config` -- the part of the line every summary keeps
     headline = out["config"].setdefault("headline", {"ntt_fr_ops_per_s_k%d" % log_n: value, "ntt_hbm_roofline_frac": achieved_gbs / HBM_PEAK_GBS})
@@ -523,6 +560,27 @@ def main():
                         "max_registers": st["max_registers"], "achieved_mul_per_s": muls, "peak_mul_per_s": MUL_HW_BOUND,
                         "frac": muls / MUL_HW_BOUND, "frac_of_multiplier_in_a_loop": muls / MUL_MEASURED},
                 "limiter": "integer VALU: the field products of the gate and argument terms, not HBM"}
+
+    def comm_summary(D, phases_s):
+        """N > 1: what rank 0's collectives cost in the phase-split proof (prover.Device.last_comm: every collective bracketed by
+        stream synchronisations, the asynchronous broadcasts measured serialised), next to the phase's whole time -- the part of
+        a scaling curve that is links, not kernels.  MAX over ranks of the per-phase communication seconds."""
+        comm = getattr(D, "last_comm", None)
+        if dist is None or not comm:
+            return None
+        names = list(phases_s)
+        t = torch.tensor([comm.get(n, {}).get("seconds", 0.0) for n in names], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst = [float(v) for v in t.tolist()]
+        return {
+            "what": "per phase: seconds inside collectives (max over ranks; measured serialised in the phase-split proof -- the timed "
+                    "proofs overlap the bulk broadcasts with compute), the phase's whole time, payload bytes and calls of rank 0",
+            "phases": {n: {"comm_ms": round(w * 1e3, 3), "phase_ms": round(phases_s[n] * 1e3, 2),
+                           "bytes": comm.get(n, {}).get("bytes", 0), "calls": comm.get(n, {}).get("calls", 0),
+                           "by_collective_ms": {c: round(v * 1e3, 3) for c, v in comm.get(n, {}).get("by_collective", {}).items()}}
+                       for n, w in zip(names, worst)},
+            "comm_ms_total": round(sum(worst) * 1e3, 2), "phases_ms_total": round(sum(phases_s.values()) * 1e3, 2),
+        }
 
     # ---------------------------------------------------------------- create_proof legs (configs[3] k = 22; configs[4]'s k = 24)
     def prove_leg(pk_k, steps, verify):
@@ -630,6 +688,7 @@ def main():
             "proof_bytes": len(proof),
             "verified": verified,
             "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
+            "communication": comm_summary(D, phases),
             "evaluate_h": {"roofline": evalh_roofline(pk, phases)},
             "steps": steps,
             "peak_device_memory_gib": round(peak_gib, 1),
@@ -699,6 +758,7 @@ def main():
                 "library_memory_gib": round(L.h2_library_memory_bytes() / 2**30, 2),
                 "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof),
                 "evaluate_h": {"roofline": evalh_roofline(pk, phases)},
+                "communication": comm_summary(D, phases),
             }
             if dist is not None:
                 res[mode]["sharding"] = prover.sharding_description(D)
@@ -801,6 +861,44 @@ def main():
         torch.cuda.empty_cache()
         headline["create_proof_k%d_seconds" % kk] = seconds_of(out[key], "seconds")
         headline["create_proof_k%d_evaluate_h_alu_frac" % kk] = seconds_of(out[key], "evaluate_h", "roofline", "alu", "frac")
+    # N > 1: the same circuit as INDEPENDENT proofs, one per GPU (prover.Device.replica: a singleton group, no collective on
+    # the data path) -- the throughput a node reaches when there are at least N proofs to make, next to the latency form above
+    if world > 1 and args.prove_k and "error" not in out.get("create_proof", {"error": 1}):
+        try:
+            from halo2_gpu_specific_amd import circuits, prover
+            from halo2_gpu_specific_amd.rng import ProverRng
+
+            kk = args.prove_k
+            D = prover.Device.replica(local_rank)
+            params = prover.Params.unsafe_setup(D, kk, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
+            adv, fixed, copies = circuits.mini_plonk_synthesize(kk, alloc=D.pinned_columns)
+            pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
+            proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1))
+            D.sync()
+            barrier()
+            r0 = time.perf_counter()
+            for i in range(args.prove_steps):
+                prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(2 + i))
+            D.sync()
+            barrier()
+            rsec = time.perf_counter() - r0
+            t = torch.tensor([rsec], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rsec = float(t[0].item())
+            one = out["create_proof"].get("seconds")
+            out["create_proof_replicas"] = {
+                "what": "one independent mini-PLONK proof per GPU at k = %d, no collective on the data path: N x K proofs between two "
+                        "barriers, max over ranks" % kk,
+                "k": kk, "proofs_per_s": world * args.prove_steps / rsec, "seconds_per_proof_per_gpu": rsec / args.prove_steps,
+                "scaling": "weak", "proof_bytes": len(proof),
+                "one_proof_over_all_ranks_seconds": one,
+                "one_proof_over_all_ranks_proofs_per_s": (1.0 / one) if one else None,
+            }
+            headline["create_proof_k%d_replicas_proofs_per_s" % kk] = out["create_proof_replicas"]["proofs_per_s"]
+            del pk, params, adv, D
+        except Exception as e:  # noqa: BLE001
+            out["create_proof_replicas"] = leg_failed("create_proof_replicas", e)
+        torch.cuda.empty_cache()
     if watchdog_done is not None:
         watchdog_done.set()
 

@@ -472,8 +472,8 @@ int h2_dev_coset_ntt(const void* d_coeffs, void* d_out, void* d_tmp, uint32_t lo
         ntt_split(log_n, bits);
         if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
         PlanRef pl = plan_locked(ctx, log_n, omega, s, false);
-        const Fr* tab = ntt_scale_table(pl.get(), fr_from_u64x4(g), nullptr, s);
-        ntt_run(ctx, pl.get(), (const Fr*)d_coeffs, (Fr*)d_out, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab, 1u);
+        ScaleTabRef tab = ntt_scale_table(pl.get(), fr_from_u64x4(g), nullptr, s);
+        ntt_run(ctx, pl.get(), (const Fr*)d_coeffs, (Fr*)d_out, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab.get(), 1u);
         return (int)H2_OK;
     });
 }
@@ -494,13 +494,13 @@ static int dev_ntt_batch_impl(const void* const* srcs, void* const* dsts, size_t
         ntt_split(log_n, bits);
         if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
         PlanRef pl = plan_locked(ctx, log_n, omega, s, false);
-        const Fr* tab = nullptr;
+        ScaleTabRef tab_ref;
         Fr d{};
         Fr post3[3];
         const Fr* post = nullptr;
         if (divisor) d = fr_from_u64x4(divisor);
         if (g) {
-            tab = ntt_scale_table(pl.get(), fr_from_u64x4(g), divisor ? &d : nullptr, s);
+            tab_ref = ntt_scale_table(pl.get(), fr_from_u64x4(g), divisor ? &d : nullptr, s);
         } else if (divisor) {
             post3[0] = post3[1] = post3[2] = d;
             post = post3;
@@ -514,6 +514,7 @@ static int dev_ntt_batch_impl(const void* const* srcs, void* const* dsts, size_t
             tmp[i] = d_tmp ? (Fr*)d_tmp + (i % 16) * n : nullptr;
         }
         const uint32_t in_len = in_log == 0xffffffffu ? (uint32_t)n : (1u << in_log);   // shorter: zero-extended (coeff_to_extended)
+        const Fr* tab = tab_ref.get();
         ntt_run_many(ctx, pl.get(), in.data(), out.data(), tmp.data(), count, in_len, pre3, post, s, tab,
                      tab ? scale_mode : 0u);
         return (int)H2_OK;
@@ -561,8 +562,8 @@ int h2_dev_coset_intt(void* d_a, void* d_tmp, uint32_t log_n, const uint64_t g_i
         if (bits.size() >= 2 && d_tmp == nullptr) return bad("NTT of this size needs a scratch buffer (d_tmp)");
         PlanRef pl = plan_locked(ctx, log_n, omega_inv, s, false);
         const Fr d = fr_from_u64x4(divisor);
-        const Fr* tab = ntt_scale_table(pl.get(), fr_from_u64x4(g_inv), &d, s);
-        ntt_run(ctx, pl.get(), (const Fr*)d_a, (Fr*)d_a, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab, 2u);
+        ScaleTabRef tab = ntt_scale_table(pl.get(), fr_from_u64x4(g_inv), &d, s);
+        ntt_run(ctx, pl.get(), (const Fr*)d_a, (Fr*)d_a, (Fr*)d_tmp, 1u << log_n, nullptr, nullptr, s, tab.get(), 2u);
         return (int)H2_OK;
     });
 }

@@ -67,6 +67,7 @@ struct ResidentCopy {
 struct DeviceShared {
     std::mutex mu;                     // guards `resident` (a lookup may upload an SRS) and plan creation across the slots
     std::map<const void*, ResidentCopy> resident;  // registered host base ranges -> device copies (msm.hip)
+    std::vector<ResidentCopy> retired;  // copies whose registration was replaced: freed by the next h2_bases_unregister, under every slot's lock
     std::map<std::string, NttPlan*> plans;
     size_t ntt_last_table_bytes = 0;   // of the optional last-pass tables (ntt.hip; guarded by ntt.hip's table mutex)
 };

@@ -861,10 +861,10 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
                     dsts.push_back(kv.second.second);
                     tmps.push_back(d_tmp + (tmps.size() % batch_width) * n);
                 }
-                const Fr* tab = ntt_scale_table(pl.get(), g, nullptr, stream);
+                ScaleTabRef tab = ntt_scale_table(pl.get(), g, nullptr, stream);
                 for (size_t at = 0; at < srcs.size(); at += batch_width)   // (a chunk's scratch slots are distinct)
                     ntt_run_many(ctx, pl.get(), srcs.data() + at, dsts.data() + at, tmps.data() + at,
-                                 std::min(batch_width, srcs.size() - at), (uint32_t)n, nullptr, nullptr, stream, tab, 1u);
+                                 std::min(batch_width, srcs.size() - at), (uint32_t)n, nullptr, nullptr, stream, tab.get(), 1u);
             }
             if (d_active) {
                 hipLaunchKernelGGL(k_coset_gather, dim3(nblocks), dim3(256), 0, stream, d_active, d_active_j, n, log_c, j);

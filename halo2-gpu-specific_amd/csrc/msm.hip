@@ -2170,6 +2170,11 @@ int bases_unregister(const uint64_t* bases) {
                 (void)hipFree(it->second.ptr);
                 dv.first->resident.erase(it);
             }
+            for (ResidentCopy& c : dv.first->retired) {
+                bases_forget((const uint64_t*)c.ptr);
+                (void)hipFree(c.ptr);
+            }
+            dv.first->retired.clear();
         }
         for (DeviceCtx* ctx : dv.second) ctx->mu.unlock();
     }
@@ -2187,12 +2192,15 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
     std::lock_guard<std::mutex> shared_lock(ctx->shared->mu);
     {
         std::lock_guard<std::mutex> g(g_reg_mu);
-        // drop device copies whose registration is gone or was replaced
+        // Device copies whose registration is gone or was replaced are never FREED here: this caller holds its own slot's
+        // lock only, and the other host-API slot of the device may be in the middle of an MSM over such a copy.
+        // A copy whose registration is gone is about to be freed by the h2_bases_unregister that removed it (under every
+        // slot's lock); one whose registration was REPLACED (register again without unregister) steps aside into `retired`,
+        // which the next unregister empties the same way.
         for (auto it = ctx->resident.begin(); it != ctx->resident.end();) {
             auto r = g_registered.find((const uint64_t*)it->first);
-            if (r == g_registered.end() || r->second.gen != it->second.gen || r->second.len != it->second.len) {
-                bases_forget((const uint64_t*)it->second.ptr);
-                (void)hipFree(it->second.ptr);
+            if (r != g_registered.end() && (r->second.gen != it->second.gen || r->second.len != it->second.len)) {
+                ctx->shared->retired.push_back(it->second);
                 it = ctx->resident.erase(it);
             } else {
                 ++it;
@@ -2206,6 +2214,7 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         reg = it->second;
     }
     auto rit = ctx->resident.find((const void*)key);
+    if (rit != ctx->resident.end() && (rit->second.gen != reg.gen || rit->second.len != reg.len)) return nullptr;  // (cannot happen: swept above)
     if (rit == ctx->resident.end()) {
         ResidentCopy c;
         c.len = reg.len;

@@ -509,7 +509,7 @@ static void free_plan(NttPlan* pl) {
     for (auto& kv : pl->scaled_hi)
         if (kv.second) (void)hipFree(kv.second);
     for (auto& kv : pl->scale_tabs)
-        if (kv.second) (void)hipFree(kv.second);
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto& kv : pl->last_direct)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     delete pl;
@@ -707,7 +707,7 @@ static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr
 
 // The two-level table of g^i (i < 2^log_n) with `d` folded into the high level, cached with the plan: the coset transforms
 // of a proof use quotient_poly_degree generators per direction, again and again.
-const Fr* ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream) {
+ScaleTabRef ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream) {
     char kb[200];
     int at = 0;
     for (int l = 7; l >= 0; l--) at += snprintf(kb + at, sizeof kb - at, "%08x", g.l[l]);
@@ -715,26 +715,69 @@ const Fr* ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t str
     if (d)
         for (int l = 7; l >= 0; l--) at += snprintf(kb + at, sizeof kb - at, "%08x", d->l[l]);
     const std::string key(kb, (size_t)at);
-    std::lock_guard<std::mutex> lk(pl->mu);
-    auto it = pl->scale_tabs.find(key);
-    if (it != pl->scale_tabs.end()) return it->second;
+    {
+        std::lock_guard<std::mutex> lk(pl->mu);
+        auto it = pl->scale_tabs.find(key);
+        if (it != pl->scale_tabs.end()) {
+            it->second.users++;
+            it->second.last_use = ++pl->scale_clock;
+            return ScaleTabRef(pl, &it->second);
+        }
+    }
+    // built OUTSIDE the plan's lock (the other host-API slot of the device keeps transforming meanwhile); the device
+    // block is owned by a guard until it is published
     const uint32_t n = 1u << pl->log_n;
     const uint32_t lo_count = n < (1u << LO_BITS) ? n : (1u << LO_BITS);
     const uint32_t hi_count = pl->log_n > LO_BITS ? (n >> LO_BITS) : 1u;
-    Fr* tab = nullptr;
-    H2_HIP(hipMalloc(&tab, ((size_t)(1u << LO_BITS) + hi_count) * sizeof(Fr)));
-    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, tab, g, 1u, lo_count);
-    Fr* hi = tab + (1u << LO_BITS);
+    const size_t bytes = ((size_t)(1u << LO_BITS) + hi_count) * sizeof(Fr);
+    struct Block {
+        Fr* p = nullptr;
+        ~Block() {
+            if (p) (void)hipFree(p);
+        }
+    } block;
+    H2_HIP(hipMalloc((void**)&block.p, bytes));
+    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, block.p, g, 1u, lo_count);
+    Fr* hi = block.p + (1u << LO_BITS);
     hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, g, 1u << LO_BITS, hi_count);
     if (d) hipLaunchKernelGGL(k_scale_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, hi, *d, hi_count);
     H2_HIP(hipGetLastError());
     H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per generator)
-    pl->scale_tabs[key] = tab;
+    std::vector<Fr*> evicted;
+    size_t evicted_bytes = 0;
+    NttPlan::ScaleTab* entry = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(pl->mu);
+        auto it = pl->scale_tabs.find(key);
+        if (it != pl->scale_tabs.end()) {  // another caller built the same table meanwhile: theirs stays, ours goes with `block`
+            it->second.users++;
+            it->second.last_use = ++pl->scale_clock;
+            return ScaleTabRef(pl, &it->second);
+        }
+        while (pl->scale_tabs.size() >= NttPlan::SCALE_TABS_MAX) {
+            auto lru = pl->scale_tabs.end();
+            for (auto jt = pl->scale_tabs.begin(); jt != pl->scale_tabs.end(); ++jt)
+                if (jt->second.users == 0 && (lru == pl->scale_tabs.end() || jt->second.last_use < lru->second.last_use)) lru = jt;
+            if (lru == pl->scale_tabs.end()) break;  // every table is held: over the cap for now
+            evicted.push_back(lru->second.ptr);
+            evicted_bytes += lru->second.bytes;
+            pl->scale_tabs.erase(lru);
+        }
+        NttPlan::ScaleTab& e = pl->scale_tabs[key];
+        e.ptr = block.p;
+        e.bytes = bytes;
+        e.users = 1;
+        e.last_use = ++pl->scale_clock;
+        block.p = nullptr;
+        entry = &e;
+    }
     {
         std::lock_guard<std::mutex> g2(g_tab_mu);
-        pl->table_bytes += ((size_t)(1u << LO_BITS) + hi_count) * sizeof(Fr);
+        pl->table_bytes += bytes;
+        pl->table_bytes -= std::min(pl->table_bytes, evicted_bytes);
     }
-    return tab;
+    for (Fr* q : evicted) (void)hipFree(q);  // (waits for the passes already launched against it)
+    return ScaleTabRef(pl, entry);
 }
 
 void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const Fr* pre3,

@@ -19,7 +19,17 @@ struct NttPlan {
     size_t table_bytes = 0;            // of `tables` and the per-pass direct tables
     std::mutex mu;                     // guards scaled_hi, last_direct
     std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)
-    std::map<std::string, Fr*> scale_tabs; // (generator, divisor) -> two-level table of g^i (coset transforms): 4096 + n/4096 entries
+    // (generator, divisor) -> two-level table of g^i (coset transforms): 4096 + n/4096 entries.  At most SCALE_TABS_MAX per
+    // plan: the public coset entry points take any generator, so the least recently used table nobody holds is dropped
+    struct ScaleTab {
+        Fr* ptr = nullptr;
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+        int users = 0;  // ScaleTabRef holders: between looking the table up and having launched the pass that reads it
+    };
+    static constexpr size_t SCALE_TABS_MAX = 32;
+    std::map<std::string, ScaleTab> scale_tabs;
+    uint64_t scale_clock = 0;
     // the last pass's complete inter-pass twiddle set, w^(rho * K) at [(K << B_last) | rho] (2^log_n entries, streamed in
     // the order the pass loads its elements), keyed by the divisor folded into it ("" = none).  These are the large
     // optional tables (32 B x n each): they count against the per-device budget (ntt_table_budget) and the least
@@ -81,7 +91,37 @@ void ntt_set_table_budget(size_t bytes);
 // final store -- the transforms between coefficients and ONE coset g H of a larger domain, without a separate scaling pass.
 void ntt_run(DeviceCtx* ctx, NttPlan* pl, const Fr* src, Fr* dst, Fr* tmp, uint32_t in_len, const Fr* pre3,
              const Fr* post3, hipStream_t stream, const Fr* scale_tab = nullptr, uint32_t scale_mode = 0);
-const Fr* ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream);
+// the returned reference pins the table until the caller has launched what reads it (an evicted table is released with
+// hipFree, which waits for the work already launched)
+struct ScaleTabRef {
+    NttPlan* pl = nullptr;
+    NttPlan::ScaleTab* tab = nullptr;
+    ScaleTabRef() = default;
+    ScaleTabRef(NttPlan* p, NttPlan::ScaleTab* t) : pl(p), tab(t) {}
+    ScaleTabRef(ScaleTabRef&& o) noexcept : pl(o.pl), tab(o.tab) { o.pl = nullptr; o.tab = nullptr; }
+    ScaleTabRef& operator=(ScaleTabRef&& o) noexcept {
+        if (this != &o) {
+            drop();
+            pl = o.pl;
+            tab = o.tab;
+            o.pl = nullptr;
+            o.tab = nullptr;
+        }
+        return *this;
+    }
+    ScaleTabRef(const ScaleTabRef&) = delete;
+    ScaleTabRef& operator=(const ScaleTabRef&) = delete;
+    ~ScaleTabRef() { drop(); }
+    const Fr* get() const { return tab ? tab->ptr : nullptr; }
+    void drop() {
+        if (tab) {
+            std::lock_guard<std::mutex> g(pl->mu);
+            tab->users--;
+        }
+        tab = nullptr;
+    }
+};
+ScaleTabRef ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t stream);
 // `count` transforms of one plan with the same scales, several vectors per launch; tmps[i] = scratch of vector i
 void ntt_run_many(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr* const* dsts, Fr* const* tmps, size_t count,
                   uint32_t in_len, const Fr* pre3, const Fr* post3, hipStream_t stream, const Fr* scale_tab = nullptr,

@@ -93,6 +93,71 @@ class _on_stream:
         return False
 
 
+# ---- what the collectives of one proof cost, per phase (bench.py --gpus N: "communication next to compute") ------------
+# While a TRACED proof runs (prover.create_proof_ext with `timings`: an extra, untimed proof that already synchronises at
+# every phase boundary) each collective below is bracketed by stream synchronisations and its wall time, payload and name
+# are recorded; the asynchronous broadcasts are then waited for at once, i.e. measured SERIALISED -- an upper bound of what
+# the timed proofs, which overlap them with compute, expose.  Off (None) otherwise: no synchronisation is added.
+COMM_TRACE = None
+
+
+def comm_trace_begin():
+    global COMM_TRACE
+    COMM_TRACE = []
+
+
+def comm_trace_phase(name):
+    """the phase that just ended: every entry recorded since the previous boundary belongs to it"""
+    if COMM_TRACE is not None:
+        for e in COMM_TRACE:
+            if e[0] is None:
+                e[0] = name
+
+
+def comm_trace_end():
+    """-> {phase: {"seconds", "bytes", "calls", "by_collective": {name: seconds}}}"""
+    global COMM_TRACE
+    trace, COMM_TRACE = COMM_TRACE or [], None
+    out = {}
+    for phase, name, sec, nbytes in trace:
+        d = out.setdefault(phase or "after the last phase", {"seconds": 0.0, "bytes": 0, "calls": 0, "by_collective": {}})
+        d["seconds"] += sec
+        d["bytes"] += int(nbytes)
+        d["calls"] += 1
+        d["by_collective"][name] = d["by_collective"].get(name, 0.0) + sec
+    return out
+
+
+class _traced:
+    def __init__(self, name, nbytes, stream=None):
+        self.name, self.nbytes, self.stream, self.t0 = name, nbytes, stream, None
+
+    def _sync(self):
+        import torch
+
+        if torch.cuda.is_available():
+            if self.stream is not None:
+                self.stream.synchronize()
+            else:
+                torch.cuda.synchronize()
+
+    def __enter__(self):
+        if COMM_TRACE is not None:
+            import time
+
+            self._sync()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t0 is not None and COMM_TRACE is not None:
+            import time
+
+            self._sync()
+            COMM_TRACE.append([None, self.name, time.perf_counter() - self.t0, self.nbytes])
+        return False
+
+
 def allgather_fold(partial_xyz, group=None, device=None):
     """All-gather every rank's partial point and fold; every rank returns the full sum."""
     return allgather_fold_many(np.asarray(partial_xyz, dtype=np.uint64).reshape(1, 12), group, device)[0]
@@ -114,7 +179,7 @@ def allgather_fold_many(partials_xyz, group=None, device=None, stream=None):
     count = mine_np.shape[0]
     mine = torch.from_numpy(mine_np.view(np.int64).copy())
     if device is not None and _backend(group) == "nccl":
-        with _on_stream(stream) as handle:
+        with _traced("all_gather (partial points)", world * count * 96, stream), _on_stream(stream) as handle:
             mine = mine.to(device)
             gathered = torch.empty((world, count, 12), dtype=torch.int64, device=device)
             dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
@@ -126,7 +191,8 @@ def allgather_fold_many(partials_xyz, group=None, device=None, stream=None):
                 check(lib().h2_synchronize(), "h2_synchronize")
             return out.cpu().numpy().view(np.uint64)
     gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
+    with _traced("all_gather (partial points)", world * count * 96, stream):
+        dist.all_gather(gathered, mine, group=group)
     pts = np.stack([t.numpy().view(np.uint64) for t in gathered])      # (world, count, 12)
     return np.stack([g1_sum(pts[:, j, :]) for j in range(count)])
 
@@ -139,8 +205,10 @@ def allreduce_max(values, group=None, device=None):
     t = torch.tensor(list(values), dtype=torch.int64)
     if device is not None and _backend(group) == "nccl":
         t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return [int(v) for v in t.cpu().tolist()]
+    with _traced("all_reduce max (scalar bounds)", t.numel() * 8):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        out = [int(v) for v in t.cpu().tolist()]
+    return out
 
 
 def allreduce_counts(counts, group=None, stream=None):
@@ -149,7 +217,7 @@ def allreduce_counts(counts, group=None, stream=None):
     addition -- and the total of the last counter returned (the same on every rank, so that all of them raise or none)."""
     import torch.distributed as dist
 
-    with _on_stream(stream):
+    with _traced("all_reduce sum (logup counts)", counts.numel() * 4, stream), _on_stream(stream):
         if _backend(group) == "nccl":
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
         else:
@@ -167,7 +235,7 @@ def allgather_rows(t, lo, hi, group=None, stream=None):
 
     world = dist.get_world_size(group)
     assert t.shape[0] % world == 0 and hi - lo == t.shape[0] // world
-    with _on_stream(stream):
+    with _traced("all_gather (rows)", t.numel() * 8, stream), _on_stream(stream):
         if _backend(group) == "nccl":
             dist.all_gather_into_tensor(t.view(-1), t[lo:hi].reshape(-1), group=group)
             return t
@@ -194,7 +262,7 @@ def gather_rows_to(t, lo, hi, dst, group=None, stream=None):
     m = t.shape[0] // world
     assert t.shape[0] % world == 0 and hi - lo == m
     gdst = dist.get_global_rank(group, dst) if group is not None else dst
-    with _on_stream(stream):
+    with _traced("gather (rows to the transforming rank)", t.numel() * 8, stream), _on_stream(stream):
         if _backend(group) == "nccl":
             parts = [t[r * m:(r + 1) * m] for r in range(world)] if rank == dst else None
             dist.gather(t[lo:hi].clone(), gather_list=parts, dst=gdst, group=group)
@@ -232,8 +300,9 @@ def broadcast_columns_begin(cols, owners, group=None, stream=None, side=None):
     import torch.distributed as dist
 
     rank = dist.get_rank(group)
+    nbytes = sum(t.numel() * 8 for t in cols)
     if _backend(group) != "nccl":
-        with _on_stream(stream):
+        with _traced("broadcast (coefficient vectors)", nbytes, stream), _on_stream(stream):
             for t, owner in zip(cols, owners):
                 buf = t.cpu()
                 dist.broadcast(buf, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
@@ -251,7 +320,18 @@ def broadcast_columns_begin(cols, owners, group=None, stream=None, side=None):
                 t.record_stream(side)
             works.append(dist.broadcast(t, src=dist.get_global_rank(group, owner) if group is not None else owner,
                                         group=group, async_op=True))
-    return _Arrival(works, stream)
+    arrival = _Arrival(works, stream)
+    if COMM_TRACE is not None:
+        # a traced proof: the transfer alone, serialised (the timed proofs run it under the next phase's compute)
+        import time
+
+        stream.synchronize()
+        t0 = time.perf_counter()
+        arrival.wait()
+        stream.synchronize()
+        COMM_TRACE.append([None, "broadcast (coefficient vectors; serialised here, overlapped in the timed proofs)",
+                           time.perf_counter() - t0, nbytes])
+    return arrival
 
 
 # ---- coset sharding of the extended-domain phase ---------------------------------------------------------------------
@@ -292,7 +372,7 @@ def exchange_cosets(mine, c, shards, group=None, stream=None):
     staged = _backend(group) != "nccl"          # gloo: through host memory
     template = next(iter(mine.values()))
     out = []
-    with _on_stream(stream):
+    with _traced("broadcast (coset polynomials)", c * template.numel() * 8, stream), _on_stream(stream):
         for j in range(c):
             src = j % shards
             t = mine[j] if (j in mine and rank == src) else _empty_like(template)
@@ -330,7 +410,7 @@ def exchange_row_slices(columns, owners, n, G, g, halo_lo, halo_hi, group=None, 
     per = n // G + halo_lo + halo_hi
     mine = [i for i, o in enumerate(owners) if o == g]
     theirs = {m: [i for i, o in enumerate(owners) if o == m] for m in range(G)}
-    with _on_stream(stream):
+    with _traced("all_to_all (row slices inside a coset group)", (G - 1) * per * len(mine) * 32, stream), _on_stream(stream):
         # (the index vectors are built by kernels too: on THIS stream -- torch's default stream and a stream created with
         # torch.cuda.Stream() do not order each other, and an index_select that overtakes its own indices reads garbage rows)
         rows = {m: slice_rows(n, G, m, halo_lo, halo_hi, device) for m in range(G)}
@@ -381,7 +461,8 @@ def allgather_scalars(values, group=None, device=None):
     if device is not None and _backend(group) == "nccl":
         mine = mine.to(device)
     out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine, group=group)
+    with _traced("all_gather (field elements)", world * mine.numel() * 8):
+        dist.all_gather(out, mine, group=group)
     res = []
     for t in out:
         rows = t.cpu().numpy().view(np.uint64).reshape(-1, 4)
@@ -436,7 +517,7 @@ def scatter_cosets(mine, c, shards, lo, hi, group=None, stream=None):
     n = template.shape[0]
     assert n % world == 0 and hi - lo == n // world
     out = []
-    with _on_stream(stream):
+    with _traced("scatter (coset polynomial slices)", c * (hi - lo) * 32 * (world - 1), stream), _on_stream(stream):
         for j in range(c):
             src = j % shards
             full = mine[j] if j in mine else _empty_like(template)

@@ -142,6 +142,25 @@ class CosetTables:
                 del self.tabs[min(self.tabs, key=lambda i: self.tabs[i][1])]
 
 
+_PROCESS_GROUPS = {}
+
+
+def _process_group_cache(key, make):
+    """communicators made once per process (a Device per bench leg / per fuzzed circuit used to call
+    dist.new_group() each, piling up RCCL communicators and turning Device() into an implicit collective every time); dropped
+    when the default group they were made under is gone"""
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    alive = _PROCESS_GROUPS.get("_default")
+    if alive is None or alive is not dist.group.WORLD:
+        _PROCESS_GROUPS.clear()
+        _PROCESS_GROUPS["_default"] = dist.group.WORLD
+    if (key, world) not in _PROCESS_GROUPS:
+        _PROCESS_GROUPS[(key, world)] = make()
+    return _PROCESS_GROUPS[(key, world)]
+
+
 class Device:
     """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
 
@@ -187,8 +206,23 @@ class Device:
             if self.group_size > 1 and group is None:
                 # a second communicator for the bulk column traffic (parallel.broadcast_columns_begin): collectives of one
                 # communicator run in issue order, and the 96-byte all-gathers of the commitments must not wait behind
-                # half a gigabyte of coefficients.  (Collective: every rank constructs its Device at the same point.)
-                self.bulk_group = dist.new_group()
+                # half a gigabyte of coefficients.  ONE per process, made by the first Device of a multi-rank process
+                # (collective: every rank constructs its first Device at the same point) and reused by every later one --
+                # bench.py and the fuzzers build a Device per leg / per circuit, and communicators are never freed by torch
+                # before destroy_process_group.
+                self.bulk_group = _process_group_cache("bulk", dist.new_group)
+
+    @classmethod
+    def replica(cls, device=0, **kw):
+        """a Device that proves ALONE inside a multi-rank process group -- one proof per GPU, no collective on the data path
+        (the throughput form of N GPUs; `Device()` in such a process spreads ONE proof over the ranks).  Collective the first
+        time: every rank builds the singleton groups of all ranks, in order."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return cls(device, **kw)
+        groups = _process_group_cache("singletons", lambda: [dist.new_group(ranks=[r]) for r in range(dist.get_world_size())])
+        return cls(device, group=groups[dist.get_rank()], **kw)
 
     # -- memory -----------------------------------------------------------------------------------------
     def empty(self, n):
@@ -450,14 +484,12 @@ class Device:
         P = self.group_size
         if P <= 1 or c < 1 or P % c or P // c < 2 or self.group is not None or os.environ.get("H2_COSET_GROUPS") == "0":
             return None
-        cache = self.__dict__.setdefault("_coset_groups", {})
-        if c not in cache:
-            import torch.distributed as dist
+        import torch.distributed as dist
 
-            G = P // c
-            groups = [dist.new_group(ranks=[j + c * m for m in range(G)]) for j in range(c)]
-            cache[c] = (groups[self.group_rank % c], G, self.group_rank // c)
-        return cache[c]
+        G = P // c
+        # (per process, not per Device: the same c groups serve every Device of this world size)
+        groups = _process_group_cache(("coset", P, c), lambda: [dist.new_group(ranks=[j + c * m for m in range(G)]) for j in range(c)])
+        return groups[self.group_rank % c], G, self.group_rank // c
 
     def coeffs_to_coset_rows(self, polys, dom, j, sub, halo):
         """the values of `polys` on coset j where THIS member of the coset's rank group needs them: member g transforms
@@ -1366,10 +1398,17 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     usable = n - (bf + 1)
     marks = [("start", time.perf_counter())]
 
+    if timings is not None and D.group_size > 1:
+        from . import parallel as _par
+
+        _par.comm_trace_begin()              # this (untimed) proof records what its collectives cost, phase by phase
+
     def mark(name):
         if timings is not None:
             D.sync()
             marks.append((name, time.perf_counter()))
+            if D.group_size > 1:
+                _par.comm_trace_phase(name)
         if TRACE_TRANSCRIPT:                 # where two runs (or two ranks) of one proof part ways: the transcript after a phase
             import sys
 
@@ -1979,6 +2018,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if timings is not None:
         for (_, t0), (name, t1) in zip(marks, marks[1:]):
             timings[name] = timings.get(name, 0.0) + (t1 - t0)
+        if D.group_size > 1:
+            # per phase: seconds / bytes / calls of this rank's collectives (parallel.COMM_TRACE), next to `timings`
+            D.last_comm = _par.comm_trace_end()
     return transcript.finalize()
 
 

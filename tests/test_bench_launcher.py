@@ -39,6 +39,15 @@ def test_bare_gpus_2_starts_two_ranks():
     wide = line["create_proof_wide"]
     assert "error" not in wide, wide
     assert "2 rank(s)" in wide["sharded"]["sharding"] and wide["verified"] is True
+    # round 5: communication next to compute per phase, the replicas leg, the whole metric inside `config`
+    comm = line["create_proof"]["communication"]
+    assert comm["comm_ms_total"] > 0 and set(comm["phases"]) == set(line["create_proof"]["phases_ms"])
+    assert any(p["calls"] for p in comm["phases"].values()) and wide["sharded"]["communication"]["comm_ms_total"] > 0
+    rep = line["create_proof_replicas"]
+    assert "error" not in rep and rep["proofs_per_s"] > 0 and rep["proof_bytes"] == line["create_proof"]["proof_bytes"]
+    head = line["config"]["headline"]
+    assert head["create_proof_k12_seconds"] == line["create_proof"]["seconds"] and head["msm_g1_adds_per_s"] > 0
+    assert head["create_proof_wide_k10_seconds"] == wide["sharded"]["seconds"]
     # the same circuits on one rank: the sharded proofs carry the same bytes
     q, _ = run_bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--k24", "0", "--prove-k", "0", "--wide-k", "10",
                       "--wide-quads", "2", "--log-n", "16", "--no-msm", "--no-cpu-baseline"], {}, 600)

@@ -622,7 +622,8 @@ def test_rccl_collective_shapes_on_one_rank(tmp_path):
     scatter_cosets, gather_rows_to, the asynchronous broadcasts of broadcast_columns_begin on a second communicator and a
     side stream, the device-side fold, the small all-gathers / all-reduces) under a ONE-rank RCCL group, each at least
     twice and with the view sizes a larger world would use: a mis-sized view or a wrong stream order fails here, on one
-    GPU, not on eight"""
+    GPU, not on eight.  Round 5: a 256 MiB broadcast on the second communicator / side stream in flight while the first
+    communicator runs 96-byte all-gathers in a loop (the two-communicator overlap of DESIGN section 6)"""
     import subprocess
     import sys
 
@@ -677,6 +678,24 @@ for rep in range(3):
     pts = np.zeros((2, 12), dtype=np.uint64); pts[:, 4] = 1          # two identities (0 : 1 : 0) in canonical limbs ...
     out = parallel.allgather_fold_many(pts, device=dev, stream=stream)
     assert out.shape == (2, 12) and not out[:, 8:].any()               # ... fold to the identity (z = 0)
+# the overlap DESIGN section 6 depends on: a BULK broadcast (8 x 32 MiB = 256 MiB) in flight on the second communicator and
+# the side stream WHILE the first communicator runs the commitments' 96-byte all-gathers on the compute stream -- both
+# complete, in either order of completion, with the right contents
+with torch.cuda.stream(stream):
+    big = [torch.randint(-2**62, 2**62, (1 << 20, 4), dtype=torch.int64, device=dev, generator=g) for _ in range(8)]
+    want_big = [b.clone() for b in big]
+for rep in range(2):
+    arrival = parallel.broadcast_columns_begin(big, [0] * 8, group=bulk, stream=stream, side=side)
+    pts = np.zeros((3, 12), dtype=np.uint64); pts[:, 4] = 1
+    for i in range(150):
+        out = parallel.allgather_fold_many(pts, device=dev, stream=stream)
+        assert out.shape == (3, 12) and not out[:, 8:].any()
+        if i == 75 and rep == 1:
+            arrival.wait()                           # ... and a wait in the middle of the small collectives
+    arrival.wait()
+    stream.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(big, want_big)), "bulk broadcast under small all-gathers"
+del big, want_big
 # the sharded inverse transforms of a proof, through Device: one rank owns every column
 dom = prover.Domain(12, 3)
 with torch.cuda.stream(stream):
