@@ -751,9 +751,22 @@ def main():
             sec /= steps
             phases = {}
             prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=phases)
+            # up to k = 20 the advice columns' inverse transforms and extensions run on a SIDE stream under the lookup and
+            # permutation phases (prover.Device.intt_on_side_stream): whichever phase they happen to overlap is charged with
+            # them above.  The same proof with that work kept on the compute stream attributes every kernel to its own phase
+            serial_phases = None
+            if pk_k <= 20 and dist is None:
+                os.environ["H2_SIDE_INTT"] = "0"
+                try:
+                    serial_phases = {}
+                    prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(1), timings=serial_phases)
+                finally:
+                    del os.environ["H2_SIDE_INTT"]
             res[mode] = {
                 "residency": pk.residency, "seconds": sec, "witness_synthesis_seconds": synth_s, "keygen_seconds": keygen_s,
                 "phases_ms": {n: round(v * 1e3, 2) for n, v in phases.items()},
+                "phases_ms_without_side_stream_overlap": ({n: round(v * 1e3, 2) for n, v in serial_phases.items()}
+                                                          if serial_phases else None),
                 "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                 "library_memory_gib": round(L.h2_library_memory_bytes() / 2**30, 2),
                 "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof),

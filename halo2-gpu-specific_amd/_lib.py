@@ -103,6 +103,7 @@ SYMBOLS = {
     "h2_dev_prefix_sum": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),
     "h2_logup_scratch_bytes": (_sz, [_sz]),
     "h2_dev_logup_multiplicity": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
+    "h2_dev_logup_multiplicity_bits": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp, _vp]),
     "h2_dev_logup_counts": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
     "h2_dev_logup_emit": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "h2_dev_fixed_base_mul": (ctypes.c_int, [_vp, _vp, _sz, _vp, _vp]),

@@ -946,6 +946,22 @@ int h2_dev_logup_multiplicity(const void* d_table, const void* const* d_inputs, 
     });
 }
 
+int h2_dev_logup_multiplicity_bits(const void* d_table, const void* const* d_inputs, size_t n_inputs, size_t usable_rows,
+                                   size_t n, void* d_m, void* d_scratch, size_t scratch_bytes, uint32_t* max_bits_out,
+                                   void* stream) {
+    if (!d_table || !d_m || !d_scratch || !max_bits_out || (n_inputs && !d_inputs)) return bad("h2_dev_logup_multiplicity_bits: null argument");
+    return guarded([&] {
+        DeviceCtx* ctx = current_ctx();
+        uint32_t max_count = 0;
+        const int rc = logup_multiplicity_launch((const Fr*)d_table, (const Fr* const*)d_inputs, n_inputs, usable_rows, n, (Fr*)d_m,
+                                                 d_scratch, scratch_bytes, pick_stream(ctx, stream), &max_count);
+        uint32_t bits = 0;
+        while (bits < 32 && (max_count >> bits)) bits++;
+        *max_bits_out = bits;
+        return rc;
+    });
+}
+
 // ------------------------------------------------------------------ evaluate_h: the generated form
 int h2_evalh_prepare(const h2_evalh_desc* desc, h2_evalh_info* info) {
     if (!desc) return bad("h2_evalh_prepare: null argument");

@@ -86,15 +86,26 @@ __global__ void __launch_bounds__(256) k_logup_count(const Fr* table, const Fr* 
     if ((active >> lane) & 1) atomicAdd(&count[hit], 1u);
 }
 
-__global__ void __launch_bounds__(256) k_logup_emit(const uint32_t* count, uint32_t usable, size_t n, Fr* m) {
+// `max_out` (nullable): the largest multiplicity, for the caller's scalar bound of m's commitment -- one atomic per wave
+__global__ void __launch_bounds__(256) k_logup_emit(const uint32_t* count, uint32_t usable, size_t n, Fr* m, uint32_t* max_out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr v = fp_zero<FrParams>();
-    if (i < usable) {
-        v.l[0] = count[i];
-        v = fp_to_mont(v);
+    uint32_t c = 0;
+    if (i < n) {
+        Fr v = fp_zero<FrParams>();
+        if (i < usable) {
+            c = count[i];
+            v.l[0] = c;
+            v = fp_to_mont(v);
+        }
+        fp_store(m + i, v);
     }
-    fp_store(m + i, v);
+    if (max_out) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)c, off, 64);
+            c = o > c ? o : c;
+        }
+        if ((threadIdx.x & 63) == 0 && c) atomicMax(max_out, c);
+    }
 }
 
 static uint32_t table_capacity(size_t usable) {
@@ -106,7 +117,7 @@ static uint32_t table_capacity(size_t usable) {
 size_t logup_scratch_bytes(size_t n) { return ((size_t)table_capacity(n) + n + 64) * sizeof(uint32_t); }
 
 int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size_t n_inputs, size_t usable, size_t n,
-                              Fr* d_m, void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+                              Fr* d_m, void* d_scratch, size_t scratch_bytes, hipStream_t stream, uint32_t* max_count_out) {
     if (usable > n || n >= 0x7fffffffu) {
         set_last_error("h2_dev_logup_multiplicity: bad sizes");
         return H2_ERR_INVALID;
@@ -120,7 +131,7 @@ int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size
     uint32_t* count = slots + cap;
     uint32_t* miss = count + n;
     H2_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, stream));
-    H2_HIP(hipMemsetAsync(count, 0, (n + 1) * 4, stream));
+    H2_HIP(hipMemsetAsync(count, 0, (n + 2) * 4, stream));   // n counters, the misses, the largest counter
     const unsigned blocks = (unsigned)((usable + 255) / 256);
     if (usable) {
         hipLaunchKernelGGL(k_logup_build, dim3(blocks), dim3(256), 0, stream, d_table, (uint32_t)usable, mask, slots);
@@ -129,11 +140,13 @@ int logup_multiplicity_launch(const Fr* d_table, const Fr* const* d_inputs, size
                                mask, slots, count, miss);
     }
     hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, (uint32_t)usable, n,
-                       d_m);
+                       d_m, max_count_out ? miss + 1 : (uint32_t*)nullptr);
     H2_HIP(hipGetLastError());
-    uint32_t h_miss = 0;
-    H2_HIP(hipMemcpyAsync(&h_miss, miss, 4, hipMemcpyDeviceToHost, stream));
+    uint32_t h_tail[2] = {0, 0};
+    H2_HIP(hipMemcpyAsync(h_tail, miss, 8, hipMemcpyDeviceToHost, stream));
     H2_HIP(hipStreamSynchronize(stream));
+    const uint32_t h_miss = h_tail[0];
+    if (max_count_out) *max_count_out = h_tail[1];
     if (h_miss) {
         set_last_error("logup: " + std::to_string(h_miss) + " input value(s) are missing from the table");
         return H2_ERR_INVALID;
@@ -176,7 +189,8 @@ int logup_emit_launch(const uint32_t* d_counts, size_t usable, size_t n, Fr* d_m
         set_last_error("h2_dev_logup_emit: bad sizes");
         return H2_ERR_INVALID;
     }
-    hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_counts, (uint32_t)usable, n, d_m);
+    hipLaunchKernelGGL(k_logup_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_counts, (uint32_t)usable, n, d_m,
+                       (uint32_t*)nullptr);
     H2_HIP(hipGetLastError());
     return H2_OK;
 }

@@ -489,7 +489,9 @@ class Device:
         G = P // c
         # (per process, not per Device: the same c groups serve every Device of this world size)
         groups = _process_group_cache(("coset", P, c), lambda: [dist.new_group(ranks=[j + c * m for m in range(G)]) for j in range(c)])
-        return groups[self.group_rank % c], G, self.group_rank // c
+        sub = (groups[self.group_rank % c], G, self.group_rank // c)
+        self.__dict__.setdefault("_coset_groups", {})[c] = sub      # (what this Device used: the multi-rank tests look)
+        return sub
 
     def coeffs_to_coset_rows(self, polys, dom, j, sub, halo):
         """the values of `polys` on coset j where THIS member of the coset's rank group needs them: member g transforms
@@ -1420,6 +1422,26 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if D.group_size > 1:
         rng = rng.shared(D.group)            # every rank of one proof draws the same blinding values
 
+    def commit_lagrange_with_tail(cols_, bits_, split_tail):
+        """commit_lagrange of columns whose USABLE rows are bounded by bits_[i] and whose bf + 1 blinding rows are 16-bit
+        values (advice columns, the lookups' multiplicities).  `split_tail`: a column whose usable rows are narrower than the
+        blinding rows (and large enough for the narrow shapes of the MSM to matter) is committed as two sums -- the usable
+        rows under THEIR bound, the blinding rows as one more (fused, few-point) MSM -- and the two points are added; the
+        others are committed whole, under the bound of the whole column."""
+        narrow_ = [i for i, b in enumerate(bits_) if split_tail and b <= 12 and n >= (1 << 20)]
+        whole_ = [i for i in range(len(cols_)) if i not in narrow_]
+        points_ = [None] * len(cols_)
+        if whole_:
+            wb = [max(bits_[i], 16) if split_tail else bits_[i] for i in whole_]
+            for i, P in zip(whole_, D.msm_batch([cols_[i] for i in whole_], params.g_lagrange, n, wb)):
+                points_[i] = P
+        if narrow_:
+            main_ = D.msm_batch([cols_[i] for i in narrow_], params.g_lagrange, usable, [bits_[i] for i in narrow_])
+            tail_ = D.msm_batch([cols_[i][usable:] for i in narrow_], params.g_lagrange[usable:], n - usable, 16)
+            for i, a_, b_ in zip(narrow_, main_, tail_):
+                points_[i] = g1_add_affine(a_, b_)
+        return points_
+
     multi = len(advice) > 0 and isinstance(advice[0], (list, tuple))
     advice_sets = [list(a) for a in advice] if multi else [list(advice)]
     instance_sets = [list(i) for i in instances] if multi else [list(instances)]
@@ -1547,19 +1569,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             check(L.h2_dev_batch_mont(t[lo_r:hi_r].data_ptr(), hi_r - lo_r, D.stream), "h2_dev_batch_mont")
         # ... for the columns whose usable rows are narrower than the blinding rows (and large enough for the narrow shapes
         # to matter): the others are committed whole, under the bound of the whole column
-        narrow_ = [i for i, b in enumerate(bits_) if split_tail and b <= 12 and n >= (1 << 20)]
-        whole_ = [i for i in range(len(cols_)) if i not in narrow_]
-        points_ = [None] * len(cols_)
-        if whole_:
-            wb = [max(bits_[i], 16) if split_tail else bits_[i] for i in whole_]
-            for i, P in zip(whole_, D.msm_batch([cols_[i] for i in whole_], params.g_lagrange, n, wb)):
-                points_[i] = P
-        if narrow_:
-            main_ = D.msm_batch([cols_[i] for i in narrow_], params.g_lagrange, usable, [bits_[i] for i in narrow_])
-            tail_ = D.msm_batch([cols_[i][usable:] for i in narrow_], params.g_lagrange[usable:], n - usable, 16)
-            for i, a_, b_ in zip(narrow_, main_, tail_):
-                points_[i] = g1_add_affine(a_, b_)
-        for P in points_:
+        for P in commit_lagrange_with_tail(cols_, bits_, split_tail):
             transcript.write_point(P)
         if sharded_upload and whole_advice_rows:
             for t in cols_:
@@ -1603,7 +1613,16 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             m = D.empty(n)
             nbytes = L.h2_logup_scratch_bytes(n)
             ptrs = (_vp * len(flat))(*[c.data_ptr() for c in flat])
-            if rows_c is None:
+            m_usable_bits = None
+            if rows_c is None and hasattr(L, "h2_dev_logup_multiplicity_bits") and os.environ.get("H2_M_BITS", "1") != "0":
+                # ... and the width of the largest multiplicity: a range lookup's counts are a few bits wide, nowhere near
+                # the log2(rows x inputs) their sum allows -- m's commitment then takes the narrow-column shapes of the MSM
+                got_bits = ctypes.c_uint32(0)
+                check(L.h2_dev_logup_multiplicity_bits(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
+                                                       D.scratch(nbytes).data_ptr(), nbytes, ctypes.byref(got_bits), D.stream),
+                      "h2_dev_logup_multiplicity_bits")
+                m_usable_bits = max(int(got_bits.value), 1)
+            elif rows_c is None:
                 check(L.h2_dev_logup_multiplicity(st["table"].data_ptr(), ptrs, len(flat), usable, n, m.data_ptr(),
                                                   D.scratch(nbytes).data_ptr(), nbytes, D.stream), "h2_dev_logup_multiplicity")
             else:
@@ -1618,12 +1637,18 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                     raise ValueError("logup: %d input value(s) are missing from the table" % missing)
                 check(L.h2_dev_logup_emit(counts.data_ptr(), usable, n, m.data_ptr(), D.stream), "h2_dev_logup_emit")
             D.set_rows(m, usable, [rng.u16() for _ in range(usable, n)])
-            st["m"], st["m_bits"] = m, max(16, (usable * len(flat)).bit_length())
+            st["m"], st["m_bits"], st["m_usable_bits"] = m, max(16, (usable * len(flat)).bit_length()), m_usable_bits
             C["lookups"].append(st)
         # ---- shuffles: compressed expressions (shuffle/prover.rs:40-80) ------------------------------------------
         C["shuffles"] = [[(compress(ip, rows=rows_c), compress(sp, rows=rows_c)) for ip, sp in group] for group in pk.shuffle_programs]
     all_lookups = [st for C in circuits for st in C["lookups"]]
-    if all_lookups:
+    if all_lookups and all(st["m_usable_bits"] is not None for st in all_lookups):
+        split_m = not (D.group_size > 1 or D.force_collective) and usable >= (1 << 12)
+        # (committed whole, a column's bound covers its 16-bit blinding rows too)
+        m_bits_ = [st["m_usable_bits"] if split_m else max(st["m_usable_bits"], 16) for st in all_lookups]
+        for P in commit_lagrange_with_tail([st["m"] for st in all_lookups], m_bits_, split_m):
+            transcript.write_point(P)
+    elif all_lookups:
         for P in D.msm_batch([st["m"] for st in all_lookups], params.g_lagrange, n, max(st["m_bits"] for st in all_lookups)):
             transcript.write_point(P)
     mark("lookups compress")

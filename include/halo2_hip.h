@@ -218,6 +218,12 @@ int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d
 size_t h2_logup_scratch_bytes(size_t n);
 int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
+/* h2_dev_logup_multiplicity that also returns the bit length of the LARGEST multiplicity (0 when every count is zero): the
+ * bound for m's commitment (find_max_scalar_bits of the usable rows, arithmetic.rs's `max_bits`) without another pass --
+ * a range lookup's multiplicities are a few bits wide, not the log2(rows x inputs) their sum allows */
+int h2_dev_logup_multiplicity_bits(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
+                                   size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, uint32_t *max_bits_out,
+                                   void *stream);
 /* The same counting restricted to the input rows [row_begin, row_end) -- one device's share when the rows of a proof are dealt
  * over several devices -- with the RAW counters out: d_counts = n + 1 u32 (credits per table row, then the number of input
  * values missing from the table).  Integer counts are an RCCL reduction (sum), field elements are not: the ranks all-reduce
