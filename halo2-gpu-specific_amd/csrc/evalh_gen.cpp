@@ -760,7 +760,6 @@ Options Options::from_env() {
     o.max_regs = env_u32("H2_JIT_MAX_REGS", o.max_regs);
     o.waves = env_u32("H2_JIT_WAVES", o.waves);
     o.factor = env_u32("H2_JIT_FACTOR", 1) != 0;
-    o.mul2 = env_u32("H2_JIT_MUL2", 1) != 0;
     return o;
 }
 
@@ -830,7 +829,7 @@ void program_hash(const h2_evalh_desc* d, const Options& opt, uint8_t out[32]) {
     h.update(h2_embed_field_hpp, strlen(h2_embed_field_hpp));
     h.update(h2_embed_fp_mul_gen_hpp, strlen(h2_embed_fp_mul_gen_hpp));
     const uint32_t o[] = {opt.group, opt.max_ahead, opt.gap, opt.inline_muls, opt.stage_products, opt.max_cols, opt.max_regs,
-                          (uint32_t)opt.factor, (uint32_t)opt.mul2, opt.waves};
+                          (uint32_t)opt.factor, opt.waves};
     h.update(o, sizeof o);
     h.u32(d->blinding_factors);
     h.u32(d->chunk_len);

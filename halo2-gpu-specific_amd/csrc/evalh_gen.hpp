@@ -82,7 +82,6 @@ struct Options {
     uint32_t waves = 0;        // ask the compiler for at least this many waves per SIMD (amdgpu_waves_per_eu; 0 = its own choice)
     uint32_t max_regs = 256;   // a stage compiled to more registers than this (or to scratch) is cut in two and rebuilt
     bool factor = true;        // terms that share a factor (a selector, l_0, l_last, l_active_row) are summed before it multiplies them
-    bool mul2 = true;          // a b + c d with one reduction where both products are used once
     static Options from_env();
 };
 

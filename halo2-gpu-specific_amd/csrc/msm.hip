@@ -76,6 +76,10 @@ struct MsmShape {
         off_buckets, off_winpart, off_rcount, off_bflags, off_tmpa, total;
     uint32_t two_level;         // table shape: partition in two coalesced passes (k_part_a / k_part_b), a_bits + b_bits = hi_bits
     uint32_t a_bits;
+    // table shape, reduce by bit planes (k_reduce_chunks / k_reduce_planes): `planes` points leave the device per MSM --
+    // P_0 .. P_(planes-2) and the sum of the chunks' own weighted sums -- in winpart[Wt ..]; 0 = the classic k_reduce
+    uint32_t planes, chunks, plane_l, plane_seg;
+    size_t off_planes;          // the chunk sums R[chunks], then the plane partials [planes][plane_seg], then `planes` counters
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -301,8 +305,23 @@ static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const Shi
     s.off_heavy = take(((size_t)s.nbt + 2) * 4);
     s.off_partials = take(s.max_items * sizeof(XYZZ));
     s.off_buckets = take((size_t)s.nbt * sizeof(XYZZ));
-    s.off_winpart = take((size_t)s.Wt * (1 + s.RG) * sizeof(XYZZ));
+    // Reduce by bit planes (below, k_reduce_chunks): for power-of-two chunk lengths and at least a workgroup of chunks
+    static const bool planes_on = !(getenv("H2_MSM_REDUCE_PLANES") && atoi(getenv("H2_MSM_REDUCE_PLANES")) == 0);
+    s.planes = 0;
+    if (planes_on && (s.qm & (s.qm - 1)) == 0 && s.nb >= 4 * s.qm) {
+        s.chunks = (s.nb + s.qm - 1) / s.qm;
+        uint32_t nbits = 0;
+        while ((1u << nbits) < s.chunks) nbits++;
+        s.planes = nbits + 1;
+        // the planes' workgroups together fill the chip about once: plane_seg workgroups per plane, plane_l chunk sums per quad
+        s.plane_seg = std::max<uint32_t>(1, 256 / s.planes);
+        const uint32_t half = nbits ? (1u << (nbits - 1)) : 1u;
+        while (s.plane_seg > 1 && (s.plane_seg - 1) * (REDUCE_T / 4) >= half) s.plane_seg--;   // no empty workgroups
+        s.plane_l = (half + s.plane_seg * (REDUCE_T / 4) - 1) / (s.plane_seg * (REDUCE_T / 4));
+    }
+    s.off_winpart = take(((size_t)s.Wt * (1 + s.RG) + s.planes) * sizeof(XYZZ));
     s.off_rcount = take((size_t)s.Wt * 4);
+    s.off_planes = s.planes ? take(((size_t)s.chunks + (size_t)s.planes * s.plane_seg) * sizeof(XYZZ) + (size_t)s.planes * 4 + 64) : 0;
     s.off_bflags = take(n / 256 + 4);  // one byte per 256-row block: the block is one entry of the dominant-value bucket
     s.off_coltab = take(64);
     // two-level partition (H2_MSM_TWO_LEVEL=0: the single pass): the entries pass through a second 8-byte-per-entry buffer
@@ -1204,6 +1223,85 @@ __global__ void __launch_bounds__(REDUCE_T) k_reduce(const XYZZ* buckets, uint32
     if (qd == 0) xyzz_store_q(winsum + w, res, q);
 }
 
+// ---------------------------------------------------------------- reduce by bit planes (shifted-base tables)
+// k_reduce's quads each lift their chunk by the index of its first bucket -- a double-and-add over up to 16-21 bits, ~80
+// dependent product levels, the longest part of a chain that is latency and nothing else (273 us for the 2^16 buckets of a
+// 2^20 MSM however few points they hold).  The weights factor instead:
+//     sum_b (b + 1) B_b  =  sum_c acc_c  +  qm * sum_c c * R_c          (chunk c = buckets c qm .. c qm + qm - 1,
+//                                                                         acc_c = sum (b - c qm + 1) B_b,  R_c = sum B_b)
+//     sum_c c * R_c      =  sum_p 2^p P_p,   P_p = sum of the R_c whose index has bit p set
+// k_reduce_chunks computes acc_c / R_c by summation by parts (2 qm additions per quad) and tree-sums the acc_c of a
+// workgroup; k_reduce_planes forms the P_p -- UNWEIGHTED sums, a few elements per quad and two trees deep -- and the sum
+// of the workgroups' acc sums; the host adds the planes up by Horner (log2(chunks) doublings and additions on one core,
+// ~20 us, next to the window Horner it already does).  Same group element, a different (equally valid) Jacobian
+// representative of it; ~4 extra additions per chunk of work, a third of the dependent depth.
+__global__ void __launch_bounds__(REDUCE_T) k_reduce_chunks(const XYZZ* buckets, uint32_t nb, uint32_t qm, uint32_t chunks,
+                                                            XYZZ* R, XYZZ* group_acc) {
+    __shared__ XYZZ sh[REDUCE_T / 4];
+    const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2;
+    const uint32_t c = blockIdx.x * (REDUCE_T / 4) + qd;
+    XYZZ acc = xyzz_identity();
+    if (c < chunks) {
+        const uint32_t k0 = c * qm;
+        uint32_t k1 = k0 + qm;
+        if (k1 > nb) k1 = nb;
+        XYZZ running = xyzz_identity();
+        XYZZ nxt = xyzz_load(buckets + (k1 - 1));
+        for (uint32_t b = k1; b-- > k0;) {
+            const XYZZ cur = nxt;
+            if (b > k0) nxt = xyzz_load(buckets + (b - 1));  // in flight during the two additions below
+            running = xyzz_add_q(running, cur, q);
+            acc = xyzz_add_q(acc, running, q);
+        }
+        xyzz_store_q(R + c, running, q);
+    }
+    acc = quad_tree_sum<REDUCE_T / 4>(acc, sh, qd, q);
+    if (qd == 0) xyzz_store_q(group_acc + blockIdx.x, acc, q);
+}
+
+// grid (plane_seg, planes): plane p < nbits sums the chunk sums R[c] with bit p of c set -- quad t of the plane takes the
+// L consecutive members t L .. t L + L - 1 of that half of the index space; the last plane sums the group_acc of
+// k_reduce_chunks' workgroups (segment 0 alone).  Each workgroup's tree result goes to part[p][segment]; the last
+// workgroup of a plane to finish (a counter per plane) folds the segments and writes out[p].
+__global__ void __launch_bounds__(REDUCE_T) k_reduce_planes(const XYZZ* R, uint32_t chunks, uint32_t nbits, const XYZZ* group_acc,
+                                                            uint32_t groups, uint32_t L, XYZZ* part, uint32_t* counters, XYZZ* out) {
+    __shared__ XYZZ sh[REDUCE_T / 4];
+    __shared__ uint32_t last_flag;
+    const uint32_t q = threadIdx.x & 3, qd = threadIdx.x >> 2, seg = blockIdx.x, p = blockIdx.y, nseg = gridDim.x;
+    XYZZ acc = xyzz_identity();
+    uint32_t expected = nseg;
+    if (p == nbits) {
+        expected = 1;
+        if (seg != 0) return;
+        for (uint32_t g = qd; g < groups; g += REDUCE_T / 4) acc = xyzz_add_q(acc, xyzz_load(group_acc + g), q);
+    } else {
+        const uint32_t half = 1u << (nbits - 1), low_mask = (1u << p) - 1;
+        const uint32_t t = seg * (REDUCE_T / 4) + qd;
+        uint32_t j = t * L;
+        const uint32_t j1 = j + L < half ? j + L : half;
+        for (; j < j1; j++) {
+            const uint32_t c = ((j >> p) << (p + 1)) | (1u << p) | (j & low_mask);
+            if (c < chunks) acc = xyzz_add_q(acc, xyzz_load(R + c), q);
+        }
+    }
+    acc = quad_tree_sum<REDUCE_T / 4>(acc, sh, qd, q);
+    if (expected == 1) {
+        if (qd == 0) xyzz_store_q(out + p, acc, q);
+        return;
+    }
+    if (qd == 0) xyzz_store_q(part + (size_t)p * nseg + seg, acc, q);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_flag = atomicAdd(counters + p, 1u) == expected - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    acc = xyzz_identity();
+    for (uint32_t s2 = qd; s2 < nseg; s2 += REDUCE_T / 4) acc = xyzz_add_q(acc, xyzz_load_coherent(part + (size_t)p * nseg + s2), q);
+    acc = quad_tree_sum<REDUCE_T / 4>(acc, sh, qd, q);
+    if (qd == 0) xyzz_store_q(out + p, acc, q);
+}
+
 // ---------------------------------------------------------------- synthetic bases (bench / tests)
 // n deterministic G1 points by try-and-increment: x = mix(seed, i), y = (x^3 + 3)^((q+1)/4) when that
 // is a square root (q = 3 mod 4).  Cofactor 1: every curve point is in G1.  Not part of the prover
@@ -1791,7 +1889,20 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
     hipLaunchKernelGGL(k_finish_heavy2, dim3(256), dim3(4 * HEAVY_SPLIT), 0, stream, partials, starts, s.log_s, heavy + 1,
                        heavy, buckets);
     if (s.RG > 1) H2_HIP(hipMemsetAsync(scratch + s.off_rcount, 0, (size_t)s.Wt * 4, stream));
-    if (s.tab) {
+    if (s.tab && s.planes) {
+        XYZZ* R = (XYZZ*)(scratch + s.off_planes);
+        XYZZ* part = R + s.chunks;
+        uint32_t* counters = (uint32_t*)(part + (size_t)s.planes * s.plane_seg);
+        XYZZ* group_acc = winpart + s.Wt + s.planes;
+        const uint32_t groups = (s.chunks + REDUCE_T / 4 - 1) / (REDUCE_T / 4);
+        H2_HIP(hipMemsetAsync(counters, 0, (size_t)s.planes * 4, stream));
+        hipLaunchKernelGGL(k_reduce_chunks, dim3(groups), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.qm, s.chunks, R, group_acc);
+        hipLaunchKernelGGL(k_reduce_planes, dim3(s.plane_seg, s.planes), dim3(REDUCE_T), 0, stream, (const XYZZ*)R, s.chunks,
+                           s.planes - 1, (const XYZZ*)group_acc, groups, s.plane_l, part, counters, winpart + s.Wt);
+        if (s.Wt > 1)
+            hipLaunchKernelGGL(k_reduce, dim3(1, 1), dim3(REDUCE_T), 0, stream, buckets + s.nb, 1u, 1u, s.qm,
+                               winpart + s.Wt, winpart + 1, (uint32_t*)(scratch + s.off_rcount));
+    } else if (s.tab) {
         // one window of nb buckets; the dominant-scalar window only ever fills its bucket 0
         hipLaunchKernelGGL(k_reduce, dim3(s.RG, 1), dim3(REDUCE_T), 0, stream, buckets, s.nb, s.RG, s.qm, winpart + s.Wt,
                            winpart, (uint32_t*)(scratch + s.off_rcount));
@@ -1809,7 +1920,18 @@ static void msm_launch(const MsmShape& s, const Hot& hot, const Fr* d_scalars, c
 static void msm_host_tail(const MsmShape& s, const Hot& hot, const std::vector<XYZZ>& winpart, uint64_t out_xyz[12],
                           size_t w0 = 0) {  // w0: first window of the column inside a fused shape
     XYZZ acc = xyzz_identity();
-    if (s.tab) acc = winpart[w0];  // the digits' weights are in the table's points: one window, no Horner
+    if (s.tab && s.planes) {
+        // the window's sum from its bit planes: qm * sum_p 2^p P_p + (the chunks' own weighted sums)
+        const XYZZ* P = winpart.data() + w0 + s.Wt;
+        for (int p = (int)s.planes - 2; p >= 0; p--) {
+            acc = xyzz_double(acc);
+            acc = xyzz_add(acc, P[p]);
+        }
+        for (uint32_t m = s.qm; m > 1; m >>= 1) acc = xyzz_double(acc);
+        acc = xyzz_add(acc, P[s.planes - 1]);
+    } else if (s.tab) {
+        acc = winpart[w0];  // the digits' weights are in the table's points: one window, no Horner
+    }
     for (int w = (int)(s.tab ? 0 : s.W) - 1; w >= 0; w--) {
         const uint32_t cw = s.c - ((uint32_t)w >= s.wfull ? 1u : 0u);  // the windows above w sit 2^cw higher
         for (uint32_t k = 0; k < cw; k++) acc = xyzz_double(acc);
@@ -1878,7 +2000,7 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
         return H2_ERR_INVALID;
     }
     msm_launch(s, hot, d_scalars, use_tab ? tab.table : (const Affine*)d_bases, max_bits, (char*)d_scratch, stream);
-    const size_t wp = (size_t)s.Wt * s.G;
+    const size_t wp = (size_t)s.Wt * s.G + s.planes;
     XYZZ* h_win = (XYZZ*)staging.get(wp * sizeof(XYZZ));
     export_to_host((const XYZZ*)((char*)d_scratch + s.off_winpart), h_win, wp, stream);
     H2_HIP(hipStreamSynchronize(stream));
@@ -1895,7 +2017,7 @@ int msm_device(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* d_bases, siz
 static int msm_device_fused(DeviceCtx* ctx, const Fr* const* d_scalars, uint32_t cols, const uint64_t* d_bases, size_t n,
                             uint32_t bits, char* scratch, uint64_t* const* outs, hipStream_t stream) {
     const MsmShape s = msm_shape(n, bits, false, cols);
-    const size_t wp = (size_t)s.Wt * s.G;
+    const size_t wp = (size_t)s.Wt * s.G + s.planes;
     char* pinned = (char*)ctx->pinned.get((size_t)cols * HOT_SAMPLES * sizeof(Fr) + wp * sizeof(XYZZ));
     Fr* h_samples = (Fr*)pinned;
     XYZZ* h_win = (XYZZ*)(pinned + (size_t)cols * HOT_SAMPLES * sizeof(Fr));
@@ -2038,7 +2160,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         shapes[2 * i] = msm_shape(n, bits ? bits : 1, false);
         shapes[2 * i + 1] = msm_shape(n, bits ? bits : 1, true);
         per = std::max(per, align_up(std::max(shapes[2 * i].total, shapes[2 * i + 1].total), 256));
-        wp_max = std::max(wp_max, (size_t)shapes[2 * i + 1].Wt * shapes[2 * i + 1].G);
+        wp_max = std::max(wp_max, (size_t)shapes[2 * i + 1].Wt * shapes[2 * i + 1].G + shapes[2 * i + 1].planes);
         if (use_tab[i]) {
             tshapes[2 * i] = msm_shape_table(n, bits, false, tabs[i]);
             tshapes[2 * i + 1] = msm_shape_table(n, bits, true, tabs[i]);
@@ -2103,7 +2225,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         hipStream_t q = st[lane_of % lanes];
         lane_of++;
         msm_launch(s, hots[i], d_scalars[i], use_tab[i] ? tabs[i].table : (const Affine*)bases, bits, scratch, q);
-        export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G, q);
+        export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win + i * wp_max, (size_t)s.Wt * s.G + s.planes, q);
         H2_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         H2_HIP(hipEventRecord(done[i], q));
     }
@@ -2116,7 +2238,7 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
         const MsmShape& s = shapes[2 * i + (hots[i].on ? 1 : 0)];
         H2_HIP(hipEventSynchronize(done[i]));
         H2_HIP(hipEventDestroy(done[i]));
-        std::vector<XYZZ> winpart(h_win + i * wp_max, h_win + i * wp_max + (size_t)s.Wt * s.G);
+        std::vector<XYZZ> winpart(h_win + i * wp_max, h_win + i * wp_max + (size_t)s.Wt * s.G + s.planes);
         msm_host_tail(s, hots[i], winpart, out_xyz + 12 * i);
     }
     return H2_OK;
