@@ -829,7 +829,7 @@ def main():
         import threading
 
         watchdog_done = threading.Event()
-        budget = float(os.environ.get("H2_BENCH_PROOF_BUDGET_S", "240"))
+        budget = float(os.environ.get("H2_BENCH_PROOF_BUDGET_S", "360"))
 
         def watchdog():
             if watchdog_done.wait(budget):
@@ -851,7 +851,8 @@ def main():
         torch.cuda.empty_cache()
         headline["create_proof_wide_k%d_seconds" % args.wide_k] = seconds_of(out["create_proof_wide"], "resident" if dist is None else "sharded", "seconds")
         headline["create_proof_wide_k%d_compact_witness_seconds" % args.wide_k] = seconds_of(out["create_proof_wide"], "resident_compact_witness", "seconds")
-    if args.wide_k22 and args.wide_k != 22 and (dist is None or world >= 2):
+    if args.wide_k22 and args.wide_k != 22 and dist is None:      # (N = 1 only: 8 GiB of witness per rank and a fifth proof leg
+        #                                                              would eat the multi-rank legs' time budget for no new information)
         # the zkWasm-sized leg: 64 advice columns x 2^22 rows (8 GiB of 32-byte cells; 2 GiB handed over compact)
         try:
             out["create_proof_wide_k22"] = wide_leg(22, args.wide_quads, 2, only_resident=True)

@@ -31,20 +31,22 @@ python3 tools/rocprof_summary.py "$(find "$out/p_ntt" -name '*results.db' | head
 bash tools/experiments/nttpmc.sh > "$out/ntt_pass_pmc.txt" 2>&1
 rm -rf gpurun_out/pmc1 gpurun_out/pmc2
 python3 tools/wide_bench.py 20 16 > "$out/create_proof_wide_k20.txt" 2>&1
+H2_SIDE_INTT=0 python3 tools/wide_bench.py 20 16 - compact >> "$out/create_proof_wide_k20.txt" 2>&1   # phases without the side-stream overlap
 python3 tools/wide_bench.py 20 16 coset >> "$out/create_proof_wide_k20.txt" 2>&1
 python3 tools/wide_bench.py 22 16 > "$out/create_proof_wide_k22.txt" 2>&1
 python3 tools/wide_bench.py 22 16 coset >> "$out/create_proof_wide_k22.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/p_wide" -o w -- python3 tools/wide_bench.py 20 16 > /dev/null 2>&1
 python3 tools/rocprof_summary.py "$(find "$out/p_wide" -name '*results.db' | head -1)" "$out/create_proof_wide_k20_kernel_stats.txt" > /dev/null
 python3 tools/rocprof_timeline.py "$(find "$out/p_wide" -name '*results.db' | head -1)" 1200 0 > "$out/create_proof_wide_k20_timeline.txt"
-# round 4: evaluate_h alone (gate kernel + library argument kernels vs the fused generated kernel) and the fused kernel's counters
-python3 tools/experiments/evalh_probe.py mini 25 > "$out/evalh_probe.txt" 2>&1
-python3 tools/experiments/evalh_probe.py wide 22 >> "$out/evalh_probe.txt" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d "$out/p_e1" -o e -- python3 tools/experiments/evalh_probe.py mini 25 single > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/p_e2" -o e -- python3 tools/experiments/evalh_probe.py mini 25 single > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/p_e3" -o e -- python3 tools/experiments/evalh_probe.py mini 25 single > /dev/null 2>&1
-{ echo "# rocprofv3 --pmc passes over tools/experiments/evalh_probe.py mini 25 single (mini-PLONK, 2^25 points): the gate-only"
-  echo "# generated kernel (first launches of h2_evalh_jit) + k_evalh_perm, then the fused generated kernel; per-launch averages"
+# round 5: evaluate_h alone -- the interpreter kernels against the kernels the library generates (csrc/evalh_gen.cpp), with the
+# generator's options swept -- and the generated kernel's counters
+python3 tools/experiments/evalh_probe.py mini 25 H2_JIT_FACTOR=0 H2_JIT_WAVES=3 > "$out/evalh_probe.txt" 2>&1
+python3 tools/experiments/evalh_probe.py wide 22 H2_JIT_FACTOR=0 H2_JIT_WAVES=3 H2_JIT_STAGE_PRODUCTS=60 >> "$out/evalh_probe.txt" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d "$out/p_e1" -o e -- python3 tools/experiments/evalh_probe.py mini 25 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/p_e2" -o e -- python3 tools/experiments/evalh_probe.py mini 25 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/p_e3" -o e -- python3 tools/experiments/evalh_probe.py mini 25 > /dev/null 2>&1
+{ echo "# rocprofv3 --pmc passes over tools/experiments/evalh_probe.py mini 25 (mini-PLONK, 2^25 points): the interpreter kernels"
+  echo "# (k_evalh_expr + k_evalh_perm, 4 launches each) and the library-generated kernel h2_evalh_gen (31 launches); per-launch averages"
   for d in p_e1 p_e2 p_e3; do python3 tools/pmc_summary.py "$(find "$out/$d" -name '*results.db' | head -1)" evalh; done; } > "$out/evalh_pmc.txt" 2>&1
 rm -rf "$out"/p_*
 ls -la "$out"
