@@ -54,7 +54,7 @@ namespace evgen {
 
 namespace {
 
-constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.1";
+constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.4";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("evaluate_h generator: " + what); }
 
@@ -381,33 +381,53 @@ struct Builder {
         if (opt.factor) factor_gates();
     }
 
-    // value parts of the form S * (...) with the same column value S (a selector) get S as their group factor
+    // value parts that are products containing the same column value S (a selector: `q * (...)`, `q * (...) * (...)`) get S
+    // as their group factor: the product tree is flattened (a b c d = any association), S is taken out, the rest is multiplied
+    // back together -- no more products than the gate had, one fewer whenever S sat inside a nested product
+    void flatten(int n, std::vector<int>& out) {
+        if (is(n, N_MUL)) {
+            flatten(nodes[n].a, out);
+            flatten(nodes[n].b, out);
+        } else if (is(n, N_SQR)) {
+            flatten(nodes[n].a, out);
+            flatten(nodes[n].a, out);
+        } else {
+            out.push_back(n);
+        }
+    }
     void factor_gates() {
         std::map<int, int> freq;
-        auto candidates = [&](int n, int out[2]) {
-            out[0] = out[1] = -1;
-            if (!is(n, N_MUL)) return;
-            if (is(nodes[n].a, N_LOAD)) out[0] = nodes[n].a;
-            if (is(nodes[n].b, N_LOAD)) out[1] = nodes[n].b;
-        };
+        std::vector<std::vector<int>> factors(d->n_value_parts);
         for (uint32_t i = 0; i < d->n_value_parts; i++) {
-            int c[2];
-            candidates(terms[i].x, c);
-            for (int k = 0; k < 2; k++)
-                if (c[k] >= 0) freq[c[k]]++;
+            flatten(terms[i].x, factors[i]);
+            if (factors[i].size() < 2) continue;
+            std::vector<int> seen;
+            for (int f : factors[i])
+                if (is(f, N_LOAD) && std::find(seen.begin(), seen.end(), f) == seen.end()) {
+                    seen.push_back(f);
+                    freq[f]++;
+                }
         }
         for (uint32_t i = 0; i < d->n_value_parts; i++) {
-            int c[2];
-            const int n = terms[i].x;
-            candidates(n, c);
+            if (factors[i].size() < 2) continue;
             int best = -1;
-            for (int k = 0; k < 2; k++) {
-                if (c[k] < 0 || freq[c[k]] < 2) continue;
-                if (best < 0 || freq[c[k]] > freq[best] ||
-                    (freq[c[k]] == freq[best] && cols[nodes[c[k]].x].table == T_FIXED && cols[nodes[best].x].table != T_FIXED))
-                    best = c[k];
+            for (int f : factors[i]) {
+                if (!is(f, N_LOAD) || freq[f] < 2) continue;
+                if (best < 0 || freq[f] > freq[best] ||
+                    (freq[f] == freq[best] && cols[nodes[f].x].table == T_FIXED && cols[nodes[best].x].table != T_FIXED))
+                    best = f;
             }
-            if (best >= 0) terms[i] = Term{best == nodes[n].a ? nodes[n].b : nodes[n].a, best};
+            if (best < 0) continue;
+            int rest = -1;
+            bool taken = false;
+            for (int f : factors[i]) {
+                if (f == best && !taken) {
+                    taken = true;
+                    continue;
+                }
+                rest = rest < 0 ? f : mul(rest, f);
+            }
+            terms[i] = Term{rest, best};
         }
     }
 
@@ -492,7 +512,20 @@ struct StageEmitter {
         } else {
             slot = it->second;
         }
-        return text("a.sc[" + std::to_string(slot) + "]");
+        // a uniform scalar is a LOAD like a column value: read from the workgroup's LDS copy of the argument block right
+        // where it is needed (value-numbered, kept within the live budget, issued a group ahead) -- key (-(slot + 1), 0)
+        auto key = std::make_pair(-(slot + 1), 0);
+        auto kt = load_key_id.find(key);
+        Operand o;
+        o.kind = Operand::LOAD;
+        if (kt == load_key_id.end()) {
+            o.id = (int)load_keys.size();
+            load_keys.push_back(key);
+            load_key_id[key] = o.id;
+        } else {
+            o.id = kt->second;
+        }
+        return o;
     }
     Operand ypow(uint32_t e) {
         const int n = B.scalar(SC_Y_POW, e);
@@ -588,6 +621,11 @@ struct StageEmitter {
     }
     size_t args_bytes() const { return ARGS_FIXED_BYTES + 32 * std::max<size_t>(scalars.size(), 1) + 8 * std::max<size_t>(cols.size(), 1); }
 
+    bool args_in_lds = false;   // decided in finish(): see Options::lds_args
+    std::string load_text(const std::pair<int, int>& key) const {
+        if (key.first < 0) return std::string(args_in_lds ? "fp_load(sh_sc + " : "fp_load(a.sc + ") + std::to_string(-key.first - 1) + ")";
+        return std::string(args_in_lds ? "fp_load(sh_cols[" : "fp_load(a.cols[") + std::to_string(key.first) + "] + " + rot_var(key.second) + ")";
+    }
     static std::string rot_var(int rot) {
         if (rot == 0) return "idx";
         return rot > 0 ? "rp" + std::to_string(rot) : "rm" + std::to_string(-rot);
@@ -597,25 +635,78 @@ struct StageEmitter {
     // scheduling group BEFORE the one that first needs it) and write the translation unit
     void finish(bool accumulate, uint32_t stage_index, uint32_t stage_count, Stage& out) {
         const uint32_t n = (uint32_t)stmts.size();
+        // Where the lanes read the argument block from.  Field by field from the kernel arguments (scalar loads, SGPR-based
+        // addressing) is the fastest form -- 3-4 % on mini-PLONK and the wide circuit -- as long as everything fits: the
+        // compiler loads EVERY argument it will ever need at the kernel's entry and parks what the ~100 SGPRs cannot hold in
+        // AGPRs and VGPR lanes for the whole kernel (a 40-gate set with a constant per gate: 474 dwords -> 464 registers, one
+        // wave per SIMD, scratch).  Above `lds_args` dwords of scalars + pointers the workgroup copies the block to LDS first
+        // (a lane-indexed copy the compiler cannot take apart) and each value is read where the schedule wants it.
+        const size_t arg_dwords = 8 * scalars.size() + 2 * cols.size();
+        args_in_lds = opt.lds_args == 1 || (opt.lds_args > 1 && arg_dwords > opt.lds_args);
         std::vector<std::vector<uint32_t>> uses(load_keys.size());
         for (uint32_t i = 0; i < n; i++)
             for (const Operand& o : stmts[i].args)
                 if (o.kind == Operand::LOAD && (uses[o.id].empty() || uses[o.id].back() != i)) uses[o.id].push_back(i);
         // the final store of an accumulating stage reads `values`; nothing else to place
+        // A loaded value is a register octet for as long as it is kept: value numbering must not outgrow the register file
+        // (a gate set that reads 30 columns at three rotations in no particular order would keep them all; the compiler then
+        // spills or drops to one wave per SIMD).  One forward sweep: a value stays in its variable while it is used again
+        // within `gap` statements AND the values alive at that point -- the statements' own results plus the loads kept --
+        // fit `live_budget`; beyond it the kept load whose next use is farthest away is dropped and loaded again there
+        // (Belady's rule; a second load of a line this lane read a few statements ago hits the cache).
         struct LoadVar { int key; uint32_t first, last; std::string name; };
         std::vector<LoadVar> lvars;
         std::map<std::pair<int, uint32_t>, int> lvar_at;  // (key, statement) -> load variable
-        for (size_t k = 0; k < uses.size(); k++) {
-            int cur = -1;
-            uint32_t prev = 0;
-            for (uint32_t i : uses[k]) {
-                if (cur < 0 || i - prev > opt.gap) {
-                    cur = (int)lvars.size();
-                    lvars.push_back(LoadVar{(int)k, i, i, "v" + std::to_string(lvars.size())});
+        {
+            std::vector<uint32_t> last_use(nvars, 0);
+            for (uint32_t i = 0; i < n; i++)
+                for (const Operand& o : stmts[i].args)
+                    if (o.kind == Operand::VAR) last_use[o.id] = i;
+            if (has_total && total.kind == Operand::VAR) last_use[total.id] = n;
+            std::vector<int> delta(n + 2, 0);
+            for (uint32_t i = 0; i < n; i++) {
+                delta[i] += 1;
+                delta[std::max(last_use[stmts[i].def], i) + 1] -= 1;
+            }
+            std::vector<int> ssa_live(n + 1, 0);
+            for (uint32_t i = 0, live = 0; i <= n; i++) {
+                live += delta[i];
+                ssa_live[i] = (int)live;
+            }
+            std::vector<size_t> next_at(uses.size(), 0);   // per key: position in uses[key] of its next use
+            std::map<int, int> kept;                        // key -> load variable currently holding it
+            const int reserve = (int)std::min<uint32_t>(opt.max_ahead, 4);  // loads issued ahead of their group
+            for (uint32_t i = 0; i < n; i++) {
+                for (const Operand& o : stmts[i].args) {
+                    if (o.kind != Operand::LOAD) continue;
+                    const int k = o.id;
+                    if (lvar_at.count(std::make_pair(k, i))) continue;
+                    auto it = kept.find(k);
+                    int lv;
+                    if (it == kept.end()) {
+                        lv = (int)lvars.size();
+                        lvars.push_back(LoadVar{k, i, i, "v" + std::to_string(lvars.size())});
+                        kept[k] = lv;
+                    } else {
+                        lv = it->second;
+                    }
+                    lvars[lv].last = i;
+                    lvar_at[std::make_pair(k, i)] = lv;
+                    while (next_at[k] < uses[k].size() && uses[k][next_at[k]] <= i) next_at[k]++;
                 }
-                lvars[cur].last = i;
-                lvar_at[std::make_pair((int)k, i)] = cur;
-                prev = i;
+                // what is kept past statement i
+                for (auto it = kept.begin(); it != kept.end();) {
+                    const int k = it->first;
+                    const bool again = next_at[k] < uses[k].size();
+                    if (!again || uses[k][next_at[k]] - i > opt.gap) it = kept.erase(it);
+                    else ++it;
+                }
+                while (!kept.empty() && ssa_live[i + 1] + (int)kept.size() + reserve > (int)opt.live_budget) {
+                    auto far = kept.begin();
+                    for (auto it = kept.begin(); it != kept.end(); ++it)
+                        if (uses[it->first][next_at[it->first]] > uses[far->first][next_at[far->first]]) far = it;
+                    kept.erase(far);
+                }
             }
         }
         std::vector<int> order(lvars.size());
@@ -683,7 +774,7 @@ struct StageEmitter {
                 if (it != issue.end())
                     for (int lv : it->second) {
                         const auto& key = load_keys[lvars[lv].key];
-                        body += "        const Fr " + lvars[lv].name + " = fp_load(a.cols[" + std::to_string(key.first) + "] + " + rot_var(key.second) + ");\n";
+                        body += "        const Fr " + lvars[lv].name + " = " + load_text(key) + ";\n";
                     }
                 body += "        __builtin_amdgcn_sched_barrier(0);\n";
             }
@@ -697,7 +788,7 @@ struct StageEmitter {
             result = "x" + std::to_string(total.id);
         } else if (total.kind == Operand::LOAD) {
             const auto& key = load_keys[total.id];
-            result = "fp_load(a.cols[" + std::to_string(key.first) + "] + " + rot_var(key.second) + ")";
+            result = load_text(key);
             if (key.second != 0 && std::find(rots.begin(), rots.end(), key.second) == rots.end())
                 body = "        const size_t " + rot_var(key.second) + " = (size_t)(((long long)idx + (long long)(" + std::to_string(key.second) +
                        ") * (long long)a.rot_scale) & mask);\n" + body;
@@ -727,10 +818,20 @@ struct StageEmitter {
         }
         const std::string waves = opt.waves ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(opt.waves) + ")))" : "";
         src += "extern \"C\" __global__ void __launch_bounds__(256)" + waves + " " + std::string(KERNEL_NAME) + "(Args a) {\n"
+               "    // ONE row per lane, no loop: inside a loop the compiler hoists the vector copies of every uniform scalar operand\n"
+               "    // (loop-invariant) and keeps them all alive -- 8 registers per scalar, 350 for a gate set with 40 constants\n"
                "    const size_t size = (size_t)1 << a.extended_k;\n"
                "    const long long mask = (long long)size - 1;\n"
-               "    const size_t stride = (size_t)gridDim.x * 256;\n"
-               "    for (size_t idx = a.row_begin + (size_t)blockIdx.x * 256 + threadIdx.x; idx < a.row_end; idx += stride) {\n";
+               + (args_in_lds ?
+               "    // the argument block goes to LDS first, through a lane-indexed copy (evalh_gen.cpp, StageEmitter::finish)\n"
+               "    __shared__ Fr sh_sc[" + std::to_string(ns) + "];\n"
+               "    __shared__ const Fr* sh_cols[" + std::to_string(nc) + "];\n"
+               "    for (unsigned t = threadIdx.x; t < " + std::to_string(ns) + "u; t += 256) fp_store(sh_sc + t, fp_load(a.sc + t));\n"
+               "    for (unsigned t = threadIdx.x; t < " + std::to_string(nc) + "u; t += 256) sh_cols[t] = a.cols[t];\n"
+               "    __syncthreads();\n" : std::string()) +
+               "    const size_t idx = a.row_begin + (size_t)blockIdx.x * 256 + threadIdx.x;\n"
+               "    if (idx >= a.row_end) return;\n"
+               "    {\n";
         src += body;
         src += "    }\n}\n";
         out.source = std::move(src);
@@ -755,6 +856,8 @@ Options Options::from_env() {
     o.group = std::max<uint32_t>(env_u32("H2_JIT_GROUP", o.group), 1);
     o.max_ahead = env_u32("H2_JIT_MAX_AHEAD", o.max_ahead);
     o.gap = env_u32("H2_JIT_GAP", o.gap);
+    o.live_budget = std::max<uint32_t>(env_u32("H2_JIT_LIVE", o.live_budget), 4);
+    o.lds_args = env_u32("H2_JIT_LDS_ARGS", o.lds_args);
     o.inline_muls = env_u32("H2_JIT_INLINE_MULS", o.inline_muls);
     o.stage_products = env_u32("H2_JIT_STAGE_PRODUCTS", o.stage_products);
     o.max_regs = env_u32("H2_JIT_MAX_REGS", o.max_regs);
@@ -829,7 +932,7 @@ void program_hash(const h2_evalh_desc* d, const Options& opt, uint8_t out[32]) {
     h.update(h2_embed_field_hpp, strlen(h2_embed_field_hpp));
     h.update(h2_embed_fp_mul_gen_hpp, strlen(h2_embed_fp_mul_gen_hpp));
     const uint32_t o[] = {opt.group, opt.max_ahead, opt.gap, opt.inline_muls, opt.stage_products, opt.max_cols, opt.max_regs,
-                          (uint32_t)opt.factor, opt.waves};
+                          (uint32_t)opt.factor, opt.waves, opt.live_budget, opt.lds_args};
     h.update(o, sizeof o);
     h.u32(d->blinding_factors);
     h.u32(d->chunk_len);

@@ -76,6 +76,9 @@ struct Options {
     uint32_t group = 6;        // statements per scheduling group
     uint32_t max_ahead = 6;    // loads issued ahead per group (8 VGPRs each)
     uint32_t gap = 30;         // a loaded value unused for this many statements is dropped and loaded again
+    uint32_t live_budget = 20; // field values (8 registers each) kept alive at once: statement results + loaded values
+    uint32_t lds_args = 320;   // scalars + pointers of more than this many dwords are read through an LDS copy of the
+                               // argument block instead of field by field from the kernel arguments (0 never, 1 always)
     uint32_t inline_muls = 14; // programs with at most this many products inline the multiplier
     uint32_t stage_products = 0;   // cut the program into stages of about this many products (0 = as few stages as fit)
     uint32_t max_cols = 440;   // column pointers per stage (kernel arguments are limited to 4 KiB)

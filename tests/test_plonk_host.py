@@ -542,6 +542,23 @@ def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     # the wide circuit: 16 gates q (a b c - d) share their selector, the lookups' terms share l_0 / l_last / l_active_row
     wide = ev.compile_only(prover.program_descriptor(circuits.wide(16), 6, 8))
     assert wide["products_per_row"] <= 0.75 * wide["reference_products_per_row"]
+    # a gate set with a constant per gate and 30 columns read at three rotations in no order (tools/evalh_bench.py's shape):
+    # 470 dwords of scalars and pointers.  Read field by field from the kernel arguments that compiled to 464 registers and
+    # scratch; the generator switches to an LDS copy of the argument block, keeps the loaded values within its live budget and
+    # takes the selectors out of the nested products: ONE stage, two waves per SIMD, fewer products than written
+    rnd = random.Random(1)
+    big = hc.ConstraintSystem("big")
+    adv = [big.advice_column() for _ in range(30)]
+    fix = [big.fixed_column() for _ in range(8)]
+    for g in range(40):
+        q = big.query_fixed(rnd.choice(fix))
+        a = [big.query_advice(rnd.choice(adv), rnd.choice([0, 0, 0, 1, -1])) for _ in range(5)]
+        big.create_gate("g%d" % g, [q * (a[0] * a[1] + a[2] - a[3]) * (a[4] + rnd.randrange(1, 100))])
+    bb = prover.program_descriptor(big, 6, 8)
+    info = ev.compile_only(bb)
+    assert info["stages"] == 1 and info["scratch_bytes"] == 0 and info["max_registers"] <= 256
+    assert info["products_per_row"] < 0.9 * info["reference_products_per_row"]
+    assert "sh_sc" in ev.generated_source(bb) and "sh_sc" not in src
     with pytest.raises(Exception):
         ev.generated_source(b, 99)
 

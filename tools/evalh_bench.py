@@ -37,7 +37,7 @@ D = prover.Device()
 cols_a = [D.empty(size) for _ in range(A)]
 cols_f = [D.empty(size) for _ in range(8)]
 for i, t in enumerate(cols_a + cols_f):
-    check(D.L.h2_dev_random_fr(100 + i, size, t.data_ptr(), D.stream), "rnd")
+    check(D.L.h2_dev_random_fr(bytes([100 + i]) * 32, size, t.data_ptr(), D.stream), "rnd")
 zero = fr_to_mont_limbs(0)
 b = ev.Builder().build(
     k=k, extended_k=ek, blinding_factors=5, chunk_len=1,
