@@ -54,7 +54,7 @@ namespace evgen {
 
 namespace {
 
-constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.4";
+constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.8";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("evaluate_h generator: " + what); }
 
@@ -473,7 +473,10 @@ struct StageEmitter {
     std::map<int, int> col_slot;  // program column id -> Args::cols slot
     std::vector<ScalarRef> scalars;
     std::map<int, int> scalar_slot;
-    std::vector<std::pair<int, int>> load_keys;  // (cols slot, rotation)
+    static constexpr int CONST_KEY = 1 << 20;    // load keys (-(CONST_KEY + slot), 0): entry `slot` of the module's constant table
+    std::vector<uint32_t> consts;                // constants[] indices the stage reads, in table order
+    std::map<uint32_t, int> const_slot;
+    std::vector<std::pair<int, int>> load_keys;  // (cols slot, rotation); (-(scalar slot + 1), 0) for a uniform scalar
     std::map<std::pair<int, int>, int> load_key_id;
     uint32_t products = 0, n_terms = 0;
     bool uses_omega = false;
@@ -503,6 +506,33 @@ struct StageEmitter {
         return o;
     }
     Operand scalar_operand(int scalar_id) {
+        if (B.scalars[scalar_id].kind == SC_CONST) {
+            // a constant of the circuit is part of the program (and of its hash): it lives in the code object as initialised
+            // data (`h2_consts`), read like any other value where the schedule wants it -- not a kernel argument: a gate set with
+            // a constant per gate would fill the 4 KiB of arguments with them and be cut into stages for that alone
+            const uint32_t index = B.scalars[scalar_id].arg;
+            auto ct = const_slot.find(index);
+            int slot;
+            if (ct == const_slot.end()) {
+                slot = (int)consts.size();
+                consts.push_back(index);
+                const_slot[index] = slot;
+            } else {
+                slot = ct->second;
+            }
+            auto key = std::make_pair(-(CONST_KEY + slot), 0);
+            auto kt = load_key_id.find(key);
+            Operand o;
+            o.kind = Operand::LOAD;
+            if (kt == load_key_id.end()) {
+                o.id = (int)load_keys.size();
+                load_keys.push_back(key);
+                load_key_id[key] = o.id;
+            } else {
+                o.id = kt->second;
+            }
+            return o;
+        }
         auto it = scalar_slot.find(scalar_id);
         int slot;
         if (it == scalar_slot.end()) {
@@ -623,6 +653,7 @@ struct StageEmitter {
 
     bool args_in_lds = false;   // decided in finish(): see Options::lds_args
     std::string load_text(const std::pair<int, int>& key) const {
+        if (key.first <= -CONST_KEY) return "fp_load(h2_consts + " + std::to_string(-key.first - CONST_KEY) + ")";
         if (key.first < 0) return std::string(args_in_lds ? "fp_load(sh_sc + " : "fp_load(a.sc + ") + std::to_string(-key.first - 1) + ")";
         return std::string(args_in_lds ? "fp_load(sh_cols[" : "fp_load(a.cols[") + std::to_string(key.first) + "] + " + rot_var(key.second) + ")";
     }
@@ -808,6 +839,18 @@ struct StageEmitter {
         src += "#include \"field.hpp\"\nusing namespace h2;\n\n";
         src += "struct Args {\n    Fr* values;\n    const Fr* tw_lo;\n    const Fr* tw_hi;\n    unsigned long long row_begin, row_end;\n"
                "    unsigned int extended_k, rot_scale;\n    Fr sc[" + std::to_string(ns) + "];\n    const Fr* cols[" + std::to_string(nc) + "];\n};\n\n";
+        if (!consts.empty()) {
+            src += "// the circuit's constants this stage reads (Montgomery form)\n__device__ Fr h2_consts[" + std::to_string(consts.size()) + "] = {\n";
+            for (uint32_t index : consts) {
+                const uint64_t* v = B.d->constants + 4 * (size_t)index;
+                char buf[160];
+                snprintf(buf, sizeof buf, "    {{0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu}},\n", (uint32_t)v[0],
+                         (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32), (uint32_t)v[2], (uint32_t)(v[2] >> 32),
+                         (uint32_t)v[3], (uint32_t)(v[3] >> 32));
+                src += buf;
+            }
+            src += "};\n\n";
+        }
         if (inline_mul) {
             src += "__device__ __forceinline__ Fr jmul(const Fr& x, const Fr& y) { return fp_mul(x, y); }\n"
                    "__device__ __forceinline__ Fr jsqr(const Fr& x) { return fp_sqr(x); }\n\n";
@@ -1128,8 +1171,9 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
                 memcpy(&stage_products, &blob[8], 4);
                 memcpy(&nstages, &blob[12], 4);
                 Options o2 = opt;
-                o2.stage_products = stage_products;
-                Generated g2 = stage_products == opt.stage_products ? std::move(g) : generate(d, o2);
+                o2.stage_products = stage_products & 0x7fffffffu;   // (top bit: built with the argument block through LDS)
+                if (stage_products >> 31) o2.lds_args = 1;
+                Generated g2 = (o2.stage_products == opt.stage_products && o2.lds_args == opt.lds_args) ? std::move(g) : generate(d, o2);
                 size_t at = 16;
                 bool ok = nstages == g2.stages.size();
                 for (uint32_t s = 0; ok && s < nstages; s++) {
@@ -1167,7 +1211,11 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
         }
         // a stage the compiler could not keep within the register budget (one wave per SIMD, or spills): cut the
         // program into stages of half that many products and build again -- each stage keeps fewer values live
-        if (over && attempt < 4 && worst_products >= 16) {
+        if (over && opt.lds_args != 1 && attempt < 6) {
+            opt.lds_args = 1;   // first remedy: the argument block through LDS (fewer registers, the same stages)
+            continue;
+        }
+        if (over && attempt < 6 && worst_products >= 16) {
             opt.stage_products = (worst_products + 1) / 2;
             continue;
         }
@@ -1176,7 +1224,8 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
             FILE* f = fopen(tmp.c_str(), "wb");
             if (f) {
                 const uint32_t ns = (uint32_t)g.stages.size();
-                bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(&opt.stage_products, 4, 1, f) == 1 && fwrite(&ns, 4, 1, f) == 1;
+                const uint32_t layout = opt.stage_products | (opt.lds_args == 1 && opt_in.lds_args != 1 ? 0x80000000u : 0u);
+                bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(&layout, 4, 1, f) == 1 && fwrite(&ns, 4, 1, f) == 1;
                 for (const Stage& st : g.stages) {
                     const uint32_t len = (uint32_t)st.code.size();
                     ok = ok && fwrite(&len, 4, 1, f) == 1 && fwrite(st.code.data(), 1, len, f) == len;

@@ -542,10 +542,11 @@ def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     # the wide circuit: 16 gates q (a b c - d) share their selector, the lookups' terms share l_0 / l_last / l_active_row
     wide = ev.compile_only(prover.program_descriptor(circuits.wide(16), 6, 8))
     assert wide["products_per_row"] <= 0.75 * wide["reference_products_per_row"]
-    # a gate set with a constant per gate and 30 columns read at three rotations in no order (tools/evalh_bench.py's shape):
-    # 470 dwords of scalars and pointers.  Read field by field from the kernel arguments that compiled to 464 registers and
-    # scratch; the generator switches to an LDS copy of the argument block, keeps the loaded values within its live budget and
-    # takes the selectors out of the nested products: ONE stage, two waves per SIMD, fewer products than written
+    # a gate set with a constant per gate and 30 columns read at three rotations in no order (tools/evalh_bench.py's shape).
+    # With everything a kernel argument read field by field that compiled to 464 registers and scratch; the constants are module
+    # data, the loaded values stay within the live budget, a build that still exceeds the register file is rebuilt with the
+    # argument block read through LDS, and the selectors come out of the nested products: ONE stage, two waves per SIMD, fewer
+    # products than written
     rnd = random.Random(1)
     big = hc.ConstraintSystem("big")
     adv = [big.advice_column() for _ in range(30)]
@@ -558,7 +559,11 @@ def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     info = ev.compile_only(bb)
     assert info["stages"] == 1 and info["scratch_bytes"] == 0 and info["max_registers"] <= 256
     assert info["products_per_row"] < 0.9 * info["reference_products_per_row"]
-    assert "sh_sc" in ev.generated_source(bb) and "sh_sc" not in src
+    big_src = ev.generated_source(bb)
+    assert "h2_consts[" in big_src and big_src.count("fp_load(h2_consts + ") >= 30 and "h2_consts" not in src        # a constant per gate: module data, not kernel arguments
+    monkeypatch.setenv("H2_JIT_LDS_ARGS", "1")
+    assert "sh_cols" in ev.generated_source(bb) and "sh_cols" not in big_src
+    monkeypatch.delenv("H2_JIT_LDS_ARGS")
     with pytest.raises(Exception):
         ev.generated_source(b, 99)
 
