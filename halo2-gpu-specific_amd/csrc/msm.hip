@@ -2165,6 +2165,8 @@ int msm_device_batch_ex(DeviceCtx* ctx, const Fr* const* d_scalars, const uint64
             tshapes[2 * i] = msm_shape_table(n, bits, false, tabs[i]);
             tshapes[2 * i + 1] = msm_shape_table(n, bits, true, tabs[i]);
             per = std::max(per, align_up(std::max(tshapes[2 * i].total, tshapes[2 * i + 1].total), 256));
+            // (the table form exports its window sum as bit planes: up to 24 points where the windowed form has its W + 1)
+            wp_max = std::max(wp_max, (size_t)tshapes[2 * i + 1].Wt * tshapes[2 * i + 1].G + tshapes[2 * i + 1].planes);
         }
     }
     if (!d_scratch || scratch_bytes < 2 * per) {
