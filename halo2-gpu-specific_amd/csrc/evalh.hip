@@ -510,6 +510,11 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
         set_last_error("h2_evaluate_h: chunk_len must be non-zero when permutation sets are present");
         return H2_ERR_INVALID;
     }
+    if (d->reserved != nullptr) {
+        set_last_error("h2_evaluate_h: `reserved` must be NULL (round 4's caller-supplied kernel slot: the library generates the "
+                       "program's kernels itself now, see h2_evalh_prepare)");
+        return H2_ERR_INVALID;
+    }
     const size_t size = (size_t)1 << d->extended_k;
     const uint32_t rot_scale = 1u << (d->extended_k - d->k);
     if ((size_t)d->row_begin + d->row_count > size) {

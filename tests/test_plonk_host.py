@@ -2,6 +2,7 @@
 the big-integer big-integer prover is accepted by the (trapdoor) verifier, rejects tampering and a bad witness,
 and the product's host-side pieces (transcript, permutation mapping, gate flattening, domain scalars, rng)
 agree with the independent restatements in ref_plonk.py."""
+import ctypes
 import random
 
 import numpy as np
@@ -566,6 +567,25 @@ def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     monkeypatch.delenv("H2_JIT_LDS_ARGS")
     with pytest.raises(Exception):
         ev.generated_source(b, 99)
+    # a malformed program is refused with an error, not compiled into a kernel that reads outside its tables
+    import copy as _copy
+
+    for breakage in ("intermediate", "constant", "column", "rotation", "perm"):
+        bad = prover.program_descriptor(circuits.mini_plonk(), 6, 8)
+        d = bad.desc
+        calcs = ctypes.cast(d.calculations, ctypes.POINTER(ev.Calculation))
+        if breakage == "intermediate":
+            calcs[0].a = ev.vs(ev.VS_INTERMEDIATE, 5)          # used before it is defined
+        elif breakage == "constant":
+            calcs[0].a = ev.vs(ev.VS_CONSTANT, 10 ** 6)
+        elif breakage == "column":
+            calcs[0].a = ev.vs(ev.VS_ADVICE, d.n_advice)
+        elif breakage == "rotation":
+            calcs[0].a = ev.vs(ev.VS_ADVICE, 0, d.n_rotations)
+        else:
+            ctypes.cast(d.perm_col_index, ctypes.POINTER(ctypes.c_uint32))[0] = d.n_advice + 7
+        with pytest.raises(Exception, match="out of range|before it is defined"):
+            ev.compile_only(bad)
 
 
 # ---- CircuitData (plonk.rs:126-204, helpers.rs write_cs / read_cs) ------------------------------------------------
