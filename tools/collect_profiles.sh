@@ -48,5 +48,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/p_e3" -o e -- python3 tools/e
 { echo "# rocprofv3 --pmc passes over tools/experiments/evalh_probe.py mini 25 (mini-PLONK, 2^25 points): the interpreter kernels"
   echo "# (k_evalh_expr + k_evalh_perm, 4 launches each) and the library-generated kernel h2_evalh_gen (31 launches); per-launch averages"
   for d in p_e1 p_e2 p_e3; do python3 tools/pmc_summary.py "$(find "$out/$d" -name '*results.db' | head -1)" evalh; done; } > "$out/evalh_pmc.txt" 2>&1
+python3 tools/evalh_bench.py 20 30 40 > "$out/evalh_gate_sets.txt" 2>&1
+python3 tools/evalh_bench.py 20 60 200 >> "$out/evalh_gate_sets.txt" 2>&1
+# the multi-rank flow of the default bench, dry-run with four gloo ranks sharing the GPU (communication per phase, replicas leg)
+H2_BENCH_BACKEND=gloo python3 bench.py --gpus 4 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_line_gloo4_dry_run.json" 2> "$out/bench_gloo4.err"
 rm -rf "$out"/p_*
 ls -la "$out"
