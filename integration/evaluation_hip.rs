@@ -11,7 +11,11 @@
 //! per node, re-deriving extended cosets through a 5-entry cache, then nine `eval_h_*` kernels.  Here the `Evaluator`'s own
 //! straight-line program -- `constants`, `rotations`, `calculations`, `value_parts`, `lookup_results`,
 //! `shuffle_results` (evaluation.rs:270-296), i.e. what the CPU twin interprets per row -- is handed to the library as
-//! is, together with the coefficient forms, and ONE call returns h's numerator on the extended domain.
+//! is, together with the coefficient forms, and ONE call returns h's numerator on the extended domain.  The library
+//! turns the program into generated kernels itself the first time it sees it (csrc/evalh_gen.cpp: hipRTC, cached by program
+//! hash in memory and on disk -- nothing to build or pass in from here; `hip::prepare_evaluate_h` moves that cost to keygen)
+//! and deals the cosets of the extended domain over the `HALO2_PROOFS_N_GPU` device pool inside the call, as the cuda body
+//! deals its gates / lookups / shuffles (evaluation.rs:1262-1275,1513-1520,1830-1837).
 #![cfg(feature = "hip")]
 
 use super::evaluation::{Calculation, Evaluator, LcChallenge, ValueSource};
