@@ -505,6 +505,20 @@ struct StageEmitter {
         o.id = stmts.back().def;
         return o;
     }
+    // a value that comes from memory: one load key per (source, rotation), interned
+    Operand load_operand(const std::pair<int, int>& key) {
+        Operand o;
+        o.kind = Operand::LOAD;
+        auto kt = load_key_id.find(key);
+        if (kt == load_key_id.end()) {
+            o.id = (int)load_keys.size();
+            load_keys.push_back(key);
+            load_key_id[key] = o.id;
+        } else {
+            o.id = kt->second;
+        }
+        return o;
+    }
     Operand scalar_operand(int scalar_id) {
         if (B.scalars[scalar_id].kind == SC_CONST) {
             // a constant of the circuit is part of the program (and of its hash): it lives in the code object as initialised
@@ -520,18 +534,7 @@ struct StageEmitter {
             } else {
                 slot = ct->second;
             }
-            auto key = std::make_pair(-(CONST_KEY + slot), 0);
-            auto kt = load_key_id.find(key);
-            Operand o;
-            o.kind = Operand::LOAD;
-            if (kt == load_key_id.end()) {
-                o.id = (int)load_keys.size();
-                load_keys.push_back(key);
-                load_key_id[key] = o.id;
-            } else {
-                o.id = kt->second;
-            }
-            return o;
+            return load_operand(std::make_pair(-(CONST_KEY + slot), 0));
         }
         auto it = scalar_slot.find(scalar_id);
         int slot;
@@ -542,20 +545,9 @@ struct StageEmitter {
         } else {
             slot = it->second;
         }
-        // a uniform scalar is a LOAD like a column value: read from the workgroup's LDS copy of the argument block right
-        // where it is needed (value-numbered, kept within the live budget, issued a group ahead) -- key (-(slot + 1), 0)
-        auto key = std::make_pair(-(slot + 1), 0);
-        auto kt = load_key_id.find(key);
-        Operand o;
-        o.kind = Operand::LOAD;
-        if (kt == load_key_id.end()) {
-            o.id = (int)load_keys.size();
-            load_keys.push_back(key);
-            load_key_id[key] = o.id;
-        } else {
-            o.id = kt->second;
-        }
-        return o;
+        // a uniform scalar is a LOAD like a column value -- from the kernel arguments or their LDS copy (finish() decides),
+        // value-numbered, kept within the live budget, issued a group ahead: key (-(slot + 1), 0)
+        return load_operand(std::make_pair(-(slot + 1), 0));
     }
     Operand ypow(uint32_t e) {
         const int n = B.scalar(SC_Y_POW, e);
@@ -576,18 +568,7 @@ struct StageEmitter {
                 } else {
                     slot = it->second;
                 }
-                auto key = std::make_pair(slot, (int)nd.y);
-                auto kt = load_key_id.find(key);
-                Operand o;
-                o.kind = Operand::LOAD;
-                if (kt == load_key_id.end()) {
-                    o.id = (int)load_keys.size();
-                    load_keys.push_back(key);
-                    load_key_id[key] = o.id;
-                } else {
-                    o.id = kt->second;
-                }
-                return o;
+                return load_operand(std::make_pair(slot, (int)nd.y));
             }
             default: break;
         }
@@ -662,8 +643,8 @@ struct StageEmitter {
         return rot > 0 ? "rp" + std::to_string(rot) : "rm" + std::to_string(-rot);
     }
 
-    // place the loads (each distinct (column, rotation) once per `gap` statements of use, issued at the start of the
-    // scheduling group BEFORE the one that first needs it) and write the translation unit
+    // place the loads (a (column, rotation) or scalar is loaded once for as long as it is kept -- see below -- and issued at the
+    // start of the scheduling group BEFORE the one that first needs it) and write the translation unit
     void finish(bool accumulate, uint32_t stage_index, uint32_t stage_count, Stage& out) {
         const uint32_t n = (uint32_t)stmts.size();
         // Where the lanes read the argument block from.  Field by field from the kernel arguments (scalar loads, SGPR-based
@@ -678,7 +659,6 @@ struct StageEmitter {
         for (uint32_t i = 0; i < n; i++)
             for (const Operand& o : stmts[i].args)
                 if (o.kind == Operand::LOAD && (uses[o.id].empty() || uses[o.id].back() != i)) uses[o.id].push_back(i);
-        // the final store of an accumulating stage reads `values`; nothing else to place
         // A loaded value is a register octet for as long as it is kept: value numbering must not outgrow the register file
         // (a gate set that reads 30 columns at three rotations in no particular order would keep them all; the compiler then
         // spills or drops to one wave per SIMD).  One forward sweep: a value stays in its variable while it is used again
@@ -700,10 +680,7 @@ struct StageEmitter {
                 delta[std::max(last_use[stmts[i].def], i) + 1] -= 1;
             }
             std::vector<int> ssa_live(n + 1, 0);
-            for (uint32_t i = 0, live = 0; i <= n; i++) {
-                live += delta[i];
-                ssa_live[i] = (int)live;
-            }
+            for (uint32_t i = 0; i <= n; i++) ssa_live[i] = (i ? ssa_live[i - 1] : 0) + delta[i];
             std::vector<size_t> next_at(uses.size(), 0);   // per key: position in uses[key] of its next use
             std::map<int, int> kept;                        // key -> load variable currently holding it
             const int reserve = (int)std::min<uint32_t>(opt.max_ahead, 4);  // loads issued ahead of their group
