@@ -54,7 +54,7 @@ namespace evgen {
 
 namespace {
 
-constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.8";
+constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.10";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("evaluate_h generator: " + what); }
 
@@ -379,6 +379,7 @@ struct Builder {
         }
         if (ref_products) ref_products--;  // the first term starts the fold
         if (opt.factor) factor_gates();
+        count_uses();
     }
 
     // value parts that are products containing the same column value S (a selector: `q * (...)`, `q * (...) * (...)`) get S
@@ -430,6 +431,40 @@ struct Builder {
             terms[i] = Term{rest, best};
         }
     }
+
+    // how many nodes / terms consume each node (a product consumed once can be fused into its consumer: fp_mul2)
+    std::vector<int> uses_;
+    void count_uses() {
+        uses_.assign(nodes.size(), 0);
+        std::vector<char> seen(nodes.size(), 0);
+        std::vector<int> stack;
+        auto root = [&](int n) {
+            if (n < 0) return;
+            uses_[n]++;
+            if (!seen[n]) {
+                seen[n] = 1;
+                stack.push_back(n);
+            }
+        };
+        for (const Term& t : terms) {
+            root(t.x);
+            root(t.f);
+        }
+        while (!stack.empty()) {
+            const int n = stack.back();
+            stack.pop_back();
+            const Node& nd = nodes[n];
+            for (int c : {nd.a, nd.b}) {
+                if (c < 0) continue;
+                uses_[c]++;
+                if (!seen[c]) {
+                    seen[c] = 1;
+                    stack.push_back(c);
+                }
+            }
+        }
+    }
+    int uses(int n) const { return n >= 0 && (size_t)n < uses_.size() ? uses_[n] : 2; }   // (nodes made later: never fused)
 
     int need(int n) {
         if (need_.size() < nodes.size()) need_.resize(nodes.size(), -1);
@@ -553,6 +588,19 @@ struct StageEmitter {
         const int n = B.scalar(SC_Y_POW, e);
         return scalar_operand((int)B.nodes[n].x);
     }
+    // a*b + c*d under ONE Montgomery reduction (fp_mul2: 128 operand multiply-adds + 64 of reduction instead of 2 x 128): for a
+    // product that nothing else reads and that has not been emitted yet
+    uint32_t fused = 0;
+    bool fusible(int n) const {
+        if (!opt.mul2 || n < 0) return false;
+        const Node& nd = B.nodes[n];
+        return (nd.op == N_MUL || nd.op == N_SQR) && B.uses(n) == 1 && !var_of.count(n);
+    }
+    void product_operands(int n, Operand& a, Operand& b) {
+        const Node nd = B.nodes[n];
+        a = emit(nd.a);
+        b = nd.op == N_SQR ? a : emit(nd.b);
+    }
     Operand emit(int n) {
         const Node nd = B.nodes[n];
         switch (nd.op) {
@@ -587,6 +635,12 @@ struct StageEmitter {
         } else if (nd.op == N_NEG || nd.op == N_SQR || nd.op == N_DBL) {
             Operand a = emit(nd.a);
             r = stmt(nd.op == N_NEG ? "fp_neg(@0)" : (nd.op == N_SQR ? "jsqr(@0)" : "fp_dbl(@0)"), {a}, nd.op == N_SQR ? 1 : 0);
+        } else if ((nd.op == N_ADD || nd.op == N_SUB) && fusible(nd.a) && fusible(nd.b)) {
+            Operand a, b, c, d;
+            product_operands(nd.a, a, b);
+            product_operands(nd.b, c, d);
+            r = stmt(nd.op == N_ADD ? "jmul2(@0, @1, @2, @3)" : "jmul2(@0, @1, fp_neg(@2), @3)", {a, b, c, d}, 2);
+            fused++;
         } else {
             // the operand that needs more registers first (Sethi-Ullman); program order on a tie
             Operand a, b;
@@ -610,12 +664,30 @@ struct StageEmitter {
         group_f = f;
     }
     void add_member(int x, uint32_t e) {
-        Operand X = emit(x);
         if (group_empty) {
-            S = X;
+            S = emit(x);
             group_empty = false;
         } else {
-            S = stmt("fp_add(jmul(@0, @1), @2)", {S, ypow(e_prev - e), X}, 1);
+            // S y^gap + X: when X is (or ends in) a product nobody else reads, the Horner step and that product share a reduction
+            const Node nx = B.nodes[x];
+            const Operand Y = ypow(e_prev - e);
+            Operand p, q;
+            if (fusible(x)) {
+                product_operands(x, p, q);
+                S = stmt("jmul2(@0, @1, @2, @3)", {S, Y, p, q}, 2);
+                fused++;
+            } else if ((nx.op == N_ADD || nx.op == N_SUB) && B.uses(x) == 1 && !var_of.count(x) && (fusible(nx.a) || fusible(nx.b))) {
+                const bool first = fusible(nx.a);           // X = P (+/-) R  or  R (+/-) P, P the product
+                const Operand R = emit(first ? nx.b : nx.a);
+                product_operands(first ? nx.a : nx.b, p, q);
+                if (nx.op == N_ADD) S = stmt("fp_add(jmul2(@0, @1, @2, @3), @4)", {S, Y, p, q, R}, 2);
+                else if (first) S = stmt("fp_sub(jmul2(@0, @1, @2, @3), @4)", {S, Y, p, q, R}, 2);
+                else S = stmt("fp_add(jmul2(@0, @1, fp_neg(@2), @3), @4)", {S, Y, p, q, R}, 2);
+                fused++;
+            } else {
+                const Operand X = emit(x);
+                S = stmt("fp_add(jmul(@0, @1), @2)", {S, Y, X}, 1);
+            }
         }
         e_prev = e;
         n_terms++;
@@ -830,11 +902,18 @@ struct StageEmitter {
         }
         if (inline_mul) {
             src += "__device__ __forceinline__ Fr jmul(const Fr& x, const Fr& y) { return fp_mul(x, y); }\n"
-                   "__device__ __forceinline__ Fr jsqr(const Fr& x) { return fp_sqr(x); }\n\n";
+                   "__device__ __forceinline__ Fr jsqr(const Fr& x) { return fp_sqr(x); }\n"
+                   "__device__ __forceinline__ Fr jmul2(const Fr& x, const Fr& y, const Fr& z, const Fr& w) { return fp_mul2(x, y, z, w); }\n\n";
         } else {
             src += "// one out-of-line multiplier: the kernel stays a few instructions per product instead of ~460\n"
                    "__device__ __noinline__ Fr jmul(Fr x, Fr y) { return fp_mul(x, y); }\n"
-                   "__device__ __forceinline__ Fr jsqr(const Fr& x) { return jmul(x, x); }\n\n";
+                   "__device__ __forceinline__ Fr jsqr(const Fr& x) { return jmul(x, x); }\n";
+            if (fused)
+                // INLINE: four operands fill v0-v31, the schedule needs 67 registers, so an out-of-line fp_mul2 saves and
+                // restores 16 callee-saved VGPRs through scratch on every call -- more than the 64 multiply-adds it spares
+                src += "// x y + z w under one reduction (fp_mul2): three quarters of the multiply-adds of two products\n"
+                       "__device__ __forceinline__ Fr jmul2(const Fr& x, const Fr& y, const Fr& z, const Fr& w) { return fp_mul2(x, y, z, w); }\n";
+            src += "\n";
         }
         const std::string waves = opt.waves ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(opt.waves) + ")))" : "";
         src += "extern \"C\" __global__ void __launch_bounds__(256)" + waves + " " + std::string(KERNEL_NAME) + "(Args a) {\n"
@@ -860,6 +939,7 @@ struct StageEmitter {
         out.accumulate = accumulate;
         out.uses_omega = uses_omega;
         out.products = products;
+        out.fused_pairs = fused;
         out.statements = n;
     }
 };
@@ -878,6 +958,7 @@ Options Options::from_env() {
     o.gap = env_u32("H2_JIT_GAP", o.gap);
     o.live_budget = std::max<uint32_t>(env_u32("H2_JIT_LIVE", o.live_budget), 4);
     o.lds_args = env_u32("H2_JIT_LDS_ARGS", o.lds_args);
+    o.mul2 = env_u32("H2_JIT_MUL2", 0) != 0;
     o.inline_muls = env_u32("H2_JIT_INLINE_MULS", o.inline_muls);
     o.stage_products = env_u32("H2_JIT_STAGE_PRODUCTS", o.stage_products);
     o.max_regs = env_u32("H2_JIT_MAX_REGS", o.max_regs);
@@ -937,6 +1018,7 @@ Generated generate(const h2_evalh_desc* d, const Options& opt) {
         if (emitters[s].args_bytes() > 4096) fail("a single term reads more columns than one kernel's arguments hold");
         emitters[s].finish(s > 0, (uint32_t)s, (uint32_t)emitters.size(), out.stages[s]);
         out.products_per_row += out.stages[s].products;
+        out.fused_pairs_per_row += out.stages[s].fused_pairs;
         for (auto& kv : emitters[s].col_slot)
             if (!seen[kv.first]) {
                 seen[kv.first] = true;
@@ -952,7 +1034,7 @@ void program_hash(const h2_evalh_desc* d, const Options& opt, uint8_t out[32]) {
     h.update(h2_embed_field_hpp, strlen(h2_embed_field_hpp));
     h.update(h2_embed_fp_mul_gen_hpp, strlen(h2_embed_fp_mul_gen_hpp));
     const uint32_t o[] = {opt.group, opt.max_ahead, opt.gap, opt.inline_muls, opt.stage_products, opt.max_cols, opt.max_regs,
-                          (uint32_t)opt.factor, opt.waves, opt.live_budget, opt.lds_args};
+                          (uint32_t)opt.factor, opt.waves, opt.live_budget, opt.lds_args, (uint32_t)opt.mul2};
     h.update(o, sizeof o);
     h.u32(d->blinding_factors);
     h.u32(d->chunk_len);

@@ -56,6 +56,7 @@ struct Stage {
     bool accumulate = false;   // values[idx] += (this stage's terms) instead of values[idx] = ...
     bool uses_omega = false;   // reads the power tables of extended_omega (tw_lo / tw_hi)
     uint32_t products = 0;     // field products per row
+    uint32_t fused_pairs = 0;  // ... of which this many PAIRS run as one fp_mul2 (a b + c d under one reduction)
     uint32_t statements = 0;
     uint32_t max_live = 0;     // the generator's estimate of simultaneously live field values
     // after compile():
@@ -67,6 +68,7 @@ struct Generated {
     std::vector<Stage> stages;
     uint32_t terms = 0;             // y-folded terms of the quotient numerator (value parts + argument terms)
     uint32_t products_per_row = 0;  // over all stages
+    uint32_t fused_pairs_per_row = 0;
     uint32_t reference_products_per_row = 0;  // the products the formulas of evaluation.rs:875-1219 spend as written
     uint32_t vectors_read = 0;      // distinct column vectors
     bool from_disk = false;
@@ -84,6 +86,8 @@ struct Options {
     uint32_t max_cols = 440;   // column pointers per stage (kernel arguments are limited to 4 KiB)
     uint32_t waves = 0;        // ask the compiler for at least this many waves per SIMD (amdgpu_waves_per_eu; 0 = its own choice)
     uint32_t max_regs = 256;   // a stage compiled to more registers than this (or to scratch) is cut in two and rebuilt
+    bool mul2 = false;         // a b + c d under one reduction (fp_mul2, inlined) where both products -- or a Horner step and a
+                               // product -- allow it.  OFF: measured slower, see DESIGN.md 3.5
     bool factor = true;        // terms that share a factor (a selector, l_0, l_last, l_active_row) are summed before it multiplies them
     static Options from_env();
 };

@@ -151,7 +151,8 @@ Builder.rebind = _rebind
 class EvalHInfo(ctypes.Structure):
     """h2_evalh_info: what the library generated for a program"""
     _fields_ = [("stages", _u32), ("terms", _u32), ("products_per_row", _u32), ("reference_products_per_row", _u32),
-                ("vectors_read", _u32), ("max_registers", _u32), ("scratch_bytes", _u32), ("from_cache", _u32)]
+                ("vectors_read", _u32), ("max_registers", _u32), ("scratch_bytes", _u32), ("from_cache", _u32),
+                ("fused_pairs_per_row", _u32)]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}

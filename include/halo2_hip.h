@@ -360,6 +360,7 @@ typedef struct {
     uint32_t max_registers;              /* VGPRs + AGPRs of the widest stage */
     uint32_t scratch_bytes;              /* per-lane scratch of the worst stage (0 = no spills) */
     uint32_t from_cache;                 /* 1 = memory, 2 = disk, 0 = compiled now */
+    uint32_t fused_pairs_per_row;        /* pairs of those products that share one Montgomery reduction (a b + c d: 3/4 of the work) */
 } h2_evalh_info;
 int h2_evalh_prepare(const h2_evalh_desc *desc, h2_evalh_info *info);
 int h2_evalh_compile(const h2_evalh_desc *desc, h2_evalh_info *info);

@@ -138,6 +138,7 @@ pub struct H2EvalhInfo {
     pub max_registers: u32,
     pub scratch_bytes: u32,
     pub from_cache: u32,
+    pub fused_pairs_per_row: u32,
 }
 
 /// (field, byte offset) of `h2_evalh_desc` on the LP64 ABI both sides are built for; checked against the C header by
