@@ -54,7 +54,7 @@ namespace evgen {
 
 namespace {
 
-constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.10";
+constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.11";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("evaluate_h generator: " + what); }
 
@@ -592,7 +592,7 @@ struct StageEmitter {
     // product that nothing else reads and that has not been emitted yet
     uint32_t fused = 0;
     bool fusible(int n) const {
-        if (!opt.mul2 || n < 0) return false;
+        if (!opt.mul2 || n < 0 || fused >= opt.mul2) return false;
         const Node& nd = B.nodes[n];
         return (nd.op == N_MUL || nd.op == N_SQR) && B.uses(n) == 1 && !var_of.count(n);
     }
@@ -958,7 +958,7 @@ Options Options::from_env() {
     o.gap = env_u32("H2_JIT_GAP", o.gap);
     o.live_budget = std::max<uint32_t>(env_u32("H2_JIT_LIVE", o.live_budget), 4);
     o.lds_args = env_u32("H2_JIT_LDS_ARGS", o.lds_args);
-    o.mul2 = env_u32("H2_JIT_MUL2", 0) != 0;
+    o.mul2 = env_u32("H2_JIT_MUL2", o.mul2);
     o.inline_muls = env_u32("H2_JIT_INLINE_MULS", o.inline_muls);
     o.stage_products = env_u32("H2_JIT_STAGE_PRODUCTS", o.stage_products);
     o.max_regs = env_u32("H2_JIT_MAX_REGS", o.max_regs);

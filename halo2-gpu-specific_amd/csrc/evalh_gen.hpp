@@ -86,8 +86,10 @@ struct Options {
     uint32_t max_cols = 440;   // column pointers per stage (kernel arguments are limited to 4 KiB)
     uint32_t waves = 0;        // ask the compiler for at least this many waves per SIMD (amdgpu_waves_per_eu; 0 = its own choice)
     uint32_t max_regs = 256;   // a stage compiled to more registers than this (or to scratch) is cut in two and rebuilt
-    bool mul2 = false;         // a b + c d under one reduction (fp_mul2, inlined) where both products -- or a Horner step and a
-                               // product -- allow it.  OFF: measured slower, see DESIGN.md 3.5
+    uint32_t mul2 = 96;        // a b + c d under ONE reduction (fp_mul2: 3/4 of the multiply-adds of two products) where both
+                               // products -- or a Horner step and a product -- allow it; at most this many per stage (each is
+                               // inlined: an out-of-line fp_mul2 needs 67 registers and would save / restore 16 callee-saved
+                               // VGPRs through scratch per call).  0 = off
     bool factor = true;        // terms that share a factor (a selector, l_0, l_last, l_active_row) are summed before it multiplies them
     static Options from_env();
 };

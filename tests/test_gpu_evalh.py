@@ -43,6 +43,7 @@ GENERATOR_SETTINGS = [
     {"H2_JIT_STAGE_PRODUCTS": "8"},       # cut into many stages that each add their share into `values`
     {"H2_JIT_STAGE_PRODUCTS": "20", "H2_JIT_GROUP": "3", "H2_JIT_MAX_AHEAD": "2", "H2_JIT_GAP": "4"},
     {"H2_JIT_INLINE_MULS": "1000"},       # the multiplier inlined at every product
+    {"H2_JIT_MUL2": "0"},                 # no a b + c d fusion: every product with its own reduction
     {"H2_JIT_LDS_ARGS": "1"},             # scalars and column pointers read through an LDS copy of the argument block
     {"H2_JIT_LIVE": "6", "H2_JIT_GAP": "200"},   # a tiny live budget: loaded values dropped and loaded again by Belady's rule
 ]
