@@ -304,7 +304,7 @@ struct FastHash {
 PlanKey plan_key(const h2_evalh_desc* d, const evgen::Options& opt, int device) {
     FastHash h;
     const uint32_t o[] = {opt.group, opt.max_ahead, opt.gap, opt.inline_muls, opt.stage_products, opt.max_cols, opt.max_regs,
-                          (uint32_t)opt.factor, opt.waves, opt.live_budget, opt.lds_args, (uint32_t)opt.mul2, d->blinding_factors, d->chunk_len, d->n_fixed, d->n_advice,
+                          (uint32_t)opt.factor, opt.waves, opt.live_budget, opt.lds_args, (uint32_t)opt.mul2, opt.min_group, d->blinding_factors, d->chunk_len, d->n_fixed, d->n_advice,
                           d->n_instance, d->n_perm_sets, d->n_perm_columns, d->n_lookups, d->n_shuffles};
     h.bytes(o, sizeof o);
     h.bytes(d->constants, (size_t)d->n_constants * 32);

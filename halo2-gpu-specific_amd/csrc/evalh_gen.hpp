@@ -81,7 +81,8 @@ struct Options {
     uint32_t live_budget = 20; // field values (8 registers each) kept alive at once: statement results + loaded values
     uint32_t lds_args = 320;   // scalars + pointers of more than this many dwords are read through an LDS copy of the
                                // argument block instead of field by field from the kernel arguments (0 never, 1 always)
-    uint32_t inline_muls = 14; // programs with at most this many products inline the multiplier
+    uint32_t inline_muls = 40; // programs with at most this many products inline the multiplier (mini-PLONK's 29: 7.35 -> 7.11 ms;
+                               // the wide circuit's 120 fully inlined: 0.5 MB of code for no gain)
     uint32_t stage_products = 0;   // cut the program into stages of about this many products (0 = as few stages as fit)
     uint32_t max_cols = 440;   // column pointers per stage (kernel arguments are limited to 4 KiB)
     uint32_t waves = 0;        // ask the compiler for at least this many waves per SIMD (amdgpu_waves_per_eu; 0 = its own choice)
@@ -90,6 +91,7 @@ struct Options {
                                // products -- or a Horner step and a product -- allow it; at most this many per stage (each is
                                // inlined: an out-of-line fp_mul2 needs 67 registers and would save / restore 16 callee-saved
                                // VGPRs through scratch per call).  0 = off
+    uint32_t min_group = 3;    // a factor group with fewer members than this is folded term by term instead (with fp_mul2 pairing)
     bool factor = true;        // terms that share a factor (a selector, l_0, l_last, l_active_row) are summed before it multiplies them
     static Options from_env();
 };
