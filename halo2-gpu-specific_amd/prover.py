@@ -1405,7 +1405,14 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
         _par.comm_trace_begin()              # this (untimed) proof records what its collectives cost, phase by phase
 
+    _host_trace = [] if os.environ.get("H2_PROVER_HOST_TRACE") else None
+
+    def htrace(name):                         # host-side timestamps without any synchronisation (H2_PROVER_HOST_TRACE=1)
+        if _host_trace is not None:
+            _host_trace.append((name, time.perf_counter()))
+
     def mark(name):
+        htrace("mark " + name)
         if timings is not None:
             D.sync()
             marks.append((name, time.perf_counter()))
@@ -1773,8 +1780,10 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         C["shuffle_polys"] = C["shuffle_z"]
         del C["shuffles"]
     mark("permutation")
+    htrace("before random_commitment.result")
     transcript.write_point(random_commitment.result())
     y = transcript.squeeze_challenge_scalar()
+    htrace("y squeezed")
 
     # ---- h(X): advice to coefficient form, extended cosets, the fused evaluator --------------------------
     if side_intt is not None:
@@ -1867,6 +1876,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         advice_cosets = pre if pre is not None else cut[0]
         instance_cosets, z_cosets, lookup_z_cosets, lookup_m_cosets, shuffle_cosets = cut[1:]
         del flat, cut
+        htrace("points_of done (launched)")
         mark("cosets")
         b = ev.Builder().build(
             k=dom.k, extended_k=k_domain, blinding_factors=bf, chunk_len=chunk,
@@ -1884,7 +1894,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             flags=0 if pk.evalh_stats else ev.EVALH_INTERPRET,
             row_begin=rows[0] if rows is not None else 0, row_count=rows[1] if rows is not None else 0)
         out = D.empty(size)
+        htrace("descriptor built")
         check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")
+        htrace("h2_dev_evaluate_h returned")
         mark("evaluate_h")
         return out
 
@@ -2040,6 +2052,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     query(("random",), random_poly, 0)
     (_gwc if use_gwc else _shplonk)(D, params, transcript, queries, polys, n)
     mark("multiopen")
+    if _host_trace:
+        import sys
+
+        base = _host_trace[0][1]
+        sys.stderr.write("host trace (ms): " + ", ".join("%s %.2f" % (nm, (t - base) * 1e3) for nm, t in _host_trace) + "\n")
     if timings is not None:
         for (_, t0), (name, t1) in zip(marks, marks[1:]):
             timings[name] = timings.get(name, 0.0) + (t1 - t0)
