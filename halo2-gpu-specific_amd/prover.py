@@ -1893,8 +1893,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
             delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
             flags=0 if pk.evalh_stats else ev.EVALH_INTERPRET,
             row_begin=rows[0] if rows is not None else 0, row_count=rows[1] if rows is not None else 0)
-        out = D.empty(size)
         htrace("descriptor built")
+        out = D.empty(size)
+        htrace("output allocated")
         check(L.h2_dev_evaluate_h(ctypes.byref(b.desc), out.data_ptr(), D.stream), "h2_dev_evaluate_h")
         htrace("h2_dev_evaluate_h returned")
         mark("evaluate_h")

@@ -29,7 +29,7 @@ def main():
     for rep in range(reps):
         timings = {}
         ta = time.perf_counter()
-        proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(rep), timings=timings if rep else None)
+        proof = prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(rep), timings=timings if rep and not os.environ.get("H2_PROVE_BENCH_NO_TIMINGS") else None)
         D.sync()
         tb = time.perf_counter()
         print("rep %d: create_proof %.1f ms  (%d bytes)  %s" % (rep, (tb - ta) * 1e3, len(proof),
