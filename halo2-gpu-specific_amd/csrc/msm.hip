@@ -1582,7 +1582,7 @@ __global__ void __launch_bounds__(64) k_block_sums(const Affine* bases, size_t n
     fp_store(&out[b].y, fp_mul(acc.y, t));
 }
 
-// digits for a table over n points: fewest additions D * n plus the bucket-proportional tail (k_finish, k_reduce: ~8
+// digits for a table over n points: fewest additions D * n plus the bucket-proportional tail (k_finish, k_reduce: ~5
 // additions' worth per bucket), buckets 2^(c - 1) with c = ceil(255 / D) <= 23
 static uint32_t table_default_digits(size_t n) {
     if (const char* env = getenv("H2_MSM_TABLE_DIGITS")) {
@@ -1593,9 +1593,12 @@ static uint32_t table_default_digits(size_t n) {
     uint32_t best_d = 16;
     for (uint32_t D = 12; D <= TABLE_MAX_D; D++) {
         const uint32_t c = (255 + D - 1) / D;
-        // (~8 additions' worth per bucket; below 2^18 rows, where the chains of k_finish / k_reduce are latency whatever
-        // the bucket count, half of that ranks the measured optimum first: 2^16 16 digits 0.47 ms, 17 digits 0.51)
-        const double cost = (double)D * (double)n + (n < ((size_t)1 << 18) ? 4.0 : 8.0) * (double)(1u << (c - 1));
+        // (~4.7 additions' worth per bucket since the bit-plane reduce -- 8 with the running-sum chains before it; measured
+        // round 5, single / batch of 8: 2^20 14 digits 1.68 / 1.58 ms, 15 digits 1.78 / 1.64, 13 digits 1.79 / 1.61; 2^18 15
+        // digits 0.72, 14 digits 0.80; 2^22 13 digits 5.62, 12 digits 6.09, 14 digits 6.07.  Below 2^18 rows, where the chains
+        // of k_finish / k_reduce are latency whatever the bucket count, 4 ranks the measured optimum first: 2^16 16 digits
+        // 0.40 ms, 15 digits 0.42)
+        const double cost = (double)D * (double)n + (n < ((size_t)1 << 18) ? 4.0 : 4.7) * (double)(1u << (c - 1));
         if (cost < best) {
             best = cost;
             best_d = D;
