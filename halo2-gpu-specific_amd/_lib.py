@@ -12,7 +12,9 @@ class H2Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhalo2_hip.so")
+    """the in-tree library; H2_LIB names another build of the same ABI (tools/gen_sanitize.sh: the generator's host code
+    under ASan / UBSan) -- a library all the same: nothing is loaded in its place when the file is missing"""
+    return os.environ.get("H2_LIB") or os.path.join(_HERE, "libhalo2_hip.so")
 
 
 def build(force=False):
