@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 
@@ -54,7 +55,7 @@ namespace evgen {
 
 namespace {
 
-constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.13";
+constexpr const char* GENERATOR_VERSION = "h2-evalh-gen 5.14";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("evaluate_h generator: " + what); }
 
@@ -1202,7 +1203,8 @@ bool read_file(const std::string& path, std::vector<char>& out) {
     return ok;
 }
 
-constexpr char CACHE_MAGIC[8] = {'H', '2', 'E', 'V', 'G', '1', 0, 0};
+// file: magic, layout word, stage count, {length, code object} per stage, SHA-256 of everything before it
+constexpr char CACHE_MAGIC[8] = {'H', '2', 'E', 'V', 'G', '2', 0, 0};
 
 }  // namespace
 
@@ -1241,7 +1243,16 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
         // ---- the disk cache holds the code objects of the FINAL stage layout under the hash of the requested options
         if (attempt == 0 && use_disk) {
             std::vector<char> blob;
-            if (read_file(path, blob) && blob.size() >= 16 && memcmp(blob.data(), CACHE_MAGIC, 8) == 0) {
+            bool intact = read_file(path, blob) && blob.size() >= 16 + 32 && memcmp(blob.data(), CACHE_MAGIC, 8) == 0;
+            if (intact) {   // a torn or damaged file is a miss (and is overwritten by the rebuild below)
+                uint8_t sum[32];
+                Sha256 hs;
+                hs.update(blob.data(), blob.size() - 32);
+                hs.finish(sum);
+                intact = memcmp(sum, blob.data() + blob.size() - 32, 32) == 0;
+                blob.resize(blob.size() - 32);
+            }
+            if (intact) {
                 uint32_t stage_products = 0, nstages = 0;
                 memcpy(&stage_products, &blob[8], 4);
                 memcpy(&nstages, &blob[12], 4);
@@ -1260,7 +1271,7 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
                     g2.stages[s].code.assign(blob.begin() + at, blob.begin() + at + len);
                     at += len;
                 }
-                if (ok) {
+                if (ok && at == blob.size()) {
                     for (Stage& st : g2.stages) {
                         st.vgprs = metadata_uint(st.code, ".vgpr_count");
                         st.agprs = metadata_uint(st.code, ".agpr_count");
@@ -1295,16 +1306,27 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
             continue;
         }
         if (use_disk) {
-            std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+            // (a name of its own per writer: h2_evalh_compile / h2_evalh_prepare may run on several threads at once, for the
+            // same program too -- the last complete file renamed into place wins, and they are all the same bytes)
+            static std::atomic<unsigned> writer{0};
+            std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(writer.fetch_add(1));
             FILE* f = fopen(tmp.c_str(), "wb");
             if (f) {
                 const uint32_t ns = (uint32_t)g.stages.size();
                 const uint32_t layout = opt.stage_products | (opt.lds_args == 1 && opt_in.lds_args != 1 ? 0x80000000u : 0u);
-                bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(&layout, 4, 1, f) == 1 && fwrite(&ns, 4, 1, f) == 1;
+                Sha256 hs;
+                auto put = [&](const void* p_, size_t n_) {
+                    hs.update(p_, n_);
+                    return fwrite(p_, 1, n_, f) == n_;
+                };
+                bool ok = put(CACHE_MAGIC, 8) && put(&layout, 4) && put(&ns, 4);
                 for (const Stage& st : g.stages) {
                     const uint32_t len = (uint32_t)st.code.size();
-                    ok = ok && fwrite(&len, 4, 1, f) == 1 && fwrite(st.code.data(), 1, len, f) == len;
+                    ok = ok && put(&len, 4) && put(st.code.data(), len);
                 }
+                uint8_t sum[32];
+                hs.finish(sum);
+                ok = ok && fwrite(sum, 1, 32, f) == 32;
                 ok = fclose(f) == 0 && ok;
                 if (!ok || rename(tmp.c_str(), path.c_str()) != 0) unlink(tmp.c_str());
             }

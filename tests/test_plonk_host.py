@@ -516,6 +516,54 @@ def test_code_object_cache_directory_must_be_private(tmp_path, monkeypatch):
     assert os.listdir(shared) == []
 
 
+def test_code_object_cache_survives_damage_and_concurrent_writers(tmp_path, monkeypatch):
+    """the disk cache of generated code objects: a truncated or bit-flipped file is a miss (SHA-256 trailer) and is replaced by
+    the rebuild; h2_evalh_compile called from several threads at once -- for one program and for different ones -- leaves
+    one intact file per program (every writer has a temporary file of its own, renamed into place)"""
+    import os
+    import threading
+
+    from halo2_gpu_specific_amd import prover
+
+    cache = tmp_path / "c"
+    monkeypatch.setenv("H2_JIT_CACHE", str(cache))
+    b = prover.program_descriptor(circuits.mini_plonk(), 5, 7)
+    first = ev.compile_only(b)
+    assert first["from_cache"] == 0
+    (name,) = os.listdir(cache)
+    path = cache / name
+    whole = path.read_bytes()
+    for damaged in (whole[:len(whole) // 2], whole[:-1], whole[:100] + bytes([whole[100] ^ 1]) + whole[101:], whole + b"x"):
+        path.write_bytes(damaged)
+        again = ev.compile_only(b)
+        assert again["from_cache"] == 0 and again["products_per_row"] == first["products_per_row"]
+        assert path.read_bytes() == whole                    # rebuilt: the same bytes (the generator is deterministic)
+        assert ev.compile_only(b)["from_cache"] == 2
+    # concurrent writers
+    for f in os.listdir(cache):
+        os.unlink(cache / f)
+    descs = [b, prover.program_descriptor(circuits.mini_plonk(), 6, 8), prover.program_descriptor(circuits.wide(4), 6, 8)]
+    results, errors = [], []
+
+    def work(i):
+        try:
+            results.append((i % len(descs), ev.compile_only(descs[i % len(descs)])["products_per_row"]))
+        except Exception as e:                               # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(9)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(results) == 9
+    assert len({r for r in results}) == len({i for i, _ in results})       # one answer per program
+    files = sorted(os.listdir(cache))
+    assert len(files) == 2 and not [f for f in files if ".tmp." in f]    # (k is not part of a program: two distinct ones)
+    for d in descs:
+        assert ev.compile_only(d)["from_cache"] == 2
+
+
 def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     """csrc/evalh_gen.cpp behind the C ABI, no GPU needed: the straight-line HIP generated from a circuit's program (all three
     test circuits, with their permutation / lookup / shuffle terms) goes through hipRTC for gfx950 without spills; one store
