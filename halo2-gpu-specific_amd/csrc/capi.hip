@@ -968,7 +968,8 @@ int h2_evalh_prepare(const h2_evalh_desc* desc, h2_evalh_info* info) {
     return guarded([&] {
         current_ctx();  // the device of this thread is initialised
         int cached = 0;
-        const EvalhPlan* plan = evalh_plan_get(desc, &cached);
+        EvalhPlanRef held = evalh_plan_get(desc, &cached);
+        const EvalhPlan* plan = held.get();
         if (!plan) return bad("h2_evalh_prepare: no generated kernels for this program (H2_EVALH_JIT=0, hipRTC unavailable or a rejected program: see stderr)");
         if (info) {
             evalh_plan_info(plan, info);

@@ -260,6 +260,8 @@ struct EvalhPlan {
     int device = -1;
     bool uses_omega = false;
     int from_cache = 0;                 // 0 compiled now, 2 from the disk cache (1 = memory is decided by the caller)
+    mutable uint64_t last_use = 0;      // g_plan_mu: the cache's clock at the last lookup
+    mutable uint32_t users = 0;         // g_plan_mu: EvalhPlanRef holders -- a held plan is never evicted
 };
 
 namespace {
@@ -275,6 +277,43 @@ struct PlanKey {
 std::mutex g_plan_mu;
 std::map<PlanKey, std::unique_ptr<EvalhPlan>> g_plans;   // a null entry: generation failed for this program (said once)
 std::atomic<uint64_t> g_generated_launches{0};
+std::atomic<uint64_t> g_plan_evictions{0};
+uint64_t g_plan_clock = 0;                               // g_plan_mu
+
+size_t plans_max() {
+    static const size_t v = [] {
+        const char* e = getenv("H2_EVALH_PLANS_MAX");
+        const long n = e ? atol(e) : 0;
+        return (size_t)(n > 0 ? n : 128);
+    }();
+    return v;
+}
+
+// g_plan_mu held.  Unloads least-recently-used plans nobody holds until the cache is back at its bound; a plan's device is
+// drained first (its launches are asynchronous and the code object has to outlive them).
+void evict_plans(const PlanKey& keep) {
+    while (g_plans.size() > plans_max()) {
+        auto victim = g_plans.end();
+        for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
+            if (!(it->first < keep) && !(keep < it->first)) continue;
+            if (it->second && it->second->users) continue;
+            const uint64_t t = it->second ? it->second->last_use : 0;   // (failed generations first: they hold nothing)
+            if (victim == g_plans.end() || t < (victim->second ? victim->second->last_use : 0)) victim = it;
+        }
+        if (victim == g_plans.end()) return;   // everything else is in use: over the bound until a holder lets go
+        if (EvalhPlan* pl = victim->second.get()) {
+            int current = 0;
+            const bool have = hipGetDevice(&current) == hipSuccess;
+            if (hipSetDevice(pl->device) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                for (hipModule_t m : pl->modules) (void)hipModuleUnload(m);
+            }
+            if (have) (void)hipSetDevice(current);
+        }
+        g_plans.erase(victim);
+        g_plan_evictions.fetch_add(1);
+    }
+}
 
 // in-memory identity of a program: two multiply-xorshift lanes over the same bytes program_hash covers (the SHA-256 is
 // for the file name on disk, where a collision would load foreign code; here it would at worst pick the wrong cached plan
@@ -329,9 +368,16 @@ bool generation_enabled() {
 }
 }  // namespace
 
-const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached) {
+void evalh_plan_release(const EvalhPlan* plan) {
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    if (plan->users) plan->users--;
+}
+
+uint64_t evalh_plan_evictions() { return g_plan_evictions.load(); }
+
+EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached) {
     if (cached) *cached = 0;
-    if (!generation_enabled()) return nullptr;
+    if (!generation_enabled()) return EvalhPlanRef();
     int device = 0;
     H2_HIP(hipGetDevice(&device));
     const evgen::Options opt = evgen::Options::from_env();
@@ -341,7 +387,11 @@ const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached) {
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
         if (cached) *cached = 1;
-        return it->second.get();
+        if (const EvalhPlan* hit = it->second.get()) {
+            hit->last_use = ++g_plan_clock;
+            hit->users++;
+        }
+        return EvalhPlanRef(it->second.get());
     }
     std::unique_ptr<EvalhPlan> plan;
     try {
@@ -371,8 +421,13 @@ const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached) {
         plan.reset();
     }
     const EvalhPlan* out = plan.get();
+    if (out) {
+        out->last_use = ++g_plan_clock;
+        out->users = 1;
+    }
     g_plans[key] = std::move(plan);
-    return out;
+    evict_plans(key);
+    return EvalhPlanRef(out);
 }
 
 void evalh_plan_info(const EvalhPlan* plan, h2_evalh_info* info) {
@@ -527,7 +582,8 @@ int evalh_device(DeviceCtx* ctx, const h2_evalh_desc* d, Fr* d_values, hipStream
 
     // ---- the program as generated straight-line kernels (evalh_gen.cpp), unless switched off or unavailable
     if (!(d->flags & H2_EVALH_INTERPRET)) {
-        if (const EvalhPlan* plan = evalh_plan_get(d, nullptr)) {
+        if (EvalhPlanRef held = evalh_plan_get(d, nullptr)) {
+            const EvalhPlan* plan = held.get();
             PlanRef pl;  // the power tables of extended_omega: pinned until the kernels that read them are launched
             if (plan->uses_omega) {
                 if (have_lock) {

@@ -17,8 +17,38 @@ struct EvalhPlan;  // the loaded kernels of one program on one device
 // The plan for this descriptor's program on the CURRENT device: from the cache, or generated + compiled + loaded now
 // (*cached: 1 memory, 2 disk, 0 built now).  nullptr when generation is switched off (H2_EVALH_JIT=0) or unavailable (no
 // hipRTC, a compile failure: reported once on stderr) -- the interpreter kernels then run the program.
-const EvalhPlan* evalh_plan_get(const h2_evalh_desc* d, int* cached);
+//
+// The cache is bounded (H2_EVALH_PLANS_MAX, default 128 programs x devices): past it the least recently used plan that
+// nobody holds is unloaded (after its device has drained: launches are asynchronous) -- a prover service that sees new
+// circuits for months does not accumulate code objects; an evicted program comes back from the disk cache.  A caller holds
+// its plan through the reference below from the lookup until its launches are queued.
+void evalh_plan_release(const EvalhPlan* plan);
+class EvalhPlanRef {
+    const EvalhPlan* p_ = nullptr;
+
+public:
+    EvalhPlanRef() = default;
+    explicit EvalhPlanRef(const EvalhPlan* p) : p_(p) {}
+    EvalhPlanRef(EvalhPlanRef&& o) noexcept : p_(o.p_) { o.p_ = nullptr; }
+    EvalhPlanRef& operator=(EvalhPlanRef&& o) noexcept {
+        if (this != &o) {
+            if (p_) evalh_plan_release(p_);
+            p_ = o.p_;
+            o.p_ = nullptr;
+        }
+        return *this;
+    }
+    EvalhPlanRef(const EvalhPlanRef&) = delete;
+    EvalhPlanRef& operator=(const EvalhPlanRef&) = delete;
+    ~EvalhPlanRef() {
+        if (p_) evalh_plan_release(p_);
+    }
+    explicit operator bool() const { return p_ != nullptr; }
+    const EvalhPlan* get() const { return p_; }
+};
+EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached);
 void evalh_plan_info(const EvalhPlan* plan, h2_evalh_info* info);
+uint64_t evalh_plan_evictions();
 void evalh_gen_info(const evgen::Generated& g, h2_evalh_info* info);
 uint64_t evalh_generated_launches();
 }  // namespace h2

@@ -350,7 +350,11 @@ int h2_dev_evaluate_h(const h2_evalh_desc *desc, void *d_values, void *stream);
  *                   reports what was built; pointers to columns inside `desc` are not read.
  * h2_evalh_compile  generates and compiles into the caches without touching a device (works on a machine without a GPU).
  * h2_evalh_source   the generated source of stage `stage` (for inspection): copies up to `cap` bytes including the
- *                   terminating NUL into `buf` and stores the full length (without NUL) in *len. */
+ *                   terminating NUL into `buf` and stores the full length (without NUL) in *len.
+ * All three may be called from several threads at once (rayon workers at keygen), for the same program too.  A cache file
+ * carries a SHA-256 trailer: a torn or damaged one is a miss and is rebuilt; every writer renames a file of its own into place.
+ * Loaded code objects are kept per (program, device), at most H2_EVALH_PLANS_MAX of them (environment, default 128): the least
+ * recently used one is unloaded and comes back from the disk cache when its program is seen again. */
 typedef struct {
     uint32_t stages;                     /* kernels the program was cut into (1 unless it is too wide for one) */
     uint32_t terms;                      /* y-folded terms of the numerator: value parts + argument terms */

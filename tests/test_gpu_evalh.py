@@ -96,6 +96,19 @@ def test_generated_kernels_disk_cache(oracle, monkeypatch, tmp_path):
     assert np.array_equal(ev.evaluate_h(b), oracle_evaluate_h(oracle, b))
 
 
+def test_plan_cache_is_bounded(tmp_path):
+    """the in-memory cache of loaded code objects has a bound (H2_EVALH_PLANS_MAX; least recently used, unheld plans are
+    unloaded after their device has drained): tests/evalh_plans_worker.py in a process of its own with a bound of two"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, H2_EVALH_PLANS_MAX="2", H2_JIT_CACHE=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "evalh_plans_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "plans worker ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),
                                              (35, 5, 7, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=5)),
                                              (36, 4, 14, dict(lookup_sets=(2,), n_shuffles=1))])
