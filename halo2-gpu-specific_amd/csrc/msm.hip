@@ -313,8 +313,12 @@ static MsmShape msm_shape_table(size_t n, uint32_t max_bits, bool hot, const Shi
         uint32_t nbits = 0;
         while ((1u << nbits) < s.chunks) nbits++;
         s.planes = nbits + 1;
-        // the planes' workgroups together fill the chip about once: plane_seg workgroups per plane, plane_l chunk sums per quad
-        s.plane_seg = std::max<uint32_t>(1, 256 / s.planes);
+        // the planes' workgroups together fill three quarters of the chip: plane_seg workgroups per plane, plane_l chunk sums
+        // per quad.  Measured (profiles/r5_msm_plane_wgs_sweep.txt): MORE workgroups -- shorter chains per quad -- lose (512:
+        // +3..12 % on a single MSM, the segment fold and the launch grow), 128-256 tie for a single MSM and the smaller grids
+        // leave more of the chip to the next column's accumulation in a batch (2^16 0.25 -> 0.23 ms per MSM, 2^18 0.54 -> 0.53)
+        static const uint32_t plane_wgs = getenv("H2_MSM_PLANE_WGS") ? (uint32_t)std::max(1, atoi(getenv("H2_MSM_PLANE_WGS"))) : 192u;
+        s.plane_seg = std::max<uint32_t>(1, plane_wgs / s.planes);
         const uint32_t half = nbits ? (1u << (nbits - 1)) : 1u;
         while (s.plane_seg > 1 && (s.plane_seg - 1) * (REDUCE_T / 4) >= half) s.plane_seg--;   // no empty workgroups
         s.plane_l = (half + s.plane_seg * (REDUCE_T / 4) - 1) / (s.plane_seg * (REDUCE_T / 4));
