@@ -305,7 +305,7 @@ def main():
     # HBM bytes per k_ntt_pass launch from the PMC passes committed under profiles/ (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); null when the file is absent
     traffic, traffic_source = None, None
-    for prof in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+    for prof in ("r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", prof)) as f:
                 if log_n == 24:
