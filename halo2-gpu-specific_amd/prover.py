@@ -182,7 +182,12 @@ class Device:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.L = lib()
-        self.tstream = torch.cuda.Stream(device=self.dev)
+        # H2_STREAM_PRIORITY = "<compute>,<side>" (torch / HIP stream priorities: lower = more urgent): experiment knob
+        import os as _os
+
+        pr = _os.environ.get("H2_STREAM_PRIORITY", "")
+        self._prio = tuple(int(x) for x in pr.split(",")) if pr else (0, 0)
+        self.tstream = torch.cuda.Stream(device=self.dev, priority=self._prio[0])
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.stream = _vp(self.tstream.cuda_stream)
         self._scratch = None
@@ -562,7 +567,7 @@ class Device:
         if getattr(self, "_side", None) is None:
             import concurrent.futures
 
-            self._side = (self.torch.cuda.Stream(device=self.dev), concurrent.futures.ThreadPoolExecutor(max_workers=1))
+            self._side = (self.torch.cuda.Stream(device=self.dev, priority=self._prio[1]), concurrent.futures.ThreadPoolExecutor(max_workers=1))
         side = self._side[0]
         ready = self.torch.cuda.Event()
         ready.record(self.tstream)
@@ -658,7 +663,7 @@ class Device:
             fut.set_result(point)
             return fut
         if getattr(self, "_side", None) is None:
-            self._side = (self.torch.cuda.Stream(device=self.dev), concurrent.futures.ThreadPoolExecutor(max_workers=1))
+            self._side = (self.torch.cuda.Stream(device=self.dev, priority=self._prio[1]), concurrent.futures.ThreadPoolExecutor(max_workers=1))
         side, pool = self._side
         ready = self.torch.cuda.Event()
         ready.record(self.tstream)
