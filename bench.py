@@ -156,6 +156,7 @@ def main():
     # the CPU baseline's OpenMP teams sleep at their barriers instead of spinning (read when libgomp is loaded, i.e. before
     # torch is imported): rayon's idle workers park; a spinning team of 256 on a box whose cgroup grants fewer CPUs took 4.7 s
     # for a 2^20 transform in round 4's line
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: streams that share a hardware queue serialise (package __init__)
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     os.environ.setdefault("GOMP_SPINCOUNT", "0")
     import torch

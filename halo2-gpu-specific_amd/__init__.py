@@ -5,5 +5,15 @@ This Python layer is a thin ctypes binding used by tests and bench.py; the produ
 libhalo2_hip.so (csrc/).  There is no CPU fallback: importing `lib()` without the built
 extension raises.
 """
-from ._lib import H2Error, build, lib, lib_path  # noqa: F401
-from . import arithmetic  # noqa: F401
+import os as _os
+
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one serialise.
+# The prover runs a compute stream, a copy stream, a side stream and the library's own second MSM stream next to torch's:
+# with four queues the first commitment group of a wide witness waited for the copy stream's whole backlog (k = 22, 64
+# columns: 515 -> 452 ms with eight queues, 412 -> 390 from a compact witness; nothing else moves).  Read when the HIP
+# runtime initialises, i.e. before the first HIP call of the process (importing torch does not make one); a caller's own
+# setting wins.  libhalo2_hip.so sets the same default when it is loaded (csrc/context.hip) for hosts without Python.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from ._lib import H2Error, build, lib, lib_path  # noqa: F401,E402
+from . import arithmetic  # noqa: F401,E402

@@ -6,6 +6,13 @@
 
 #include "common.hpp"
 
+// HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
+// serialise: the library alone runs a second MSM stream and a stream per host-API slot next to its caller's compute and
+// copy streams.  Eight queues (measured: the wide circuit at k = 22 515 -> 452 ms, nothing else moves).  The runtime reads
+// the variable when it initialises -- at the first HIP call of the process -- so setting it when this library is LOADED is
+// early enough for a host that uses HIP only through this library; a value the caller has set is kept.
+__attribute__((constructor)) static void h2_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace h2 {
 
 static thread_local std::string g_last_error;

@@ -2025,31 +2025,36 @@ static int msm_device_fused(DeviceCtx* ctx, const Fr* const* d_scalars, uint32_t
                             uint32_t bits, char* scratch, uint64_t* const* outs, hipStream_t stream) {
     const MsmShape s = msm_shape(n, bits, false, cols);
     const size_t wp = (size_t)s.Wt * s.G + s.planes;
-    char* pinned = (char*)ctx->pinned.get((size_t)cols * HOT_SAMPLES * sizeof(Fr) + wp * sizeof(XYZZ));
+    // the column table (cols pointers, padded to 16 bytes, then cols dominant values) is staged in pinned memory too
+    const size_t tab_ptr_bytes = ((size_t)cols * 8 + 15) & ~(size_t)15, tab_bytes = tab_ptr_bytes + (size_t)cols * sizeof(Fr);
+    char* pinned = (char*)ctx->pinned.get((size_t)cols * HOT_SAMPLES * sizeof(Fr) + wp * sizeof(XYZZ) + tab_bytes);
     Fr* h_samples = (Fr*)pinned;
     XYZZ* h_win = (XYZZ*)(pinned + (size_t)cols * HOT_SAMPLES * sizeof(Fr));
+    char* h_tab = pinned + (size_t)cols * HOT_SAMPLES * sizeof(Fr) + wp * sizeof(XYZZ);
     for (uint32_t j = 0; j < cols; j++)
         hipLaunchKernelGGL(k_sample, dim3(1), dim3(HOT_SAMPLES), 0, stream, d_scalars[j], n, h_samples + (size_t)j * HOT_SAMPLES);
     H2_HIP(hipStreamSynchronize(stream));
     std::vector<Hot> hots(cols);
-    std::vector<uint64_t> tab((size_t)cols * 8);  // cols pointers, then cols x 4 u64 dominant values
     FusedCols fc{};
+    memset(h_tab, 0, tab_bytes);
     for (uint32_t j = 0; j < cols; j++) {
         hots[j] = detect_hot(h_samples + (size_t)j * HOT_SAMPLES);
         if (s.Wc == s.W) hots[j].on = false;  // one or two windows: no dominant-scalar slot
         if (hots[j].on) fc.hot_mask |= 1ull << j;
-        tab[j] = (uint64_t)(uintptr_t)d_scalars[j];
+        ((uint64_t*)h_tab)[j] = (uint64_t)(uintptr_t)d_scalars[j];
+        ((Fr*)(h_tab + tab_ptr_bytes))[j] = hots[j].value;
     }
-    std::vector<Fr> hv(cols);
-    for (uint32_t j = 0; j < cols; j++) hv[j] = hots[j].value;
+    // ... and goes up through the store kernel, not hipMemcpyAsync: a DMA-engine copy queues behind the bulk transfers in
+    // flight (see k_export) -- the first group of a wide witness waited here until the LAST column had crossed PCIe
+    // (k = 22, 64 compact columns: 34 ms of a 124 ms advice phase; tools/experiments/busy.sh showed the GPU idle)
     char* d_tab = scratch + s.off_coltab;
-    H2_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)cols * 8, hipMemcpyHostToDevice, stream));
-    H2_HIP(hipMemcpyAsync(d_tab + (size_t)cols * 8 + ((cols & 1) ? 8 : 0), hv.data(), (size_t)cols * sizeof(Fr), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((tab_bytes / 16 + 255) / 256)), dim3(256), 0, stream, (const uint4*)h_tab,
+                       (uint4*)d_tab, tab_bytes / 16);
     fc.scalars = (const Fr* const*)d_tab;
-    fc.hot_values = (const Fr*)(d_tab + (size_t)cols * 8 + ((cols & 1) ? 8 : 0));
+    fc.hot_values = (const Fr*)(d_tab + tab_ptr_bytes);
     msm_launch(s, Hot{}, nullptr, (const Affine*)d_bases, bits, scratch, stream, &fc);
     export_to_host((const XYZZ*)(scratch + s.off_winpart), h_win, wp, stream);
-    H2_HIP(hipStreamSynchronize(stream));  // also keeps `tab` / `hv` alive until their uploads are done
+    H2_HIP(hipStreamSynchronize(stream));  // (the pinned block is this context's until here)
     std::vector<XYZZ> winpart(h_win, h_win + wp);
     for (uint32_t j = 0; j < cols; j++) msm_host_tail(s, hots[j], winpart, outs[j], (size_t)j * s.Wc);
     return H2_OK;

@@ -1523,23 +1523,17 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 t[lo_r:hi_r] = col[lo_r:hi_r] if D.torch.is_tensor(col) else D.upload(np.ascontiguousarray(col[lo_r:hi_r]))
             uploads.append((t, None))
     else:
-        uploads = [D.upload_async(col) for col in advice]
-    # The vanishing argument's random polynomial (vanishing/prover.rs:40-67) and its commitment depend on nothing the
-    # transcript has hashed: generated and committed NOW, while the witness columns cross PCIe on the copy stream (k = 24:
-    # a 22 ms MSM under a 29 ms transfer) -- on a side stream, so that the columns that have already arrived are
-    # blinded and committed next to it instead of behind it (k = 22: advice phase 10.7 -> 9.8 ms).  The commitment is
-    # written where the protocol puts it, after the z's.
-    # (Small witnesses too: folding it into the advice columns' batch instead was measured slower, k = 18 lookup circuit
-    # 28.6 -> 30.2 ms -- the early MSM runs under the host's preparation of the blinding rows.)
-    random_poly = D.empty(n)
-    check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
-    random_commitment = D.msm_async(random_poly, params.g, n)   # collected where the transcript needs it
-    # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
-    blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
-    for ci in range(len(uploads)):
-        blind[ci, :, 0] = [rng.u16() for _ in range(usable, n)]
-    with D.torch.cuda.stream(D.tstream):
-        blind_dev = D.torch.from_numpy(blind).to(D.dev)
+        # queued a few commitment groups ahead of the group being committed (queue_uploads below), not all at once: with
+        # every column of a wide witness in the copy queue the FIRST group's commitment returned only when the LAST column
+        # had crossed PCIe (k = 22, 64 compact columns: the GPU idle for 34 of the phase's 125 ms; tools/experiments/busy.sh)
+        uploads = [None] * len(advice)
+    uploads_queued = [len(uploads) if sharded_upload else 0]
+
+    def queue_uploads(upto):
+        while uploads_queued[0] < min(upto, len(uploads)):
+            uploads[uploads_queued[0]] = D.upload_async(advice[uploads_queued[0]])
+            uploads_queued[0] += 1
+
     # columns are blinded, measured and committed in groups while later uploads are still in flight; small witnesses
     # (<= 256 MiB: already on the device by the time the random polynomial is committed) go as one group -- one
     # synchronisation and one pipelined / fused batch instead of several
@@ -1554,8 +1548,28 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     if os.environ.get("H2_ADVICE_GROUP"):
         group = int(os.environ["H2_ADVICE_GROUP"])
     group = max(group, 1)
+    ahead = max(1, int(os.environ.get("H2_ADVICE_AHEAD", "2"))) * group
+    queue_uploads(len(uploads) if len(uploads) <= group else group + ahead)
+    # The vanishing argument's random polynomial (vanishing/prover.rs:40-67) and its commitment depend on nothing the
+    # transcript has hashed: generated and committed NOW, while the witness columns cross PCIe on the copy stream (k = 24:
+    # a 22 ms MSM under a 29 ms transfer) -- on a side stream, so that the columns that have already arrived are
+    # blinded and committed next to it instead of behind it (k = 22: advice phase 10.7 -> 9.8 ms).  The commitment is
+    # written where the protocol puts it, after the z's.
+    # (Small witnesses too: folding it into the advice columns' batch instead was measured slower, k = 18 lookup circuit
+    # 28.6 -> 30.2 ms -- the early MSM runs under the host's preparation of the blinding rows.)
+    htrace("uploads queued")
+    random_poly = D.empty(n)
+    check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
+    random_commitment = D.msm_async(random_poly, params.g, n)   # collected where the transcript needs it
+    # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
+    blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
+    for ci in range(len(uploads)):
+        blind[ci, :, 0] = [rng.u16() for _ in range(usable, n)]
+    with D.torch.cuda.stream(D.tstream):
+        blind_dev = D.torch.from_numpy(blind).to(D.dev)
     advice_dev = []
     for g0 in range(0, len(uploads), group):
+        queue_uploads(g0 + group + ahead)
         cols_ = []
         for ci, (t, arrived) in enumerate(uploads[g0:g0 + group], start=g0):
             if arrived is not None:
@@ -1573,7 +1587,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         # (fused, few-point) MSM per group; the two points are added.
         split_tail = not sharded_upload and not (D.group_size > 1 or D.force_collective) and usable >= (1 << 12)
         m_rows = usable if split_tail else hi_r - lo_r
+        htrace("advice group %d queued" % g0)
         bits_ = D.max_scalar_bits_many([t[lo_r:lo_r + m_rows] for t in cols_], m_rows)
+        htrace("advice group %d bits" % g0)
         if sharded_upload:
             bits_ = allreduce_max(bits_, group=D.group, device=D.dev)       # find_max_scalar_bits over the whole column
         bits_ = [max(b, 1) for b in bits_]
@@ -1583,6 +1599,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         # to matter): the others are committed whole, under the bound of the whole column
         for P in commit_lagrange_with_tail(cols_, bits_, split_tail):
             transcript.write_point(P)
+        htrace("advice group %d committed" % g0)
         if sharded_upload and whole_advice_rows:
             for t in cols_:
                 allgather_rows(t, lo_r, hi_r, group=D.group, stream=D.tstream)

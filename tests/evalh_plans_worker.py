@@ -9,6 +9,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 import numpy as np  # noqa: E402
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises (halo2-gpu-specific_amd/__init__.py says why)
 import torch  # noqa: E402,F401  (first: the library binds to torch's HIP runtime)
 
 from evalh_cases import random_case  # noqa: E402

@@ -2,6 +2,9 @@
 import cProfile, os, pstats, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import os  # noqa: E402
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises (halo2-gpu-specific_amd/__init__.py says why)
 import torch; torch.cuda.init()
 import numpy as np
 import ref_plonk as rp

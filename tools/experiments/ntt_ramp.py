@@ -1,6 +1,9 @@
 # per-step duration of the bench's NTT step over a long run: how long the device takes to reach its steady clock
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import os  # noqa: E402
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises (halo2-gpu-specific_amd/__init__.py says why)
 import torch
 import halo2_gpu_specific_amd as h2
 from halo2_gpu_specific_amd._lib import check
