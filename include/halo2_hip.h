@@ -468,7 +468,7 @@ int h2_dev_msm_batch_ex(const void *const *d_scalars, const void *const *d_bases
 /* Shifted-base table for a device-resident base set that is committed against repeatedly -- the SRS (`params.g`,
  * `params.g_lagrange`: poly/commitment.rs:148-170 `commit` / `commit_lagrange`; the reference re-uploads them per call,
  * arithmetic.rs:354-360).  Builds T[j][i] = [2^(o_j)] bases[i] for the `digits` (11..32) digit offsets o_j (0 = chosen from n:
- * 12 at 2^24, 15 at 2^20) in library-owned device memory (h2_dev_bases_precompute_bytes: digits x n x 64 B) and
+ * 12 at 2^24, 14 at 2^20) in library-owned device memory (h2_dev_bases_precompute_bytes: digits x n x 64 B) and
  * remembers it under `d_bases`.  From then on every h2_dev_msm / _batch / _batch_ex whose bases lie inside
  * [d_bases, d_bases + n) and whose bound needs more windows than digits adds all digits of a scalar into ONE shared
  * bucket set: ~20 % fewer point additions at 2^24, one reduction instead of one per window, no host Horner.  The sums

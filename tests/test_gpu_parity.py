@@ -645,6 +645,48 @@ def test_msm_narrow_columns_row_ranges(oracle, n):
             assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, bits)) == want, (name, bits)
 
 
+def test_msm_fused_narrow_columns_at_2p22(oracle):
+    """16-bit witness columns at 2^22 rows are committed as ONE fused MSM (columns of one or two windows fuse up to 2^24
+    entries each; wider ones stop at 2^22): the fused batch gives the points of the single-column path (row ranges, its own
+    sort / finish / reduce) for every column -- dense 16-bit, a 12-bit code, 1/16 sparse, mostly one value -- and, for the
+    sparse column, of the oracle over its non-zero rows"""
+    import torch
+
+    L = h2.lib()
+    n = 1 << 22
+    d_pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    assert L.h2_dev_random_points(424242, n, d_pts.data_ptr(), None) == 0
+    rows = np.arange(n, dtype=np.uint64)
+    vals = [
+        (rows * np.uint64(2654435761) >> np.uint64(5)) % np.uint64(1 << 16),
+        (rows * np.uint64(40503) >> np.uint64(3)) % np.uint64(4096),
+        np.where(rows % np.uint64(16) == 0, (rows * np.uint64(48271)) % np.uint64(1 << 16), 0).astype(np.uint64),
+        np.where(rows % np.uint64(3) == 0, (rows * np.uint64(69621)) % np.uint64(1 << 16), 7).astype(np.uint64),
+    ]
+    d_cols = []
+    for v in vals:
+        a = np.zeros((n, 4), dtype=np.uint64)
+        a[:, 0] = v
+        t = torch.from_numpy(a.view(np.int64)).cuda()
+        assert L.h2_dev_batch_mont(t.data_ptr(), n, None) == 0
+        d_cols.append(t)
+    count = len(d_cols)
+    ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_cols])
+    nbytes = L.h2_msm_batch_scratch_bytes(n, 16, count)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = np.zeros((count, 12), dtype=np.uint64)
+    assert L.h2_dev_msm_batch(ptrs, count, d_pts.data_ptr(), n, 16, scratch.data_ptr(), nbytes, out.ctypes.data, None) == 0
+    single_bytes = L.h2_msm_scratch_bytes(n, 16)
+    for j in range(count):
+        one = np.zeros(12, dtype=np.uint64)
+        assert L.h2_dev_msm(d_cols[j].data_ptr(), d_pts.data_ptr(), n, 16, scratch.data_ptr(), single_bytes, one.ctypes.data, None) == 0
+        assert _affine(oracle, out[j]) == _affine(oracle, one), j
+    live = np.nonzero(vals[2])[0]
+    pts_live = d_pts[torch.from_numpy(live.astype(np.int64)).cuda()].cpu().numpy().view(np.uint64)
+    sc_live = d_cols[2][torch.from_numpy(live.astype(np.int64)).cuda()].cpu().numpy().view(np.uint64)
+    assert _affine(oracle, out[2]) == _affine(oracle, oracle.best_multiexp(np.ascontiguousarray(sc_live), np.ascontiguousarray(pts_live)))
+
+
 @pytest.mark.timeout(300)
 def test_msm_randomised_shapes():
     """tools/msm_fuzz.py for a short budget: random sizes, bounds and value distributions against the oracle, windowed and
