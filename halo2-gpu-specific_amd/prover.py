@@ -1616,7 +1616,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # small latency-bound kernels (k = 18 lookup circuit 28.9 -> 27.6 ms); at k = 22 / 24 they fill the chip themselves and
     # the transforms only take their time away (60.1 vs 60.2 ms, 210 vs 211)
     side_intt = None
-    if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= 20 and D.group_size <= 1 and not D.force_collective):
+    if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= int(os.environ.get("H2_SIDE_INTT_MAX_K", "20"))
+            and D.group_size <= 1 and not D.force_collective):
         side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and coset_tabs is None)
     # one proof over several ranks: the advice columns' inverse transforms are dealt by column now (a rank transforms every
     # P-th column) and the coefficient vectors cross xGMI under the lookup / permutation phases that follow
