@@ -341,6 +341,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u32x8 (254-bit Montgomery, integer)",
         "data": "synthetic",
+        "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                    "note": "HIP hardware queues the process's streams are multiplexed onto (the runtime's default is 4; streams "
+                            "that share a queue serialise: DESIGN.md section 0)"},
         "config": {
             "workload": "BASELINE configs[2]: 2^%d-point BN254 Fr forward+inverse NTT per step, resident in HBM" % log_n,
             "log_n": log_n,
