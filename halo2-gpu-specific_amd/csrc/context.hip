@@ -8,7 +8,8 @@
 
 // HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
 // serialise: the library alone runs a second MSM stream and a stream per host-API slot next to its caller's compute and
-// copy streams.  Eight queues (measured: the wide circuit at k = 22 515 -> 452 ms, nothing else moves).  The runtime reads
+// copy streams.  Eight queues (measured: the wide circuit at k = 22 515 -> 452 ms while its columns went through the two-stream
+// pipeline, 382 -> 373 ms from a compact witness on the final build; nothing else moves: profiles/r5_hw_queues_ab.txt).  The runtime reads
 // the variable when it initialises -- at the first HIP call of the process -- so setting it when this library is LOADED is
 // early enough for a host that uses HIP only through this library; a value the caller has set is kept.
 __attribute__((constructor)) static void h2_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
