@@ -155,7 +155,8 @@ static MsmShape msm_shape(size_t n, uint32_t max_bits, bool hot, uint32_t cols =
     s.qm = REDUCE_QM;
     for (uint32_t qm = 4; qm < REDUCE_QM; qm *= 2) {
         uint32_t rg = (s.nb + REDUCE_T / 4 * qm - 1) / (REDUCE_T / 4 * qm);
-        if ((size_t)s.Wt * rg <= 256 && rg <= REDUCE_T / 4) {  // one workgroup per CU: a CU with two runs both at half speed
+        static const size_t reduce_wgs = getenv("H2_MSM_REDUCE_WGS") ? (size_t)std::max(1, atoi(getenv("H2_MSM_REDUCE_WGS"))) : 256;
+        if ((size_t)s.Wt * rg <= reduce_wgs && rg <= REDUCE_T / 4) {  // one workgroup per CU: a CU with two runs both at half speed
             s.qm = qm;
             break;
         }
