@@ -54,6 +54,54 @@ def test_cpu_prover_bytes_match_big_integer_prover(oracle, which, k):
             assert first is None and len(proof) == len(want), "differs at byte %s (field %s)" % (first, first and first // 32)
 
 
+def test_advice_uploads_are_queued_a_few_groups_ahead(oracle, monkeypatch):
+    """round 5: with every column of a wide witness in the copy queue at once, the first commitment group returned only when
+    the last column had crossed PCIe -- the columns are queued `H2_ADVICE_AHEAD` groups ahead of the group being committed.
+    Here on the CPU device: the ORDER of the upload requests relative to the group commitments, and the same proof bytes
+    whatever the group size."""
+    import oracle_prover as op
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 6
+    cs = circuits.wide(4)                                   # 16 advice columns
+    adv, fixed, copies = circuits.wide_synthesize(k, 4)
+    events = []
+
+    class Logged(op.OracleDevice):
+        def upload(self, a):
+            if getattr(a, "shape", None) == (1 << k, 4):
+                events.append("U")
+            return super().upload(a)
+
+        def msm_partial(self, columns, bases, lo, hi, max_bits=254, also=None):
+            if len(columns) >= 2:
+                events.append("C%d" % len(columns))
+            return super().msm_partial(columns, bases, lo, hi, max_bits, also)
+
+    D = Logged(threads=2)
+    params = oracle_params(oracle, D, k)
+    pk = op.keygen(D, params, cs, fixed, copies)
+    proofs = []
+    for group, ahead in (("4", "1"), ("16", "2"), ("3", "2")):
+        monkeypatch.setenv("H2_ADVICE_GROUP", group)
+        monkeypatch.setenv("H2_ADVICE_AHEAD", ahead)
+        del events[:]
+        proofs.append(prover.create_proof_ext(D, params, pk, adv, ProverRng(5), False))
+        if group == "4":
+            # uploads seen before the 1st .. 4th group commitment: group + ahead, then one more group each time, never more than 16
+            seen, at = [], 0
+            for e in events:
+                if e == "U":
+                    at += 1
+                elif len(seen) < 4:
+                    seen.append(at)
+            assert seen == [8, 12, 16, 16], (seen, events[:40])
+        elif group == "16":
+            assert events[:16] == ["U"] * 16                # one group: everything goes up first
+    assert proofs[0] == proofs[1] == proofs[2]
+
+
 def test_product_device_still_needs_a_gpu():
     """the oracle device is injected by tests only: the product's own Device has no CPU path"""
     import torch
