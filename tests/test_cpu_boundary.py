@@ -78,6 +78,23 @@ def test_missing_extension_fails_loudly(tmp_path):
     assert out.startswith("LOUD") and "no CPU fallback" in out
 
 
+def test_h2_lib_names_another_build_and_nothing_else(tmp_path):
+    """H2_LIB (tools/gen_sanitize.sh: a sanitizer build of the same ABI) replaces the in-tree path; a missing file is the same
+    loud error, and the package sets its HIP hardware-queue default without overriding a caller's"""
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "os.environ['H2_LIB'] = %r\n"
+        "import halo2_gpu_specific_amd as h2\n"
+        "print('QUEUES', os.environ['GPU_MAX_HW_QUEUES'])\n"
+        "try:\n    h2.lib()\nexcept h2.H2Error as e:\n    print('LOUD', e)\n"
+    ) % (ROOT, str(tmp_path / "elsewhere.so"))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=env)
+    assert "QUEUES 8" in out and "LOUD" in out and "elsewhere.so" in out and "no CPU fallback" in out
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=dict(env, GPU_MAX_HW_QUEUES="3"))
+    assert "QUEUES 3" in out
+
+
 def test_msm_shape_and_scratch():
     L = h2.lib()
     c, W, nb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
