@@ -114,6 +114,7 @@ SYMBOLS = {
     "h2_evalh_prepare": (ctypes.c_int, [_vp, _vp]),
     "h2_evalh_compile": (ctypes.c_int, [_vp, _vp]),
     "h2_evalh_source": (ctypes.c_int, [_vp, _u32, _vp, _sz, _vp]),
+    "h2_evalh_stage_args": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _sz, _vp]),
     "h2_evalh_generated_launches": (ctypes.c_uint64, []),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_evaluate_h_coeff": (ctypes.c_int, [_vp, _vp]),

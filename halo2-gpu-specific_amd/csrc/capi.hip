@@ -1004,6 +1004,24 @@ int h2_evalh_source(const h2_evalh_desc* desc, uint32_t stage, char* buf, size_t
     });
 }
 
+int h2_evalh_stage_args(const h2_evalh_desc* desc, uint32_t stage, uint64_t* values, const uint64_t* tw_lo, const uint64_t* tw_hi,
+                        uint64_t row_begin, uint64_t row_end, void* buf, size_t cap, size_t* len) {
+    if (!desc || !len || (cap && !buf)) return bad("h2_evalh_stage_args: null argument");
+    return guarded([&] {
+        if (desc->extended_k < desc->k || desc->extended_k > 28) return bad("h2_evalh_stage_args: bad k / extended_k");
+        evgen::Generated g = evgen::generate(desc, evgen::Options::from_env());
+        if (stage >= g.stages.size()) return bad("h2_evalh_stage_args: no such stage");
+        unsigned char tmp[4096];
+        *len = evalh_fill_stage_args(g.stages[stage], desc, (Fr*)values, (const Fr*)tw_lo, (const Fr*)tw_hi, (size_t)row_begin,
+                                     (size_t)row_end, tmp, sizeof tmp);
+        if (cap) {
+            if (cap < *len) return bad("h2_evalh_stage_args: buffer too small");
+            memcpy(buf, tmp, *len);
+        }
+        return (int)H2_OK;
+    });
+}
+
 uint64_t h2_evalh_generated_launches(void) { return evalh_generated_launches(); }
 
 // ------------------------------------------------------------------ evaluate_h

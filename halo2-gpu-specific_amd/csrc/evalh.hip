@@ -454,69 +454,79 @@ void evalh_gen_info(const evgen::Generated& g, h2_evalh_info* info) {
 
 uint64_t evalh_generated_launches() { return g_generated_launches.load(); }
 
-// Fills each stage's argument block (evalh_gen.hpp: fixed part, uniform scalars, column pointers) and launches it.
-static void evalh_plan_launch(const EvalhPlan* plan, const h2_evalh_desc* d, Fr* d_values, const Fr* tw_lo, const Fr* tw_hi,
-                              size_t row_begin, size_t row_end, hipStream_t stream) {
+// The argument block of one generated stage (evalh_gen.hpp: fixed part, uniform scalars, column pointers) for descriptor `d`:
+// what the kernel receives by value.  Host arithmetic only -- also behind h2_evalh_stage_args, through which the CPU tests run
+// the generated source (compiled for the host) against the oracle.  Returns the block's size; throws on a program / descriptor
+// mismatch.
+size_t evalh_fill_stage_args(const evgen::Stage& st, const h2_evalh_desc* d, Fr* values, const Fr* tw_lo, const Fr* tw_hi,
+                             size_t row_begin, size_t row_end, unsigned char* buf, size_t cap) {
     const Fr y = fr_from_u64x4(d->y), beta = fr_from_u64x4(d->beta), gamma = fr_from_u64x4(d->gamma), theta = fr_from_u64x4(d->theta);
     const Fr delta = fr_from_u64x4(d->delta), delta_start = fp_mul(beta, fr_from_u64x4(d->zeta));  // evaluation.rs:1012
     size_t n_lookup_z = 0;
     for (uint32_t t = 0; t < d->n_lookups; t++) n_lookup_z += d->lookup_sets[t];
+    const size_t ns = std::max<size_t>(st.scalars.size(), 1), nc = std::max<size_t>(st.cols.size(), 1);
+    const size_t bytes = evgen::ARGS_FIXED_BYTES + 32 * ns + 8 * nc;
+    if (bytes > cap) throw std::runtime_error("h2_evaluate_h: generated stage with oversized arguments");
+    memset(buf, 0, bytes);
+    struct Fixed {
+        Fr* values;
+        const Fr* tw_lo;
+        const Fr* tw_hi;
+        unsigned long long row_begin, row_end;
+        unsigned int extended_k, rot_scale;
+    } fx{values, tw_lo, tw_hi, (unsigned long long)row_begin, (unsigned long long)row_end, d->extended_k, 1u << (d->extended_k - d->k)};
+    static_assert(sizeof(Fixed) == evgen::ARGS_FIXED_BYTES, "argument layout");
+    memcpy(buf, &fx, sizeof fx);
+    Fr* sc = (Fr*)(buf + evgen::ARGS_FIXED_BYTES);
+    std::vector<Fr> delta_pow;  // DELTA^j, grown on demand
+    for (size_t i = 0; i < st.scalars.size(); i++) {
+        const evgen::ScalarRef& r = st.scalars[i];
+        switch (r.kind) {
+            case evgen::SC_ONE: sc[i] = fp_one<FrParams>(); break;
+            case evgen::SC_CONST: sc[i] = fr_from_u64x4(d->constants + 4 * (size_t)r.arg); break;
+            case evgen::SC_Y_POW: sc[i] = fp_pow_u32(y, r.arg); break;
+            case evgen::SC_BETA_POW: sc[i] = fp_pow_u32(beta, r.arg); break;
+            case evgen::SC_GAMMA_POW: sc[i] = fp_pow_u32(gamma, r.arg); break;
+            case evgen::SC_THETA: sc[i] = theta; break;
+            default: {  // SC_DELTA_TERM: beta ZETA DELTA^arg
+                if (delta_pow.empty()) delta_pow.push_back(fp_one<FrParams>());
+                while (delta_pow.size() <= r.arg) delta_pow.push_back(fp_mul(delta_pow.back(), delta));
+                sc[i] = fp_mul(delta_start, delta_pow[r.arg]);
+            }
+        }
+    }
+    const void** cols = (const void**)(buf + evgen::ARGS_FIXED_BYTES + 32 * ns);
+    for (size_t i = 0; i < st.cols.size(); i++) {
+        const evgen::ColRef& c = st.cols[i];
+        const void* p = nullptr;
+        switch (c.table) {
+            case evgen::T_FIXED: p = c.index < d->n_fixed ? d->fixed[c.index] : nullptr; break;
+            case evgen::T_ADVICE: p = c.index < d->n_advice ? d->advice[c.index] : nullptr; break;
+            case evgen::T_INSTANCE: p = c.index < d->n_instance ? d->instance[c.index] : nullptr; break;
+            case evgen::T_PERM_Z: p = c.index < d->n_perm_sets ? d->perm_z[c.index] : nullptr; break;
+            case evgen::T_PERM_SIGMA: p = c.index < d->n_perm_columns ? d->perm_sigma[c.index] : nullptr; break;
+            case evgen::T_LOOKUP_Z: p = c.index < n_lookup_z ? d->lookup_z[c.index] : nullptr; break;
+            case evgen::T_LOOKUP_M: p = c.index < d->n_lookups ? d->lookup_m[c.index] : nullptr; break;
+            case evgen::T_SHUFFLE_Z: p = c.index < d->n_shuffles ? d->shuffle_z[c.index] : nullptr; break;
+            case evgen::T_L0: p = d->l0; break;
+            case evgen::T_L_LAST: p = d->l_last; break;
+            default: p = d->l_active_row;
+        }
+        if (!p) throw std::runtime_error("h2_evaluate_h: a column the program reads has a null pointer in the descriptor");
+        cols[i] = p;
+    }
+    return bytes;
+}
+
+// Fills each stage's argument block and launches it.
+static void evalh_plan_launch(const EvalhPlan* plan, const h2_evalh_desc* d, Fr* d_values, const Fr* tw_lo, const Fr* tw_hi,
+                              size_t row_begin, size_t row_end, hipStream_t stream) {
     const size_t rows = row_end - row_begin;
     const unsigned blocks = (unsigned)std::min<size_t>((rows + 255) / 256, 0x7fffffffu);
-    std::vector<Fr> delta_pow;  // DELTA^j, grown on demand
     for (size_t s = 0; s < plan->gen.stages.size(); s++) {
         const evgen::Stage& st = plan->gen.stages[s];
-        const size_t ns = std::max<size_t>(st.scalars.size(), 1), nc = std::max<size_t>(st.cols.size(), 1);
-        const size_t bytes = evgen::ARGS_FIXED_BYTES + 32 * ns + 8 * nc;
         alignas(16) unsigned char buf[4096];
-        if (bytes > sizeof buf) throw std::runtime_error("h2_evaluate_h: generated stage with oversized arguments");
-        memset(buf, 0, bytes);
-        struct Fixed {
-            Fr* values;
-            const Fr* tw_lo;
-            const Fr* tw_hi;
-            unsigned long long row_begin, row_end;
-            unsigned int extended_k, rot_scale;
-        } fx{d_values, tw_lo, tw_hi, (unsigned long long)row_begin, (unsigned long long)row_end, d->extended_k, 1u << (d->extended_k - d->k)};
-        static_assert(sizeof(Fixed) == evgen::ARGS_FIXED_BYTES, "argument layout");
-        memcpy(buf, &fx, sizeof fx);
-        Fr* sc = (Fr*)(buf + evgen::ARGS_FIXED_BYTES);
-        for (size_t i = 0; i < st.scalars.size(); i++) {
-            const evgen::ScalarRef& r = st.scalars[i];
-            switch (r.kind) {
-                case evgen::SC_ONE: sc[i] = fp_one<FrParams>(); break;
-                case evgen::SC_CONST: sc[i] = fr_from_u64x4(d->constants + 4 * (size_t)r.arg); break;
-                case evgen::SC_Y_POW: sc[i] = fp_pow_u32(y, r.arg); break;
-                case evgen::SC_BETA_POW: sc[i] = fp_pow_u32(beta, r.arg); break;
-                case evgen::SC_GAMMA_POW: sc[i] = fp_pow_u32(gamma, r.arg); break;
-                case evgen::SC_THETA: sc[i] = theta; break;
-                default: {  // SC_DELTA_TERM: beta ZETA DELTA^arg
-                    if (delta_pow.empty()) delta_pow.push_back(fp_one<FrParams>());
-                    while (delta_pow.size() <= r.arg) delta_pow.push_back(fp_mul(delta_pow.back(), delta));
-                    sc[i] = fp_mul(delta_start, delta_pow[r.arg]);
-                }
-            }
-        }
-        const void** cols = (const void**)(buf + evgen::ARGS_FIXED_BYTES + 32 * ns);
-        for (size_t i = 0; i < st.cols.size(); i++) {
-            const evgen::ColRef& c = st.cols[i];
-            const void* p = nullptr;
-            switch (c.table) {
-                case evgen::T_FIXED: p = c.index < d->n_fixed ? d->fixed[c.index] : nullptr; break;
-                case evgen::T_ADVICE: p = c.index < d->n_advice ? d->advice[c.index] : nullptr; break;
-                case evgen::T_INSTANCE: p = c.index < d->n_instance ? d->instance[c.index] : nullptr; break;
-                case evgen::T_PERM_Z: p = c.index < d->n_perm_sets ? d->perm_z[c.index] : nullptr; break;
-                case evgen::T_PERM_SIGMA: p = c.index < d->n_perm_columns ? d->perm_sigma[c.index] : nullptr; break;
-                case evgen::T_LOOKUP_Z: p = c.index < n_lookup_z ? d->lookup_z[c.index] : nullptr; break;
-                case evgen::T_LOOKUP_M: p = c.index < d->n_lookups ? d->lookup_m[c.index] : nullptr; break;
-                case evgen::T_SHUFFLE_Z: p = c.index < d->n_shuffles ? d->shuffle_z[c.index] : nullptr; break;
-                case evgen::T_L0: p = d->l0; break;
-                case evgen::T_L_LAST: p = d->l_last; break;
-                default: p = d->l_active_row;
-            }
-            if (!p) throw std::runtime_error("h2_evaluate_h: a column the program reads has a null pointer in the descriptor");
-            cols[i] = p;
-        }
+        const size_t bytes = evalh_fill_stage_args(st, d, d_values, tw_lo, tw_hi, row_begin, row_end, buf, sizeof buf);
         static const bool debug = getenv("H2_JIT_DEBUG") != nullptr;
         if (debug)
             fprintf(stderr, "h2_evalh_gen stage %zu: %u blocks, rows [%zu, %zu), %zu scalars, %zu columns, %zu argument bytes, values %p\n", s,

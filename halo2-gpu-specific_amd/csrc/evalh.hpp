@@ -50,5 +50,7 @@ EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached);
 void evalh_plan_info(const EvalhPlan* plan, h2_evalh_info* info);
 uint64_t evalh_plan_evictions();
 void evalh_gen_info(const evgen::Generated& g, h2_evalh_info* info);
+size_t evalh_fill_stage_args(const evgen::Stage& st, const h2_evalh_desc* d, Fr* values, const Fr* tw_lo, const Fr* tw_hi,
+                             size_t row_begin, size_t row_end, unsigned char* buf, size_t cap);
 uint64_t evalh_generated_launches();
 }  // namespace h2

@@ -181,6 +181,15 @@ def generated_source(builder, stage=0):
     return buf.value.decode()
 
 
+def stage_args(builder, stage, values_ptr, tw_lo_ptr, tw_hi_ptr, row_begin, row_end):
+    """h2_evalh_stage_args: the bytes stage `stage` of the generated program receives by value for this descriptor"""
+    n = ctypes.c_size_t(0)
+    buf = ctypes.create_string_buffer(4096)
+    check(lib().h2_evalh_stage_args(ctypes.byref(builder.desc), stage, values_ptr, tw_lo_ptr, tw_hi_ptr, row_begin, row_end, buf, 4096,
+                                    ctypes.byref(n)), "h2_evalh_stage_args")
+    return buf.raw[:n.value]
+
+
 def generated_launches():
     return int(lib().h2_evalh_generated_launches())
 

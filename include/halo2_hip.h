@@ -369,6 +369,13 @@ typedef struct {
 int h2_evalh_prepare(const h2_evalh_desc *desc, h2_evalh_info *info);
 int h2_evalh_compile(const h2_evalh_desc *desc, h2_evalh_info *info);
 int h2_evalh_source(const h2_evalh_desc *desc, uint32_t stage, char *buf, size_t cap, size_t *len);
+/* The argument block stage `stage` of the generated program receives for THIS descriptor (its column pointers, challenges and
+ * constants), `values`, the power tables of extended_omega (tw_lo[i] = omega^i for i < min(2^extended_k, 4096), tw_hi[j] =
+ * omega^(4096 j)) and the row range -- exactly the bytes the launch passes by value; host arithmetic only, no device needed.
+ * For inspection and for tests: with h2_evalh_source it lets a test compile the generated text for the host and run it against
+ * the CPU oracle (tests/test_evalh_host_exec.py).  Copies into `buf` (cap bytes; 0 = only report) and stores the size in *len. */
+int h2_evalh_stage_args(const h2_evalh_desc *desc, uint32_t stage, uint64_t *values, const uint64_t *tw_lo, const uint64_t *tw_hi,
+                        uint64_t row_begin, uint64_t row_end, void *buf, size_t cap, size_t *len);
 /* stages of generated kernels launched so far in this process (a test's proof that they, not the interpreter, ran) */
 uint64_t h2_evalh_generated_launches(void);
 
