@@ -31,6 +31,8 @@ SHIM = r'''
 #define __forceinline__ inline
 #define __noinline__
 #define __launch_bounds__(...)
+#define __shared__ static
+#define __syncthreads() do {} while (0)
 #define __builtin_amdgcn_sched_barrier(x) do {} while (0)
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
@@ -45,6 +47,13 @@ extern "C" void h2_host_run(const unsigned char* block, unsigned long long bytes
     memset(&a, 0, sizeof a);
     memcpy(&a, block, bytes < sizeof a ? bytes : sizeof a);
     blockDim.x = 256;
+    // a stage that reads its arguments through LDS copies them cooperatively (lane t takes entries t, t + 256, ...) before
+    // anything else: every lane of a workgroup past the row range fills the (here: static) arrays once, and returns
+    blockIdx.x = 0x7fffffu;
+    for (unsigned t = 0; t < 256; t++) {
+        threadIdx.x = t;
+        h2_evalh_gen(a);
+    }
     for (unsigned long long r = a.row_begin; r < a.row_end; r++) {
         const unsigned long long i = r - a.row_begin;
         blockIdx.x = (unsigned)(i / 256);
@@ -54,7 +63,6 @@ extern "C" void h2_host_run(const unsigned char* block, unsigned long long bytes
 }
 '''
 
-# every option set keeps the argument block a kernel argument (the LDS copy is a cooperative load of a workgroup: device only)
 SETTINGS = [
     {},
     {"H2_JIT_FACTOR": "0"},
@@ -63,6 +71,8 @@ SETTINGS = [
     {"H2_JIT_MUL2": "0"},
     {"H2_JIT_LIVE": "6", "H2_JIT_GAP": "200"},
     {"H2_JIT_MIN_GROUP": "1"},
+    {"H2_JIT_LDS_ARGS": "1"},             # scalars and column pointers through the LDS copy of the argument block
+    {"H2_JIT_LDS_ARGS": "1", "H2_JIT_STAGE_PRODUCTS": "13"},
 ]
 
 
@@ -92,7 +102,6 @@ def _run_generated(tmp_path, b, kw, tag):
             src = ev.generated_source(b, stage)
         except Exception:                                   # "no such stage": past the last one
             break
-        assert "__shared__" not in src, "a host run needs the argument block as a kernel argument"
         cpp = tmp_path / ("%s_s%d.cpp" % (tag, stage))
         so = tmp_path / ("%s_s%d.so" % (tag, stage))
         cpp.write_text(SHIM + src + DRIVER)
@@ -112,7 +121,6 @@ def _run_generated(tmp_path, b, kw, tag):
     (8, 7, 9, dict(lookup_sets=(2,), n_shuffles=1, n_calcs=60)), (6, 13, 13, dict(n_calcs=16, lookup_sets=(1,), n_shuffles=1))])
 def test_generated_source_run_on_the_host_matches_the_oracle(oracle, monkeypatch, tmp_path, seed, k, ek, kwargs):
     monkeypatch.setenv("H2_JIT_CACHE", str(tmp_path / "cache"))
-    monkeypatch.setenv("H2_JIT_LDS_ARGS", "1000000")        # never through LDS (see SETTINGS)
     kw = random_case(seed, k, ek, oracle, **({"n_calcs": 30} | kwargs))
     b = ev.Builder().build(**kw)
     want = oracle_evaluate_h(oracle, b)
@@ -144,3 +152,14 @@ def test_stage_args_layout_and_errors(oracle):
     kw2 = dict(kw, l0=None)
     with pytest.raises(Exception):
         ev.stage_args(ev.Builder().build(**kw2), 0, values.ctypes.data, 0, 0, 0, 64)
+
+
+@pytest.mark.timeout(300)
+def test_generator_fuzz_on_the_host():
+    """tools/gen_host_fuzz.py for a short budget: the product circuits' programs, random circuits and random Evaluator programs
+    under random generator options, each generated, compiled for the host and run against the oracle (long runs: DESIGN.md)"""
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_host_fuzz.py"), "25", "11"], capture_output=True, text=True,
+                         timeout=280)
+    assert out.returncode == 0 and "all equal to the oracle" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
