@@ -95,6 +95,23 @@ def test_h2_lib_names_another_build_and_nothing_else(tmp_path):
     assert "QUEUES 3" in out
 
 
+def test_library_sets_its_hardware_queue_default_when_loaded():
+    """libhalo2_hip.so's load-time constructor: GPU_MAX_HW_QUEUES=8 for a host that reaches HIP only through the library (the
+    runtime reads it at its first call), unless the caller has set it"""
+    code = (
+        "import ctypes, sys\n"
+        "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; libc.getenv.argtypes = [ctypes.c_char_p]\n"
+        "before = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+        "ctypes.CDLL(%r)\n"
+        "print('BEFORE', before, 'AFTER', libc.getenv(b'GPU_MAX_HW_QUEUES'))\n"
+    ) % h2.lib_path()
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=env)
+    assert "BEFORE None AFTER b'8'" in out, out
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=dict(env, GPU_MAX_HW_QUEUES="5"))
+    assert "BEFORE b'5' AFTER b'5'" in out, out
+
+
 def test_msm_shape_and_scratch():
     L = h2.lib()
     c, W, nb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
