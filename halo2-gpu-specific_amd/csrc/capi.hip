@@ -1011,7 +1011,7 @@ int h2_evalh_stage_args(const h2_evalh_desc* desc, uint32_t stage, uint64_t* val
         if (desc->extended_k < desc->k || desc->extended_k > 28) return bad("h2_evalh_stage_args: bad k / extended_k");
         evgen::Generated g = evgen::generate(desc, evgen::Options::from_env());
         if (stage >= g.stages.size()) return bad("h2_evalh_stage_args: no such stage");
-        unsigned char tmp[4096];
+        alignas(16) unsigned char tmp[4096];  // (pointers, u64 and Fr values are stored into it)
         *len = evalh_fill_stage_args(g.stages[stage], desc, (Fr*)values, (const Fr*)tw_lo, (const Fr*)tw_hi, (size_t)row_begin,
                                      (size_t)row_end, tmp, sizeof tmp);
         if (cap) {

@@ -12,7 +12,14 @@
 // pipeline, 382 -> 373 ms from a compact witness on the final build; nothing else moves: profiles/r5_hw_queues_ab.txt).  The runtime reads
 // the variable when it initialises -- at the first HIP call of the process -- so setting it when this library is LOADED is
 // early enough for a host that uses HIP only through this library; a value the caller has set is kept.
-__attribute__((constructor)) static void h2_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// This changes HIP's behaviour for EVERY user of the runtime in the process, and setenv is not safe against other threads
+// reading the environment: load the library before the host starts threads, or opt out with H2_NO_RUNTIME_DEFAULTS=1 and set
+// GPU_MAX_HW_QUEUES (or not) yourself.
+__attribute__((constructor)) static void h2_runtime_defaults() {
+    const char* off = getenv("H2_NO_RUNTIME_DEFAULTS");
+    if (off && *off && strcmp(off, "0") != 0) return;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 namespace h2 {
 

@@ -1101,12 +1101,19 @@ Rtc& rtc() {
     static Rtc r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // H2_HIPRTC_LIB names the library to load instead of the default search (a test points it at a file that is not
+        // there: the caller then keeps the interpreter kernels, with one warning)
+        const char* forced = getenv("H2_HIPRTC_LIB");
+        std::string why = "?";
         for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            r.handle = dlopen(forced && *forced ? forced : name, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
+            const char* e = dlerror();  // (the call clears the message: read it once)
+            if (e) why = e;
+            if (forced && *forced) break;
         }
         if (!r.handle) {
-            r.error = std::string("libhiprtc.so could not be loaded (") + (dlerror() ? dlerror() : "?") + ")";
+            r.error = std::string("libhiprtc.so could not be loaded (") + why + ")";
             return;
         }
         auto sym = [&](const char* n) { return dlsym(r.handle, n); };

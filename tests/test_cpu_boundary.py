@@ -110,6 +110,8 @@ def test_library_sets_its_hardware_queue_default_when_loaded():
     assert "BEFORE None AFTER b'8'" in out, out
     out = subprocess.check_output([sys.executable, "-c", code], text=True, env=dict(env, GPU_MAX_HW_QUEUES="5"))
     assert "BEFORE b'5' AFTER b'5'" in out, out
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=dict(env, H2_NO_RUNTIME_DEFAULTS="1"))
+    assert "BEFORE None AFTER None" in out, out          # the opt-out: the host's environment is left alone
 
 
 def test_msm_shape_and_scratch():

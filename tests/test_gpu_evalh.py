@@ -109,6 +109,21 @@ def test_plan_cache_is_bounded(tmp_path):
     assert r.returncode == 0 and "plans worker ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_without_hiprtc_the_interpreter_kernels_run(tmp_path):
+    """a machine without libhiprtc.so (H2_HIPRTC_LIB names a file that is not there; a process of its own, the library loads
+    hipRTC once): one warning per program, the interpreter kernels, the oracle's bits -- this path used to crash building its
+    own error message"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, H2_HIPRTC_LIB=str(tmp_path / "no_such_libhiprtc.so"), H2_JIT_CACHE=str(tmp_path / "c"))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "evalh_plans_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no-hiprtc worker ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runs on the interpreter kernels" in r.stderr and "could not be loaded" in r.stderr, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("seed,j,k,kwargs", [(31, 3, 5, {}), (32, 5, 8, {}), (33, 9, 11, dict(n_calcs=60)), (34, 2, 6, {}),
                                              (35, 5, 7, dict(with_perm=False, lookup_sets=(), n_shuffles=0, n_calcs=5)),
                                              (36, 4, 14, dict(lookup_sets=(2,), n_shuffles=1))])

@@ -587,6 +587,34 @@ def test_msm_2p20_proof_shaped_columns(oracle):
         assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(w, pts, bits)) == want, bits
 
 
+@pytest.mark.parametrize("which", ["zero_one_rm1", "half_zero", "repeated", "neg_pairs"])
+def test_msm_2p20_adversarial(oracle, which):
+    """BASELINE config 2's extra distributions AT ITS STATED SIZE ("each also at 2^20"; the 2^13 forms are
+    test_msm_skewed_and_adversarial): scalars in {0, 1, r - 1}, every other scalar zero (commitment.rs:207-212), four points
+    repeated 2^18 times, and P / -P pairs -- every bucket of a window receives the same few points, the doubling and the
+    P + (-P) branches of the accumulation are the common case, not the exception"""
+    n = 1 << 20
+    pts = oracle.random_g1(2030, n)
+    if which == "zero_one_rm1":
+        three = np.concatenate([fr_mont(0).reshape(1, 4), fr_mont(1).reshape(1, 4), fr_mont(R_MOD - 1).reshape(1, 4)])
+        scalars = np.ascontiguousarray(np.tile(three, ((n + 2) // 3, 1))[:n])
+    else:
+        scalars = oracle.random_fr(2031, n)
+    if which == "half_zero":
+        scalars[1::2] = 0
+    if which == "repeated":
+        pts = np.ascontiguousarray(np.tile(pts[:4], (n // 4, 1)))
+    if which == "neg_pairs":                                   # P0, -P0, P1, -P1, P0, ...
+        four = np.repeat(pts[:2], 2, axis=0)
+        four[1::2, 4:] = to_mont([(-y) % Q_MOD for _, y in arr_to_points(pts[:2])], Q_MOD)
+        pts = np.ascontiguousarray(np.tile(four, (n // 4, 1)))
+    want = _affine(oracle, oracle.best_multiexp(scalars, pts))
+    assert _affine(oracle, ar.gpu_multiexp_single_gpu_with_bound(scalars, pts, 254)) == want
+    if which == "neg_pairs":
+        same = np.ascontiguousarray(np.tile(fr_mont(5).reshape(1, 4), (n, 1)))   # sum of 5 P - 5 P pairs: the identity
+        assert _affine(oracle, ar.best_multiexp(same, pts)) == _affine(oracle, oracle.best_multiexp(same, pts)) == (0, 0)
+
+
 @pytest.mark.parametrize("n", [1 << 8, 1 << 12, 5000])
 def test_msm_fused_group(oracle, n):
     """h2_dev_msm_batch with h2_msm_batch_scratch_bytes of scratch: the columns become the windows of ONE wide MSM

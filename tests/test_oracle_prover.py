@@ -25,7 +25,7 @@ def cols_to_arr(cols):
     return [ints_to_arr(c) for c in cols]
 
 
-@pytest.mark.parametrize("which,k", [("mini", 5), ("rot", 6), ("lookup", 6)])
+@pytest.mark.parametrize("which,k", [("mini", 5), ("mini", 8), ("rot", 6), ("lookup", 6)])   # ("mini", 8): BASELINE configs[0], literally
 def test_cpu_prover_bytes_match_big_integer_prover(oracle, which, k):
     import oracle_prover as op
     from halo2_gpu_specific_amd import circuits, prover

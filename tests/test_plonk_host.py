@@ -3,6 +3,7 @@ the big-integer big-integer prover is accepted by the (trapdoor) verifier, rejec
 and the product's host-side pieces (transcript, permutation mapping, gate flattening, domain scalars, rng)
 agree with the independent restatements in ref_plonk.py."""
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -13,6 +14,7 @@ from halo2_gpu_specific_amd import circuit as hc
 from halo2_gpu_specific_amd import circuits, evaluation as ev, prover, transcript
 from halo2_gpu_specific_amd.rng import ProverRng
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from product_circuits import lookup_shuffle_cs, rot_gate_cs  # noqa: E402,F401 (re-exported for test_gpu_plonk)
 
 S_TRAPDOOR = 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203
@@ -562,6 +564,35 @@ def test_code_object_cache_survives_damage_and_concurrent_writers(tmp_path, monk
     assert len(files) == 2 and not [f for f in files if ".tmp." in f]    # (k is not part of a program: two distinct ones)
     for d in descs:
         assert ev.compile_only(d)["from_cache"] == 2
+
+
+def test_missing_hiprtc_is_an_error_message_not_a_crash(tmp_path):
+    """a machine without libhiprtc.so (H2_HIPRTC_LIB names a file that is not there; own process: the library loads hipRTC
+    once): h2_evalh_compile returns a status with the loader's message -- the error string used to be built from a second
+    dlerror() call, which returns NULL -- and a program already in the disk cache still loads without hipRTC"""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path[:0] = %r\n"
+        "import halo2_gpu_specific_amd as h2\n"
+        "from halo2_gpu_specific_amd import circuits, prover, evaluation as ev\n"
+        "b = prover.program_descriptor(circuits.mini_plonk(), 5, 7)\n"
+        "try:\n"
+        "    r = ev.compile_only(b); print('COMPILED', r['from_cache'])\n"
+        "except Exception as e:\n"
+        "    print('ERROR', e)\n"
+    ) % [ROOT, os.path.join(ROOT, "tests")]
+    env = dict(os.environ, H2_JIT_CACHE=str(tmp_path / "c"), H2_HIPRTC_LIB=str(tmp_path / "no_such_libhiprtc.so"))
+    out = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ERROR" in out.stdout and "libhiprtc.so could not be loaded" in out.stdout and "no_such_libhiprtc.so" in out.stdout, out.stdout
+    env.pop("H2_HIPRTC_LIB")
+    out = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)
+    assert "COMPILED 0" in out.stdout, out.stdout + out.stderr[-2000:]
+    env["H2_HIPRTC_LIB"] = str(tmp_path / "no_such_libhiprtc.so")
+    out = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)
+    assert "COMPILED 2" in out.stdout, out.stdout + out.stderr[-2000:]      # from the disk cache: hipRTC not needed
 
 
 def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):

@@ -26,8 +26,13 @@ python3 tools/rocprof_summary.py "$(find "$out/p_k22" -name '*results.db' | head
 python3 tools/prove_bench.py 24 3 > "$out/create_proof_k24.txt" 2>&1
 python3 tools/lookup_bench.py 18 > "$out/lookup_k18.txt" 2>&1
 # round 3: the NTT leg alone under the profiler (the k_ntt_pass average the roofline quotes), its SQ counters, the wide circuit
-rocprofv3 --kernel-trace --stats -d "$out/p_ntt" -o ntt -- python3 bench.py --steps 20 --warmup 5 --no-msm --prove-k 0 --k24 0 --wide-k 0 --no-cpu-baseline > "$out/bench_ntt_only_line.json" 2>/dev/null
+# (--wide-k22 0 too: round 5's run lacked it and its "NTT-only" summary held a whole wide k = 22 proof)
+rocprofv3 --kernel-trace --stats -d "$out/p_ntt" -o ntt -- python3 bench.py --steps 20 --warmup 5 --no-msm --prove-k 0 --k24 0 --wide-k 0 --wide-k22 0 --no-cpu-baseline > "$out/bench_ntt_only_line.json" 2>/dev/null
 python3 tools/rocprof_summary.py "$(find "$out/p_ntt" -name '*results.db' | head -1)" "$out/bench_ntt_only_kernel_stats.txt" > /dev/null
+if grep -q "k_acc_slice\|h2_evalh_gen\|k_msm" "$out/bench_ntt_only_kernel_stats.txt"; then
+    echo "collect_profiles.sh: bench_ntt_only_kernel_stats.txt is NOT NTT-only (MSM / evaluate_h kernels in it): a leg was left on" >&2
+    mv "$out/bench_ntt_only_kernel_stats.txt" "$out/bench_ntt_only_kernel_stats.CONTAMINATED.txt"
+fi
 bash tools/experiments/nttpmc.sh > "$out/ntt_pass_pmc.txt" 2>&1
 rm -rf gpurun_out/pmc1 gpurun_out/pmc2
 python3 tools/wide_bench.py 20 16 > "$out/create_proof_wide_k20.txt" 2>&1
