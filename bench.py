@@ -324,6 +324,13 @@ def main():
     # middle passes and one in the last (a complete table for 2^18 .. 2^26 points; lo x hi and the product otherwise)
     last_tw = 1 if 18 <= log_n <= 26 else 2   # the last pass reads its twiddle from a complete table at these sizes
     mults_per_transform = n * (passes * 3.06 + max(passes - 2, 0) + (last_tw if passes > 1 else 0)) if log_n >= 8 else (log_n / 2.0 + passes) * n
+    # multiply-adds per product: the twiddles read from tables (butterflies, the middle passes' inter-pass twiddles) are
+    # (plain value, quotient) pairs multiplied in 115 multiply-adds (field.hpp fp_mul_const; transforms >= 2^18, H2_NTT_CONSTW=0:
+    # off); the last pass's table product stays a Montgomery product (136): the bound below is priced with the mix
+    constw = log_n >= 18 and os.environ.get("H2_NTT_CONSTW", "1") != "0"
+    const_products = n * (passes * 3.06 + max(passes - 2, 0)) if log_n >= 8 else 0.0
+    mads_per_product = ((115.0 * const_products + 136.0 * (mults_per_transform - const_products)) / mults_per_transform) if constw else 136.0
+    ntt_mul_bound = MAD_RATE / mads_per_product
     out = {
         "metric": "NTT Fr-ops/s @ k=24 (forward+inverse 2^24 BN254 Fr NTT; MSM G1-adds/s under 'msm')",
         "value": value,
@@ -364,10 +371,13 @@ def main():
             "limiter": "integer VALU (254-bit modular multiplication), not HBM: the HBM figure above is the contract's "
             "definition; the ALU accounting follows",
             "alu": {
-                "bound": "v_mad_u64_u32 issue rate / 136 multiply-adds per product (hardware rates, tools/mulbench.hip)",
+                "bound": "v_mad_u64_u32 issue rate / multiply-adds per product (hardware rates, tools/mulbench.hip): 115 for a product "
+                         "by a tabulated twiddle (constant-operand form), 136 for a Montgomery product",
+                "multiply_adds_per_product": mads_per_product,
                 "achieved_mul_per_s": mults_per_transform / (passes * avg_launch_ms * 1e-3),
-                "peak_mul_per_s": MUL_HW_BOUND,
-                "frac": mults_per_transform / (passes * avg_launch_ms * 1e-3) / MUL_HW_BOUND,
+                "peak_mul_per_s": ntt_mul_bound,
+                "frac": mults_per_transform / (passes * avg_launch_ms * 1e-3) / ntt_mul_bound,
+                "frac_at_136_multiply_adds": mults_per_transform / (passes * avg_launch_ms * 1e-3) / MUL_HW_BOUND,
                 "multiplier_in_a_loop_per_s": MUL_MEASURED,
                 "note": "products per transform: 3.06 per element per 8-bit pass (4 butterflies, the twiddle-1 ones of the early "
                 "stages skipped) + one tabulated inter-pass twiddle product per element in the middle passes and in the last",

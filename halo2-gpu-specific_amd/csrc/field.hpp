@@ -33,6 +33,10 @@ struct FrParams {
                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr uint32_t MOD2[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
                                          0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};  // 2r (the lazy domain of the NTT)
+    static constexpr uint32_t NMOD[8] = {0x0fffffffu, 0xbc1e0a6cu, 0x86468f6eu, 0xd7cc17b7u,
+                                         0x7e7ea7a2u, 0x47afba49u, 0x1ece5fd6u, 0xcf9bb18du};  // 2^256 - r (fp_mul_const)
+    static constexpr uint32_t PINV256[8] = {0xefffffffu, 0xc2e1f593u, 0x4c6911b3u, 0x6586864bu,
+                                         0x99062391u, 0xe39a9828u, 0x0d8341b2u, 0x73f82f1du};  // -r^-1 mod 2^256 (fp_const_pair)
     static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
     static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
                                         0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod r
@@ -45,6 +49,10 @@ struct FqParams {
                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr uint32_t MOD2[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
                                          0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};  // 2q
+    static constexpr uint32_t NMOD[8] = {0x278302b9u, 0xc3df73e9u, 0x978e3572u, 0x687e956eu,
+                                         0x7e7ea7a2u, 0x47afba49u, 0x1ece5fd6u, 0xcf9bb18du};  // 2^256 - q
+    static constexpr uint32_t PINV256[8] = {0xe4866389u, 0x87d20782u, 0x1eca6ac9u, 0x9ede7d65u,
+                                         0x1833da80u, 0xd8afcbd0u, 0x91888c6bu, 0xf57a22b7u};  // -q^-1 mod 2^256
     static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
     static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
                                         0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod q
@@ -410,6 +418,8 @@ template <class P>
 __device__ __forceinline__ Fp<P> fp_mul2_dev(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d);  // a b + c d, ONE reduction
 template <class P>
 __device__ __forceinline__ Fp<P> fp_mul_wide_dev(const Fp<P>& a, const Fp<P>& b);  // a < 2^256, b canonical -> < 2p, unreduced
+template <class P>
+__device__ __forceinline__ Fp<P> fp_mul_const_dev(const Fp<P>& a, const Fp<P>& w, const Fp<P>& wq);  // a < 2^256; see fp_mul_const
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
 #include "fp_mul_gen.hpp"
 #endif
@@ -543,6 +553,63 @@ H2_DEV Fp<P> fp_mul_wide(const Fp<P>& a, const Fp<P>& b) {
     }
     return r;
 #endif
+}
+
+// x * w for a CONSTANT w tabulated with its quotient (the twiddle factors of the NTT): w < p PLAIN (not Montgomery), wq =
+// floor(w 2^256 / p), x ANY 256-bit value.  q = floor(x wq / 2^256) summed over the anti-diagonals >= 6 only (exact or one
+// short), result x w - q p mod 2^256: 43 + 36 + 36 = 115 multiply-adds and no m = t n' steps (tools/gen_fp_mul.py
+// schedule_const has the bounds).  Below 2p like fp_mul_wide's result, and congruent to x w: for x = X R (Montgomery data) that
+// is (X w) R -- the data never leave Montgomery form.  The short quotient leaves a value in [2p, 2p + 2^-29 p): seen in the
+// top limb, taken back by one subtraction of 2p (about once in 2^29 products).
+template <class P>
+H2_DEV Fp<P> fp_mul_const(const Fp<P>& x, const Fp<P>& w, const Fp<P>& wq) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_PORTABLE_MUL)
+    Fp<P> r = fp_mul_const_dev(x, w, wq);
+    if (__builtin_expect(r.l[7] >= P::MOD2[7], 0)) r = fp_lazy_red2p(r);
+    return r;
+#else
+    // portable form: the exact quotient (all 64 products of x wq), the same residue below 2p
+    uint32_t q[8];
+    {
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+        for (int i = 0; i < 15; i++) {
+            for (int j = (i > 7 ? i - 7 : 0); j <= (i < 7 ? i : 7); j++) mad_acc(lo, hi, x.l[j], wq.l[i - j]);
+            if (i >= 8) q[i - 8] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        q[7] = (uint32_t)lo;
+    }
+    Fp<P> r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    for (int i = 0; i < 8; i++) {
+        for (int j = 0; j <= i; j++) {
+            mad_acc(lo, hi, x.l[j], w.l[i - j]);
+            mad_acc(lo, hi, q[j], P::NMOD[i - j]);
+        }
+        r.l[i] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    return r;
+#endif
+}
+// w (Montgomery form, as the table kernels compute their powers) -> the pair fp_mul_const reads: the plain value and
+// floor(w_plain 2^256 / p).  w_plain 2^256 = wq p + w_mont exactly (w_mont = w_plain 2^256 mod p), so wq = -w_mont / p mod 2^256:
+// one low-half product by the constant -p^-1 mod 2^256 (PINV256), no division.
+template <class P>
+H2_DEV void fp_const_pair(const Fp<P>& w_mont, Fp<P>& w_plain, Fp<P>& wq) {
+    w_plain = fp_from_mont(w_mont);
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    for (int i = 0; i < 8; i++) {
+        for (int j = 0; j <= i; j++) mad_acc(lo, hi, w_mont.l[j], P::PINV256[i - j]);
+        wq.l[i] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
 }
 
 // The two conversions take RAW caller data (h2_batch_mont, the scalars of an MSM, point encodings): the wide-operand

@@ -33,32 +33,47 @@ static constexpr int NTT_BATCH_MAX = 16;  // vectors per launch of a batched tra
 static constexpr int LO_BITS = 12;  // two-level twiddle tables: w^e = lo[e & 4095] * hi[e >> 12]
 
 // ---------------------------------------------------------------- table generation
+// A twiddle table in one of two forms.  pair = 0: out[i] = w, Montgomery form (the operand of fp_mul / fp_mul_wide).
+// pair = 1: out[2 i] = w as a PLAIN residue, out[2 i + 1] = floor(w 2^256 / r) -- the operands of fp_mul_const (field.hpp), the
+// constant-operand product the passes with CW use for every twiddle they read from a table.
+__device__ __forceinline__ void tw_store(Fr* out, uint32_t i, const Fr& w_mont, uint32_t pair) {
+    if (!pair) {
+        fp_store(out + i, w_mont);
+        return;
+    }
+    Fr w, q;
+    fp_const_pair(w_mont, w, q);
+    fp_store(out + 2 * (size_t)i, w);
+    fp_store(out + 2 * (size_t)i + 1, q);
+}
+
 // out[i] = base^(i * mul)   (i < count)
-__global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, uint32_t mul, uint32_t count) {
+__global__ void __launch_bounds__(256) k_pow_table(Fr* out, Fr base, uint32_t mul, uint32_t count, uint32_t pair) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     // base^(i*mul): exponent < 2^28 always (order of omega divides 2^28)
-    fp_store(out + i, fp_pow_u32(base, i * mul));
+    tw_store(out, i, fp_pow_u32(base, i * mul), pair);
 }
 
 // out[(rho << kbits) | K] = base^((rho * K << s_log) mod n)   -- the complete inter-pass twiddle set of a pass
 __global__ void __launch_bounds__(256) k_direct_table(Fr* out, Fr base, uint32_t kbits, uint32_t s_log, uint32_t log_n,
-                                                      uint32_t count) {
+                                                      uint32_t count, uint32_t pair) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t rho = i >> kbits, K = i & ((1u << kbits) - 1);
     uint32_t e = (uint32_t)(((uint64_t)rho * K) << s_log) & ((1u << log_n) - 1);
-    fp_store(out + i, fp_pow_u32(base, e));
+    tw_store(out, i, fp_pow_u32(base, e), pair);
 }
 
 // out[(K << bits) | rho] = base^((rho * K) mod n) (* d when `scale`): the last pass's inter-pass twiddles in load order
-__global__ void __launch_bounds__(256) k_last_table(Fr* out, Fr base, uint32_t bits, uint32_t log_n, Fr d, uint32_t scale) {
+__global__ void __launch_bounds__(256) k_last_table(Fr* out, Fr base, uint32_t bits, uint32_t log_n, Fr d, uint32_t scale,
+                                                    uint32_t pair) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers 2^log_n exactly (log_n >= 8)
     const uint32_t rho = i & ((1u << bits) - 1), K = i >> bits;
     const uint32_t e = (uint32_t)((uint64_t)rho * K) & ((1u << log_n) - 1);
     Fr w = fp_pow_u32(base, e);
     if (scale) w = fp_mul(w, d);
-    fp_store(out + i, w);
+    tw_store(out, i, w, pair);
 }
 
 // out[i] = in[i] * d
@@ -71,7 +86,7 @@ __global__ void __launch_bounds__(256) k_scale_table(Fr* out, const Fr* in, Fr d
 struct PassArgs {
     const Fr* in;
     Fr* out;
-    const Fr* tw_bfly;  // R/2 entries: (w^(n/R))^e
+    const Fr* tw_bfly;  // R/2 entries: (w^(n/R))^e   (CW kernels: R/2 PAIRS -- plain value, quotient -- like tw_direct; see tw_store)
     const Fr* tw_lo;    // min(n, 4096) entries: w^i
     const Fr* tw_hi;    // n >> 12 entries: w^(i << 12)   (unused when n <= 4096)
     const Fr* tw_direct;  // non-null: inter-pass twiddle = tw_direct[(rho << consumed) | K] (no generation multiply)
@@ -152,8 +167,16 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const 
 // FB != 0: the pass geometry as compile-time constants (B = FB bits, 4 columns per tile, no zero-padding skip, RADIX4 lanes):
 // the stage loop unrolls with constant strides, the LDS planes sit at immediate offsets and the loops over a tile collapse to
 // one iteration -- the same instructions on the same operands minus most of the index arithmetic.  FB = 0: everything from `a`.
-template <bool RADIX4, bool LAZY, uint32_t FB = 0>
+// CW: the twiddles this pass reads from tables -- the butterfly twiddles in LDS and the tabulated inter-pass twiddles (tw_direct)
+// -- are (plain value, quotient) pairs and multiply by fp_mul_const: 115 multiply-adds per product instead of 136 (field.hpp).
+// Twiddles COMPOSED at run time (lo x hi of the two-level tables, the coset scales, pre3 / post3) stay Montgomery products.
+// DP: tw_direct holds pairs too (the 2^16-entry table of a middle pass: 4 MiB, read out of L2).  The LAST pass's complete table
+// stays in Montgomery form whatever CW says: as pairs it is 64 B per element streamed from HBM next to the 64 B of data, and the
+// pass -- 2.1 GB per launch at 2^24 -- stopped following its instruction count (590 us either way, profiles/r6_ntt_constw.txt).
+template <bool RADIX4, bool LAZY, uint32_t FB = 0, bool CW = false, bool DP = false>
 __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
+    static_assert(!CW || LAZY, "the constant-operand product returns values of the lazy domain");
+    static_assert(!DP || CW, "pairs in tw_direct only next to pairs in tw_bfly");
     // x * w for a canonical twiddle w: canonical arithmetic, or any x < 2^256 -> a value below 2p
     auto tmul = [](const Fr& x, const Fr& w) -> Fr {
         if constexpr (LAZY) return fp_mul_wide(x, w);
@@ -164,14 +187,39 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
     uint4* t_lo = h2_smem;                  // R*C low halves
     uint4* t_hi = t_lo + (R << log_c);      // R*C high halves
     uint4* w_lo = t_hi + (R << log_c);      // R/2 butterfly twiddles, low / high halves
-    uint4* w_hi = w_lo + (R >> 1) + 1;
+    uint4* w_hi = w_lo + (R >> 1) + (CW ? 0 : 1);
+    // CW: two more planes for the quotients, no padding: a 256 x 4 tile + 128 pairs is 40 KiB exactly, four workgroups per CU
+    uint4* q_lo = w_hi + (R >> 1);
+    uint4* q_hi = q_lo + (R >> 1);
+    // x * (butterfly twiddle i)
+    struct Tw {
+        Fr w, q;
+    };
+    auto tw_get = [&](uint32_t i) __attribute__((always_inline)) -> Tw {
+        Tw t;
+        t.w = lds_get(w_lo, w_hi, i);
+        if constexpr (CW) t.q = lds_get(q_lo, q_hi, i);
+        return t;
+    };
+    auto bmul = [](const Fr& x, const Tw& t) __attribute__((always_inline)) -> Fr {
+        if constexpr (CW) return fp_mul_const(x, t.w, t.q);
+        else if constexpr (LAZY) return fp_mul_wide(x, t.w);
+        else return fp_mul(x, t.w);
+    };
     const uint32_t nthreads = FB ? ((RADIX4 ? (R >> 2) : (R >> 1)) << log_c) : blockDim.x;  // == max(R/2 * C, 1) (RADIX4: half)
     const uint32_t tid = threadIdx.x;
     const Fr* const in_p = a.batch ? a.in_b[blockIdx.y] : a.in;   // (wave-uniform: scalar loads from the kernel arguments)
     Fr* const out_p = a.batch ? a.out_b[blockIdx.y] : a.out;
     const uint32_t n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
 
-    for (uint32_t i = tid; i < (R >> 1); i += nthreads) lds_put(w_lo, w_hi, i, fp_load(a.tw_bfly + i));
+    for (uint32_t i = tid; i < (R >> 1); i += nthreads) {
+        if constexpr (CW) {
+            lds_put(w_lo, w_hi, i, fp_load(a.tw_bfly + 2 * i));
+            lds_put(q_lo, q_hi, i, fp_load(a.tw_bfly + 2 * i + 1));
+        } else {
+            lds_put(w_lo, w_hi, i, fp_load(a.tw_bfly + i));
+        }
+    }
 
     const uint32_t tile_id = blockIdx.x;
     const uint32_t total = R << log_c;
@@ -236,12 +284,22 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
             if (a.tw_direct != nullptr && !pre_scale) {
 #pragma unroll
                 for (uint32_t q0 = 0; q0 < NE; q0 += 2) {
-                    Fr w[2];
+                    if constexpr (DP) {
+                        // (plain value, quotient) pairs, one at a time: two pairs in flight next to the four elements spilled
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; q++)
-                        w[q] = fp_load(a.tw_direct + (a.direct_kmajor ? ((Kk[q0 + q] << B) | rho[q0 + q]) : ((rho[q0 + q] << a.t_log) | Kk[q0 + q])));
+                        for (uint32_t q = q0; q < q0 + 2; q++) {
+                            const size_t at = a.direct_kmajor ? ((Kk[q] << B) | rho[q]) : ((rho[q] << a.t_log) | Kk[q]);
+                            const Fr w = fp_load(a.tw_direct + 2 * at), wq = fp_load(a.tw_direct + 2 * at + 1);
+                            x[q] = fp_mul_const(x[q], w, wq);
+                        }
+                    } else {
+                        Fr w[2];
 #pragma unroll
-                    for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], w[q]);
+                        for (uint32_t q = 0; q < 2; q++)
+                            w[q] = fp_load(a.tw_direct + (a.direct_kmajor ? ((Kk[q0 + q] << B) | rho[q0 + q]) : ((rho[q0 + q] << a.t_log) | Kk[q0 + q])));
+#pragma unroll
+                        for (uint32_t q = 0; q < 2; q++) x[q0 + q] = tmul(x[q0 + q], w[q]);
+                    }
                 }
             } else if (a.log_n <= LO_BITS && !pre_scale) {
 #pragma unroll
@@ -319,30 +377,30 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
                     x0 = fp_lazy_red2p(x0);
                     x2 = fp_lazy_red2p(x2);
                     if (!unit) {
-                        const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
-                        x1 = fp_mul_wide(x1, wa);
-                        x3 = fp_mul_wide(x3, wa);
+                        const Tw wa = tw_get(r << (B - 1 - s));
+                        x1 = bmul(x1, wa);
+                        x3 = bmul(x3, wa);
                     } else {
                         x1 = fp_lazy_red2p(x1);
                         x3 = fp_lazy_red2p(x3);
                     }
                     const Fr y0 = fp_lazy_add_red(x0, x1), y1 = fp_lazy_sub_red(x0, x1);   // below 2p: added to next
                     Fr y2 = fp_lazy_add(x2, x3), y3 = fp_lazy_sub(x2, x3);                  // below 4p: multiplied next
-                    y2 = unit ? fp_lazy_red2p(y2) : fp_mul_wide(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
-                    y3 = fp_mul_wide(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
+                    y2 = unit ? fp_lazy_red2p(y2) : bmul(y2, tw_get(r << (B - 2 - s)));
+                    y3 = bmul(y3, tw_get((r + h) << (B - 2 - s)));
                     lds_put(t_lo, t_hi, i0, fp_lazy_add(y0, y2));
                     lds_put(t_lo, t_hi, i0 + 2 * step, fp_lazy_sub(y0, y2));
                     lds_put(t_lo, t_hi, i0 + step, fp_lazy_add(y1, y3));
                     lds_put(t_lo, t_hi, i0 + 3 * step, fp_lazy_sub(y1, y3));
                 } else {
                     if (!unit) {
-                        const Fr wa = lds_get(w_lo, w_hi, r << (B - 1 - s));
-                        x1 = fp_mul(x1, wa);
-                        x3 = fp_mul(x3, wa);
+                        const Tw wa = tw_get(r << (B - 1 - s));
+                        x1 = bmul(x1, wa);
+                        x3 = bmul(x3, wa);
                     }
                     Fr y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
-                    if (!unit) y2 = fp_mul(y2, lds_get(w_lo, w_hi, r << (B - 2 - s)));
-                    y3 = fp_mul(y3, lds_get(w_lo, w_hi, (r + h) << (B - 2 - s)));
+                    if (!unit) y2 = bmul(y2, tw_get(r << (B - 2 - s)));
+                    y3 = bmul(y3, tw_get((r + h) << (B - 2 - s)));
                     lds_put(t_lo, t_hi, i0, fp_add(y0, y2));
                     lds_put(t_lo, t_hi, i0 + 2 * step, fp_sub(y0, y2));
                     lds_put(t_lo, t_hi, i0 + step, fp_add(y1, y3));
@@ -384,11 +442,11 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
             const bool skip = s == 0 || (by_r && r == 0);
             if constexpr (LAZY) {
                 u = fp_lazy_red2p(u);
-                v = skip ? fp_lazy_red2p(v) : fp_mul_wide(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
+                v = skip ? fp_lazy_red2p(v) : bmul(v, tw_get(r << (B - 1 - s)));
                 lds_put(t_lo, t_hi, iu, fp_lazy_add(u, v));
                 lds_put(t_lo, t_hi, iv, fp_lazy_sub(u, v));
             } else {
-                if (!skip) v = fp_mul(v, lds_get(w_lo, w_hi, r << (B - 1 - s)));
+                if (!skip) v = bmul(v, tw_get(r << (B - 1 - s)));
                 lds_put(t_lo, t_hi, iu, fp_add(u, v));
                 lds_put(t_lo, t_hi, iv, fp_sub(u, v));
             }
@@ -441,6 +499,41 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(PassArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------- pass geometry (shared by the plan builder and the launcher)
+struct PassShape {
+    uint32_t log_c, threads;
+    bool radix4, lazy, fixed, cw;
+};
+// `avail`: the columns a tile can take -- log2 of the stride (s_log) for the passes before the last, of the DFT count for the last
+static PassShape pass_shape(uint32_t L, uint32_t B, uint32_t avail) {
+    static const int env_logc = getenv("H2_NTT_LOGC") ? atoi(getenv("H2_NTT_LOGC")) : -1;
+    // two stages per LDS round trip: four elements per lane, half the threads per tile (H2_NTT_RADIX4=0: one stage)
+    static const bool radix4 = !(getenv("H2_NTT_RADIX4") && atoi(getenv("H2_NTT_RADIX4")) == 0);
+    // the lazy domain (field.hpp: values below 4p between load and store, products without their final subtraction);
+    // H2_NTT_LAZY=0 keeps canonical residues everywhere -- same output either way
+    static const bool lazy = !(getenv("H2_NTT_LAZY") && atoi(getenv("H2_NTT_LAZY")) == 0);
+    // the common pass -- 8 bits, tiles of 4 columns, nothing skipped -- has its geometry compiled in (H2_NTT_FIXED=0: generic)
+    static const bool fixed = !(getenv("H2_NTT_FIXED") && atoi(getenv("H2_NTT_FIXED")) == 0);
+    // tabulated twiddles as (plain value, quotient) pairs, multiplied by fp_mul_const (H2_NTT_CONSTW=0: Montgomery tables)
+    static const bool constw = !(getenv("H2_NTT_CONSTW") && atoi(getenv("H2_NTT_CONSTW")) == 0);
+    PassShape sh{};
+    uint32_t log_c = (B < 8) ? (10 - B) : 2;  // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
+    if (env_logc >= 0 && B == 8) log_c = (uint32_t)env_logc;
+    if (avail < log_c) log_c = avail;
+    sh.log_c = log_c;
+    uint32_t threads = ((1u << B) >> 1) << log_c;
+    // (transforms below 2^18 are latency-bound chains of a few tiles: more lanes per tile finish them sooner)
+    sh.radix4 = radix4 && B >= 2 && threads >= 128 && L >= 18;
+    if (sh.radix4) threads >>= 1;
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    sh.threads = threads;
+    sh.lazy = lazy;
+    sh.fixed = fixed && sh.radix4 && lazy && B == 8 && log_c == 2 && threads == 256;
+    sh.cw = constw && sh.radix4 && lazy;
+    return sh;
+}
 
 // ---------------------------------------------------------------- plans
 static std::string plan_key(uint32_t log_n, const uint64_t omega[4]) {
@@ -630,24 +723,35 @@ PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hi
     uint32_t hi_count = log_n > LO_BITS ? (n >> LO_BITS) : 0;
     size_t total = lo_count + hi_count;
     std::vector<uint32_t> bf_off;
-    for (uint32_t b : pl->bits) {
+    {
+        // which passes read their tabulated twiddles as (plain, quotient) pairs: a property of the pass's geometry, fixed here
+        uint32_t consumed = 0;
+        for (size_t p = 0; p < pl->bits.size(); p++) {
+            const uint32_t B = pl->bits[p];
+            const bool last = p + 1 == pl->bits.size();
+            pl->cw.push_back(pass_shape(log_n, B, last ? consumed : log_n - consumed - B).cw ? 1 : 0);
+            consumed += B;
+        }
+    }
+    for (size_t p = 0; p < pl->bits.size(); p++) {
+        const uint32_t b = pl->bits[p];
         bf_off.push_back((uint32_t)total);
-        total += (1u << b) >> 1 ? (1u << b) >> 1 : 1;
+        total += ((1u << b) >> 1 ? (1u << b) >> 1 : 1) * (pl->cw[p] ? 2u : 1u);
     }
     H2_HIP(hipMalloc(&pl->tables, total * sizeof(Fr)));
     pl->table_bytes = total * sizeof(Fr);
     pl->tw_lo = pl->tables;
     pl->tw_hi = pl->tables + lo_count;
-    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, pl->tables, w, 1u, lo_count);
+    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, pl->tables, w, 1u, lo_count, 0u);
     if (hi_count)
         hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, pl->tables + lo_count, w,
-                           1u << LO_BITS, hi_count);
+                           1u << LO_BITS, hi_count, 0u);
     for (size_t p = 0; p < pl->bits.size(); p++) {
         uint32_t R = 1u << pl->bits[p], half = R >> 1;
         pl->tw_bfly.push_back(pl->tables + bf_off[p]);
         if (half)
             hipLaunchKernelGGL(k_pow_table, dim3((half + 255) / 256), dim3(256), 0, stream, pl->tables + bf_off[p], w,
-                               n >> pl->bits[p], half);
+                               n >> pl->bits[p], half, (uint32_t)pl->cw[p]);
     }
     // passes whose whole inter-pass twiddle set has <= 2^16 entries get it tabulated (2 MiB, L2-resident):
     // the pass then spends one multiplication per element on twiddles instead of two
@@ -659,10 +763,11 @@ PlanRef ntt_get_plan(DeviceCtx* ctx, uint32_t log_n, const uint64_t omega[4], hi
             Fr* tab = nullptr;
             if (p > 0 && !last && B + consumed <= 16) {
                 uint32_t cnt = 1u << (B + consumed);
-                H2_HIP(hipMalloc(&tab, (size_t)cnt * sizeof(Fr)));
-                pl->table_bytes += (size_t)cnt * sizeof(Fr);
+                const size_t tab_bytes = (size_t)cnt * sizeof(Fr) * (pl->cw[p] ? 2 : 1);
+                H2_HIP(hipMalloc(&tab, tab_bytes));
+                pl->table_bytes += tab_bytes;
                 hipLaunchKernelGGL(k_direct_table, dim3((cnt + 255) / 256), dim3(256), 0, stream, tab, w, consumed,
-                                   log_n - consumed - B, log_n, cnt);
+                                   log_n - consumed - B, log_n, cnt, (uint32_t)pl->cw[p]);
             }
             pl->tw_direct.push_back(tab);
             consumed += B;
@@ -737,9 +842,9 @@ ScaleTabRef ntt_scale_table(NttPlan* pl, const Fr& g, const Fr* d, hipStream_t s
         }
     } block;
     H2_HIP(hipMalloc((void**)&block.p, bytes));
-    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, block.p, g, 1u, lo_count);
+    hipLaunchKernelGGL(k_pow_table, dim3((lo_count + 255) / 256), dim3(256), 0, stream, block.p, g, 1u, lo_count, 0u);
     Fr* hi = block.p + (1u << LO_BITS);
-    hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, g, 1u << LO_BITS, hi_count);
+    hipLaunchKernelGGL(k_pow_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, g, 1u << LO_BITS, hi_count, 0u);
     if (d) hipLaunchKernelGGL(k_scale_table, dim3((hi_count + 255) / 256), dim3(256), 0, stream, hi, hi, *d, hi_count);
     H2_HIP(hipGetLastError());
     H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it (once per generator)
@@ -915,7 +1020,7 @@ static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr
                          post3[0].l[4], post3[0].l[3], post3[0].l[2], post3[0].l[1], post3[0].l[0]);
                 key = kb;
             }
-            const size_t bytes = sizeof(Fr) << L;
+            const size_t bytes = sizeof(Fr) << L;   // (Montgomery form also under CW: see k_ntt_pass's DP)
             auto pin = [&]() -> NttPlan::LastTable* {  // with g_tab_mu held
                 auto it = pl->last_direct.find(key);
                 if (it == pl->last_direct.end() || it->second.ptr == nullptr) return nullptr;
@@ -938,7 +1043,7 @@ static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr
                     tab = nullptr;
                 } else {
                     hipLaunchKernelGGL(k_last_table, dim3((1u << L) / 256), dim3(256), 0, stream, tab, pl->w, B, L,
-                                       scaled ? post3[0] : pl->w, scaled ? 1u : 0u);
+                                       scaled ? post3[0] : pl->w, scaled ? 1u : 0u, 0u);
                     H2_HIP(hipStreamSynchronize(stream));  // complete before other streams can find it
                 }
                 Fr* loser = nullptr;
@@ -965,47 +1070,43 @@ static void ntt_run_chunk(DeviceCtx* ctx, NttPlan* pl, const Fr* const* srcs, Fr
             }
         }
         {
-            // generic LDS radix-2 kernel: tile = R rows x C columns, about 1024 elements
-            static const int env_logc = getenv("H2_NTT_LOGC") ? atoi(getenv("H2_NTT_LOGC")) : -1;
-            uint32_t log_c = (B < 8) ? (10 - B) : 2;
-            if (env_logc >= 0 && B == 8) log_c = (uint32_t)env_logc;
-            uint32_t avail = last ? consumed : a.s_log;  // last pass: number of DFTs = 2^consumed
-            if (avail < log_c) log_c = avail;
-            a.log_c = log_c;
-            uint32_t R = 1u << B, C = 1u << log_c;
-            uint32_t threads = (R >> 1) * C;
-            // two stages per LDS round trip: four elements per lane, half the threads per tile (H2_NTT_RADIX4=0: one stage)
-            static const bool radix4 = !(getenv("H2_NTT_RADIX4") && atoi(getenv("H2_NTT_RADIX4")) == 0);
-            // (transforms below 2^18 are latency-bound chains of a few tiles: more lanes per tile finish them sooner)
-            a.radix4 = (radix4 && B >= 2 && threads >= 128 && L >= 18) ? 1u : 0u;
-            if (a.radix4) threads >>= 1;
-            if (threads < 64) threads = 64;
-            if (threads > 512) threads = 512;
-            uint32_t ntiles = (1u << L) / (R * C);
-            size_t lds = ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
+            const PassShape sh = pass_shape(L, B, last ? consumed : a.s_log);
+            const bool cw = pl->cw[p] != 0;   // (== sh.cw: the plan's tables were built for it)
+            a.log_c = sh.log_c;
+            a.radix4 = sh.radix4 ? 1u : 0u;
+            const uint32_t R = 1u << B, C = 1u << sh.log_c, threads = sh.threads;
+            const uint32_t ntiles = (1u << L) / (R * C);
+            // tile planes + butterfly twiddles: R/2 values and a pad, or (CW) R/2 pairs exactly -- 40 KiB for the common pass
+            const size_t lds = cw ? ((size_t)R * C + R) * sizeof(Fr) : ((size_t)R * C + (R >> 1) + 2) * sizeof(Fr);
             if (lds > 64 * 1024) {  // beyond the default dynamic LDS limit: raise it once
                 static bool raised[64] = {};  // per device
                 const int dev = ctx->device;
                 if (dev < 0 || dev >= 64 || !raised[dev]) {
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, true, 0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     H2_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     if (dev >= 0 && dev < 64) raised[dev] = true;
                 }
             }
-            // the lazy domain (field.hpp: values below 4p between load and store, products without their final subtraction);
-            // H2_NTT_LAZY=0 keeps canonical residues everywhere -- same output either way
-            static const bool lazy = !(getenv("H2_NTT_LAZY") && atoi(getenv("H2_NTT_LAZY")) == 0);
-            // the common pass -- 8 bits, tiles of 4 columns, nothing skipped -- has its geometry compiled in (H2_NTT_FIXED=0: generic)
-            static const bool fixed = !(getenv("H2_NTT_FIXED") && atoi(getenv("H2_NTT_FIXED")) == 0);
-            if (fixed && a.radix4 && lazy && B == 8 && log_c == 2 && a.zskip == 0 && threads == 256)
+            const bool dp = cw && !last;      // pairs in tw_direct: the middle passes' tables (a first pass has none)
+            if (cw && sh.fixed && a.zskip == 0 && dp)
+                hipLaunchKernelGGL((k_ntt_pass<true, true, 8, true, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
+            else if (cw && sh.fixed && a.zskip == 0)
+                hipLaunchKernelGGL((k_ntt_pass<true, true, 8, true, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
+            else if (cw && dp)
+                hipLaunchKernelGGL((k_ntt_pass<true, true, 0, true, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
+            else if (cw)
+                hipLaunchKernelGGL((k_ntt_pass<true, true, 0, true, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
+            else if (sh.fixed && a.zskip == 0)
                 hipLaunchKernelGGL((k_ntt_pass<true, true, 8>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
-            else if (a.radix4 && lazy)
+            else if (a.radix4 && sh.lazy)
                 hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else if (a.radix4)
                 hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
-            else if (lazy)
+            else if (sh.lazy)
                 hipLaunchKernelGGL((k_ntt_pass<false, true>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);
             else
                 hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(ntiles, cnt), dim3(threads), lds, stream, a);

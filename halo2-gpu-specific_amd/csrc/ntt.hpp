@@ -16,6 +16,9 @@ struct NttPlan {
     const Fr* tw_hi = nullptr;         // w^(i<<12),  i < n >> 12
     std::vector<const Fr*> tw_bfly;    // per pass: (w^(n/R))^e, e < R/2
     std::vector<const Fr*> tw_direct;  // per pass: full inter-pass twiddle table or nullptr
+    // per pass: 1 = its tw_bfly / tw_direct / last-pass tables hold (plain value, floor(value 2^256 / r)) PAIRS, the operands of
+    // the constant-operand product fp_mul_const (the radix-4 lazy passes of transforms >= 2^18; H2_NTT_CONSTW=0: none)
+    std::vector<uint8_t> cw;
     size_t table_bytes = 0;            // of `tables` and the per-pass direct tables
     std::mutex mu;                     // guards scaled_hi, last_direct
     std::map<std::string, Fr*> scaled_hi;  // divisor -> tw_hi * divisor (iNTT: 1/n folded into the last pass)

@@ -16,7 +16,7 @@ gen = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(gen)
 
 M32, M64 = (1 << 32) - 1, (1 << 64) - 1
-MAD = re.compile(r"H2_MAD_(FREE|SET|ACC)_[VS]\(([^,]+), ([^)]+)\);")
+MAD = re.compile(r"H2_MAD_(FREE|SET|ACC|WRAP)_[VS]\(([^,]+), ([^)]+)\);")
 
 
 def limbs(v):
@@ -46,6 +46,9 @@ def run(lines, p, ops, raw=False):
         g = re.fullmatch(r"P::MOD\[(\d)\]", tok)
         if g:
             return mod[int(g.group(1))]
+        g = re.fullmatch(r"P::NMOD\[(\d)\]", tok)
+        if g:
+            return limbs((1 << 256) - p)[int(g.group(1))]
         if tok in m:
             return m[tok]
         return env[tok]
@@ -59,6 +62,8 @@ def run(lines, p, ops, raw=False):
             assert carry <= 1
             if g.group(1) == "FREE":
                 assert carry == 0, "a multiply-add emitted as carry-free carried: " + ln
+            elif g.group(1) == "WRAP":
+                pass                       # the top column of a result taken mod 2^256: its carries are not wanted
             elif g.group(1) == "SET":
                 hi = carry
             else:
@@ -72,6 +77,13 @@ def run(lines, p, ops, raw=False):
         if g:
             r[int(g.group(1))] = lo & M32
             continue
+        g = re.match(r"const uint32_t (q\d) = \(uint32_t\)lo;", ln)
+        if g:
+            m[g.group(1)] = lo & M32
+            continue
+        if ln.startswith("H2_RESET"):
+            lo, hi = 0, 0
+            continue
         if ln.startswith("H2_SHIFT1"):
             lo = (lo >> 32) | (hi << 32)
             continue
@@ -80,6 +92,8 @@ def run(lines, p, ops, raw=False):
             continue
         assert ln.startswith("//") or not ln, "unparsed schedule line: " + ln
     out = sum(x << (32 * i) for i, x in enumerate(r))
+    if raw == "const":
+        return out, sum(m["q%d" % i] << (32 * i) for i in range(8))
     assert out < 2 * p, "schedule result not below 2p"
     if raw:
         return out
@@ -109,14 +123,20 @@ def run_lowered(lowered, p, ops, raw=False):
         g = re.fullmatch(r"P::MOD\[(\d)\]", tok)
         if g:
             return mod[int(g.group(1))]
+        g = re.fullmatch(r"P::NMOD\[(\d)\]", tok)
+        if g:
+            return limbs((1 << 256) - p)[int(g.group(1))]
         return m[tok] if tok in m else env[tok]
 
     for item in lowered:
         if item[0] == "asm":
             cy, written, clock = [None] * 3, [None] * 3, 0       # carry registers: value, clock of the write
+            # (the top column of the constant-operand product: a bare multiply-add whose carry is not wanted -- its blocks
+            #  consume no carry at all, which is what tells them apart here)
+            wrap_ok = raw == "const" and not any(ins[0] in ("set", "acc") for ins in item[1])
             for ins in item[1]:
                 if ins[0] == "mad":
-                    assert cy[ins[4]] is None or cy[ins[4]] == 0 or written[ins[4]] is None, "a pending carry was overwritten"
+                    assert wrap_ok or cy[ins[4]] is None or cy[ins[4]] == 0 or written[ins[4]] is None, "a pending carry was overwritten"
                     sm = lo + val(ins[1]) * val(ins[2])
                     cy[ins[4]], lo, written[ins[4]] = sm >> 64, sm & M64, clock
                     clock += 1
@@ -127,7 +147,7 @@ def run_lowered(lowered, p, ops, raw=False):
                     hi = cy[ins[1]] if ins[0] == "set" else (hi + cy[ins[1]]) & M32
                     cy[ins[1]], written[ins[1]] = None, None
                     clock += 1
-            assert all(c in (None, 0) for c in cy), "a carry was dropped at the end of a block"
+            assert wrap_ok or all(c in (None, 0) for c in cy), "a carry was dropped at the end of a block"
             continue
         ln = item[1]
         g = re.match(r"const uint32_t (m\d) = \(uint32_t\)lo \* P::INV;", ln)
@@ -135,6 +155,10 @@ def run_lowered(lowered, p, ops, raw=False):
             m[g.group(1)] = ((lo & M32) * inv) & M32
         elif re.match(r"r\.l\[(\d)\] = \(uint32_t\)lo;", ln):
             r[int(ln[4])] = lo & M32
+        elif re.match(r"const uint32_t (q\d) = \(uint32_t\)lo;", ln):
+            m[ln[15:17]] = lo & M32
+        elif ln.startswith("lo = 0;"):
+            lo, hi = 0, 0
         elif ln.startswith("lo = (lo >> 32) |"):
             lo = (lo >> 32) | (hi << 32)
         elif ln.startswith("lo >>= 32"):
@@ -142,6 +166,8 @@ def run_lowered(lowered, p, ops, raw=False):
         else:
             assert ln.startswith("//") or not ln, "unparsed line: " + ln
     out = sum(x << (32 * i) for i, x in enumerate(r))
+    if raw == "const":
+        return out, sum(m["q%d" % i] << (32 * i) for i in range(8))
     if raw:
         return out
     return out - p if out >= p else out
@@ -222,3 +248,48 @@ def test_lowered_blocks_compute_what_the_schedules_do(name):
             else:
                 ops = {"a": a, "b": b}
             assert run_lowered(lowered, p, ops, raw=True) == run(lines, p, ops, raw=True), (vname, i)
+
+
+@pytest.mark.parametrize("name", sorted(gen.FIELDS))
+def test_constant_operand_schedule_of_the_ntt_twiddles(name):
+    """fp_mul_const: x * w for a tabulated constant w < p with its quotient w' = floor(w 2^256 / p) and ANY 256-bit x, 115
+    multiply-adds: q from the anti-diagonals >= 6 of x w' is the exact quotient floor(x w' / 2^256) or one less, the result
+    x w - q p is congruent to x w, below 2p (1 + 2^-30), and at or above 2p only when q came out short (then the top limb says
+    so, which is the test fp_mul_const makes before its rare subtraction).  Logical schedule and lowered blocks alike."""
+    p = gen.FIELDS[name]
+    rng = random.Random(5)
+    lines, stats = gen.schedule_const(p)
+    assert stats["free"] + stats["set"] + stats["acc"] + stats["wrap"] == 43 + 36 + 36
+    lowered = gen.lower(lines)
+    top2p = (2 * p) >> 224
+    xs = [0, 1, p, 2 * p - 1, 2 * p, 4 * p - 1, (1 << 256) - 1, (1 << 255), 3 * p + 12345, (1 << 224) - 1, 1 << 224] + [rng.randrange(1 << 256) for _ in range(300)]
+    ws = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, 1 << 253, (1 << 224) - 1, 1 << 224] + [rng.randrange(p) for _ in range(60)]
+    short = 0
+    for i, x in enumerate(xs):
+        for w in (ws if i < 11 else ws[i % 7::7]):
+            wq = (w << 256) // p
+            out, q = run(lines, p, {"a": x, "b": w, "c": wq}, raw="const")
+            assert run_lowered(lowered, p, {"a": x, "b": w, "c": wq}, raw="const") == (out, q)
+            exact = (x * wq) >> 256
+            assert q in (exact, exact - 1) and out == x * w - q * p, (hex(x), hex(w))
+            assert out % p == x * w % p and out < 2 * p + (p >> 29)
+            if out >= 2 * p:
+                assert q == exact - 1 and (out >> 224) >= top2p
+            short += q != exact
+    # operands built so that x w' mod 2^256 is tiny -- the case in which the truncated quotient IS one short
+    hits = 0
+    for _ in range(200):
+        w = rng.randrange(1, p)
+        wq = (w << 256) // p
+        if wq % 2 == 0:
+            continue
+        x = (rng.randrange(1 << 200) * pow(wq, -1, 1 << 256)) % (1 << 256)          # x w' = (something < 2^200) mod 2^256
+        out, q = run(lines, p, {"a": x, "b": w, "c": wq}, raw="const")
+        assert run_lowered(lowered, p, {"a": x, "b": w, "c": wq}, raw="const") == (out, q)
+        exact = (x * wq) >> 256
+        assert q in (exact, exact - 1) and out == x * w - q * p and out < 2 * p + (p >> 29)
+        if q != exact:
+            hits += 1
+            fixed = out - 2 * p if (out >> 224) >= top2p and out >= 2 * p else out    # what fp_mul_const returns
+            assert fixed < 2 * p and fixed % p == x * w % p
+    assert hits > 20, "the short-quotient case was not exercised"

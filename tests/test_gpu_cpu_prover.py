@@ -23,6 +23,9 @@ def device():
     return prover.Device()
 
 
+K24_SEED_INLINE = 22
+
+
 def prove_both(device, cs, k, adv, fixed, copies, insts=(), modes=((1, False), (2, True)), cpu_kw=None, fixed_ints=False):
     """keygen + create_proof on the device and on the CPU; returns the timings of the last proof (device s, cpu s)"""
     import oracle_prover as op
@@ -120,14 +123,46 @@ def test_one_advice_column_proof_and_the_side_stream_extension(device):
 
 @pytest.mark.timeout(2400)
 @pytest.mark.parametrize("k", [20, 22] + ([] if os.environ.get("H2_TEST_CPU_PROVER_K24") == "0" else [24]))
-def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k):
-    """configs[3] (k = 22) and configs[4]'s size (k = 24: ~4 minutes of CPU work, part of the default run;
+def test_full_size_proof_bytes_equal_cpu_proof_bytes(device, k, k24_cpu_worker):
+    """configs[3] (k = 22) and configs[4]'s size (k = 24: ~3 minutes of CPU work, part of the default run;
     H2_TEST_CPU_PROVER_K24=0 skips it): the CPU side of k = 24 runs coset by coset (2 x 2^24 points instead of one
-    2^26-point extended domain per column: the same bytes, a quarter of the host memory)"""
+    2^26-point extended domain per column: the same bytes, a quarter of the host memory).  In a whole-suite run the CPU half
+    of k = 24 has been running in a process of its own since the session began (tests/conftest.py, tests/cpu_prover_worker.py)
+    and this case runs last: same SRS, witness, seed and code path, the minutes overlap with the tests in between."""
     from halo2_gpu_specific_amd import circuits
 
     adv, fixed, copies = circuits.mini_plonk_synthesize(k)
-    prove_both(device, circuits.mini_plonk(), k, adv, fixed, copies, modes=((22, False),),
+    if k == 24 and k24_cpu_worker is not None:
+        import json
+
+        from conftest import K24_SEED
+        from halo2_gpu_specific_amd import prover
+        from halo2_gpu_specific_amd.rng import ProverRng
+
+        params = prover.Params.unsafe_setup(device, k, S_TRAPDOOR)
+        pk = prover.keygen(device, params, circuits.mini_plonk(), fixed, copies)
+        prover.create_proof_ext(device, params, pk, adv, ProverRng(K24_SEED), False)   # warm
+        t0 = time.perf_counter()
+        proof = prover.create_proof_ext(device, params, pk, adv, ProverRng(K24_SEED), False)
+        t_dev = time.perf_counter() - t0
+        w = k24_cpu_worker
+        try:
+            rc = w["proc"].wait(timeout=1800)
+        finally:
+            tail = open(w["log"]).read()[-3000:]
+        assert rc == 0, "the CPU worker failed:\n" + tail
+        doc = json.load(open(w["out"]))
+        assert (doc["k"], doc["seed"], doc["use_gwc"]) == (24, K24_SEED, False)
+        assert repr(pk.fixed_commitments) == doc["fixed_commitments"] and repr(pk.perm_commitments) == doc["perm_commitments"]
+        assert repr(pk.transcript_repr) == doc["transcript_repr"]
+        want = bytes.fromhex(doc["proof"])
+        first = next((i for i in range(min(len(proof), len(want))) if proof[i] != want[i]), None)
+        assert first is None and len(proof) == len(want), \
+            "device proof differs from the CPU proof at byte %s (field %s)" % (first, first and first // 32)
+        print("k=24: device %.3f s, cpu %.1f s (keygen %.1f s) on %d threads, in a process of its own"
+              % (t_dev, doc["cpu_seconds"], doc["keygen_seconds"], doc["threads"]))
+        return
+    prove_both(device, circuits.mini_plonk(), k, adv, fixed, copies, modes=((K24_SEED_INLINE, False),),
                cpu_kw={"eval_cache": 0} if k >= 24 else None)
 
 

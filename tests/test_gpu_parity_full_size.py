@@ -38,7 +38,27 @@ def _affine(oracle, jac):
 
 @pytest.fixture(scope="module")
 def bases24(oracle):
-    return oracle.random_g1(0x48414C4F32 + 24, 1 << LOG_N)
+    """2^24 curve points.  The oracle's try-and-increment generator (the 2^20 cases) takes a minute of host time
+    at this size: these come from the library's generator (h2_dev_random_points, the same construction on the device) and a
+    sample of them is checked here with big integers -- on the curve, in the field, not all alike.  What the MSM is compared
+    with stays the oracle's own sum over exactly these points."""
+    import torch
+
+    from h2util import Q_MOD
+
+    n = 1 << LOG_N
+    t = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    from halo2_gpu_specific_amd._lib import check, lib
+    check(lib().h2_dev_random_points(0x48414C4F32 + 24, n, t.data_ptr(), None), "h2_dev_random_points")
+    check(lib().h2_synchronize(), "h2_synchronize")
+    pts = np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+    del t
+    idx = np.unique(np.concatenate([np.arange(64), np.random.default_rng(24).integers(0, n, 2048), [n - 1]]))
+    sample = arr_to_points(pts[idx])
+    assert all(0 <= x < Q_MOD and 0 <= y < Q_MOD and (y * y - x * x * x - 3) % Q_MOD == 0 for x, y in sample)
+    assert len(set(sample)) == len(sample)
+    return pts
 
 
 @pytest.fixture(scope="module")

@@ -97,6 +97,73 @@ def schedule(p, square=False, dual=False, wide=False):
     return lines, stats
 
 
+def schedule_const(p):
+    """The product by a CONSTANT (a twiddle factor of the NTT): next to the plain value w < p the table holds its quotient
+    w' = floor(w * 2^256 / p), and for ANY 256-bit x
+
+        q = floor(x w' / 2^256)   -- only the anti-diagonals i + j >= 6 of x w' are summed (43 of 64 products): the dropped
+                                     ones are below 7 * 2^224, so q is the exact quotient or one less
+        r = (x w + q (2^256 - p)) mod 2^256 = x w - q p   -- the low halves of two products (36 + 36; the top column's carries
+                                     fall off the end)
+
+    115 multiply-adds and no `m = t n'` steps, against 64 + 64 + 8 for the Montgomery form.  x w - q_exact p =
+    (f p + x e) / 2^256 with f = x w' mod 2^256 and e = w 2^256 mod p, below 2p; the truncated q is one short only when
+    f < 7 * 2^224, and then r = (f p + x e) / 2^256 + p < 2p + 7 * 2^-32 p.  So r < 2p (1 + 2^-30) always and r >= 2p almost
+    never: the caller tests the top limb and subtracts 2p in that case (field.hpp fp_mul_const).  The data stay in Montgomery
+    form (x = X R): x w = (X w) R for a PLAIN w, nothing to convert.  Operands: a = x, b = w, c = w'."""
+    nmod = [(((1 << 256) - p) >> (32 * i)) & W for i in range(8)]
+    wmax = [W] * 7 + [(p - 1) >> 224]
+    lines, stats = [], {"free": 0, "set": 0, "acc": 0, "wrap": 0}
+
+    def column(i, terms, carry_in, last):
+        """-> (exact upper bound of the carry-over, whether the third word was written)"""
+        terms = sorted(terms, key=lambda t: t[0])
+        total, nfree = carry_in, 0
+        for t in terms:
+            if total + t[0] < (1 << 64):
+                total += t[0]
+                nfree += 1
+            else:
+                break
+        lines.append("    // column %d: %d terms, %d cannot carry%s" % (i, len(terms), nfree, " (carries out of the top column are not wanted)" if last else ""))
+        carried = False
+        for k, (_, x, y, cls) in enumerate(terms):
+            kind = "WRAP" if (last and k >= nfree) else ("FREE" if k < nfree else ("ACC" if carried else "SET"))
+            if kind == "SET":
+                carried = True
+            stats[kind.lower()] += 1
+            lines.append("    H2_MAD_%s_%s(%s, %s);" % (kind, cls, x, y))
+        column_max = carry_in + sum(t[0] for t in terms)
+        assert column_max < (1 << 96)
+        return column_max >> 32, carried
+
+    # ---- q: anti-diagonals 6 .. 14 of a * c; limbs 8 .. 15 of the sum are q0 .. q7
+    lines.append("    // ---- q = floor(a c / 2^256), anti-diagonals 6..14 only (exact or one short)")
+    carry_in = 0
+    for i in range(6, 15):
+        terms = [(W * W, "a.l[%d]" % j, "c.l[%d]" % (i - j), "V") for j in range(max(0, i - 7), min(i, 7) + 1)]
+        carry_in, carried = column(i, terms, carry_in, False)
+        if i >= 8:
+            lines.append("    const uint32_t q%d = (uint32_t)lo;" % (i - 8))
+        lines.append("    H2_SHIFT%d();" % (1 if carried else 0))
+    assert carry_in < (1 << 32)          # limb 15 of the product
+    lines.append("    const uint32_t q7 = (uint32_t)lo;")
+    lines.append("    H2_RESET();")
+    # ---- r: columns 0 .. 7 of a * b + q * (2^256 - p)
+    lines.append("    // ---- r = (a b + q (2^256 - p)) mod 2^256")
+    carry_in = 0
+    for i in range(8):
+        terms = []
+        for j in range(i + 1):
+            terms.append((W * wmax[i - j], "a.l[%d]" % j, "b.l[%d]" % (i - j), "V"))
+            terms.append((W * nmod[i - j], "q%d" % j, "P::NMOD[%d]" % (i - j), "S"))
+        carry_in, carried = column(i, terms, carry_in, i == 7)
+        lines.append("    r.l[%d] = (uint32_t)lo;" % i)
+        if i < 7:
+            lines.append("    H2_SHIFT%d();" % (1 if carried else 0))
+    return lines, stats
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Lowering of a logical schedule (the macro lines above, which tests/test_fp_mul_schedule.py executes with Python integers)
 # to inline-assembly BLOCKS.  One asm statement per instruction made the compiler put an `s_nop` behind almost every
@@ -111,7 +178,7 @@ WAIT = 2            # wait states between a VALU that writes an SGPR and a VALU 
 MAX_OPERANDS = 30   # of one asm statement (clang's limit)
 import re as _re
 
-_MAD = _re.compile(r"H2_MAD_(FREE|SET|ACC)_([VS])\(([^,]+), ([^)]+)\);")
+_MAD = _re.compile(r"H2_MAD_(FREE|SET|ACC|WRAP)_([VS])\(([^,]+), ([^)]+)\);")
 
 
 def lower(lines):
@@ -146,6 +213,8 @@ def lower(lines):
             out.append(("c", "lo = (lo >> 32) | ((uint64_t)hi << 32);"))
         elif t.startswith("H2_SHIFT0"):
             out.append(("c", "lo >>= 32;"))
+        elif t.startswith("H2_RESET"):
+            out.append(("c", "lo = 0;"))
         else:
             out.append(("c", t))
     flush()
@@ -157,7 +226,7 @@ def _schedule_block(terms):
     for k, (kind, cls, x, y) in enumerate(terms):
         reg = k % 3
         instrs.append(("mad", x, y, cls, reg))
-        if kind != "FREE":
+        if kind not in ("FREE", "WRAP"):
             pending.append((len(instrs) - 1, kind, reg))
         # consume what is WAIT instructions old (and must go before its register comes round again)
         while pending and len(instrs) - 1 - pending[0][0] >= WAIT:
@@ -175,7 +244,7 @@ def _schedule_block(terms):
     for ins in instrs:
         if ins[0] == "mad":
             assert ins[4] not in live, "carry register reused before its carry was consumed"
-            if terms[nmad][0] != "FREE":
+            if terms[nmad][0] not in ("FREE", "WRAP"):
                 live[ins[4]] = clock
             nmad += 1
             clock += 1
@@ -303,6 +372,24 @@ def main():
         out.append("}")
         out.append("")
         print(name, "wide", stats)
+        # (any 256-bit value) * (a tabulated constant with its quotient) -> below 2p (1 + 2^-30): the NTT's twiddle products
+        lines, stats = schedule_const(p)
+        out.append("// %s by a constant: a < 2^256, b = w < p plain, c = floor(w 2^256 / p); result = a w - q p < 2p (1 + 2^-30), NOT reduced:"
+                   % name)
+        out.append("// %d bare multiply-adds, %d carry-setting, %d carry-accumulating, %d whose carry falls off the top column"
+                   % (stats["free"], stats["set"], stats["acc"], stats["wrap"]))
+        out.append("template <>")
+        out.append("__device__ __forceinline__ Fp<%s> fp_mul_const_dev<%s>(const Fp<%s>& a, const Fp<%s>& b, const Fp<%s>& c) {" % ((name,) * 5))
+        out.append("    using P = %s;" % name)
+        out.append("    Fp<P> r;")
+        out.append("    uint64_t lo = 0, cy0, cy1, cy2;")
+        out.append("    uint32_t hi = 0;")
+        out += emit(lower(lines))
+        out.append("    (void)cy0; (void)cy1; (void)cy2; (void)hi;")
+        out.append("    return r;")
+        out.append("}")
+        out.append("")
+        print(name, "const", stats)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "halo2-gpu-specific_amd", "csrc", "fp_mul_gen.hpp")
     with open(path, "w") as f:
         f.write("\n".join(out))
