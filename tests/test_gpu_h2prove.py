@@ -1,0 +1,58 @@
+"""tools/h2prove.cpp on the GPU: the resident mini-PLONK prover written against the C ABI alone (plain C++: h2_dev_alloc, a
+stream, h2_dev_* calls, its own Blake2b transcript -- no Python, no torch, no HIP headers) makes the SAME PROOF BYTES as
+halo2-gpu-specific_amd/prover.py and as the hashes committed in tests/golden/proof_hash_kat.json (which the big-integer prover
+of tests/ref_plonk.py pins): the exported h2_dev_* boundary is sufficient for a whole create_proof from a host that is not Python
+(plonk/prover.rs:206-850, transcript.rs:81-215 restated in the tool)."""
+import hashlib
+import json
+import os
+import subprocess
+import time
+
+import pytest
+
+from test_h2prove_host import ROOT, build_tool
+
+pytestmark = pytest.mark.gpu
+
+KAT = {(e["k"], e["seed"]): e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "proof_hash_kat.json")))
+       if e["circuit"] == "mini-plonk" and e["scheme"] == "shplonk"}
+
+
+def run_tool(k, seed, *extra):
+    out = subprocess.run([build_tool(), str(k), str(seed), *extra], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = {ln.split(" ", 1)[0]: ln.split(" ", 1)[1] for ln in out.stdout.strip().splitlines()}
+    f = lines["k"].split()
+    stats = dict(zip(f[1::2], f[2::2]))
+    return bytes.fromhex(lines["proof"]), int(lines["vk_digest"], 16), stats
+
+
+@pytest.mark.parametrize("k,seed", [(12, 12), (16, 16), (22, 22)])
+def test_h2prove_bytes_equal_the_committed_hashes_and_the_python_prover(k, seed):
+    kat = KAT[(k, seed)]
+    proof, vk, stats = run_tool(k, seed, "--reps", "3")
+    assert vk == int(kat["vk_digest"], 16)
+    assert len(proof) == kat["length"] and hashlib.sha256(proof).hexdigest() == kat["sha256"]
+    assert int(stats["generated_launches"]) >= 1, "evaluate_h must have run as generated kernels in the tool's process too"
+    # the same proof through prover.py (torch's allocator and streams around the same C ABI), timed next to the tool
+    from halo2_gpu_specific_amd import circuits, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    D = prover.Device()
+    params = prover.Params.unsafe_setup(D, k, int(kat["trapdoor"], 16))
+    adv, fixed, copies = circuits.mini_plonk_synthesize(k, alloc=D.pinned_columns)
+    pk = prover.keygen(D, params, circuits.mini_plonk(), fixed, copies)
+    assert prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(seed)) == proof
+    t0 = time.perf_counter()
+    prover.create_proof_with_shplonk(D, params, pk, adv, ProverRng(seed))
+    t_py = time.perf_counter() - t0
+    print("k=%d: h2prove (C++ over the C ABI, one stream, no overlap) create_proof %.4f s (keygen %.3f s), prover.py %.4f s"
+          % (k, float(stats["create_proof_s"]), float(stats["keygen_s"]), t_py))
+
+
+def test_h2prove_other_seed_other_proof_and_file_output(tmp_path):
+    a, _, _ = run_tool(10, 1, "--no-tables")
+    out = tmp_path / "p.bin"
+    b, _, _ = run_tool(10, 2, "--out", str(out))
+    assert a != b and len(a) == len(b) == 960 and out.read_bytes() == b
