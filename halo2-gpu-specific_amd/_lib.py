@@ -55,6 +55,8 @@ SYMBOLS = {
     "h2_msm_multi": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),
     "h2_bases_register": (ctypes.c_int, [_vp, _sz]),
     "h2_bases_unregister": (ctypes.c_int, [_vp]),
+    "h2_poly_register": (ctypes.c_int, [_vp, _sz]),
+    "h2_poly_unregister": (ctypes.c_int, [_vp]),
     "h2_g1_sum": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_msm_intt": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _u32, _vp]),
     "h2_batch_mont": (ctypes.c_int, [_vp, _sz]),

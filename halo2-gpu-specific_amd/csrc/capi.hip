@@ -59,6 +59,65 @@ int dev_extended_to_coeff_impl(DeviceCtx* ctx, Fr* d_a, Fr* d_tmp, uint32_t exte
                         have_lock);
 }
 
+// A host vector that a call only READS: the device copy of a range registered with h2_poly_register (uploaded once per device:
+// the proving key's coefficient forms, a proof's final polynomials), or nullptr -- the caller then uploads as the reference does.
+const Fr* resident_operand(DeviceCtx* ctx, const uint64_t* host, size_t n) { return host ? poly_resident(ctx, host, n) : nullptr; }
+
+// Elementwise host-slice operations over long vectors run as a pipeline of chunks on three streams of the slot: chunk c + 1
+// crosses PCIe on the copy stream while the kernel of chunk c runs on the compute stream and the result of chunk c - 1 leaves
+// on the third -- the two directions of the link at once, instead of upload-all -> compute -> download-all on one stream.
+// Two staging slots; `up` / `run` / `down` enqueue on the stream they are handed.  From page-locked host memory the copies are
+// asynchronous DMA and the overlap is real; from ordinary memory hipMemcpyAsync stages and returns when the source has been
+// read, so the chunks follow one another as before (no worse: the same bytes in smaller pieces).
+constexpr size_t PIPE_CHUNK = (size_t)1 << 19;      // elements per chunk: 16 MiB
+constexpr size_t PIPE_MIN = (size_t)1 << 21;        // shorter vectors keep the single-shot form
+template <class Up, class Run, class Down>
+void pipeline_chunks(DeviceCtx* ctx, size_t total, Up up, Run run, Down down) {
+    hipEvent_t in_done[2], k_done[2], out_done[2];
+    for (int i = 0; i < 2; i++) {
+        H2_HIP(hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming));
+        H2_HIP(hipEventCreateWithFlags(&k_done[i], hipEventDisableTiming));
+        H2_HIP(hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming));
+    }
+    struct Guard {
+        hipEvent_t* a;
+        hipEvent_t* b;
+        hipEvent_t* c;
+        DeviceCtx* ctx;
+        ~Guard() {
+            // (also on the way out of a throw: nothing may still be reading the staging slots when the caller's frame goes)
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->aux_stream[0]);
+            for (int i = 0; i < 2; i++) {
+                (void)hipEventDestroy(a[i]);
+                (void)hipEventDestroy(b[i]);
+                (void)hipEventDestroy(c[i]);
+            }
+        }
+    } guard{in_done, k_done, out_done, ctx};
+    size_t c = 0;
+    for (size_t off = 0; off < total; off += PIPE_CHUNK, c++) {
+        const size_t len = std::min(PIPE_CHUNK, total - off);
+        const int slot = (int)(c & 1);
+        if (c >= 2) H2_HIP(hipStreamWaitEvent(ctx->copy_stream, out_done[slot], 0));   // the slot's previous result has left
+        up(off, len, slot, ctx->copy_stream);
+        H2_HIP(hipEventRecord(in_done[slot], ctx->copy_stream));
+        H2_HIP(hipStreamWaitEvent(ctx->stream, in_done[slot], 0));
+        run(off, len, slot, ctx->stream);
+        H2_HIP(hipEventRecord(k_done[slot], ctx->stream));
+        H2_HIP(hipStreamWaitEvent(ctx->aux_stream[0], k_done[slot], 0));
+        down(off, len, slot, ctx->aux_stream[0]);
+        H2_HIP(hipEventRecord(out_done[slot], ctx->aux_stream[0]));
+    }
+    H2_HIP(hipStreamSynchronize(ctx->aux_stream[0]));
+    H2_HIP(hipStreamSynchronize(ctx->stream));
+}
+bool pipeline_enabled() {
+    static const bool on = !(getenv("H2_HOST_PIPELINE") && atoi(getenv("H2_HOST_PIPELINE")) == 0);
+    return on;
+}
+
 }  // namespace
 
 extern "C" {
@@ -258,8 +317,12 @@ int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint
         Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
         // into_coset = true: coset_powers = [g_coset, g_coset_inv] (domain.rs:383-385)
         Fr pre3[3] = {fr_from_u64x4(g_coset), fr_from_u64x4(g_coset), fr_from_u64x4(g_coset_inv)};
-        H2_HIP(hipMemcpyAsync(d_in, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-        int rc = dev_ntt_impl(ctx, d_in, d_in, d_t, 1u << k, extended_omega, extended_k, pre3, nullptr, ctx->stream, true);
+        const Fr* src = resident_operand(ctx, coeffs, (size_t)1 << k);
+        if (!src) {
+            H2_HIP(hipMemcpyAsync(d_in, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+            src = d_in;
+        }
+        int rc = dev_ntt_impl(ctx, src, d_in, d_t, 1u << k, extended_omega, extended_k, pre3, nullptr, ctx->stream, true);
         if (rc != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(out, d_in, ext_bytes, hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
@@ -297,6 +360,22 @@ static int host_batch_mont(uint64_t* a, size_t n, bool to_mont) {
         DeviceCtx* ctx = lease.ctx;
         size_t bytes = n * sizeof(Fr);
         if (n == 0) return (int)H2_OK;
+        if (pipeline_enabled() && n >= PIPE_MIN) {
+            Fr* slots = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
+            int rc = H2_OK;
+            pipeline_chunks(ctx, n,
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                },
+                [&](size_t, size_t len, int slot, hipStream_t st) {
+                    int r = batch_mont_launch(slots + slot * PIPE_CHUNK, len, to_mont, st);
+                    if (r != H2_OK) rc = r;
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                });
+            return rc;
+        }
         Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
         H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
         int rc = batch_mont_launch(d_a, n, to_mont, ctx->stream);
@@ -318,11 +397,43 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
         DeviceCtx* ctx = lease.ctx;
         size_t bytes = size * sizeof(Fr);
         if (size == 0) return (int)H2_OK;
+        const Fr* res_l = resident_operand(ctx, l, size);
+        const Fr* res_r = resident_operand(ctx, r, size);
+        if (pipeline_enabled() && size >= PIPE_MIN && l_rot == 0 && r_rot == 0) {
+            // no rotation: element i depends on element i of the operands only -- chunk by chunk, both directions of PCIe at once
+            Fr* sl = (l && !res_l) ? (Fr*)ctx->buf_b.get(2 * PIPE_CHUNK * sizeof(Fr)) : nullptr;
+            Fr* sr = (r && !res_r) ? (Fr*)ctx->buf_c.get(2 * PIPE_CHUNK * sizeof(Fr)) : nullptr;
+            Fr* so = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
+            int rc = H2_OK;
+            pipeline_chunks(ctx, size,
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    if (sl) H2_HIP(hipMemcpyAsync(sl + slot * PIPE_CHUNK, l + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                    if (sr) H2_HIP(hipMemcpyAsync(sr + slot * PIPE_CHUNK, r + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    const Fr* pl = !l ? nullptr : (res_l ? res_l + off : sl + slot * PIPE_CHUNK);
+                    const Fr* pr = !r ? nullptr : (res_r ? res_r + off : sr + slot * PIPE_CHUNK);
+                    int rr = eval_op_launch(op, so + slot * PIPE_CHUNK, pl, pr, 0, 0, len, c, st);
+                    if (rr != H2_OK) rc = rr;
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(res + 4 * off, so + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                });
+            return rc;
+        }
         Fr* d_res = (Fr*)ctx->buf_a.get(bytes);
-        Fr* d_l = l ? (Fr*)ctx->buf_b.get(bytes) : nullptr;
-        Fr* d_r = r ? (Fr*)ctx->buf_c.get(bytes) : nullptr;
-        if (l) H2_HIP(hipMemcpyAsync(d_l, l, bytes, hipMemcpyHostToDevice, ctx->stream));
-        if (r) H2_HIP(hipMemcpyAsync(d_r, r, bytes, hipMemcpyHostToDevice, ctx->stream));
+        const Fr* d_l = res_l;
+        const Fr* d_r = res_r;
+        if (l && !d_l) {
+            Fr* up = (Fr*)ctx->buf_b.get(bytes);
+            H2_HIP(hipMemcpyAsync(up, l, bytes, hipMemcpyHostToDevice, ctx->stream));
+            d_l = up;
+        }
+        if (r && !d_r) {
+            Fr* up = (Fr*)ctx->buf_c.get(bytes);
+            H2_HIP(hipMemcpyAsync(up, r, bytes, hipMemcpyHostToDevice, ctx->stream));
+            d_r = up;
+        }
         int rc = eval_op_launch(op, d_res, d_l, d_r, l_rot, r_rot, size, c, ctx->stream);
         if (rc != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -337,6 +448,26 @@ int h2_divide_by_vanishing_poly(uint64_t* a, size_t size, const uint64_t* t_eval
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
         if (size == 0) return (int)H2_OK;
+        if (pipeline_enabled() && size >= PIPE_MIN && t_len && PIPE_CHUNK % t_len == 0) {
+            // a[i] *= t[i % t_len]: a chunk that starts at a multiple of t_len sees the table from its first entry
+            Fr* slots = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
+            Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
+            H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            H2_HIP(hipStreamSynchronize(ctx->stream));
+            int rc = H2_OK;
+            pipeline_chunks(ctx, size,
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                },
+                [&](size_t, size_t len, int slot, hipStream_t st) {
+                    int r = divide_by_vanishing_launch(slots + slot * PIPE_CHUNK, len, d_t, t_len, st);
+                    if (r != H2_OK) rc = r;
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                });
+            return rc;
+        }
         Fr* d_a = (Fr*)ctx->buf_a.get(size * sizeof(Fr));
         Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
         H2_HIP(hipMemcpyAsync(d_a, a, size * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
@@ -360,6 +491,16 @@ int h2_msm(const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t ma
         DeviceLease lease;
         return msm_host(lease.ctx, scalars, bases, n, max_bits, out_xyz);
     });
+}
+
+int h2_poly_register(const uint64_t* values, size_t n) {
+    if (!values || n == 0) return bad("h2_poly_register: null / empty range");
+    return poly_register(values, n);
+}
+
+int h2_poly_unregister(const uint64_t* values) {
+    if (!values) return bad("h2_poly_unregister: null argument");
+    return guarded([&] { return bases_unregister(values); });   // one registry: the device copies are freed the same way
 }
 
 int h2_bases_register(const uint64_t* bases, size_t n) {
@@ -749,9 +890,13 @@ int h2_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], 
     return guarded([&] {
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
-        Fr* d = (Fr*)ctx->buf_a.get((n ? n : 1) * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(eval_polynomial_tmp_elems(n) * sizeof(Fr));
-        if (n) H2_HIP(hipMemcpyAsync(d, poly, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr* d = n ? resident_operand(ctx, poly, n) : nullptr;
+        if (!d) {
+            Fr* up = (Fr*)ctx->buf_a.get((n ? n : 1) * sizeof(Fr));
+            if (n) H2_HIP(hipMemcpyAsync(up, poly, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            d = up;
+        }
         return eval_polynomial_launch(d, n, point, tmp, out, ctx->stream);
     });
 }
@@ -797,10 +942,14 @@ int h2_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t*
         if (n < 2) return (int)H2_OK;
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
-        Fr* d_a = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         Fr* d_q = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
-        H2_HIP(hipMemcpyAsync(d_a, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr* d_a = resident_operand(ctx, a, n);
+        if (!d_a) {
+            Fr* up = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+            H2_HIP(hipMemcpyAsync(up, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            d_a = up;
+        }
         int rc = kate_division_launch(d_a, n, b, d_q, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
         H2_HIP(hipMemcpyAsync(q, d_q, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
@@ -860,12 +1009,41 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
             memset(res, 0, bytes);
             return (int)H2_OK;
         }
-        Fr* d_all = (Fr*)ctx->buf_a.get(bytes * count);
-        Fr* d_res = (Fr*)ctx->buf_b.get(bytes);
+        // operands inside a range registered with h2_poly_register are read where they lie on the device; the others cross PCIe
         std::vector<const Fr*> ptrs(count);
+        std::vector<size_t> staged;                     // operands that have to be uploaded
         for (size_t i = 0; i < count; i++) {
-            ptrs[i] = d_all + i * size;
-            H2_HIP(hipMemcpyAsync(d_all + i * size, polys[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+            ptrs[i] = resident_operand(ctx, polys[i], size);
+            if (!ptrs[i]) staged.push_back(i);
+        }
+        if (pipeline_enabled() && size >= PIPE_MIN) {
+            // chunk by chunk: the operands' chunk c + 1 goes up while chunk c is combined and the result of chunk c - 1 comes down
+            Fr* sin = staged.empty() ? nullptr : (Fr*)ctx->buf_a.get(2 * staged.size() * PIPE_CHUNK * sizeof(Fr));
+            Fr* sout = (Fr*)ctx->buf_b.get(2 * PIPE_CHUNK * sizeof(Fr));
+            int rc = H2_OK;
+            pipeline_chunks(ctx, size,
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    for (size_t j = 0; j < staged.size(); j++)
+                        H2_HIP(hipMemcpyAsync(sin + (slot * staged.size() + j) * PIPE_CHUNK, polys[staged[j]] + 4 * off, len * sizeof(Fr),
+                                              hipMemcpyHostToDevice, st));
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    std::vector<const Fr*> at(count);
+                    for (size_t i = 0; i < count; i++) at[i] = ptrs[i] ? ptrs[i] + off : nullptr;
+                    for (size_t j = 0; j < staged.size(); j++) at[staged[j]] = sin + (slot * staged.size() + j) * PIPE_CHUNK;
+                    int r = lincomb_launch(sout + slot * PIPE_CHUNK, at.data(), coeffs, count, len, st);
+                    if (r != H2_OK) rc = r;
+                },
+                [&](size_t off, size_t len, int slot, hipStream_t st) {
+                    H2_HIP(hipMemcpyAsync(res + 4 * off, sout + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                });
+            return rc;
+        }
+        Fr* d_all = staged.empty() ? nullptr : (Fr*)ctx->buf_a.get(bytes * staged.size());
+        Fr* d_res = (Fr*)ctx->buf_b.get(bytes);
+        for (size_t j = 0; j < staged.size(); j++) {
+            ptrs[staged[j]] = d_all + j * size;
+            H2_HIP(hipMemcpyAsync(d_all + j * size, polys[staged[j]], bytes, hipMemcpyHostToDevice, ctx->stream));
         }
         int rc = lincomb_launch(d_res, ptrs.data(), coeffs, count, size, ctx->stream);
         if (rc != H2_OK) return rc;

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "evalh.hpp"
+#include "msm.hpp"
 #include "evalh_gen.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
@@ -872,9 +873,14 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
         std::map<const uint64_t*, std::pair<Fr*, Fr*>> cols;
         auto add = [&](const uint64_t* h) {
             if (!h || cols.count(h)) return;
-            Fr* dc = (Fr*)dmalloc(nbytes);
+            // a vector inside a range registered with h2_poly_register (the proving key's fixed / sigma / l_0 / l_last forms,
+            // plonk.rs:226-240) already has its device copy: only read here, never written
+            Fr* dc = const_cast<Fr*>(poly_resident(ctx, h, n));
+            if (!dc) {
+                dc = (Fr*)dmalloc(nbytes);
+                H2_HIP(hipMemcpyAsync(dc, h, nbytes, hipMemcpyHostToDevice, stream));
+            }
             Fr* dv = (Fr*)dmalloc(nbytes);
-            H2_HIP(hipMemcpyAsync(dc, h, nbytes, hipMemcpyHostToDevice, stream));
             cols[h] = {dc, dv};
         };
         size_t n_lookup_z = 0;

@@ -2275,17 +2275,28 @@ size_t msm_batch_scratch_bytes(size_t n, uint32_t max_bits, size_t count) {
 // about as long as the MSM itself.
 namespace {
 struct Registration {
-    size_t len;
+    size_t len;    // in units of `unit` bytes: points (64) for an SRS range, field elements (32) for a polynomial
     uint64_t gen;  // bumped by every register / unregister: a device copy made for another generation is stale
+    uint32_t unit; // 64: G1Affine points (h2_bases_register); 32: Fr coefficients / values (h2_poly_register: no table)
 };
 std::mutex g_reg_mu;
-std::map<const uint64_t*, Registration> g_registered;  // host base pointer -> points, generation
+std::map<const uint64_t*, Registration> g_registered;  // host pointer -> length, generation, element size
 uint64_t g_reg_gen = 0;
 }  // namespace
 
 int bases_register(const uint64_t* bases, size_t n) {
     std::lock_guard<std::mutex> g(g_reg_mu);
-    g_registered[bases] = Registration{n, ++g_reg_gen};
+    g_registered[bases] = Registration{n, ++g_reg_gen, 64u};
+    return H2_OK;
+}
+
+// h2_poly_register: a host vector of n field elements the caller promises not to modify -- the proving key's fixed / sigma / l_0 /
+// l_last coefficient forms (plonk.rs:226-240), read by every proof (plonk/evaluation.rs:1229-1241, prover.rs:731-737) -- so that
+// the host-slice entry points that READ vectors find a device copy uploaded once per device instead of crossing PCIe per call.
+// Same registry, generations and unregister path as the SRS ranges; no shifted-base table, of course.
+int poly_register(const uint64_t* values, size_t n) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_registered[values] = Registration{n, ++g_reg_gen, 32u};
     return H2_OK;
 }
 
@@ -2325,9 +2336,23 @@ int bases_unregister(const uint64_t* bases) {
 // device copy of a registered range that contains [bases, bases + n) -- or nullptr.  A copy is reused only for the
 // registration (generation, length) it was uploaded for: unregister + refill + register of the same address uploads
 // the new points.
+static const void* resident_lookup_unit(DeviceCtx* ctx, const uint64_t* bases, size_t n, uint32_t unit);
 static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size_t n) {
+    return (const Affine*)resident_lookup_unit(ctx, bases, n, 64u);
+}
+// the device copy of host Fr values [values, values + n) when they lie inside a range registered with h2_poly_register (uploaded
+// on this device's first use, complete when this returns) -- or nullptr: the caller uploads as before.  Call with the slot's lock.
+const Fr* poly_resident(DeviceCtx* ctx, const uint64_t* values, size_t n) {
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        if (g_registered.empty()) return nullptr;     // (the common case of a caller that registers nothing: no device lock taken)
+    }
+    return (const Fr*)resident_lookup_unit(ctx, values, n, 32u);
+}
+static const void* resident_lookup_unit(DeviceCtx* ctx, const uint64_t* bases, size_t n, uint32_t unit) {
     const uint64_t* key = nullptr;
-    Registration reg{0, 0};
+    Registration reg{0, 0, 0};
+    const size_t words = unit / 8;
     // the device copies are shared by the host-API slots of the device: one slot uploads (and tabulates) an SRS, the other
     // waits here and finds it complete
     std::lock_guard<std::mutex> shared_lock(ctx->shared->mu);
@@ -2350,7 +2375,9 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         auto it = g_registered.upper_bound(bases);
         if (it == g_registered.begin()) return nullptr;
         --it;
-        if (bases + 8 * n > it->first + 8 * it->second.len) return nullptr;
+        if (it->second.unit != unit) return nullptr;      // points asked of a polynomial's range or the reverse
+        if (bases + words * n > it->first + words * it->second.len) return nullptr;
+        if ((size_t)(bases - it->first) % words) return nullptr;   // (not on an element boundary of the registered range)
         key = it->first;
         reg = it->second;
     }
@@ -2360,8 +2387,8 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         ResidentCopy c;
         c.len = reg.len;
         c.gen = reg.gen;
-        H2_HIP(hipMalloc(&c.ptr, reg.len * sizeof(Affine)));
-        H2_HIP(hipMemcpyAsync(c.ptr, key, reg.len * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+        H2_HIP(hipMalloc(&c.ptr, reg.len * (size_t)unit));
+        H2_HIP(hipMemcpyAsync(c.ptr, key, reg.len * (size_t)unit, hipMemcpyHostToDevice, ctx->stream));
         rit = ctx->resident.emplace((const void*)key, c).first;
         // a registered SRS is committed against for the life of the process: give its device copy a shifted-base table
         // when that takes less than half of the free memory (H2_MSM_TABLES=0: never)
@@ -2369,7 +2396,7 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         // windowed pipeline answers with the same point
         const char* env = getenv("H2_MSM_TABLES");
         size_t free_b = 0, total_b = 0;
-        if (!(env && env[0] == '0') && reg.len >= ((size_t)1 << 15) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        if (unit == 64u && !(env && env[0] == '0') && reg.len >= ((size_t)1 << 15) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
             bases_precompute_bytes(reg.len, 0) < free_b / 2) {
             try {
                 if (bases_precompute((const uint64_t*)c.ptr, reg.len, 0, ctx->stream) != H2_OK) (void)hipGetLastError();
@@ -2379,7 +2406,7 @@ static const Affine* resident_lookup(DeviceCtx* ctx, const uint64_t* bases, size
         }
         H2_HIP(hipStreamSynchronize(ctx->stream));  // complete before another slot (another stream) can find it
     }
-    return (const Affine*)rit->second.ptr + (bases - key) / 8;
+    return (const char*)rit->second.ptr + (size_t)(bases - key) * 8;
 }
 
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n, uint32_t max_bits,

@@ -15,6 +15,11 @@ int msm_device_batch(DeviceCtx* ctx, const Fr* const* d_scalars, size_t count, c
                      uint32_t max_bits, void* d_scratch, size_t scratch_bytes, uint64_t* out_xyz, hipStream_t stream);
 int bases_register(const uint64_t* bases, size_t n);
 int bases_unregister(const uint64_t* bases);
+// h2_poly_register: host Fr vectors the caller will not modify (the proving key's coefficient forms, a proof's final polynomials):
+// the same registry / generations / unregister path as the SRS ranges, no table.  poly_resident: the device copy of
+// [values, values + n) when it lies inside such a range (uploaded on the device's first use, complete on return), else nullptr.
+int poly_register(const uint64_t* values, size_t n);
+const Fr* poly_resident(DeviceCtx* ctx, const uint64_t* values, size_t n);
 int msm_host(DeviceCtx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
              uint64_t out_xyz[12]);
 int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_t* bases, size_t n,

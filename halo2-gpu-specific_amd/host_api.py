@@ -290,12 +290,13 @@ class HostApiDevice(P.Device):
     call per circuit instance, as `Evaluator::evaluate_h` under the cuda / hip feature does."""
     quotient_from_coeffs = True
 
-    def __init__(self, device=0, pinned=False, workers=4):
+    def __init__(self, device=0, pinned=False, workers=4, register_polys=True):
         """`pinned`: every host vector lives in page-locked memory (a Rust-side allocator over h2_host_alloc_pinned for
         `Polynomial::values`): the same calls, but their transfers are DMA instead of staged pageable copies.  `workers`:
         threads that issue the calls of a per-column loop (the reference's rayon par_iters); 1 = strictly sequential"""
         self.pinned = pinned
         self.workers = workers
+        self.register_polys, self._retained = register_polys, []     # register_polys=False: the data flow of rounds 4-5
         import torch
 
         if not torch.cuda.is_available():
@@ -363,6 +364,37 @@ class HostApiDevice(P.Device):
 
     def sync(self):
         pass
+
+    # -- h2_poly_register: what the Rust side does at the same points (integration/hip.rs register_polys / unregister_polys) --
+    def retain(self, vectors, owner=None):
+        """final host vectors -> registered with the library: every later host-slice call that READS one of them (the evaluator's
+        columns, h2_eval_polynomial, h2_lincomb operands, h2_kate_division) uses a device copy uploaded once.  `owner`: kept
+        for the owner's life (the proving key); otherwise until release_retained (the end of the proof)."""
+        import weakref
+
+        if not self.register_polys:
+            return
+        R = self.L.R
+        ptrs = []
+        for t in vectors:
+            if t is None or t.numel() == 0:
+                continue
+            assert t.is_contiguous()
+            check(R.h2_poly_register(t.data_ptr(), t.shape[0]), "h2_poly_register")
+            ptrs.append(t.data_ptr())
+        if owner is not None:
+            weakref.finalize(owner, _unregister_polys, R, ptrs).atexit = False
+        else:
+            self._retained += ptrs
+
+    def release_retained(self):
+        _unregister_polys(self.L.R, self._retained)
+        self._retained = []
+
+
+def _unregister_polys(R, ptrs):
+    for p in ptrs:
+        R.h2_poly_unregister(p)
 
 
 def _unregister(R, ptrs):

@@ -369,6 +369,16 @@ class Device:
     def sync(self):
         self.tstream.synchronize()
 
+    # -- vectors that will not change any more (hooks for the host-slice data flow; nothing to do for resident vectors) ----------
+    def retain(self, vectors, owner=None):
+        """`vectors` are final from here on -- the proving key's coefficient forms (owner = the key), or a proof's advice /
+        product / quotient polynomials (until `release_retained`).  On this device they already live in HBM; the literal
+        drop-in (host_api.HostApiDevice) registers them with the library (h2_poly_register) so that later calls that read them
+        find a device copy instead of uploading them again."""
+
+    def release_retained(self):
+        """end of a proof: the per-proof registrations of `retain` go"""
+
     def scratch(self, nbytes):
         if self._scratch is None or self._scratch.numel() < nbytes:
             self._scratch = None
@@ -1163,6 +1173,7 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     # residency decided here for one and then runs coset by coset from tables built on demand (create_proof_ext)
     pk.coset_builder = coset_tables
     pk.l0_poly, pk.l_last_poly = l0_poly, l_last_poly     # (the cuda-shaped evaluator takes l0 / l_last as coefficient forms)
+    D.retain(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly], owner=pk)   # read by every proof, never written
     if plan is None:
         pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
         pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)
@@ -1431,6 +1442,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     transcript = Blake2bWrite()
     transcript.common_scalar(pk.transcript_repr)
+    D.release_retained()                     # (a proof that raised half way left its registrations behind)
     if D.group_size > 1:
         rng = rng.shared(D.group)            # every rank of one proof draws the same blinding values
 
@@ -1561,6 +1573,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     random_poly = D.empty(n)
     check(L.h2_dev_random_fr(rng.random_poly_key(), n, random_poly.data_ptr(), D.stream), "h2_dev_random_fr")
     random_commitment = D.msm_async(random_poly, params.g, n)   # collected where the transcript needs it
+    D.retain([random_poly])
     # the blinding rows of every column (drawn column by column, as the reference does) go up in one copy
     blind = np.zeros((max(len(uploads), 1), n - usable, 4), dtype=np.int64)
     for ci in range(len(uploads)):
@@ -1825,6 +1838,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     else:
         for C in circuits:
             C["advice_polys"] = D.intt_many(C["advice"], dom)           # in place: the Lagrange values are not needed again
+    # the coefficient forms of the witness and of the product columns are final: evaluator, evaluations and openings read them
+    D.retain([t for C in circuits for t in list(C["advice_polys"]) + list(C["instance_polys"]) + list(C["z_polys"]) +
+              [z_ for st in C["lookups"] for z_ in st["z_polys"]] + [st["m_poly"] for st in C["lookups"]] + list(C["shuffle_polys"])])
     g = pk.graph
     plan = D.coset_plan(dom)
     if D.group_size <= 1:                      # on one device the proving key decides which tables exist
@@ -1992,7 +2008,9 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
 
     # ---- evaluations (prover.rs:700-790): every (polynomial, point) pair of the proof in one batched launch ------
     # h(X) = sum_i x^(n i) piece_i (vanishing/prover.rs:120-124)
+    D.retain(pieces)
     h_poly = D.lincomb_range(D.empty(n), pieces, [pow(xn, i, R_MOD) for i in range(len(pieces))], n)
+    D.retain([h_poly])
     wanted, written = [], []            # (key, poly, rotation); the subset the transcript receives, in its order
 
     def want(key, poly, rot, write=True):
@@ -2075,6 +2093,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     query(("h",), h_poly, 0)
     query(("random",), random_poly, 0)
     (_gwc if use_gwc else _shplonk)(D, params, transcript, queries, polys, n)
+    D.release_retained()
     mark("multiopen")
     if _host_trace:
         import sys

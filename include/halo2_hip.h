@@ -105,6 +105,20 @@ int h2_msm_multi(const uint64_t *scalars, const uint64_t *bases, size_t n, uint3
  * H2_MSM_TABLES=0 in the environment keeps the copy only. */
 int h2_bases_register(const uint64_t *bases, size_t n);
 int h2_bases_unregister(const uint64_t *bases);
+/* Resident polynomials, the same idea for Fr vectors: the proving key's coefficient forms -- fixed_polys, permutation.polys, l0,
+ * l_last (plonk.rs:226-240, made once by keygen_pk, plonk/keygen.rs:330-440) -- are read by EVERY proof: by the evaluator
+ * (plonk/evaluation.rs:1229-1241), by the evaluations at x (plonk/prover.rs:731-737) and by the multiopen folds
+ * (poly/multiopen/shplonk/prover.rs:110-209, gwc/prover.rs:57-151), and the reference's cuda path uploads them each time.
+ * After h2_poly_register(values, n) every host-slice entry point that only READS a vector lying inside [values, values + n)
+ * -- h2_evaluate_h_coeff's columns, h2_eval_polynomial, h2_lincomb's operands, h2_kate_division's dividend, h2_eval_op's
+ * operands, h2_coeff_to_extended's input -- uses a device copy uploaded once per device (on first use).  The caller must not
+ * modify a registered range before h2_poly_unregister, which frees the copies on every device; a stale registration is never
+ * served: register / unregister bump a generation and a copy made for another generation (or length) is dropped.  A host may
+ * also register a proof's own final polynomials (advice / product coefficient forms) for the rest of that proof.
+ * Entry points that WRITE through the pointer (h2_ntt, h2_intt, h2_batch_mont, h2_eval_op's result ...) never consult the
+ * registry for it. */
+int h2_poly_register(const uint64_t *values, size_t n);
+int h2_poly_unregister(const uint64_t *values);
 /* Host-side fold of `count` partial results (12 x u64 Jacobian each): the
  * `.reduce(|acc, x| acc + x)` of arithmetic.rs:433-435; also used after an all-gather of per-rank
  * partial points when one MSM is split across processes (one process per GPU). */

@@ -14,6 +14,7 @@
 //!   poly/domain.rs  coeff_to_extended :270-287, extended_to_coeff :328-350,
 //!                   divide_by_vanishing_poly :354-373                                     -> the functions of the same name
 //!   poly/commitment.rs  Params::unsafe_setup :56-124, Params::read :256-294               -> register_params (+ Drop)
+//!   plonk/keygen.rs     keygen_pk :330-455, keygen_pk_from_info :458-553                   -> register_proving_key (+ Drop)
 //!   poly/multiopen/gwc/prover.rs :57-151  (poly_batch = sum v^i p_i)                      -> lincomb
 //!   plonk/evaluation.rs  Evaluator::evaluate_h (cuda) :1229-1241,
 //!                        evaluate / evaluate_with_theta (cuda) :2315-2326, :2393-2396     -> plonk/evaluation_hip.rs over
@@ -273,6 +274,10 @@ extern "C" {
     // resident SRS: Params::g / g_lagrange are uploaded once per device instead of once per MSM
     pub fn h2_bases_register(bases: *const u64, n: usize) -> c_int;
     pub fn h2_bases_unregister(bases: *const u64) -> c_int;
+    // resident polynomials: Fr vectors the prover will not modify any more (the proving key's coefficient forms, a proof's final
+    // polynomials) are uploaded once per device; every entry point that only READS a vector looks them up
+    pub fn h2_poly_register(values: *const u64, n: usize) -> c_int;
+    pub fn h2_poly_unregister(values: *const u64) -> c_int;
     pub fn h2_g1_sum(points: *const c_void, count: usize, out_xyz: *mut c_void) -> c_int;
     // device memory and streams for a host without a HIP binding (the device-resident h2_dev_* family of the header takes
     // these pointers: what `Polynomial` would hold instead of a Vec once the data stays on the device)
@@ -533,6 +538,50 @@ pub fn unregister_params<C: CurveAffine>(g: &[C], g_lagrange: &[C]) {
         check(h2_bases_unregister(g.as_ptr() as *const u64), "bases_unregister");
         check(h2_bases_unregister(g_lagrange.as_ptr() as *const u64), "bases_unregister");
     }
+}
+
+/// Registers coefficient / value vectors that will not change while registered (include/halo2_hip.h, h2_poly_register): the
+/// host-slice calls that only READ a vector -- `evaluate_h`'s columns, `eval_polynomial`, the operands of `lincomb`, the
+/// dividend of `kate_division` -- then use a device copy uploaded once per device instead of crossing PCIe per call.
+pub fn register_polys<F: FieldExt>(polys: &[&[F]]) {
+    for p in polys {
+        if !p.is_empty() {
+            unsafe { check(h2_poly_register(p.as_ptr() as *const u64, p.len()), "poly_register") };
+        }
+    }
+}
+
+pub fn unregister_polys<F: FieldExt>(polys: &[&[F]]) {
+    for p in polys {
+        if !p.is_empty() {
+            unsafe { check(h2_poly_unregister(p.as_ptr() as *const u64), "poly_unregister") };
+        }
+    }
+}
+
+/// The vectors of a proving key that every proof reads and none writes (plonk.rs:226-240 under `hip`: coefficient forms):
+/// `fixed_polys`, `permutation.polys`, `l0`, `l_last`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
+/// (plonk/keygen.rs:442-455, :540-553); `ProvingKey`'s `Drop` (added by the patch) unregisters before the vectors go.
+/// A proving key is not moved out of its `Vec`s after keygen: the registered addresses are those of the heap buffers.
+pub fn proving_key_polys<'a, C: CurveAffine>(pk: &'a crate::plonk::ProvingKey<C>) -> Vec<&'a [C::Scalar]> {
+    let mut out: Vec<&[C::Scalar]> = Vec::new();
+    for p in pk.fixed_polys.iter() {
+        out.push(&p.values[..]);
+    }
+    for p in pk.permutation.polys.iter() {
+        out.push(&p.values[..]);
+    }
+    out.push(&pk.l0.values[..]);
+    out.push(&pk.l_last.values[..]);
+    out
+}
+
+pub fn register_proving_key<C: CurveAffine>(pk: &crate::plonk::ProvingKey<C>) {
+    register_polys(&proving_key_polys(pk));
+}
+
+pub fn unregister_proving_key<C: CurveAffine>(pk: &crate::plonk::ProvingKey<C>) {
+    unregister_polys(&proving_key_polys(pk));
 }
 
 /// `N_GPU`'s default (plonk/prover.rs:56-74: `Device::all().len()` under cuda): the devices the library's pool sees.

@@ -63,3 +63,133 @@ def test_host_slice_device_needs_a_gpu_and_touches_no_oracle():
 
     src = inspect.getsource(host_api)
     assert "oracle" not in src.replace("no oracle", "") and "liboracle" not in src
+
+
+def _ptr(a):
+    import ctypes
+
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _evalpoly(L, poly, x):
+    out = np.zeros(4, dtype=np.uint64)
+    assert L.h2_eval_polynomial(_ptr(poly), len(poly), _ptr(x), _ptr(out)) == 0
+    return out
+
+
+def _oracle_evalpoly(oracle, poly, x):
+    out = np.zeros(4, dtype=np.uint64)
+    oracle.lib.oracle_eval_polynomial(_ptr(poly), len(poly), _ptr(x), _ptr(out))
+    return out
+
+
+@pytest.mark.parametrize("n", [1 << 12, (1 << 21) + 4097])
+def test_registered_polynomials_are_read_on_the_device_and_never_served_stale(oracle, n):
+    """h2_poly_register (the proving key's fixed / sigma / l_0 / l_last coefficient forms, plonk.rs:226-240, read by every
+    proof): a registered vector gives the entry points that READ it -- h2_eval_polynomial, h2_lincomb operands (whole and
+    sub-ranges), h2_kate_division, h2_eval_op -- the oracle's results from a device copy made once; after unregister the host
+    contents count again; registering the same address anew (another generation) uploads the new contents: a copy made for an
+    earlier registration is never used."""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import arithmetic as ar
+
+    L = h2.lib()
+    p, q = oracle.random_fr(9000 + n % 97, n), oracle.random_fr(9100 + n % 97, n)
+    x, coeffs = oracle.random_fr(9200, 1)[0], oracle.random_fr(9300, 2)
+    assert L.h2_poly_register(_ptr(p), n) == 0
+    try:
+        for _ in range(2):                                  # the second round runs from the device copy
+            assert np.array_equal(_evalpoly(L, p, x), _oracle_evalpoly(oracle, p, x))
+        # operands: one registered (whole), one not; then a sub-range of the registered vector
+        for lo, m in ((0, n), (n // 4, n // 2)):
+            want = oracle.eval_op(ar.OP_SUM, oracle.eval_op(ar.OP_MUL_C, p[lo:lo + m], None, 0, 0, coeffs[0]),
+                                  oracle.eval_op(ar.OP_MUL_C, q[lo:lo + m], None, 0, 0, coeffs[1]), 0, 0, None)
+            res = np.zeros((m, 4), dtype=np.uint64)
+            ptrs = (ctypes.c_void_p * 2)(p[lo:].ctypes.data, q[lo:].ctypes.data)
+            assert L.h2_lincomb(_ptr(res), ptrs, _ptr(coeffs), 2, m) == 0
+            assert np.array_equal(res, want), (lo, m)
+        got = np.zeros((n, 4), dtype=np.uint64)
+        want = np.zeros((n, 4), dtype=np.uint64)
+        assert L.h2_kate_division(_ptr(p), n, _ptr(x), _ptr(got)) == 0
+        oracle.lib.oracle_kate_division(_ptr(p), n, _ptr(x), _ptr(want))
+        assert np.array_equal(got[:n - 1], want[:n - 1])
+        assert np.array_equal(ar.eval_op(ar.OP_MUL, p, q), oracle.eval_op(ar.OP_MUL, p, q, 0, 0, None))
+        assert np.array_equal(ar.eval_op(ar.OP_SUM, q, p, 0, 3), oracle.eval_op(ar.OP_SUM, q, p, 0, 3, None))   # rotated: single shot
+    finally:
+        assert L.h2_poly_unregister(_ptr(p)) == 0
+    # unregistered: the host contents are what counts again
+    p[5] = q[7]
+    assert np.array_equal(_evalpoly(L, p, x), _oracle_evalpoly(oracle, p, x))
+    # a new registration of the same address: new generation, new upload -- never the copy of the first one
+    assert L.h2_poly_register(_ptr(p), n) == 0
+    try:
+        assert np.array_equal(_evalpoly(L, p, x), _oracle_evalpoly(oracle, p, x))
+        assert L.h2_poly_register(_ptr(p), n // 2) == 0     # registered again (replaced) without unregistering: half the length
+        p2 = p.copy()
+        assert np.array_equal(_evalpoly(L, p, x), _oracle_evalpoly(oracle, p2, x))      # whole vector: outside the range, uploaded
+        assert np.array_equal(_evalpoly(L, p[:n // 2], x), _oracle_evalpoly(oracle, p2[:n // 2], x))
+    finally:
+        assert L.h2_poly_unregister(_ptr(p)) == 0
+    assert L.h2_poly_unregister(_ptr(p)) == 0               # idempotent
+    assert L.h2_poly_register(None, 4) != 0 and L.h2_poly_register(_ptr(p), 0) != 0
+
+
+def test_pipelined_elementwise_entry_points_at_long_sizes_vs_oracle(oracle):
+    """from 2^21 elements on, h2_lincomb / h2_eval_op / h2_batch_mont / h2_batch_unmont / h2_divide_by_vanishing_poly run chunk
+    by chunk over three streams (upload of chunk c + 1, kernel of chunk c, download of chunk c - 1): a ragged length (the last
+    chunk short), in-place forms and the table of the vanishing division across chunk boundaries, against the oracle"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import arithmetic as ar
+
+    L = h2.lib()
+    n = (1 << 21) + (1 << 19) + 12345
+    a, b, c3 = oracle.random_fr(9500, n), oracle.random_fr(9501, n), oracle.random_fr(9502, n)
+    coeffs = oracle.random_fr(9503, 3)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    for v, cf in zip((a, b, c3), coeffs):
+        want = oracle.eval_op(ar.OP_SUM, want, oracle.eval_op(ar.OP_MUL_C, v, None, 0, 0, cf), 0, 0, None)
+    res = np.zeros((n, 4), dtype=np.uint64)
+    ptrs = (ctypes.c_void_p * 3)(a.ctypes.data, b.ctypes.data, c3.ctypes.data)
+    assert L.h2_lincomb(_ptr(res), ptrs, _ptr(coeffs), 3, n) == 0
+    assert np.array_equal(res, want)
+    assert np.array_equal(ar.eval_op(ar.OP_MUL, a, b), oracle.eval_op(ar.OP_MUL, a, b, 0, 0, None))
+    assert np.array_equal(ar.eval_op(ar.OP_LCTHETA, a, b, c=coeffs[0]), oracle.eval_op(ar.OP_LCTHETA, a, b, 0, 0, coeffs[0]))
+    inplace = a.copy()
+    assert L.h2_eval_op(ar.OP_SUB, _ptr(inplace), _ptr(inplace), _ptr(b), 0, 0, n, None) == 0          # res aliases l
+    assert np.array_equal(inplace, oracle.eval_op(ar.OP_SUB, a, b, 0, 0, None))
+    raw = oracle.random_fr(9504, n)
+    m = ar.gpu_mont(raw.copy())
+    assert np.array_equal(ar.gpu_unmont(m.copy()), raw)
+    one = np.zeros((n, 4), dtype=np.uint64)
+    one[:, 0] = 1
+    assert np.array_equal(oracle.eval_op(ar.OP_MUL, m, ar.gpu_mont(one), 0, 0, None), m)                  # m * mont(1) = m
+    assert np.array_equal(ar.gpu_mont(one)[::100003], np.tile(ar.gpu_mont(one[:1]), (len(one[::100003]), 1)))
+    d, t = oracle.domain(5, 20)                       # extended_k = 22: 2^22 values, t_len = 4
+    ext = oracle.random_fr(9505, 1 << d.extended_k)
+    got = ar.divide_by_vanishing_poly(ext.copy(), t)
+    oracle.lib.oracle_divide_by_vanishing_poly(ext.ctypes.data, len(ext), t.ctypes.data, len(t), 16)
+    assert np.array_equal(got, ext)
+
+
+@pytest.mark.parametrize("register", [True, False])
+def test_host_slice_proof_at_a_pipelined_size(oracle, device, register):
+    """the literal drop-in at k = 21 (every vector 64 MiB: the chunked pipeline and, with `register`, the device copies of the
+    proving key's and the proof's final polynomials carry every read): the resident prover's bytes, SHPLONK and GWC"""
+    from halo2_gpu_specific_amd import circuits, host_api, prover
+    from halo2_gpu_specific_amd.rng import ProverRng
+
+    k = 21
+    cs, (adv, fixed, copies) = circuits.mini_plonk(), circuits.mini_plonk_synthesize(k)
+    params = prover.Params.unsafe_setup(device, k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
+    pk = prover.keygen(device, params, cs, fixed, copies)
+    H = host_api.HostApiDevice(pinned=register, register_polys=register)
+    hparams = host_api.params_like(H, params)
+    hpk = prover.keygen(H, hparams, cs, fixed, copies)
+    for seed, gwc in ((3, False), (4, True)):
+        want = prover.create_proof_ext(device, params, pk, adv, ProverRng(seed), gwc)
+        assert prover.create_proof_ext(H, hparams, hpk, adv, ProverRng(seed), gwc) == want
+    assert not H._retained, "the per-proof registrations are released at the end of the proof"

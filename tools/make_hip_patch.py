@@ -331,6 +331,17 @@ impl<C: CurveAffine> Drop for Params<C> {
 '''
 
 
+PK_DROP = '''/// `hip`: the device copies of `fixed_polys` / `permutation.polys` / `l0` / `l_last` registered by `keygen_pk` go with the key.
+#[cfg(feature = "hip")]
+impl<C: CurveAffine> Drop for ProvingKey<C> {
+    fn drop(&mut self) {
+        crate::hip::unregister_proving_key(self);
+    }
+}
+
+'''
+
+
 def edit(rel, text):
     if rel.endswith("Cargo.toml"):
         return replace_once(text, 'cuda = ["ec-gpu-gen/cuda", "pairing/gpu"]\n',
@@ -413,8 +424,19 @@ def edit(rel, text):
         return text
     if rel.endswith("src/plonk.rs"):
         text = replace_once(text, "mod evaluation;\n", 'mod evaluation;\n#[cfg(feature = "hip")]\nmod evaluation_hip;\n', "mod evaluation")
+        text = replace_once(text, "impl<C: CurveAffine> ProvingKey<C> {\n    /// Get the underlying [`VerifyingKey`].\n",
+                            PK_DROP + "impl<C: CurveAffine> ProvingKey<C> {\n    /// Get the underlying [`VerifyingKey`].\n", "ProvingKey Drop")
         return switch_shape(text, 5)
     if rel.endswith("plonk/keygen.rs"):
+        # keygen_pk (:442-455) and keygen_pk_from_info (:540-553): the key's coefficient forms are registered with the library once
+        for head, what in (("    Ok(ProvingKey {\n        vk,\n", "keygen_pk tail"), ("    Ok(ProvingKey {\n        vk: vk.clone(),\n", "keygen_pk_from_info tail")):
+            at = text.index(head)
+            end = text.index("    })\n}\n", at)
+            body = text[at + len("    Ok("):end] + "    };\n"
+            text = (text[:at] + "    let pk = " + body + '    #[cfg(feature = "hip")]\n    crate::hip::register_proving_key(&pk);\n    Ok(pk)\n}\n'
+                    + text[end + len("    })\n}\n"):])
+            assert text.count("crate::hip::register_proving_key(&pk);") >= 1, what
+        assert text.count("crate::hip::register_proving_key(&pk);") == 2
         return switch_shape(text, 8)
     if rel.endswith("plonk/permutation.rs"):
         return switch_shape(text, 1)
