@@ -117,6 +117,27 @@ bool pipeline_enabled() {
     static const bool on = !(getenv("H2_HOST_PIPELINE") && atoi(getenv("H2_HOST_PIPELINE")) == 0);
     return on;
 }
+// page-locked host memory (hipHostMalloc / h2_host_alloc_pinned / hipHostRegister)?  Only then are the chunk copies asynchronous
+// DMA; from ordinary memory every hipMemcpyAsync stages and blocks, and sixteen small blocking copies are slower than one large
+// one (measured: the k = 22 drop-in proof from ordinary memory 1.25 -> 1.52 s with the pipeline forced on): single shot there.
+bool host_pinned(const void* p) {
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+bool use_pipeline(size_t size, std::initializer_list<const void*> host) {
+    if (!pipeline_enabled() || size < PIPE_MIN) return false;
+    for (const void* p : host)
+        if (!host_pinned(p)) return false;
+    return true;
+}
+void fr_to_u64x4(const Fr& v, uint64_t out[4]) {
+    for (int i = 0; i < 4; i++) out[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
+}
 
 }  // namespace
 
@@ -360,7 +381,7 @@ static int host_batch_mont(uint64_t* a, size_t n, bool to_mont) {
         DeviceCtx* ctx = lease.ctx;
         size_t bytes = n * sizeof(Fr);
         if (n == 0) return (int)H2_OK;
-        if (pipeline_enabled() && n >= PIPE_MIN) {
+        if (use_pipeline(n, {a})) {
             Fr* slots = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
             int rc = H2_OK;
             pipeline_chunks(ctx, n,
@@ -399,7 +420,7 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
         if (size == 0) return (int)H2_OK;
         const Fr* res_l = resident_operand(ctx, l, size);
         const Fr* res_r = resident_operand(ctx, r, size);
-        if (pipeline_enabled() && size >= PIPE_MIN && l_rot == 0 && r_rot == 0) {
+        if (l_rot == 0 && r_rot == 0 && use_pipeline(size, {res, res_l ? nullptr : (const void*)l, res_r ? nullptr : (const void*)r})) {
             // no rotation: element i depends on element i of the operands only -- chunk by chunk, both directions of PCIe at once
             Fr* sl = (l && !res_l) ? (Fr*)ctx->buf_b.get(2 * PIPE_CHUNK * sizeof(Fr)) : nullptr;
             Fr* sr = (r && !res_r) ? (Fr*)ctx->buf_c.get(2 * PIPE_CHUNK * sizeof(Fr)) : nullptr;
@@ -448,7 +469,7 @@ int h2_divide_by_vanishing_poly(uint64_t* a, size_t size, const uint64_t* t_eval
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
         if (size == 0) return (int)H2_OK;
-        if (pipeline_enabled() && size >= PIPE_MIN && t_len && PIPE_CHUNK % t_len == 0) {
+        if (t_len && PIPE_CHUNK % t_len == 0 && use_pipeline(size, {a})) {
             // a[i] *= t[i % t_len]: a chunk that starts at a multiple of t_len sees the table from its first entry
             Fr* slots = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
             Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
@@ -1016,7 +1037,9 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
             ptrs[i] = resident_operand(ctx, polys[i], size);
             if (!ptrs[i]) staged.push_back(i);
         }
-        if (pipeline_enabled() && size >= PIPE_MIN) {
+        bool pinned_all = host_pinned(res);
+        for (size_t j : staged) pinned_all = pinned_all && host_pinned(polys[j]);
+        if (pinned_all && use_pipeline(size, {})) {
             // chunk by chunk: the operands' chunk c + 1 goes up while chunk c is combined and the result of chunk c - 1 comes down
             Fr* sin = staged.empty() ? nullptr : (Fr*)ctx->buf_a.get(2 * staged.size() * PIPE_CHUNK * sizeof(Fr));
             Fr* sout = (Fr*)ctx->buf_b.get(2 * PIPE_CHUNK * sizeof(Fr));
@@ -1060,6 +1083,57 @@ int h2_dev_permutation_sigma(void* d_out, const void* d_map_col, const void* d_m
         DeviceCtx* ctx = current_ctx();
         return perm_sigma_launch((Fr*)d_out, (const uint32_t*)d_map_col, (const uint32_t*)d_map_row, n, delta, omega,
                                  pick_stream(ctx, stream));
+    });
+}
+
+// host buffers: the reference computes these products in a rayon loop between its GPU calls (permutation/prover.rs:89-128); a
+// host that wants them on the device calls this -- value / sigma (sigma: a proving-key column, found on the device when
+// registered with h2_poly_register) in, num / den out (first == 0: read, multiplied into, written back), chunk-pipelined
+int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, const uint64_t* sigma, size_t n,
+                         const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4], const uint64_t omega[4], int first) {
+    if (n && (!num || !den || !value || !sigma || !beta || !gamma || !delta_pow || !omega)) return bad("h2_permutation_terms: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        const Fr* res_sigma = resident_operand(ctx, sigma, n);
+        const Fr* res_value = resident_operand(ctx, value, n);
+        const bool pipe = use_pipeline(n, {num, den, res_value ? nullptr : (const void*)value, res_sigma ? nullptr : (const void*)sigma});
+        const size_t chunk = pipe ? PIPE_CHUNK : n;
+        Fr* s_num = (Fr*)ctx->buf_a.get(2 * chunk * sizeof(Fr));
+        Fr* s_den = (Fr*)ctx->buf_b.get(2 * chunk * sizeof(Fr));
+        Fr* s_val = res_value ? nullptr : (Fr*)ctx->buf_c.get(2 * chunk * sizeof(Fr));
+        Fr* s_sig = res_sigma ? nullptr : (Fr*)ctx->buf_d.get(2 * chunk * sizeof(Fr));
+        int rc = H2_OK;
+        auto up = [&](size_t off, size_t len, int slot, hipStream_t st) {
+            if (s_val) H2_HIP(hipMemcpyAsync(s_val + slot * chunk, value + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+            if (s_sig) H2_HIP(hipMemcpyAsync(s_sig + slot * chunk, sigma + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+            if (!first) {
+                H2_HIP(hipMemcpyAsync(s_num + slot * chunk, num + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                H2_HIP(hipMemcpyAsync(s_den + slot * chunk, den + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+            }
+        };
+        auto run = [&](size_t off, size_t len, int slot, hipStream_t st) {
+            // rows [off, off + len): the numerator's delta^c omega^i starts at delta_pow * omega^off
+            uint64_t dp[4];
+            fr_to_u64x4(fp_mul(fr_from_u64x4(delta_pow), fp_pow_u32(fr_from_u64x4(omega), (uint32_t)off)), dp);
+            int r = perm_terms_launch(s_num + slot * chunk, s_den + slot * chunk, res_value ? res_value + off : s_val + slot * chunk,
+                                      res_sigma ? res_sigma + off : s_sig + slot * chunk, len, beta, gamma, dp, omega, first, st);
+            if (r != H2_OK) rc = r;
+        };
+        auto down = [&](size_t off, size_t len, int slot, hipStream_t st) {
+            H2_HIP(hipMemcpyAsync(num + 4 * off, s_num + slot * chunk, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+            H2_HIP(hipMemcpyAsync(den + 4 * off, s_den + slot * chunk, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+        };
+        if (pipe) {
+            pipeline_chunks(ctx, n, up, run, down);
+        } else {
+            up(0, n, 0, ctx->stream);
+            run(0, n, 0, ctx->stream);
+            down(0, n, 0, ctx->stream);
+            H2_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return rc;
     });
 }
 

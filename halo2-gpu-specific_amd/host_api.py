@@ -22,7 +22,7 @@ from . import prover as P
 from ._lib import check, lib
 
 _vp = ctypes.c_void_p
-STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_terms", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity",
+STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity",
           "h2_dev_random_fr", "h2_dev_distribute_powers")
 
 
@@ -190,15 +190,8 @@ class HostSliceLib:
         return rc
 
     def h2_dev_permutation_terms(self, num, den, value, sigma, n, beta, gamma, delta_pow, omega, first, stream):
-        self._count("h2_dev_permutation_terms (staged)")
-        tn, td = self._up(num, 32 * n), self._up(den, 32 * n)
-        tv, ts = self._up(value, 32 * n), self._up(sigma, 32 * n)
-        rc = self.R.h2_dev_permutation_terms(tn.data_ptr(), td.data_ptr(), tv.data_ptr(), ts.data_ptr(), n, _addr(beta),
-                                             _addr(gamma), _addr(delta_pow), _addr(omega), first, None)
-        self._sync()
-        self._down(tn, num, 32 * n)
-        self._down(td, den, 32 * n)
-        return rc
+        self._count("h2_permutation_terms")
+        return self.R.h2_permutation_terms(num, den, value, sigma, n, _addr(beta), _addr(gamma), _addr(delta_pow), _addr(omega), first)
 
     def h2_dev_permutation_sigma(self, out, map_col, map_row, n, delta, omega, stream):
         self._count("h2_dev_permutation_sigma (staged)")

@@ -1173,7 +1173,8 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     # residency decided here for one and then runs coset by coset from tables built on demand (create_proof_ext)
     pk.coset_builder = coset_tables
     pk.l0_poly, pk.l_last_poly = l0_poly, l_last_poly     # (the cuda-shaped evaluator takes l0 / l_last as coefficient forms)
-    D.retain(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly], owner=pk)   # read by every proof, never written
+    # read by every proof, never written (sigma_values: the permutation argument's denominators, permutation/prover.rs:89-128)
+    D.retain(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly] + list(pk.sigma_values), owner=pk)
     if plan is None:
         pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
         pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)

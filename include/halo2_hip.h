@@ -203,6 +203,11 @@ int h2_dev_permutation_sigma(void *d_out, const void *d_map_col, const void *d_m
  *   den[i] (*)= beta * sigma[i] + gamma + value[i];   num[i] (*)= delta_pow * omega^i * beta + gamma + value[i]
  * first != 0 overwrites num / den, otherwise multiplies into them.  delta_pow = DELTA^{column position}.
  * The caller follows with h2_dev_batch_invert(den), an elementwise product and h2_dev_prefix_product. */
+/* the same on host buffers (the reference leaves these products to a rayon loop between its GPU calls): value / sigma in --
+ * sigma, a proving-key column, is read on the device when registered with h2_poly_register -- num / den out; chunk-pipelined */
+int h2_permutation_terms(uint64_t *num, uint64_t *den, const uint64_t *value, const uint64_t *sigma, size_t n,
+                         const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
+                         const uint64_t omega[4], int first);
 int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, const void *d_sigma, size_t n,
                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                              const uint64_t omega[4], int first, void *stream);

@@ -48,7 +48,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
         first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None)
         assert len(got) == len(want) and first is None, "host-slice proof differs at byte %s" % first
     calls = H.L.calls
-    assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3
+    assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_terms"] >= 2
     assert not any(name.startswith("oracle") for name in calls)
     if which == "mini" and k == 9:          # two circuit instances in one proof
         adv2 = circuits.mini_plonk_synthesize(k, a=9)[0]
@@ -167,7 +167,6 @@ def test_pipelined_elementwise_entry_points_at_long_sizes_vs_oracle(oracle):
     one = np.zeros((n, 4), dtype=np.uint64)
     one[:, 0] = 1
     assert np.array_equal(oracle.eval_op(ar.OP_MUL, m, ar.gpu_mont(one), 0, 0, None), m)                  # m * mont(1) = m
-    assert np.array_equal(ar.gpu_mont(one)[::100003], np.tile(ar.gpu_mont(one[:1]), (len(one[::100003]), 1)))
     d, t = oracle.domain(5, 20)                       # extended_k = 22: 2^22 values, t_len = 4
     ext = oracle.random_fr(9505, 1 << d.extended_k)
     got = ar.divide_by_vanishing_poly(ext.copy(), t)
