@@ -19,11 +19,13 @@
 //     share of the sum into `values`.
 #include "evalh_gen.hpp"
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -1094,6 +1096,7 @@ struct Rtc {
     int (*code_size)(void*, size_t*) = nullptr;
     int (*code)(void*, char*) = nullptr;
     int (*destroy)(void**) = nullptr;
+    int (*version)(int*, int*) = nullptr;
     std::string error;
 };
 
@@ -1124,9 +1127,18 @@ Rtc& rtc() {
         r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
         r.code = (decltype(r.code))sym("hiprtcGetCode");
         r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+        r.version = (decltype(r.version))sym("hiprtcVersion");
         if (!r.create || !r.compile || !r.log_size || !r.log || !r.code_size || !r.code || !r.destroy) r.error = "libhiprtc.so lacks the hiprtc* entry points";
     });
     return r;
+}
+
+// the compiler a cached code object must come from: (major << 8 | minor) of hipRTC, 0 when it cannot be loaded or does not say
+uint16_t rtc_version() {
+    Rtc& r = rtc();
+    int major = 0, minor = 0;
+    if (!r.error.empty() || !r.version || r.version(&major, &minor) != 0) return 0;
+    return (uint16_t)(((major & 0xff) << 8) | (minor & 0xff));
 }
 
 std::vector<char> rtc_compile(const std::string& source) {
@@ -1211,7 +1223,10 @@ bool read_file(const std::string& path, std::vector<char>& out) {
 }
 
 // file: magic, layout word, stage count, {length, code object} per stage, SHA-256 of everything before it
-constexpr char CACHE_MAGIC[8] = {'H', '2', 'E', 'V', 'G', '2', 0, 0};
+// file header: 6 bytes of magic + the hipRTC version the code objects were compiled by (2 bytes).  A file from ANOTHER compiler
+// version is a miss when this process can compile (after a ROCm upgrade the objects are rebuilt, not kept for ever); a process
+// without hipRTC takes what is there -- it could not rebuild it.
+constexpr char CACHE_MAGIC[6] = {'H', '2', 'E', 'V', 'G', '3'};
 
 }  // namespace
 
@@ -1226,7 +1241,24 @@ std::string cache_dir() {
         dir = std::string(tmp && *tmp ? tmp : "/tmp") + "/halo2_hip_jit_" + std::to_string((unsigned)getuid());
     }
     mkdir(dir.c_str(), 0700);
-    if (is_private_dir(dir)) return dir;
+    if (is_private_dir(dir)) {
+        // once per process: temporary files of writers that were killed before their rename (older than an hour) go
+        static bool swept = false;
+        if (!swept) {
+            swept = true;
+            if (DIR* dp = opendir(dir.c_str())) {
+                const time_t now = time(nullptr);
+                while (struct dirent* e = readdir(dp)) {
+                    if (!strstr(e->d_name, ".h2ev.tmp.")) continue;
+                    const std::string f = dir + "/" + e->d_name;
+                    struct stat st;
+                    if (stat(f.c_str(), &st) == 0 && now - st.st_mtime > 3600) unlink(f.c_str());
+                }
+                closedir(dp);
+            }
+        }
+        return dir;
+    }
     if (g_private_dir.empty()) {
         fprintf(stderr, "libhalo2_hip: code-object cache directory %s is not private to this user: using a per-process directory\n", dir.c_str());
         const char* tmp = getenv("TMPDIR");
@@ -1250,7 +1282,13 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
         // ---- the disk cache holds the code objects of the FINAL stage layout under the hash of the requested options
         if (attempt == 0 && use_disk) {
             std::vector<char> blob;
-            bool intact = read_file(path, blob) && blob.size() >= 16 + 32 && memcmp(blob.data(), CACHE_MAGIC, 8) == 0;
+            bool intact = read_file(path, blob) && blob.size() >= 16 + 32 && memcmp(blob.data(), CACHE_MAGIC, 6) == 0;
+            if (intact) {
+                uint16_t made_by = 0;
+                memcpy(&made_by, &blob[6], 2);
+                const uint16_t mine = rtc_version();
+                if (mine != 0 && made_by != mine) intact = false;
+            }
             if (intact) {   // a torn or damaged file is a miss (and is overwritten by the rebuild below)
                 uint8_t sum[32];
                 Sha256 hs;
@@ -1326,7 +1364,8 @@ Generated compile(const h2_evalh_desc* d, const Options& opt_in) {
                     hs.update(p_, n_);
                     return fwrite(p_, 1, n_, f) == n_;
                 };
-                bool ok = put(CACHE_MAGIC, 8) && put(&layout, 4) && put(&ns, 4);
+                const uint16_t made_by = rtc_version();
+                bool ok = put(CACHE_MAGIC, 6) && put(&made_by, 2) && put(&layout, 4) && put(&ns, 4);
                 for (const Stage& st : g.stages) {
                     const uint32_t len = (uint32_t)st.code.size();
                     ok = ok && put(&len, 4) && put(st.code.data(), len);

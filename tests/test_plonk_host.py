@@ -595,6 +595,28 @@ def test_missing_hiprtc_is_an_error_message_not_a_crash(tmp_path):
     assert "COMPILED 2" in out.stdout, out.stdout + out.stderr[-2000:]      # from the disk cache: hipRTC not needed
 
 
+def test_code_objects_of_another_compiler_version_are_rebuilt(tmp_path, monkeypatch):
+    """the cache file's header names the hipRTC version that made its code objects: an intact file (valid SHA-256 trailer) from
+    ANOTHER version is a miss for a process that can compile -- after a ROCm upgrade the objects are rebuilt instead of being
+    loaded for ever -- and the rebuild puts the current version back"""
+    import hashlib
+
+    from halo2_gpu_specific_amd import prover
+
+    cache = tmp_path / "c"
+    monkeypatch.setenv("H2_JIT_CACHE", str(cache))
+    b = prover.program_descriptor(circuits.mini_plonk(), 5, 7)
+    assert ev.compile_only(b)["from_cache"] == 0
+    (name,) = os.listdir(cache)
+    whole = (cache / name).read_bytes()
+    assert whole[:6] == b"H2EVG3" and whole[6:8] != b"\0\0"
+    body = bytearray(whole[:-32])
+    body[6] ^= 0x01                                              # "made by hipRTC of another major version"
+    (cache / name).write_bytes(bytes(body) + hashlib.sha256(bytes(body)).digest())
+    assert ev.compile_only(b)["from_cache"] == 0               # not trusted: rebuilt
+    assert (cache / name).read_bytes() == whole and ev.compile_only(b)["from_cache"] == 2
+
+
 def test_generated_evaluate_h_compiles_for_gfx950(tmp_path, monkeypatch):
     """csrc/evalh_gen.cpp behind the C ABI, no GPU needed: the straight-line HIP generated from a circuit's program (all three
     test circuits, with their permutation / lookup / shuffle terms) goes through hipRTC for gfx950 without spills; one store

@@ -529,17 +529,37 @@ static U256 vk_digest(const Domain& dom, const std::vector<Affine>& fixed_c, con
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static void* g_stream = nullptr;
-struct DVec {  // n Fr on the device (RAII over h2_dev_alloc)
+// Device blocks are recycled by size (a proof allocates the same few sizes again and again, and hipMalloc / hipFree cost more
+// than the kernels between them at small k): everything this tool launches is ordered on ONE stream -- and the library's MSM /
+// evaluator calls return with their own streams drained -- so a block handed out again is only ever touched behind its last use.
+static std::multimap<size_t, void*> g_pool;
+static void* pool_get(size_t bytes) {
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end()) {
+        void* p = it->second;
+        g_pool.erase(it);
+        return p;
+    }
     void* p = nullptr;
-    size_t n = 0;
+    CK(h2_dev_alloc(bytes, &p));
+    return p;
+}
+static void pool_drain() {
+    for (auto& kv : g_pool) h2_dev_free(kv.second);
+    g_pool.clear();
+}
+struct DVec {  // n elements on the device (32 bytes each unless said otherwise)
+    void* p = nullptr;
+    size_t n = 0, bytes = 0;
     DVec() = default;
-    explicit DVec(size_t n_, size_t elt = 32) : n(n_) { CK(h2_dev_alloc(n_ * elt, &p)); }
-    DVec(DVec&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+    explicit DVec(size_t n_, size_t elt = 32) : p(pool_get(n_ * elt)), n(n_), bytes(n_ * elt) {}
+    DVec(DVec&& o) noexcept : p(o.p), n(o.n), bytes(o.bytes) { o.p = nullptr; }
     DVec& operator=(DVec&& o) noexcept {
         if (this != &o) {
-            if (p) h2_dev_free(p);
+            if (p) g_pool.emplace(bytes, p);
             p = o.p;
             n = o.n;
+            bytes = o.bytes;
             o.p = nullptr;
         }
         return *this;
@@ -547,7 +567,7 @@ struct DVec {  // n Fr on the device (RAII over h2_dev_alloc)
     DVec(const DVec&) = delete;
     DVec& operator=(const DVec&) = delete;
     ~DVec() {
-        if (p) h2_dev_free(p);
+        if (p) g_pool.emplace(bytes, p);
     }
     void* at(size_t i) const { return (char*)p + 32 * i; }
 };
@@ -569,7 +589,7 @@ static DVec clone(const DVec& s) {
 }
 static DVec g_scratch;
 static void* scratch(size_t bytes) {
-    if (g_scratch.n * 32 < bytes) g_scratch = DVec((bytes + 31) / 32);
+    if (g_scratch.bytes < bytes) g_scratch = DVec((bytes + 31) / 32);
     return g_scratch.p;
 }
 static Affine msm(const DVec& scalars, const void* bases, size_t n, uint32_t bits = 254) {
@@ -578,15 +598,27 @@ static Affine msm(const DVec& scalars, const void* bases, size_t n, uint32_t bit
     CK(h2_dev_msm(scalars.p, bases, n, bits, scratch(sb), sb, out, g_stream));
     return jac_to_affine(out);
 }
+// one MSM per column over the same bases, pipelined inside the library (plonk/prover.rs:293-299, :477-487: the per-column loops)
+static std::vector<Affine> msm_batch(const std::vector<const DVec*>& cols, const void* bases, size_t n, const std::vector<uint32_t>& bits) {
+    const size_t count = cols.size();
+    if (count == 1) return {msm(*cols[0], bases, n, bits[0])};
+    size_t sb = 0;
+    for (uint32_t b : bits) sb = std::max(sb, std::max(2 * ((h2_msm_scratch_bytes(n, b) + 255) / 256 * 256), h2_msm_batch_scratch_bytes(n, b, count)));
+    std::vector<const void*> sp, bp(count, bases);
+    for (const DVec* c : cols) sp.push_back(c->p);
+    std::vector<u64> out(12 * count);
+    CK(h2_dev_msm_batch_ex(sp.data(), bp.data(), bits.data(), count, n, scratch(sb), sb, out.data(), g_stream));
+    std::vector<Affine> pts;
+    for (size_t i = 0; i < count; i++) pts.push_back(jac_to_affine(&out[12 * i]));
+    return pts;
+}
 static void intt(const DVec& t, const Domain& dom) {
     DVec tmp(dom.n);
     CK(h2_dev_intt(t.p, tmp.p, dom.omega_inv.l, dom.ifft_div.l, dom.k, g_stream));
-    CK(h2_stream_synchronize(g_stream));  // tmp leaves scope
 }
 static DVec to_extended(const DVec& coeffs, const Domain& dom) {
     DVec out(dom.en), tmp(dom.en);
     CK(h2_dev_coeff_to_extended(coeffs.p, out.p, tmp.p, dom.k, dom.ek, dom.g_coset.l, dom.g_coset_inv.l, dom.ext_omega.l, g_stream));
-    CK(h2_stream_synchronize(g_stream));
     return out;
 }
 static void eval_op(int op, const DVec& res, const DVec* l, const DVec* r, const U256* c, size_t size) {
@@ -897,13 +929,22 @@ static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, 
         DVec t(n);
         upload(t, 0, w.advice[c].data(), n);
         set_rows(t, usable, blind[c]);
-        const void* cols[1] = {t.p};
-        uint32_t bits = 0;
-        DVec words(8, 4);
-        CK(h2_dev_max_scalar_bits(cols, 1, n, words.p, &bits, g_stream));  // find_max_scalar_bits (prover.rs:237-254)
-        CK(h2_dev_batch_mont(t.p, n, g_stream));
-        tr.write_point(msm(t, P.g_lagrange.p, n, std::max(bits, 1u)));
         advice.push_back(std::move(t));
+    }
+    {
+        const void* cols[N_ADVICE];
+        uint32_t bits[N_ADVICE];
+        for (size_t c = 0; c < N_ADVICE; c++) cols[c] = advice[c].p;
+        DVec words(8 * N_ADVICE, 4);
+        CK(h2_dev_max_scalar_bits(cols, N_ADVICE, n, words.p, bits, g_stream));  // find_max_scalar_bits (prover.rs:237-254)
+        std::vector<const DVec*> ptrs;
+        std::vector<uint32_t> vb;
+        for (size_t c = 0; c < N_ADVICE; c++) {
+            CK(h2_dev_batch_mont(advice[c].p, n, g_stream));
+            ptrs.push_back(&advice[c]);
+            vb.push_back(std::max(bits[c], 1u));
+        }
+        for (const Affine& pt : msm_batch(ptrs, P.g_lagrange.p, n, vb)) tr.write_point(pt);
     }
     (void)tr.squeeze();  // theta (no lookups in this circuit)
     const U256 beta = tr.squeeze(), gamma = tr.squeeze();
@@ -930,7 +971,11 @@ static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, 
         set_rows(zs, n - bf, b);
         z.push_back(std::move(zs));
     }
-    for (size_t s = 0; s < nsets; s++) tr.write_point(msm(z[s], P.g_lagrange.p, n));
+    {
+        std::vector<const DVec*> ptrs;
+        for (DVec& t : z) ptrs.push_back(&t);
+        for (const Affine& pt : msm_batch(ptrs, P.g_lagrange.p, n, std::vector<uint32_t>(nsets, 254))) tr.write_point(pt);
+    }
     tr.write_point(random_commitment);
     const U256 y = tr.squeeze();
     // h(X): coefficient forms, extended cosets, the fused evaluator (plonk/evaluation.rs:1229-1985)
@@ -964,7 +1009,7 @@ static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, 
         memcpy(d.y, y.l, 32); memcpy(d.beta, beta.l, 32); memcpy(d.gamma, gamma.l, 32);
         memcpy(d.delta, delta.l, 32); memcpy(d.zeta, dom.g_coset.l, 32); memcpy(d.extended_omega, dom.ext_omega.l, 32);
         CK(h2_dev_evaluate_h(&d, h.p, g_stream));
-        CK(h2_stream_synchronize(g_stream));
+        CK(h2_stream_synchronize(g_stream));  // (the descriptor's host arrays leave scope)
     }
     advice_ext.clear();
     z_ext.clear();
@@ -973,15 +1018,18 @@ static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, 
     {
         DVec tmp(en);
         CK(h2_dev_extended_to_coeff(h.p, tmp.p, dom.ek, dom.g_coset.l, dom.g_coset_inv.l, dom.ext_omega_inv.l, dom.ext_ifft_div.l, g_stream));
-        CK(h2_stream_synchronize(g_stream));
     }
     const size_t npieces = DEGREE - 1;
     std::vector<DVec> pieces;
     for (size_t i = 0; i < npieces; i++) {
         DVec pc(n);
         CK(h2_dev_eval_op(H2_OP_SUM_C, pc.p, h.at(i * n), nullptr, 0, 0, n, U256{{0, 0, 0, 0}}.l, g_stream));
-        tr.write_point(msm(pc, P.g.p, n));
         pieces.push_back(std::move(pc));
+    }
+    {
+        std::vector<const DVec*> ptrs;
+        for (DVec& t : pieces) ptrs.push_back(&t);
+        for (const Affine& pt : msm_batch(ptrs, P.g.p, n, std::vector<uint32_t>(npieces, 254))) tr.write_point(pt);
     }
     const U256 x = tr.squeeze(), xn = FR.pow_u64(x, n);
     // h(X) = sum_i x^(n i) piece_i (vanishing/prover.rs:120-124)
@@ -1164,6 +1212,7 @@ int main(int argc, char** argv) {
         printf("vk_digest 0x%s\n", fr_str(pk.transcript_repr).c_str());
         g_scratch = DVec();
     }
+    pool_drain();
     if (reps < 2) t_best = t_first;
     printf("k %u seed %llu proof_bytes %zu setup_s %.4f keygen_s %.4f first_proof_s %.4f create_proof_s %.4f generated_launches %llu\n", k,
            (unsigned long long)seed, proof.size(), t_setup, t_keygen, t_first, t_best, (unsigned long long)h2_evalh_generated_launches());
