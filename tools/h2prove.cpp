@@ -410,13 +410,34 @@ struct Domain {  // EvaluationDomain::new, poly/domain.rs:44-149 (the scalars; M
 
 // synthesize (:224-254) as circuits.mini_plonk_synthesize: canonical (n, 4) u64 columns and the copy constraints
 struct Witness {
-    std::vector<std::vector<u64>> advice, fixed;  // [col][4 n]
+    std::vector<u64*> advice;                     // [col][4 n], in PAGE-LOCKED host memory when `pinned` (DMA to the device)
+    std::vector<std::vector<u64>> advice_store;   // ... or here (the host-check mode, which never touches the device)
+    std::vector<std::vector<u64>> fixed;          // [col][4 n]
     std::vector<std::array<u64, 4>> copies;       // (left column, left row, right column, right row)
+    bool pinned = false;
+    Witness() = default;
+    Witness(const Witness&) = delete;
+    Witness& operator=(const Witness&) = delete;
+    ~Witness() {
+        if (pinned)
+            for (u64* p : advice) h2_host_free_pinned(p);
+    }
 };
-static Witness synthesize(uint32_t k, u64 a = 5) {
-    Witness w;
+static void synthesize(Witness& w, uint32_t k, bool pinned, u64 a = 5) {
     const size_t n = (size_t)1 << k, pairs = (size_t)1 << (k - 4);
-    w.advice.assign(3, std::vector<u64>(4 * n, 0));
+    w.pinned = pinned;
+    for (int c = 0; c < 3; c++) {
+        if (pinned) {
+            void* p = nullptr;
+            CK(h2_host_alloc_pinned(32 * n, &p));
+            memset(p, 0, 32 * n);
+            w.advice.push_back((u64*)p);
+        } else {
+            w.advice_store.emplace_back(4 * n, 0);
+        }
+    }
+    if (!pinned)
+        for (auto& v : w.advice_store) w.advice.push_back(v.data());
     w.fixed.assign(4, std::vector<u64>(4 * n, 0));
     const u64 a2 = a * a;
     for (size_t i = 0; i < pairs; i++) {
@@ -428,7 +449,6 @@ static Witness synthesize(uint32_t k, u64 a = 5) {
     }
     for (size_t i = 0; i < pairs; i++) w.copies.push_back({0, 2 * i, 0, 2 * i + 1});
     for (size_t i = 0; i < pairs; i++) w.copies.push_back({1, 2 * i + 1, 2, 2 * i});
-    return w;
 }
 
 // plonk/permutation/keygen.rs:112-143: every cycle sorted by (column, row), each cell pointing at its successor
@@ -529,6 +549,7 @@ static U256 vk_digest(const Domain& dom, const std::vector<Affine>& fixed_c, con
 
 // ------------------------------------------------------------------------------------------------ device helpers
 static void* g_stream = nullptr;
+static void* g_copy_stream = nullptr;
 // Device blocks are recycled by size (a proof allocates the same few sizes again and again, and hipMalloc / hipFree cost more
 // than the kernels between them at small k): everything this tool launches is ordered on ONE stream -- and the library's MSM /
 // evaluator calls return with their own streams drained -- so a block handed out again is only ever touched behind its last use.
@@ -914,23 +935,25 @@ static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, 
     ProverRng rng(seed);
     Transcript tr;
     tr.common_scalar(pk.transcript_repr);
-    // the vanishing argument's random polynomial (vanishing/prover.rs:40-67): depends on nothing hashed so far
+    // the witness columns start crossing PCIe now, on a stream of their own (DMA out of page-locked memory) ...
+    std::vector<DVec> advice;
+    for (size_t c = 0; c < N_ADVICE; c++) {
+        advice.emplace_back(n);
+        CK(h2_dev_upload(advice[c].p, w.advice[c], 32 * n, g_copy_stream));
+    }
+    // ... under the vanishing argument's random polynomial and its commitment (vanishing/prover.rs:40-67), which depend on
+    // nothing the transcript has hashed
     uint8_t key[32];
     rng.poly_key(key);
     DVec random_poly(n);
     CK(h2_dev_random_fr(key, n, random_poly.p, g_stream));
     const Affine random_commitment = msm(random_poly, P.g.p, n);
+    CK(h2_stream_synchronize(g_copy_stream));  // the columns have arrived
     // advice columns: blinding rows (16-bit values, drawn column by column), bounded commitments (prover.rs:255-312)
-    std::vector<DVec> advice;
     std::vector<std::vector<U256>> blind(N_ADVICE);
     for (size_t c = 0; c < N_ADVICE; c++)
         for (size_t r = usable; r < n; r++) blind[c].push_back(U256{{rng.u16(), 0, 0, 0}});  // canonical for now
-    for (size_t c = 0; c < N_ADVICE; c++) {
-        DVec t(n);
-        upload(t, 0, w.advice[c].data(), n);
-        set_rows(t, usable, blind[c]);
-        advice.push_back(std::move(t));
-    }
+    for (size_t c = 0; c < N_ADVICE; c++) set_rows(advice[c], usable, blind[c]);
     {
         const void* cols[N_ADVICE];
         uint32_t bits[N_ADVICE];
@@ -1126,7 +1149,8 @@ static int host_check(uint32_t k, u64 seed) {
     printf("challenge %s writer %s\n", fr_str(ch1).c_str(), hex(tr.writer.data(), tr.writer.size()).c_str());
     printf("challenge2 %s\n", fr_str(tr.squeeze()).c_str());
     printf("vk_digest_of_generators %s\n", fr_str(vk_digest(dom, {G, G}, {G})).c_str());
-    Witness w = synthesize(k);
+    Witness w;
+    synthesize(w, k, false);
     std::vector<std::vector<uint32_t>> mc, mr;
     permutation_mapping(N_ADVICE, dom.n, w.copies, mc, mr);
     u64 acc = 1469598103934665603ULL;  // FNV-1a over the mapping and the witness
@@ -1138,8 +1162,8 @@ static int host_check(uint32_t k, u64 seed) {
         }
     printf("mapping_fnv %016llx\n", (unsigned long long)acc);
     acc = 1469598103934665603ULL;
-    for (auto& col : w.advice)
-        for (u64 v : col) mix(v);
+    for (u64* col : w.advice)
+        for (size_t i = 0; i < 4 * dom.n; i++) mix(col[i]);
     for (auto& col : w.fixed)
         for (u64 v : col) mix(v);
     printf("witness_fnv %016llx\n", (unsigned long long)acc);
@@ -1182,6 +1206,7 @@ int main(int argc, char** argv) {
     if (h2_device_count() < 1) die("no HIP device");
     CK(h2_set_device(0));
     CK(h2_stream_create(&g_stream));
+    CK(h2_stream_create(&g_copy_stream));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
     Domain dom(k);
@@ -1192,7 +1217,8 @@ int main(int argc, char** argv) {
         auto t0 = now();
         unsafe_setup(P, k, fr_hex(TRAPDOOR), dom, tables);
         t_setup = secs(t0, now());
-        Witness w = synthesize(k);
+        Witness w;
+        synthesize(w, k, true);
         ProvingKey pk;
         t0 = now();
         keygen(pk, P, dom, w);
@@ -1225,6 +1251,7 @@ int main(int argc, char** argv) {
         }
         fclose(f);
     }
+    CK(h2_stream_destroy(g_copy_stream));
     CK(h2_stream_destroy(g_stream));
     return 0;
 }
