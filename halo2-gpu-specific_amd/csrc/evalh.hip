@@ -18,6 +18,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <set>
+#include <condition_variable>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -277,6 +280,13 @@ struct PlanKey {
 };
 std::mutex g_plan_mu;
 std::map<PlanKey, std::unique_ptr<EvalhPlan>> g_plans;   // a null entry: generation failed for this program (said once)
+// programs some caller is generating / compiling / loading right now, OUTSIDE g_plan_mu (a hipRTC build takes seconds): callers
+// of the SAME program wait on the condition variable instead of compiling it again; lookups of every other program -- cache
+// hits included, on any device or host-API slot -- go on meanwhile
+std::set<PlanKey> g_building;
+std::condition_variable g_plan_cv;
+std::map<PlanKey, std::chrono::steady_clock::time_point> g_failed_at;   // when a null entry was made: retried after a minute
+constexpr int FAILED_RETRY_SECONDS = 60;
 std::atomic<uint64_t> g_generated_launches{0};
 std::atomic<uint64_t> g_plan_evictions{0};
 uint64_t g_plan_clock = 0;                               // g_plan_mu
@@ -383,17 +393,43 @@ EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached) {
     H2_HIP(hipGetDevice(&device));
     const evgen::Options opt = evgen::Options::from_env();
     const PlanKey key = plan_key(d, opt, device);
-    // one builder at a time: two callers with the same new program would otherwise both compile it
-    std::lock_guard<std::mutex> g(g_plan_mu);
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) {
-        if (cached) *cached = 1;
-        if (const EvalhPlan* hit = it->second.get()) {
-            hit->last_use = ++g_plan_clock;
-            hit->users++;
+    // one builder per PROGRAM: two callers with the same new program would otherwise both compile it.  The build itself runs
+    // without the lock.
+    std::unique_lock<std::mutex> g(g_plan_mu);
+    for (;;) {
+        auto it = g_plans.find(key);
+        if (it != g_plans.end()) {
+            if (!it->second) {
+                // a failed generation is not for ever: a transient failure (a full disk, a compiler that was being replaced)
+                // is tried again after a minute
+                auto f = g_failed_at.find(key);
+                if (f != g_failed_at.end() && std::chrono::steady_clock::now() - f->second > std::chrono::seconds(FAILED_RETRY_SECONDS)) {
+                    g_failed_at.erase(f);
+                    g_plans.erase(it);
+                    continue;
+                }
+            }
+            if (cached) *cached = 1;
+            if (const EvalhPlan* hit = it->second.get()) {
+                hit->last_use = ++g_plan_clock;
+                hit->users++;
+            }
+            return EvalhPlanRef(it->second.get());
         }
-        return EvalhPlanRef(it->second.get());
+        if (!g_building.count(key)) break;
+        g_plan_cv.wait(g);
     }
+    g_building.insert(key);
+    g.unlock();
+    struct Done {   // whatever happens below, the waiters of this program are released
+        const PlanKey& key;
+        std::unique_lock<std::mutex>& g;
+        ~Done() {
+            if (!g.owns_lock()) g.lock();
+            g_building.erase(key);
+            g_plan_cv.notify_all();
+        }
+    } done{key, g};
     std::unique_ptr<EvalhPlan> plan;
     try {
         plan.reset(new EvalhPlan);
@@ -421,10 +457,13 @@ EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached) {
                 (int)e.code, e.expr);
         plan.reset();
     }
+    g.lock();
     const EvalhPlan* out = plan.get();
     if (out) {
         out->last_use = ++g_plan_clock;
         out->users = 1;
+    } else {
+        g_failed_at[key] = std::chrono::steady_clock::now();
     }
     g_plans[key] = std::move(plan);
     evict_plans(key);
