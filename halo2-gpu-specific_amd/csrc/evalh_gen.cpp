@@ -1267,6 +1267,16 @@ std::string cache_dir() {
         buf.push_back('\0');
         if (!mkdtemp(buf.data())) fail("no private cache directory could be made");
         g_private_dir = buf.data();
+        // a directory of this process alone: it goes when the process does (its files first)
+        atexit([] {
+            if (g_private_dir.empty()) return;
+            if (DIR* dp = opendir(g_private_dir.c_str())) {
+                while (struct dirent* e = readdir(dp))
+                    if (strcmp(e->d_name, ".") && strcmp(e->d_name, "..")) unlink((g_private_dir + "/" + e->d_name).c_str());
+                closedir(dp);
+            }
+            rmdir(g_private_dir.c_str());
+        });
     }
     return g_private_dir;
 }

@@ -1582,6 +1582,16 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     with D.torch.cuda.stream(D.tstream):
         blind_dev = D.torch.from_numpy(blind).to(D.dev)
     advice_dev = []
+    # A witness that crosses PCIe in SEVERAL groups (the wide circuit at k = 22: 64 columns of 32-byte cells, 8 GiB, 157 ms on the
+    # link against ~80 ms of narrow commitments) leaves the GPU idle half of this phase: the columns of a group are final once they
+    # are blinded, so their coefficient forms and extended cosets -- needed from the quotient on -- are computed on the SIDE stream
+    # group by group, under the later groups' transfers, instead of after the whole phase (H2_SIDE_GROUPS=0: as before; k above
+    # H2_SIDE_INTT_MAX_K only -- below it the whole-phase form further down already runs them under the lookup / permutation phases)
+    side_groups = (os.environ.get("H2_SIDE_GROUPS", "1") != "0" and os.environ.get("H2_SIDE_INTT", "1") != "0" and
+                   not sharded_upload and D.group_size <= 1 and not D.force_collective and len(uploads) > group and
+                   (dom.k > int(os.environ.get("H2_SIDE_INTT_MAX_K", "20")) or os.environ.get("H2_SIDE_GROUPS") == "force") and
+                   hasattr(D, "intt_on_side_stream"))
+    side_parts = []
     for g0 in range(0, len(uploads), group):
         queue_uploads(g0 + group + ahead)
         cols_ = []
@@ -1617,6 +1627,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         if sharded_upload and whole_advice_rows:
             for t in cols_:
                 allgather_rows(t, lo_r, hi_r, group=D.group, stream=D.tstream)
+        if side_groups:
+            side_parts.append(D.intt_on_side_stream(cols_, dom, extend=D.coset_plan(dom) is None and coset_tabs is None))
         advice_dev += cols_
     del blind_dev
     del uploads
@@ -1630,7 +1642,12 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # small latency-bound kernels (k = 18 lookup circuit 28.9 -> 27.6 ms); at k = 22 / 24 they fill the chip themselves and
     # the transforms only take their time away (60.1 vs 60.2 ms, 210 vs 211)
     side_intt = None
-    if (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= int(os.environ.get("H2_SIDE_INTT_MAX_K", "20"))
+    if side_parts:
+        # (group by group above; the events of one stream are ordered: the last one covers them all)
+        exts_ = [e for _, ext_g, _ in side_parts for e in (ext_g or [])]
+        side_intt = ([p_ for polys_g, _, _ in side_parts for p_ in polys_g],
+                     exts_ if all(ext_g is not None for _, ext_g, _ in side_parts) else None, side_parts[-1][2])
+    elif (os.environ.get("H2_SIDE_INTT", "1") != "0" and dom.k <= int(os.environ.get("H2_SIDE_INTT_MAX_K", "20"))
             and D.group_size <= 1 and not D.force_collective):
         side_intt = D.intt_on_side_stream(advice_dev, dom, extend=D.coset_plan(dom) is None and coset_tabs is None)
     # one proof over several ranks: the advice columns' inverse transforms are dealt by column now (a rank transforms every

@@ -595,6 +595,26 @@ def test_missing_hiprtc_is_an_error_message_not_a_crash(tmp_path):
     assert "COMPILED 2" in out.stdout, out.stdout + out.stderr[-2000:]      # from the disk cache: hipRTC not needed
 
 
+def test_per_process_cache_directory_goes_with_the_process(tmp_path):
+    """a cache directory that is not private to the user is neither read nor written: the process makes one of its own under
+    TMPDIR -- and removes it, with its files, when it exits (it used to stay behind, one per process)"""
+    import subprocess
+    import sys
+
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    code = (
+        "import sys; sys.path[:0] = %r\n"
+        "from halo2_gpu_specific_amd import circuits, prover, evaluation as ev\n"
+        "print('FROM', ev.compile_only(prover.program_descriptor(circuits.mini_plonk(), 5, 7))['from_cache'])\n"
+    ) % [ROOT, os.path.join(ROOT, "tests")]
+    out = subprocess.run([sys.executable, "-c", code], text=True, capture_output=True,
+                         env=dict(os.environ, H2_JIT_CACHE=str(shared), TMPDIR=str(tmp_path)))
+    assert "FROM 0" in out.stdout and "per-process directory" in out.stderr, out.stdout + out.stderr[-1000:]
+    assert os.listdir(shared) == [] and sorted(os.listdir(tmp_path)) == ["shared"]
+
+
 def test_code_objects_of_another_compiler_version_are_rebuilt(tmp_path, monkeypatch):
     """the cache file's header names the hipRTC version that made its code objects: an intact file (valid SHA-256 trailer) from
     ANOTHER version is a miss for a process that can compile -- after a ROCm upgrade the objects are rebuilt instead of being
