@@ -306,13 +306,15 @@ def main():
     # HBM bytes per k_ntt_pass launch from the PMC passes committed under profiles/ (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); null when the file is absent
     traffic, traffic_source = None, None
-    for prof in ("r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+    for prof in ("r6_hbm_traffic.json", "r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", prof)) as f:
                 if log_n == 24:
                     kern = json.load(f)["kernels"]
-                    name = [k for k in kern if "k_ntt_pass" in k][0]
-                    traffic = kern[name]["hbm_bytes_per_launch_corrected"]
+                    # every instantiation of the pass kernel (since round 6 the last pass is one of its own), launch-weighted
+                    passes_ = [v for k, v in kern.items() if "k_ntt_pass" in k]
+                    traffic = (sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in passes_) /
+                               sum(v["launches"] for v in passes_))
                     traffic_source = ("profiles/%s: separate rocprofv3 --pmc passes of this kernel (tools/hbm_traffic.py), "
                                       "NOT measured in this run" % prof)
                     break
