@@ -1585,11 +1585,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # A witness that crosses PCIe in SEVERAL groups (the wide circuit at k = 22: 64 columns of 32-byte cells, 8 GiB, 157 ms on the
     # link against ~80 ms of narrow commitments) leaves the GPU idle half of this phase: the columns of a group are final once they
     # are blinded, so their coefficient forms and extended cosets -- needed from the quotient on -- are computed on the SIDE stream
-    # group by group, under the later groups' transfers, instead of after the whole phase (H2_SIDE_GROUPS=0: as before; k above
-    # H2_SIDE_INTT_MAX_K only -- below it the whole-phase form further down already runs them under the lookup / permutation phases)
+    # group by group, under the later groups' transfers, instead of after the whole phase (H2_SIDE_GROUPS=0: as before).  Measured
+    # (profiles/r6_side_groups_ab.txt): wide k = 22 447 -> 352 ms (344 from a compact witness, was 369), wide k = 20 122 -> 113,
+    # mini-PLONK k = 24 185 -> 177, k = 22 51.5 -> 50.6.  A witness that fits ONE group keeps the whole-phase form further down.
     side_groups = (os.environ.get("H2_SIDE_GROUPS", "1") != "0" and os.environ.get("H2_SIDE_INTT", "1") != "0" and
                    not sharded_upload and D.group_size <= 1 and not D.force_collective and len(uploads) > group and
-                   (dom.k > int(os.environ.get("H2_SIDE_INTT_MAX_K", "20")) or os.environ.get("H2_SIDE_GROUPS") == "force") and
                    hasattr(D, "intt_on_side_stream"))
     side_parts = []
     for g0 in range(0, len(uploads), group):

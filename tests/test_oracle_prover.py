@@ -102,12 +102,12 @@ def test_advice_uploads_are_queued_a_few_groups_ahead(oracle, monkeypatch):
     assert proofs[0] == proofs[1] == proofs[2]
     # round 6: a witness that arrives in several groups has each group's columns taken to coefficient form (and to the extended
     # domain) right behind the group's commitment -- on the side stream of a HIP device, under the later groups' transfers -- instead
-    # of after the whole phase: same bytes (forced here: by default only above k = 20)
+    # of after the whole phase: same bytes
     calls = []
     orig = D.intt_on_side_stream
     D.intt_on_side_stream = lambda cols, dom, extend=False: (calls.append(len(cols)), orig(cols, dom, extend))[1]
     monkeypatch.setenv("H2_ADVICE_GROUP", "4")
-    monkeypatch.setenv("H2_SIDE_GROUPS", "force")
+    monkeypatch.setenv("H2_SIDE_GROUPS", "1")
     assert prover.create_proof_ext(D, params, pk, adv, ProverRng(5), False) == proofs[0]
     assert calls == [4, 4, 4, 4], calls
     monkeypatch.setenv("H2_SIDE_GROUPS", "0")
