@@ -901,13 +901,48 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
     auto cleanup = [&] {
         for (void* q : owned) (void)hipFree(q);
     };
-    auto dmalloc = [&](size_t bytes) {
+    // ONE device block for the call, handed out piece by piece (a call used to make ~2 x columns + 5 hipMalloc / hipFree pairs,
+    // every hipFree a device synchronisation); sized from the distinct vectors of the descriptor, individual allocations if the
+    // block cannot be had or turns out short
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    auto dmalloc = [&](size_t bytes) -> void* {
+        const size_t take = (bytes + 255) & ~(size_t)255;
+        if (arena && arena_used + take <= arena_bytes) {
+            void* q = arena + arena_used;
+            arena_used += take;
+            return q;
+        }
         void* q = nullptr;
         H2_HIP(hipMalloc(&q, bytes));
         owned.push_back(q);
         return q;
     };
     try {
+        {
+            std::set<const uint64_t*> distinct;
+            size_t n_lz = 0;
+            for (uint32_t t = 0; t < d->n_lookups; t++) n_lz += d->lookup_sets[t];
+            auto count = [&](const uint64_t* const* tab, size_t cnt) {
+                for (size_t i = 0; i < cnt; i++)
+                    if (tab[i]) distinct.insert(tab[i]);
+            };
+            count(d->fixed, d->n_fixed); count(d->advice, d->n_advice); count(d->instance, d->n_instance);
+            count(d->perm_z, d->n_perm_sets); count(d->perm_sigma, d->n_perm_columns); count(d->lookup_z, n_lz);
+            count(d->lookup_m, d->n_lookups); count(d->shuffle_z, d->n_shuffles);
+            if (d->l0) distinct.insert(d->l0);
+            if (d->l_last) distinct.insert(d->l_last);
+            const size_t width = std::max<size_t>(1, std::min<size_t>(16, ((size_t)1 << 30) / nbytes));
+            arena_bytes = (2 * distinct.size() + 2 + width) * (nbytes + 256) + (whole ? 2 * (ebytes + 256) : 0);
+            void* q = nullptr;
+            if (hipMalloc(&q, arena_bytes) == hipSuccess) {
+                arena = (char*)q;
+                owned.push_back(q);
+            } else {
+                (void)hipGetLastError();
+                arena_bytes = 0;
+            }
+        }
         // every distinct coefficient vector once: (device coefficients, device values on the current coset)
         std::map<const uint64_t*, std::pair<Fr*, Fr*>> cols;
         auto add = [&](const uint64_t* h) {
@@ -944,8 +979,12 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
         if (d->l_active_row) d_active_j = (Fr*)dmalloc(nbytes);
         if (whole) {
             if (d->l_active_row) {
-                d_active = (Fr*)dmalloc(ebytes);
-                H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+                // (the proving key's l_active_row, extended values: registered with the key's other vectors, plonk.rs:224)
+                d_active = const_cast<Fr*>(poly_resident(ctx, d->l_active_row, size));
+                if (!d_active) {
+                    d_active = (Fr*)dmalloc(ebytes);
+                    H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+                }
             }
             d_values = (Fr*)dmalloc(ebytes);
         } else {

@@ -1173,8 +1173,6 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
     # residency decided here for one and then runs coset by coset from tables built on demand (create_proof_ext)
     pk.coset_builder = coset_tables
     pk.l0_poly, pk.l_last_poly = l0_poly, l_last_poly     # (the cuda-shaped evaluator takes l0 / l_last as coefficient forms)
-    # read by every proof, never written (sigma_values: the permutation argument's denominators, permutation/prover.rs:89-128)
-    D.retain(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly] + list(pk.sigma_values), owner=pk)
     if plan is None:
         pk.l0, pk.l_last = D.coeff_to_extended(l0_poly, dom), D.coeff_to_extended(l_last_poly, dom)
         pk.l_active_row = active_row(pk.l_last, D.coeff_to_extended(l_blind_poly, dom), dom.extended_n)
@@ -1187,6 +1185,10 @@ def keygen(device, params, cs, fixed, copies, mapping=None, fixed_montgomery=Fal
         if keep is None:                       # one proof over several ranks: this rank's cosets stay resident
             for j in plan[2]:
                 pk.coset[j]
+    # read by every proof, never written (sigma_values: the permutation argument's denominators, permutation/prover.rs:89-128;
+    # l_active_row: the extended values the evaluator takes as they are)
+    D.retain(list(pk.fixed_polys) + list(pk.sigma_polys) + [l0_poly, l_last_poly] + list(pk.sigma_values) +
+             ([pk.l_active_row] if pk.l_active_row is not None else []), owner=pk)
     pk.t_evaluations = D.upload(np.array([fr_to_mont_limbs(v) for v in dom.t_evaluations], dtype=np.uint64))
     # Evaluator::new: the gate program with the lookup / shuffle result calculations, and the compression programs
     # (evaluate_with_theta) of every lookup / shuffle expression list

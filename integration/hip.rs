@@ -560,7 +560,7 @@ pub fn unregister_polys<F: FieldExt>(polys: &[&[F]]) {
 }
 
 /// The vectors of a proving key that every proof reads and none writes (plonk.rs:226-240 under `hip`: coefficient forms):
-/// `fixed_polys`, `permutation.polys`, `l0`, `l_last`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
+/// `fixed_polys`, `permutation.polys`, `l0`, `l_last`, `l_active_row`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
 /// (plonk/keygen.rs:442-455, :540-553); `ProvingKey`'s `Drop` (added by the patch) unregisters before the vectors go.
 /// A proving key is not moved out of its `Vec`s after keygen: the registered addresses are those of the heap buffers.
 pub fn proving_key_polys<'a, C: CurveAffine>(pk: &'a crate::plonk::ProvingKey<C>) -> Vec<&'a [C::Scalar]> {
@@ -573,6 +573,7 @@ pub fn proving_key_polys<'a, C: CurveAffine>(pk: &'a crate::plonk::ProvingKey<C>
     }
     out.push(&pk.l0.values[..]);
     out.push(&pk.l_last.values[..]);
+    out.push(&pk.l_active_row.values[..]); // extended values: what `evaluate_h` takes as they are
     out
 }
 

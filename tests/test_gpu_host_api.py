@@ -136,42 +136,96 @@ def test_registered_polynomials_are_read_on_the_device_and_never_served_stale(or
     assert L.h2_poly_register(None, 4) != 0 and L.h2_poly_register(_ptr(p), 0) != 0
 
 
-def test_pipelined_elementwise_entry_points_at_long_sizes_vs_oracle(oracle):
-    """from 2^21 elements on, h2_lincomb / h2_eval_op / h2_batch_mont / h2_batch_unmont / h2_divide_by_vanishing_poly run chunk
-    by chunk over three streams (upload of chunk c + 1, kernel of chunk c, download of chunk c - 1): a ragged length (the last
-    chunk short), in-place forms and the table of the vanishing division across chunk boundaries, against the oracle"""
+class _Pinned:
+    """numpy (n, 4) u64 arrays in page-locked host memory (h2_host_alloc_pinned): what the chunk pipeline needs to run at all"""
+
+    def __init__(self, L):
+        self.L, self.blocks = L, []
+
+    def like(self, a):
+        import ctypes
+
+        p = ctypes.c_void_p()
+        assert self.L.h2_host_alloc_pinned(a.nbytes, ctypes.byref(p)) == 0
+        self.blocks.append(p)
+        out = np.ctypeslib.as_array((ctypes.c_uint64 * a.size).from_address(p.value)).reshape(a.shape)
+        out[...] = a
+        return out
+
+    def free(self):
+        for p in self.blocks:
+            self.L.h2_host_free_pinned(p)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_pipelined_elementwise_entry_points_at_long_sizes_vs_oracle(oracle, pinned):
+    """from 2^21 elements on, h2_lincomb / h2_eval_op / h2_batch_mont / h2_batch_unmont / h2_divide_by_vanishing_poly /
+    h2_permutation_terms run chunk by chunk over three streams when their host vectors are PAGE-LOCKED (upload of chunk c + 1,
+    kernel of chunk c, download of chunk c - 1) and single shot from ordinary memory: a ragged length (the last chunk short),
+    in-place forms, the table of the vanishing division and the omega powers of the permutation terms across chunk boundaries,
+    both ways against the oracle"""
     import ctypes
 
     import halo2_gpu_specific_amd as h2
     from halo2_gpu_specific_amd import arithmetic as ar
 
     L = h2.lib()
+    pool = _Pinned(L)
+    host = pool.like if pinned else (lambda v: v)
+    try:
+        _pipelined_cases(oracle, L, ar, host, ctypes)
+    finally:
+        pool.free()
+
+
+def _pipelined_cases(oracle, L, ar, host, ctypes):
     n = (1 << 21) + (1 << 19) + 12345
-    a, b, c3 = oracle.random_fr(9500, n), oracle.random_fr(9501, n), oracle.random_fr(9502, n)
+    a, b, c3 = host(oracle.random_fr(9500, n)), host(oracle.random_fr(9501, n)), host(oracle.random_fr(9502, n))
     coeffs = oracle.random_fr(9503, 3)
     want = np.zeros((n, 4), dtype=np.uint64)
     for v, cf in zip((a, b, c3), coeffs):
         want = oracle.eval_op(ar.OP_SUM, want, oracle.eval_op(ar.OP_MUL_C, v, None, 0, 0, cf), 0, 0, None)
-    res = np.zeros((n, 4), dtype=np.uint64)
+    res = host(np.zeros((n, 4), dtype=np.uint64))
     ptrs = (ctypes.c_void_p * 3)(a.ctypes.data, b.ctypes.data, c3.ctypes.data)
     assert L.h2_lincomb(_ptr(res), ptrs, _ptr(coeffs), 3, n) == 0
     assert np.array_equal(res, want)
-    assert np.array_equal(ar.eval_op(ar.OP_MUL, a, b), oracle.eval_op(ar.OP_MUL, a, b, 0, 0, None))
-    assert np.array_equal(ar.eval_op(ar.OP_LCTHETA, a, b, c=coeffs[0]), oracle.eval_op(ar.OP_LCTHETA, a, b, 0, 0, coeffs[0]))
-    inplace = a.copy()
+    assert L.h2_eval_op(ar.OP_MUL, _ptr(res), _ptr(a), _ptr(b), 0, 0, n, None) == 0
+    assert np.array_equal(res, oracle.eval_op(ar.OP_MUL, a, b, 0, 0, None))
+    assert L.h2_eval_op(ar.OP_LCTHETA, _ptr(res), _ptr(a), _ptr(b), 0, 0, n, _ptr(coeffs[0])) == 0
+    assert np.array_equal(res, oracle.eval_op(ar.OP_LCTHETA, a, b, 0, 0, coeffs[0]))
+    inplace = host(a.copy())
     assert L.h2_eval_op(ar.OP_SUB, _ptr(inplace), _ptr(inplace), _ptr(b), 0, 0, n, None) == 0          # res aliases l
     assert np.array_equal(inplace, oracle.eval_op(ar.OP_SUB, a, b, 0, 0, None))
     raw = oracle.random_fr(9504, n)
-    m = ar.gpu_mont(raw.copy())
-    assert np.array_equal(ar.gpu_unmont(m.copy()), raw)
+    m = host(raw.copy())
+    assert L.h2_batch_mont(_ptr(m), n) == 0
     one = np.zeros((n, 4), dtype=np.uint64)
     one[:, 0] = 1
-    assert np.array_equal(oracle.eval_op(ar.OP_MUL, m, ar.gpu_mont(one), 0, 0, None), m)                  # m * mont(1) = m
+    mont_one = ar.gpu_mont(one)
+    assert np.array_equal(oracle.eval_op(ar.OP_MUL, np.array(m), mont_one, 0, 0, None), m)                 # m * mont(1) = m
+    assert L.h2_batch_unmont(_ptr(m), n) == 0
+    assert np.array_equal(m, raw)
     d, t = oracle.domain(5, 20)                       # extended_k = 22: 2^22 values, t_len = 4
     ext = oracle.random_fr(9505, 1 << d.extended_k)
-    got = ar.divide_by_vanishing_poly(ext.copy(), t)
+    got = host(ext.copy())
+    assert L.h2_divide_by_vanishing_poly(_ptr(got), len(got), _ptr(t), len(t)) == 0
     oracle.lib.oracle_divide_by_vanishing_poly(ext.ctypes.data, len(ext), t.ctypes.data, len(t), 16)
     assert np.array_equal(got, ext)
+    # the permutation argument's numerator / denominator products (permutation/prover.rs:89-128): first column of a set, then a
+    # second one multiplied in; the numerator's delta^c omega^i must continue across the chunk boundaries
+    from h2util import R_MOD, fr_mont
+
+    value, sigma = a, b
+    beta, gamma = oracle.random_fr(9506, 2)
+    omega = fr_mont(pow(0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C, 1 << (28 - 22), R_MOD))
+    dpow = fr_mont(pow(0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2, 3, R_MOD))
+    num, den = host(np.zeros((n, 4), dtype=np.uint64)), host(np.zeros((n, 4), dtype=np.uint64))
+    wn, wd = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+    for first, (v_, s_) in ((1, (value, sigma)), (0, (c3, a))):
+        assert L.h2_permutation_terms(_ptr(num), _ptr(den), _ptr(v_), _ptr(s_), n, _ptr(beta), _ptr(gamma), _ptr(dpow), _ptr(omega), first) == 0
+        oracle.lib.oracle_permutation_terms(_ptr(wn), _ptr(wd), _ptr(np.array(v_)), _ptr(np.array(s_)), n, _ptr(beta), _ptr(gamma), _ptr(dpow),
+                                            _ptr(omega), first)
+        assert np.array_equal(num, wn) and np.array_equal(den, wd), first
 
 
 @pytest.mark.parametrize("register", [True, False])
