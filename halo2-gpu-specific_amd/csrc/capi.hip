@@ -3,6 +3,8 @@
 // per-call program creation removed: a pooled device context keeps streams, scratch and
 // twiddle plans alive across calls.  h2_dev_* = the same ops on device-resident data.
 #include <cstring>
+#include <sys/mman.h>
+#include <thread>
 
 #include "common.hpp"
 #include "evalh.hpp"
@@ -135,6 +137,49 @@ bool use_pipeline(size_t size, std::initializer_list<const void*> host) {
         if (!host_pinned(p)) return false;
     return true;
 }
+// A result vector in ORDINARY host memory that nobody has touched yet -- what every operation of the reference's data flow
+// returns: a fresh `Vec` -- faults its pages in one by one under the device-to-host copy, on the runtime's single staging thread:
+// 21 ms for the 128 MiB of a k = 22 vector against 2.5 ms on the link (tools/experiments/hostreg_probe.py).  The pages of the
+// destination are populated HERE instead, by a few threads at once (MADV_POPULATE_WRITE per slice; a read-write touch per page
+// where the kernel does not know it), started when the call begins -- under its uploads and kernels -- and joined before the
+// copy back is issued.  Page-locked destinations and short ones are left alone; H2_HOST_PREFAULT=0 switches it off.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+struct Prefault {
+    std::vector<std::thread> workers;
+    Prefault() = default;
+    Prefault(void* dst, size_t bytes) { start(dst, bytes); }
+    void start(void* dst, size_t bytes) {
+        static const int threads = [] {
+            const char* e = getenv("H2_HOST_PREFAULT");
+            const int v = e ? atoi(e) : 8;
+            return v < 0 ? 0 : (v > 32 ? 32 : v);
+        }();
+        if (!threads || !dst || bytes < ((size_t)4 << 20) || host_pinned(dst)) return;
+        const uintptr_t page = 4096, lo = ((uintptr_t)dst + page - 1) & ~(page - 1), hi = ((uintptr_t)dst + bytes) & ~(page - 1);
+        if (hi <= lo) return;
+        const size_t pages = (hi - lo) / page, per = (pages + threads - 1) / threads;
+        for (int t = 0; t < threads; t++) {
+            const size_t first = (size_t)t * per, count = first < pages ? std::min(per, pages - first) : 0;
+            if (!count) break;
+            char* at = (char*)lo + first * page;
+            workers.emplace_back([at, count] {
+                if (madvise(at, count * page, MADV_POPULATE_WRITE) == 0) return;
+                for (size_t i = 0; i < count; i++) {   // (an older kernel: touch every page; the value written is the one read)
+                    volatile char* q = at + i * page;
+                    *q = *q;
+                }
+            });
+        }
+    }
+    void join() {
+        for (std::thread& w : workers) w.join();
+        workers.clear();
+    }
+    ~Prefault() { join(); }
+};
+
 void fr_to_u64x4(const Fr& v, uint64_t out[4]) {
     for (int i = 0; i < 4; i++) out[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
 }
@@ -334,6 +379,7 @@ int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
         size_t in_bytes = sizeof(Fr) << k, ext_bytes = sizeof(Fr) << extended_k;
+        Prefault pf(out, ext_bytes);
         Fr* d_in = (Fr*)ctx->buf_a.get(ext_bytes);
         Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
         // into_coset = true: coset_powers = [g_coset, g_coset_inv] (domain.rs:383-385)
@@ -345,6 +391,7 @@ int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint
         }
         int rc = dev_ntt_impl(ctx, src, d_in, d_t, 1u << k, extended_omega, extended_k, pre3, nullptr, ctx->stream, true);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(out, d_in, ext_bytes, hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -361,12 +408,14 @@ int h2_extended_to_coeff(const uint64_t* a, uint64_t* out, size_t out_len, uint3
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
         size_t ext_bytes = sizeof(Fr) << extended_k;
+        Prefault pf(out == a ? nullptr : out, out_len * sizeof(Fr));
         Fr* d_a = (Fr*)ctx->buf_a.get(ext_bytes);
         Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
         H2_HIP(hipMemcpyAsync(d_a, a, ext_bytes, hipMemcpyHostToDevice, ctx->stream));
         int rc = dev_extended_to_coeff_impl(ctx, d_a, d_t, extended_k, g_coset, g_coset_inv, extended_omega_inv,
                                             extended_ifft_divisor, ctx->stream, true);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(out, d_a, out_len * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -442,6 +491,7 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
                 });
             return rc;
         }
+        Prefault pf((const void*)res == (const void*)l || (const void*)res == (const void*)r ? nullptr : res, bytes);
         Fr* d_res = (Fr*)ctx->buf_a.get(bytes);
         const Fr* d_l = res_l;
         const Fr* d_r = res_r;
@@ -457,6 +507,7 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
         }
         int rc = eval_op_launch(op, d_res, d_l, d_r, l_rot, r_rot, size, c, ctx->stream);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -963,6 +1014,7 @@ int h2_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t*
         if (n < 2) return (int)H2_OK;
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
+        Prefault pf(q == a ? nullptr : q, (n - 1) * sizeof(Fr));
         Fr* d_q = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
         const Fr* d_a = resident_operand(ctx, a, n);
@@ -973,6 +1025,7 @@ int h2_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t*
         }
         int rc = kate_division_launch(d_a, n, b, d_q, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(q, d_q, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -996,12 +1049,14 @@ int h2_prefix_product(const uint64_t* f, size_t n, const uint64_t init[4], uint6
         if (n == 0) return (int)H2_OK;
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
+        Prefault pf(z, n * sizeof(Fr));
         Fr* d_f = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         Fr* d_z = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
         if (n > 1) H2_HIP(hipMemcpyAsync(d_f, f, (n - 1) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         int rc = prefix_product_launch(d_f, n, init, d_z, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(z, d_z, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -1062,6 +1117,7 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
                 });
             return rc;
         }
+        Prefault pf(count && (const void*)res == (const void*)polys[0] ? nullptr : res, bytes);
         Fr* d_all = staged.empty() ? nullptr : (Fr*)ctx->buf_a.get(bytes * staged.size());
         Fr* d_res = (Fr*)ctx->buf_b.get(bytes);
         for (size_t j = 0; j < staged.size(); j++) {
@@ -1070,6 +1126,7 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
         }
         int rc = lincomb_launch(d_res, ptrs.data(), coeffs, count, size, ctx->stream);
         if (rc != H2_OK) return rc;
+        pf.join();
         H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
@@ -1098,6 +1155,7 @@ int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, co
         DeviceCtx* ctx = lease.ctx;
         const Fr* res_sigma = resident_operand(ctx, sigma, n);
         const Fr* res_value = resident_operand(ctx, value, n);
+        Prefault pf_num(first ? num : nullptr, n * sizeof(Fr)), pf_den(first ? den : nullptr, n * sizeof(Fr));
         const bool pipe = use_pipeline(n, {num, den, res_value ? nullptr : (const void*)value, res_sigma ? nullptr : (const void*)sigma});
         const size_t chunk = pipe ? PIPE_CHUNK : n;
         Fr* s_num = (Fr*)ctx->buf_a.get(2 * chunk * sizeof(Fr));
@@ -1130,6 +1188,8 @@ int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, co
         } else {
             up(0, n, 0, ctx->stream);
             run(0, n, 0, ctx->stream);
+            pf_num.join();
+            pf_den.join();
             down(0, n, 0, ctx->stream);
             H2_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -1280,6 +1340,8 @@ uint64_t h2_evalh_generated_launches(void) { return evalh_generated_launches(); 
 int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h: null argument");
     return guarded([&] {
+        Prefault pf(values, sizeof(Fr) << desc->extended_k);
+        pf.join();   // (before anything is copied back: the touch fallback must not race with the copy)
         DeviceLease lease;
         return evalh_host(lease.ctx, desc, values);
     });
@@ -1287,7 +1349,11 @@ int h2_evaluate_h(const h2_evalh_desc* desc, uint64_t* values) {
 
 int h2_evaluate_h_coeff(const h2_evalh_desc* desc, uint64_t* values) {
     if (!desc || !values) return bad("h2_evaluate_h_coeff: null argument");
-    return guarded([&] { return evalh_host_coeffs(desc, values); });
+    return guarded([&] {
+        Prefault pf(values, desc->extended_k <= 28 ? sizeof(Fr) << desc->extended_k : 0);
+        pf.join();
+        return evalh_host_coeffs(desc, values);
+    });
 }
 
 int h2_dev_evaluate_h(const h2_evalh_desc* desc, void* d_values, void* stream) {
