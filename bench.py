@@ -895,6 +895,25 @@ def main():
         torch.cuda.empty_cache()
         headline["create_proof_k%d_seconds" % kk] = seconds_of(out[key], "seconds")
         headline["create_proof_k%d_evaluate_h_alu_frac" % kk] = seconds_of(out[key], "evaluate_h", "roofline", "alu", "frac")
+    # the same k = 22 proof from a host that is not Python: tools/h2prove (plain C++ over the C ABI alone, a process of its own;
+    # its bytes are pinned by tests/test_gpu_h2prove.py) -- seconds next to prover.py's
+    if world == 1 and args.prove_k and "error" not in out.get("create_proof", {"error": 1}):
+        try:
+            import subprocess
+
+            tool = os.path.join(ROOT, "tools", "h2prove")
+            if not os.path.exists(tool):
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "h2prove"], stdout=subprocess.DEVNULL)
+            torch.cuda.synchronize()
+            res = subprocess.run([tool, str(args.prove_k), "1", "--reps", "3"], capture_output=True, text=True, timeout=600)
+            fields = [ln for ln in res.stdout.splitlines() if ln.startswith("k ")][0].split()
+            stats = dict(zip(fields[0::2], fields[1::2]))
+            out["create_proof"]["h2prove_cxx"] = {
+                "what": "tools/h2prove.cpp: keygen + create_proof (SHPLONK) in plain C++ over include/halo2_hip.h alone -- no Python, no "
+                        "torch, no HIP headers; one stream, recycled h2_dev_alloc blocks",
+                "seconds": float(stats["create_proof_s"]), "keygen_seconds": float(stats["keygen_s"]), "proof_bytes": int(stats["proof_bytes"])}
+        except Exception as e:  # noqa: BLE001 - a side figure: the line is printed without it
+            out["create_proof"]["h2prove_cxx"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # N > 1: the same circuit as INDEPENDENT proofs, one per GPU (prover.Device.replica: a singleton group, no collective on
     # the data path) -- the throughput a node reaches when there are at least N proofs to make, next to the latency form above
     if world > 1 and args.prove_k and "error" not in out.get("create_proof", {"error": 1}):
@@ -1096,6 +1115,7 @@ def main():
             ("create_proof_k%d_evalh_alu_frac" % args.prove_k, "create_proof", ("evaluate_h", "roofline", "alu", "frac")),
             ("create_proof_k%d_host_slice_pinned_s" % args.prove_k, "create_proof", ("host_slice_api", "pinned", "seconds")),
             ("create_proof_k%d_host_slice_pageable_s" % args.prove_k, "create_proof", ("host_slice_api", "pageable", "seconds")),
+            ("create_proof_k%d_h2prove_cxx_s" % args.prove_k, "create_proof", ("h2prove_cxx", "seconds")),
             ("create_proof_k%d_cpu_s" % args.cpu_prove_k, "create_proof", ("cpu_baseline", "seconds")),
             ("create_proof_k24_s", "create_proof_k24", ("seconds",)),
             ("create_proof_k24_evalh_alu_frac", "create_proof_k24", ("evaluate_h", "roofline", "alu", "frac")),

@@ -300,9 +300,10 @@ size_t plans_max() {
     return v;
 }
 
-// g_plan_mu held.  Unloads least-recently-used plans nobody holds until the cache is back at its bound; a plan's device is
-// drained first (its launches are asynchronous and the code object has to outlive them).
-void evict_plans(const PlanKey& keep) {
+// g_plan_mu held.  UNHOOKS least-recently-used plans nobody holds until the cache is back at its bound and hands them to the
+// caller, who unloads them with `unload_plans` AFTER releasing the lock: a plan's device is drained first (its launches are
+// asynchronous and the code object has to outlive them), and that wait must not stall every other lookup.
+void evict_plans(const PlanKey& keep, std::vector<std::unique_ptr<EvalhPlan>>& gone) {
     while (g_plans.size() > plans_max()) {
         auto victim = g_plans.end();
         for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
@@ -312,18 +313,24 @@ void evict_plans(const PlanKey& keep) {
             if (victim == g_plans.end() || t < (victim->second ? victim->second->last_use : 0)) victim = it;
         }
         if (victim == g_plans.end()) return;   // everything else is in use: over the bound until a holder lets go
-        if (EvalhPlan* pl = victim->second.get()) {
-            int current = 0;
-            const bool have = hipGetDevice(&current) == hipSuccess;
-            if (hipSetDevice(pl->device) == hipSuccess) {
-                (void)hipDeviceSynchronize();
-                for (hipModule_t m : pl->modules) (void)hipModuleUnload(m);
-            }
-            if (have) (void)hipSetDevice(current);
-        }
+        if (victim->second) gone.push_back(std::move(victim->second));
+        g_failed_at.erase(victim->first);
         g_plans.erase(victim);
         g_plan_evictions.fetch_add(1);
     }
+}
+// no lock held: nobody can reach these plans any more
+void unload_plans(std::vector<std::unique_ptr<EvalhPlan>>& gone) {
+    for (auto& pl : gone) {
+        int current = 0;
+        const bool have = hipGetDevice(&current) == hipSuccess;
+        if (hipSetDevice(pl->device) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            for (hipModule_t m : pl->modules) (void)hipModuleUnload(m);
+        }
+        if (have) (void)hipSetDevice(current);
+    }
+    gone.clear();
 }
 
 // in-memory identity of a program: two multiply-xorshift lanes over the same bytes program_hash covers (the SHA-256 is
@@ -466,7 +473,12 @@ EvalhPlanRef evalh_plan_get(const h2_evalh_desc* d, int* cached) {
         g_failed_at[key] = std::chrono::steady_clock::now();
     }
     g_plans[key] = std::move(plan);
-    evict_plans(key);
+    std::vector<std::unique_ptr<EvalhPlan>> gone;
+    evict_plans(key, gone);
+    if (!gone.empty()) {
+        g.unlock();
+        unload_plans(gone);
+    }
     return EvalhPlanRef(out);
 }
 
