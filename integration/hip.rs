@@ -559,6 +559,34 @@ pub fn unregister_polys<F: FieldExt>(polys: &[&[F]]) {
     }
 }
 
+/// RAII form of `register_polys` for vectors that are final for the rest of a scope -- a proof's advice / product / quotient
+/// coefficient forms from the point where they are made to the end of `create_proof` (plonk/prover.rs:639-850): every way out
+/// of the scope, `?` included, unregisters.  The vectors must not be moved out of their `Vec`s or modified while the guard lives.
+pub struct RegisteredPolys {
+    ptrs: Vec<*const u64>,
+}
+
+impl RegisteredPolys {
+    pub fn new<'a, F: FieldExt + 'a, I: IntoIterator<Item = &'a [F]>>(polys: I) -> Self {
+        let mut ptrs = Vec::new();
+        for p in polys {
+            if !p.is_empty() {
+                unsafe { check(h2_poly_register(p.as_ptr() as *const u64, p.len()), "poly_register") };
+                ptrs.push(p.as_ptr() as *const u64);
+            }
+        }
+        RegisteredPolys { ptrs }
+    }
+}
+
+impl Drop for RegisteredPolys {
+    fn drop(&mut self) {
+        for p in self.ptrs.iter() {
+            unsafe { h2_poly_unregister(*p) };
+        }
+    }
+}
+
 /// The vectors of a proving key that every proof reads and none writes (plonk.rs:226-240 under `hip`: coefficient forms):
 /// `fixed_polys`, `permutation.polys`, `l0`, `l_last`, `l_active_row`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
 /// (plonk/keygen.rs:442-455, :540-553); `ProvingKey`'s `Drop` (added by the patch) unregisters before the vectors go.

@@ -446,6 +446,16 @@ def edit(rel, text):
         return switch_shape(text, 1)
     if rel.endswith("plonk/prover.rs"):
         text = replace_once(text, N_GPU_CUDA, N_GPU_HIP, "N_GPU default")
+        # the advice columns' coefficient forms are final from here to the end of the proof (evaluator, evaluations at x, the
+        # multiopen folds read them): registered for that long -- a guard, so that every way out of the function unregisters
+        site = ("                advice_cosets,\n            }\n        })\n        .collect::<Vec<_>>();\n\n"
+                "    #[cfg(feature = \"cuda\")]\n    let h_poly = pk.ev.evaluate_h(\n")
+        guard = ('    #[cfg(feature = "hip")]\n'
+                 "    let _hip_advice_polys = crate::hip::RegisteredPolys::new(\n"
+                 "        advice.iter().flat_map(|a| a.advice_polys.iter().map(|p| &p.values[..])),\n"
+                 "    );\n\n")
+        assert text.count(site) == 2, "advice_polys sites of create_proof_ext / create_proof_from_witness"
+        text = text.replace(site, site.replace('    #[cfg(feature = "cuda")]\n    let h_poly', guard + '    #[cfg(feature = "cuda")]\n    let h_poly'))
         text = switch_shape(text, 19 - 2)          # the two sites of the N_GPU block became cuda / hip / neither
         text = text.replace("#[cfg(CUDA_ONLY)]", '#[cfg(feature = "cuda")]')
         return text.replace("#[cfg(not(CUDA_OR_HIP))]", "#[cfg(not(%s))]" % ANY)
