@@ -67,6 +67,15 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert "crate::hip::lincomb(&polys, &coeffs)" in gwc
     prover = (tmp_path / "halo2_proofs/src/plonk/prover.rs").read_text()
     assert "crate::hip::device_count().to_string()" in prover
+    # resident polynomials (round 6): the proving key's coefficient forms are registered at the end of both keygen functions
+    # and unregistered by Drop; a proof's advice polynomials by an RAII guard in both create_proof functions
+    keygen = (tmp_path / "halo2_proofs/src/plonk/keygen.rs").read_text()
+    assert keygen.count("crate::hip::register_proving_key(&pk);") == 2 and keygen.count("    Ok(pk)\n}") == 2
+    assert "impl<C: CurveAffine> Drop for ProvingKey<C>" in plonk and "crate::hip::unregister_proving_key(self);" in plonk
+    assert prover.count("let _hip_advice_polys = crate::hip::RegisteredPolys::new(") == 2
+    hip = open(HIP_RS).read()
+    for name in ("h2_poly_register", "h2_poly_unregister", "pub fn register_proving_key", "pub struct RegisteredPolys", "impl Drop for RegisteredPolys"):
+        assert name in hip, name
     for rel in ("plonk/keygen.rs", "plonk/permutation.rs", "plonk/permutation/keygen.rs", "plonk/permutation/prover.rs", "plonk/prover.rs"):
         text = (tmp_path / "halo2_proofs/src" / rel).read_text()
         left = [l for l in text.splitlines() if 'feature = "cuda"' in l and any_ not in l]
