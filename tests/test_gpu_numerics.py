@@ -320,3 +320,21 @@ def test_device_memory_and_stream_helpers_without_torch(oracle):
     finally:
         assert L.h2_dev_free(d_a) == 0 and L.h2_dev_free(d_tmp) == 0 and L.h2_dev_free(None) == 0
         assert L.h2_stream_destroy(stream) == 0 and L.h2_host_free_pinned(pinned) == 0
+
+
+def test_constant_operand_product_on_the_device_including_short_quotients(tmp_path):
+    """fp_mul_const (csrc/field.hpp, round 6: the NTT's twiddle products) as compiled gfx950 code against host arithmetic:
+    65 536 random operand triples (ANY 256-bit x) and 4 096 built so that the truncated quotient IS one short -- the branch
+    the transforms take about once in 2^29 products: raw result = exact or exact + p, the value the passes use is below 2p and
+    the same residue.  tests/fp_mul_const_check.hip, compiled here with hipcc (the schedule itself is executed line by line
+    with Python integers in tests/test_fp_mul_schedule.py)."""
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "fp_mul_const_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", os.path.join(here, "fp_mul_const_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if "fp_mul_const device vs host" in ln]
+    assert len(lines) == 2 and all(": 0 mismatches, 0 results at or above 2p" in ln for ln in lines), out.stdout
