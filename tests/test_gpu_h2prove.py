@@ -56,3 +56,24 @@ def test_h2prove_other_seed_other_proof_and_file_output(tmp_path):
     out = tmp_path / "p.bin"
     b, _, _ = run_tool(10, 2, "--out", str(out))
     assert a != b and len(a) == len(b) == 960 and out.read_bytes() == b
+
+
+def test_h2prove_with_os_entropy_is_accepted_by_the_big_integer_verifier():
+    """--entropy: every blinding value from the operating system (the reference's OsRng): two runs differ, both are accepted by
+    the big-integer verifier of tests/ref_plonk.py (an independent restatement of plonk/verifier.rs with its own pairing)"""
+    import ref_plonk as rp
+
+    k = 9
+    adv, fixed, copies = rp.MiniPlonk.synthesize(k)
+    rpk = rp.keygen(rp.MiniPlonk, k, int(KAT[(12, 12)]["trapdoor"], 16), fixed, copies)
+    a, vk_a, _ = run_tool(k, 1, "--entropy", "--no-tables")
+    b, vk_b, _ = run_tool(k, 1, "--entropy", "--no-tables")
+    assert a != b and vk_a == vk_b == rpk.transcript_repr
+    assert rp.verify_proof(rpk, a) and rp.verify_proof(rpk, b)
+    bad = bytearray(a)
+    bad[40] ^= 1
+    try:
+        accepted = rp.verify_proof(rpk, bytes(bad))
+    except AssertionError:                               # (a point that does not decode counts as a rejection)
+        accepted = False
+    assert not accepted

@@ -11,7 +11,8 @@
 // poly/multiopen/shplonk.rs:58-135 + shplonk/prover.rs:89-225, transcript.rs:81-215 (Blake2bWrite, Challenge255),
 // poly/commitment.rs:56-124 (Params::unsafe_setup); the circuit is examples/simple-example-2.rs:177-288.
 //
-//   h2prove <k> <seed> [--out proof.bin] [--reps N] [--no-tables]     prove on device 0, print seconds and the proof's hex
+//   h2prove <k> <seed> [--out proof.bin] [--reps N] [--no-tables] [--entropy]   prove on device 0, print seconds and the proof's hex
+//                                        (--entropy: blinding from the operating system, as the reference's OsRng; the seeded mode is for tests)
 //   h2prove --host-check <k> <seed>                                    the host-side pieces only (no GPU): printed for the CPU test
 #include <algorithm>
 #include <array>
@@ -312,7 +313,21 @@ struct Transcript {
 // rng.ProverRng.deterministic: xoshiro256** seeded through splitmix64; the random polynomial's ChaCha20 key from a second stream
 struct ProverRng {
     u64 s[4], seed;
+    bool secure = false;  // --entropy: every draw from the operating system (`OsRng`, as the reference): the proof hides its witness
     static u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+    static void os_entropy(void* out, size_t bytes) {
+        FILE* f = fopen("/dev/urandom", "rb");
+        if (!f || fread(out, 1, bytes, f) != bytes) {
+            fprintf(stderr, "h2prove: no entropy source\n");
+            exit(1);
+        }
+        fclose(f);
+    }
+    static ProverRng from_os() {
+        ProverRng r(0);
+        r.secure = true;
+        return r;
+    }
     explicit ProverRng(u64 sd) : seed(sd) {
         u64 z0 = sd;
         for (int i = 0; i < 4; i++) {
@@ -324,6 +339,11 @@ struct ProverRng {
         }
     }
     u64 next() {
+        if (secure) {
+            u64 v;
+            os_entropy(&v, 8);
+            return v;
+        }
         u64 out = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
         s[2] ^= s[0];
         s[3] ^= s[1];
@@ -340,6 +360,7 @@ struct ProverRng {
         return FR.from_wide((const uint8_t*)w);
     }
     void poly_key(uint8_t key[32]) const {
+        if (secure) return os_entropy(key, 32);
         ProverRng second(seed ^ 0x706F6C795F6B6579ULL);
         u64 w[4];
         for (int i = 0; i < 4; i++) w[i] = second.next();
@@ -929,10 +950,10 @@ static void shplonk(Transcript& tr, const Params& P, const std::vector<Query>& q
 }
 
 // ------------------------------------------------------------------------------------------------ create_proof
-static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, const Domain& dom, const Witness& w, u64 seed) {
+static std::vector<uint8_t> create_proof(const Params& P, const ProvingKey& pk, const Domain& dom, const Witness& w, u64 seed, bool entropy = false) {
     const size_t n = dom.n, en = dom.en, bf = BLINDING_FACTORS, usable = n - (bf + 1);
     const int last_rot = -(int)(bf + 1);
-    ProverRng rng(seed);
+    ProverRng rng = entropy ? ProverRng::from_os() : ProverRng(seed);
     Transcript tr;
     tr.common_scalar(pk.transcript_repr);
     // the witness columns start crossing PCIe now, on a stream of their own (DMA out of page-locked memory) ...
@@ -1186,18 +1207,19 @@ static int host_check(uint32_t k, u64 seed) {
 int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "--host-check")) return host_check((uint32_t)atoi(argv[2]), strtoull(argv[3], nullptr, 0));
     if (argc < 3) {
-        fprintf(stderr, "usage: h2prove <k> <seed> [--out proof.bin] [--reps N] [--no-tables]   |   h2prove --host-check <k> <seed>\n");
+        fprintf(stderr, "usage: h2prove <k> <seed> [--out proof.bin] [--reps N] [--no-tables] [--entropy]   |   h2prove --host-check <k> <seed>\n");
         return 2;
     }
     const uint32_t k = (uint32_t)atoi(argv[1]);
     const u64 seed = strtoull(argv[2], nullptr, 0);
     const char* out_path = nullptr;
     int reps = 1;
-    bool tables = true;
+    bool tables = true, entropy = false;
     for (int i = 3; i < argc; i++) {
         if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--no-tables")) tables = false;
+        else if (!strcmp(argv[i], "--entropy")) entropy = true;   // blinding from the OS (the seed is then ignored): not reproducible
     }
     if (k < 4 || k > 26) {
         fprintf(stderr, "h2prove: k out of range\n");
@@ -1224,13 +1246,13 @@ int main(int argc, char** argv) {
         keygen(pk, P, dom, w);
         t_keygen = secs(t0, now());
         t0 = now();
-        proof = create_proof(P, pk, dom, w, seed);
+        proof = create_proof(P, pk, dom, w, seed, entropy);
         t_first = secs(t0, now());
         for (int r = 1; r < reps; r++) {
             t0 = now();
-            std::vector<uint8_t> again = create_proof(P, pk, dom, w, seed);
+            std::vector<uint8_t> again = create_proof(P, pk, dom, w, seed, entropy);
             t_best = std::min(t_best, secs(t0, now()));
-            if (again != proof) {
+            if (!entropy && again != proof) {
                 fprintf(stderr, "h2prove: two proofs from one seed differ\n");
                 return 1;
             }
