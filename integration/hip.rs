@@ -543,7 +543,8 @@ pub fn unregister_params<C: CurveAffine>(g: &[C], g_lagrange: &[C]) {
 /// Registers coefficient / value vectors that will not change while registered (include/halo2_hip.h, h2_poly_register): the
 /// host-slice calls that only READ a vector -- `evaluate_h`'s columns, `eval_polynomial`, the operands of `lincomb`, the
 /// dividend of `kate_division` -- then use a device copy uploaded once per device instead of crossing PCIe per call.
-pub fn register_polys<F: FieldExt>(polys: &[&[F]]) {
+pub fn register_polys<F>(polys: &[&[F]]) {
+    assert_eq!(std::mem::size_of::<F>(), 32);
     for p in polys {
         if !p.is_empty() {
             unsafe { check(h2_poly_register(p.as_ptr() as *const u64, p.len()), "poly_register") };
@@ -551,7 +552,7 @@ pub fn register_polys<F: FieldExt>(polys: &[&[F]]) {
     }
 }
 
-pub fn unregister_polys<F: FieldExt>(polys: &[&[F]]) {
+pub fn unregister_polys<F>(polys: &[&[F]]) {
     for p in polys {
         if !p.is_empty() {
             unsafe { check(h2_poly_unregister(p.as_ptr() as *const u64), "poly_unregister") };
@@ -567,7 +568,8 @@ pub struct RegisteredPolys {
 }
 
 impl RegisteredPolys {
-    pub fn new<'a, F: FieldExt + 'a, I: IntoIterator<Item = &'a [F]>>(polys: I) -> Self {
+    pub fn new<'a, F: 'a, I: IntoIterator<Item = &'a [F]>>(polys: I) -> Self {
+        assert_eq!(std::mem::size_of::<F>(), 32);
         let mut ptrs = Vec::new();
         for p in polys {
             if !p.is_empty() {
