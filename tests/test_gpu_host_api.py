@@ -246,3 +246,49 @@ def test_host_slice_proof_at_a_pipelined_size(oracle, device, register):
         want = prover.create_proof_ext(device, params, pk, adv, ProverRng(seed), gwc)
         assert prover.create_proof_ext(H, hparams, hpk, adv, ProverRng(seed), gwc) == want
     assert not H._retained, "the per-proof registrations are released at the end of the proof"
+
+
+def test_two_threads_through_the_chunk_pipeline_at_once(oracle):
+    """the reference's entry points are called from rayon workers: two threads, each pushing its own page-locked vectors through
+    the chunk-pipelined entry points (h2_lincomb, h2_eval_op in place) at the same time -- the two host-API slots of the device
+    each run their own three-stream pipeline -- give the oracle's results"""
+    import ctypes
+    import threading
+
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import arithmetic as ar
+
+    L = h2.lib()
+    pool = _Pinned(L)
+    n = (1 << 21) + 77
+    errors = []
+    try:
+        jobs = []
+        for t in range(2):
+            a, b = pool.like(oracle.random_fr(9700 + t, n)), pool.like(oracle.random_fr(9710 + t, n))
+            coeffs = oracle.random_fr(9720 + t, 2)
+            want = oracle.eval_op(ar.OP_SUM, oracle.eval_op(ar.OP_MUL_C, a, None, 0, 0, coeffs[0]),
+                                  oracle.eval_op(ar.OP_MUL_C, b, None, 0, 0, coeffs[1]), 0, 0, None)
+            want_mul = oracle.eval_op(ar.OP_MUL, a, b, 0, 0, None)
+            jobs.append((a, b, coeffs, pool.like(np.zeros((n, 4), dtype=np.uint64)), pool.like(np.zeros((n, 4), dtype=np.uint64)), want, want_mul))
+
+        def work(job):
+            a, b, coeffs, res, res2, want, want_mul = job
+            try:
+                ptrs = (ctypes.c_void_p * 2)(a.ctypes.data, b.ctypes.data)
+                for _ in range(3):
+                    assert L.h2_lincomb(_ptr(res), ptrs, _ptr(coeffs), 2, n) == 0
+                    assert np.array_equal(res, want)
+                    assert L.h2_eval_op(ar.OP_MUL, _ptr(res2), _ptr(a), _ptr(b), 0, 0, n, None) == 0
+                    assert np.array_equal(res2, want_mul)
+            except Exception as e:                          # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+    finally:
+        pool.free()
