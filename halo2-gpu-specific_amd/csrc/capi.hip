@@ -140,9 +140,12 @@ bool use_pipeline(size_t size, std::initializer_list<const void*> host) {
 // A result vector in ORDINARY host memory that nobody has touched yet -- what every operation of the reference's data flow
 // returns: a fresh `Vec` -- faults its pages in one by one under the device-to-host copy, on the runtime's single staging thread:
 // 21 ms for the 128 MiB of a k = 22 vector against 2.5 ms on the link (tools/experiments/hostreg_probe.py).  The pages of the
-// destination are populated HERE instead, by a few threads at once (MADV_POPULATE_WRITE per slice; a read-write touch per page
-// where the kernel does not know it), started when the call begins -- under its uploads and kernels -- and joined before the
-// copy back is issued.  Page-locked destinations and short ones are left alone; H2_HOST_PREFAULT=0 switches it off.
+// destination are populated HERE instead, by a few threads at once -- huge pages advised, then one read-write touch per 4 KiB
+// page of the slice -- started when the call begins, under its uploads and kernels, and joined before the copy back is issued.
+// Touching beats MADV_POPULATE_WRITE on the same advised range (a 128 MiB result: 5.6 ms per call against 8.4, 5.3 ms when the
+// pages already exist; four calls at once 19.6-20 ms against 27-31: tools/experiments/prefault_mode_ab.sh);
+// H2_HOST_PREFAULT_POPULATE=1 selects the madvise form.  Page-locked destinations and short ones are left alone;
+// H2_HOST_PREFAULT=<threads> (default 4; 0 switches it off).
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
@@ -153,7 +156,7 @@ struct Prefault {
     void start(void* dst, size_t bytes) {
         static const int threads = [] {
             const char* e = getenv("H2_HOST_PREFAULT");
-            const int v = e ? atoi(e) : 8;
+            const int v = e ? atoi(e) : 4;
             return v < 0 ? 0 : (v > 32 ? 32 : v);
         }();
         if (!threads || !dst || bytes < ((size_t)4 << 20) || host_pinned(dst)) return;
@@ -167,8 +170,9 @@ struct Prefault {
             if (!count) break;
             char* at = (char*)lo + first * page;
             workers.emplace_back([at, count] {
-                if (madvise(at, count * page, MADV_POPULATE_WRITE) == 0) return;
-                for (size_t i = 0; i < count; i++) {   // (an older kernel: touch every page; the value written is the one read)
+                static const bool populate = getenv("H2_HOST_PREFAULT_POPULATE") && atoi(getenv("H2_HOST_PREFAULT_POPULATE")) != 0;
+                if (populate && madvise(at, count * page, MADV_POPULATE_WRITE) == 0) return;
+                for (size_t i = 0; i < count; i++) {   // (the value written is the one read)
                     volatile char* q = at + i * page;
                     *q = *q;
                 }

@@ -39,6 +39,52 @@ def _bytes_at(addr, nbytes):
     return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
 
 
+class _TimedLib:
+    """the C library with a stopwatch on it: `busy_seconds` is the wall time during which at least one of its entry points was
+    executing (calls of the worker threads overlap: the union, not the sum), `summed_seconds` the sum over calls -- what is left
+    of a proof's wall time is the host's own handling of its vectors (allocating, first-touching and freeing them)"""
+
+    def __init__(self, inner):
+        import threading
+
+        self._inner, self._mu = inner, threading.Lock()
+        self._active, self._since = 0, 0.0
+        self.busy_seconds = self.summed_seconds = 0.0
+        self.by_call = {}
+
+    def reset(self):
+        with self._mu:
+            self.busy_seconds = self.summed_seconds = 0.0
+            self.by_call = {}
+
+    def __getattr__(self, name):
+        import time
+
+        fn = getattr(self._inner, name)
+        if not callable(fn):
+            return fn
+
+        def timed(*args):
+            t0 = time.perf_counter()
+            with self._mu:
+                if self._active == 0:
+                    self._since = t0
+                self._active += 1
+            try:
+                return fn(*args)
+            finally:
+                t1 = time.perf_counter()
+                with self._mu:
+                    self._active -= 1
+                    self.summed_seconds += t1 - t0
+                    self.by_call[name] = self.by_call.get(name, 0.0) + (t1 - t0)
+                    if self._active == 0:
+                        self.busy_seconds += t1 - self._since
+
+        self.__dict__[name] = timed
+        return timed
+
+
 class HostSliceLib:
     """the entry points prover.py calls (h2_dev_* signatures), each forwarded to the host-slice entry point the Rust patch
     binds; pointers are host addresses"""
@@ -46,7 +92,7 @@ class HostSliceLib:
     def __init__(self, torch, dev, workers=4):
         import concurrent.futures
 
-        self.R = lib()
+        self.R = _TimedLib(lib())
         self.torch, self.dev = torch, dev
         self.calls = {}
         # the reference runs its per-column loops as rayon par_iters (commitments plonk/prover.rs:293-299, inverse transforms
