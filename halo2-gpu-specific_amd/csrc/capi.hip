@@ -1203,6 +1203,62 @@ int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, co
     });
 }
 
+// One grand-product column of the permutation argument in ONE call (permutation/prover.rs:72-165, for one set of columns):
+//   z[0] = init;   z[i + 1] = z[i] * prod_j (value_j[i] + beta * delta_pow * delta^j * omega^i + gamma)
+//                                   / prod_j (value_j[i] + beta * sigma_j[i] + gamma)
+// -- the per-column products, the batch inversion of the denominators, the product with the numerators and the prefix scan
+// stay on the device: the columns go up once (those registered with h2_poly_register not at all), z comes down once, instead
+// of num / den crossing PCIe in both directions around every step.  The caller writes its blinding rows into z and reads
+// z[n - (blinding_factors + 1)] as the next set's init, as the reference does on its vectors.
+int h2_permutation_product(uint64_t* z, const uint64_t* const* values, const uint64_t* const* sigmas, size_t count, size_t n,
+                           const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4], const uint64_t delta[4],
+                           const uint64_t omega[4], const uint64_t init[4]) {
+    if (n && (!z || !count || !values || !sigmas || !beta || !gamma || !delta_pow || !delta || !omega || !init))
+        return bad("h2_permutation_product: null argument");
+    for (size_t j = 0; n && j < count; j++)
+        if (!values[j] || !sigmas[j]) return bad("h2_permutation_product: null column");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(z, n * sizeof(Fr));
+        const size_t bytes = n * sizeof(Fr);
+        Fr* num = (Fr*)ctx->buf_a.get(bytes);
+        Fr* den = (Fr*)ctx->buf_b.get(bytes);
+        Fr* s_val = (Fr*)ctx->buf_c.get(std::max(bytes, scan_tmp_elems(n) * sizeof(Fr)));
+        Fr* s_sig = (Fr*)ctx->buf_d.get(std::max(bytes, scan_tmp_elems(n) * sizeof(Fr)));
+        Fr dp = fr_from_u64x4(delta_pow);
+        const Fr d = fr_from_u64x4(delta);
+        for (size_t j = 0; j < count; j++) {
+            const Fr* value = resident_operand(ctx, values[j], n);
+            const Fr* sigma = resident_operand(ctx, sigmas[j], n);
+            if (!value) {
+                H2_HIP(hipMemcpyAsync(s_val, values[j], bytes, hipMemcpyHostToDevice, ctx->stream));
+                value = s_val;
+            }
+            if (!sigma) {
+                H2_HIP(hipMemcpyAsync(s_sig, sigmas[j], bytes, hipMemcpyHostToDevice, ctx->stream));
+                sigma = s_sig;
+            }
+            uint64_t dpj[4];
+            fr_to_u64x4(dp, dpj);
+            int rc = perm_terms_launch(num, den, value, sigma, n, beta, gamma, dpj, omega, j == 0, ctx->stream);
+            if (rc != H2_OK) return rc;
+            dp = fp_mul(dp, d);
+        }
+        int rc = batch_invert_launch(den, s_val, n, ctx->stream);
+        if (rc != H2_OK) return rc;
+        rc = eval_op_launch(H2_OP_MUL, num, num, den, 0, 0, n, nullptr, ctx->stream);
+        if (rc != H2_OK) return rc;
+        rc = prefix_product_launch(num, n, init, den, s_sig, ctx->stream);      // z over the inverted denominators' block
+        if (rc != H2_OK) return rc;
+        pf.join();
+        H2_HIP(hipMemcpyAsync(z, den, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
 int h2_dev_permutation_terms(void* d_num, void* d_den, const void* d_value, const void* d_sigma, size_t n,
                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                              const uint64_t omega[4], int first, void* stream) {

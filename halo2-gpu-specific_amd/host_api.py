@@ -329,13 +329,16 @@ class HostApiDevice(P.Device):
     call per circuit instance, as `Evaluator::evaluate_h` under the cuda / hip feature does."""
     quotient_from_coeffs = True
 
-    def __init__(self, device=0, pinned=False, workers=4, register_polys=True):
+    def __init__(self, device=0, pinned=False, workers=4, register_polys=True, fused_permutation=True):
         """`pinned`: every host vector lives in page-locked memory (a Rust-side allocator over h2_host_alloc_pinned for
         `Polynomial::values`): the same calls, but their transfers are DMA instead of staged pageable copies.  `workers`:
         threads that issue the calls of a per-column loop (the reference's rayon par_iters); 1 = strictly sequential"""
         self.pinned = pinned
         self.workers = workers
         self.register_polys, self._retained = register_polys, []     # register_polys=False: the data flow of rounds 4-5
+        if not fused_permutation:
+            self.permutation_product = None                          # the permutation products step by step (rounds 4-6)
+            self.commit_lagrange_and_ifft = None                     # ... and h2_msm + h2_intt for the product columns
         import torch
 
         if not torch.cuda.is_available():
@@ -403,6 +406,38 @@ class HostApiDevice(P.Device):
 
     def sync(self):
         pass
+
+    def permutation_product(self, values, sigmas, n, beta, gamma, delta_pow, omega, init, probe):
+        """one grand-product column of the permutation argument by ONE host-slice call (h2_permutation_product: the set's
+        value / sigma columns in, z out; permutation/prover.rs:72-165) -> (z, z[probe]).  `fused_permutation=False` at
+        construction keeps the step-by-step calls (h2_permutation_terms, h2_batch_invert, h2_eval_op, h2_prefix_product)."""
+        from .prover import DELTA, _fr
+
+        z = self.empty(n)
+        vp = (_vp * len(values))(*[t.data_ptr() for t in values])
+        sp = (_vp * len(sigmas))(*[t.data_ptr() for t in sigmas])
+        self.L._count("h2_permutation_product")
+        scalars = [_fr(v) for v in (beta, gamma, delta_pow, DELTA, omega, init)]       # (alive until the call has returned)
+        check(self.L.R.h2_permutation_product(z.data_ptr(), vp, sp, len(values), n, *[_addr(v) for v in scalars]), "h2_permutation_product")
+        return z, self.get_rows(z, probe, 1)[0]
+
+    def commit_lagrange_and_ifft(self, cols, bases, dom):
+        """Params::commit_lagrange_and_ifft (poly/commitment.rs:144-197 -> gpu_multiexp_bound_and_fft, arithmetic.rs:375-410):
+        one h2_msm_intt call per column -- the commitment over `bases` and, sharing the one upload, the column taken to its
+        coefficient form in place.  -> the commitments (affine), as msm_batch returns them"""
+        from .prover import _fr, jacobians_to_affine
+
+        if not cols:
+            return []
+        out = np.zeros((len(cols), 12), dtype=np.uint64)
+        wi, dv = _fr(dom.omega_inv), _fr(dom.ifft_divisor)
+
+        def one(i):
+            self.L._count("h2_msm_intt")
+            return self.L.R.h2_msm_intt(cols[i].data_ptr(), bases.data_ptr(), dom.n, 254, _addr(wi), _addr(dv), dom.k, out[i].ctypes.data)
+
+        check(self.L._each(one, list(range(len(cols)))), "h2_msm_intt")
+        return jacobians_to_affine(out)
 
     # -- h2_poly_register: what the Rust side does at the same points (integration/hip.rs register_polys / unregister_polys) --
     def retain(self, vectors, owner=None):

@@ -1734,21 +1734,25 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     m_s = hi_s - lo_s
     rows = lambda t: t[lo_s:hi_s]  # noqa: E731
     omega_lo = pow(dom.omega, lo_s, R_MOD)
+    fused_perm = getattr(D, "permutation_product", None) if (lo_s, hi_s) == (0, n) else None
     for C in circuits:
         lookups, shuffles = C["lookups"], C["shuffles"]
         colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
-        slots = nsets + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
-        nums = D.empty(max(nsets, 1) * m_s)
+        # a device whose vectors live on the HOST makes one call per set instead (h2_permutation_product: terms, inversion,
+        # product and scan without num / den crossing PCIe around every step): its sets take no slot here
+        pslots = 0 if fused_perm else nsets
+        slots = pslots + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
+        nums = D.empty(max(pslots, 1) * m_s)
         inv = D.empty(max(slots, 1) * m_s)
         slot = lambda i, inv=inv: inv[i * m_s:(i + 1) * m_s]  # noqa: E731
-        for k_, si in enumerate(range(0, len(cols), chunk)):
+        for k_, si in enumerate(range(0, len(cols) if pslots else 0, chunk)):
             for ci in range(si, min(si + chunk, len(cols))):
                 values = colvals[cols[ci][0]][cols[ci][1]]
                 check(L.h2_dev_permutation_terms(nums[k_ * m_s:].data_ptr(), slot(k_).data_ptr(), rows(values).data_ptr(),
                                                  rows(pk.sigma_values[ci]).data_ptr(), m_s, _fr(beta), _fr(gamma),
                                                  _fr(pow(DELTA, ci, R_MOD) * omega_lo), _fr(dom.omega), 1 if ci == si else 0,
                                                  D.stream), "h2_dev_permutation_terms")
-        at = nsets
+        at = pslots
         for st in lookups:
             st["inv_inputs"] = []
             for cols_in in st["inputs"]:
@@ -1771,7 +1775,7 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         assert at == slots
         if slots:
             check(L.h2_dev_batch_invert(inv.data_ptr(), D.empty(slots * m_s).data_ptr(), slots * m_s, D.stream), "h2_dev_batch_invert")
-        if nsets:
+        if pslots:
             D.eval_op(3, nums, nums, inv[:nsets * m_s])                                     # H2_OP_MUL over all sets
         C["nums"], C["inv"] = nums, inv
 
@@ -1779,8 +1783,14 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     blinding = []         # (z, first blinding row, values): drawn in the reference's order, written in one copy below
     for C in circuits:
         C["z"], last_z = [], 1
+        colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
         for k_ in range(nsets):
-            z, last_z = D.prefix_scan(C["nums"][k_ * m_s:(k_ + 1) * m_s], n, last_z, True, usable)
+            if fused_perm:
+                cis = range(k_ * chunk, min((k_ + 1) * chunk, len(cols)))
+                z, last_z = fused_perm([colvals[cols[ci][0]][cols[ci][1]] for ci in cis], [pk.sigma_values[ci] for ci in cis], n,
+                                       beta, gamma, pow(DELTA, k_ * chunk, R_MOD), dom.omega, last_z, usable)
+            else:
+                z, last_z = D.prefix_scan(C["nums"][k_ * m_s:(k_ + 1) * m_s], n, last_z, True, usable)
             blinding.append((z, n - bf, [rng.fr() for _ in range(bf)]))
             C["z"].append(z)
         del C["nums"]
@@ -1821,12 +1831,17 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     # products of every circuit, then the lookup sums of every circuit, then the shuffle products (prover.rs:595-625)
     all_z = ([z for C in circuits for z in C["z"]] + [z for C in circuits for st in C["lookups"] for z in st["z"]] +
              [z for C in circuits for z in C["shuffle_z"]])
-    z_commitments = D.msm_batch(all_z, params.g_lagrange, n, 254)
+    # (a device whose vectors live on the HOST does both in one call per column, sharing the one upload:
+    # gpu_multiexp_bound_and_fft, arithmetic.rs:375-410)
+    commit_ifft = getattr(D, "commit_lagrange_and_ifft", None) if (lo_s, hi_s) == (0, n) and not D.force_collective else None
+    z_commitments = commit_ifft(all_z, params.g_lagrange, dom) if commit_ifft else D.msm_batch(all_z, params.g_lagrange, n, 254)
     for P in z_commitments:
         transcript.write_point(P)
     # (one proof over several ranks: every rank computed its own rows of the product columns; a column's rows go to the
     # rank that transforms it, and the coefficient vectors travel while the advice columns are taken to their cosets)
-    _, z_arrival = D.intt_columns_begin(all_z, dom, complete=False)
+    z_arrival = None
+    if not commit_ifft:
+        _, z_arrival = D.intt_columns_begin(all_z, dom, complete=False)
     _, m_arrival = D.intt_columns_begin([st["m"] for C in circuits for st in C["lookups"]], dom, complete=True)
     for C in circuits:
         C["z_polys"] = C["z"]                                       # (transformed in place, sixteen to a launch)

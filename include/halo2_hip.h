@@ -208,6 +208,17 @@ int h2_dev_permutation_sigma(void *d_out, const void *d_map_col, const void *d_m
 int h2_permutation_terms(uint64_t *num, uint64_t *den, const uint64_t *value, const uint64_t *sigma, size_t n,
                          const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                          const uint64_t omega[4], int first);
+/* One grand-product column of the permutation argument, whole, for one set of `count` columns (permutation/prover.rs:72-165:
+ * the products over the set's columns :92-127, the batch inversion :106, the running product :150-154):
+ *   z[0] = init;  z[i+1] = z[i] * prod_j (values[j][i] + beta * delta_pow * delta^j * omega^i + gamma)
+ *                                / prod_j (values[j][i] + beta * sigmas[j][i] + gamma),  i + 1 < n
+ * values / sigmas: `count` host pointers to n-element vectors (read on the device without an upload when registered with
+ * h2_poly_register); delta_pow = DELTA^(index of the set's first column).  Every intermediate stays on the device: the
+ * columns cross PCIe once, z once.  The caller then overwrites its blinding rows and takes z[n - (blinding_factors + 1)] as
+ * the next set's init (:157-162). */
+int h2_permutation_product(uint64_t *z, const uint64_t *const *values, const uint64_t *const *sigmas, size_t count, size_t n,
+                           const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
+                           const uint64_t delta[4], const uint64_t omega[4], const uint64_t init[4]);
 int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, const void *d_sigma, size_t n,
                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_pow[4],
                              const uint64_t omega[4], int first, void *stream);

@@ -262,6 +262,19 @@ extern "C" {
     pub fn h2_lincomb(res: *mut u64, polys: *const *const u64, coeffs: *const u64, count: usize, size: usize) -> c_int;
     pub fn h2_eval_polynomial(poly: *const u64, n: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
+    pub fn h2_permutation_product(
+        z: *mut u64,
+        values: *const *const u64,
+        sigmas: *const *const u64,
+        count: usize,
+        n: usize,
+        beta: *const u64,
+        gamma: *const u64,
+        delta_pow: *const u64,
+        delta: *const u64,
+        omega: *const u64,
+        init: *const u64,
+    ) -> c_int;
     pub fn h2_batch_mont(a: *mut u64, n: usize) -> c_int;
     pub fn h2_batch_unmont(a: *mut u64, n: usize) -> c_int;
     // Evaluator::evaluate_h: extended cosets in (the CPU twin's shape, evaluation.rs:778-1226) / coefficient forms in
@@ -491,6 +504,51 @@ where
     out
 }
 
+/// One grand-product column of the permutation argument (plonk/permutation/prover.rs:72-165, one set of columns):
+/// `z[0] = init`, `z[i + 1] = z[i] * prod_j (values[j][i] + beta delta_pow delta^j omega^i + gamma) / prod_j (values[j][i] +
+/// beta sigmas[j][i] + gamma)`.  The per-column products, the batch inversion and the running product stay on the device; the
+/// sigma columns (`permutation::ProvingKey::permutations`) are registered with the proving key and cross PCIe once per key.
+/// The caller writes its blinding rows and takes `z[n - (blinding_factors + 1)]` as the next set's `init`.
+pub fn permutation_product<F>(
+    values: &[&[F]],
+    sigmas: &[&[F]],
+    beta: &F,
+    gamma: &F,
+    delta_pow: &F,
+    delta: &F,
+    omega: &F,
+    init: &F,
+) -> Vec<F>
+where
+    F: Copy + Default,
+{
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    assert!(!values.is_empty() && values.len() == sigmas.len());
+    let n = values[0].len();
+    assert!(values.iter().chain(sigmas.iter()).all(|v| v.len() == n));
+    let mut z = vec![F::default(); n];
+    let vp: Vec<*const u64> = values.iter().map(|v| v.as_ptr() as *const u64).collect();
+    let sp: Vec<*const u64> = sigmas.iter().map(|v| v.as_ptr() as *const u64).collect();
+    let (b, g, dp, d, w, i0) = (limbs(beta), limbs(gamma), limbs(delta_pow), limbs(delta), limbs(omega), limbs(init));
+    let rc = unsafe {
+        h2_permutation_product(
+            z.as_mut_ptr() as *mut u64,
+            vp.as_ptr(),
+            sp.as_ptr(),
+            values.len(),
+            n,
+            b.as_ptr(),
+            g.as_ptr(),
+            dp.as_ptr(),
+            d.as_ptr(),
+            w.as_ptr(),
+            i0.as_ptr(),
+        )
+    };
+    check(rc, "permutation_product");
+    z
+}
+
 /// `h2_evaluate_h_coeff` / `h2_evaluate_h`: `values` receives 2^extended_k scalars.  The descriptor's pointers must
 /// outlive the call (plonk/evaluation_hip.rs builds it from borrowed slices on its own stack frame).
 pub fn evaluate_h<F: Copy + Default>(desc: &H2EvalhDesc, from_coefficient_forms: bool) -> Vec<F> {
@@ -590,7 +648,7 @@ impl Drop for RegisteredPolys {
 }
 
 /// The vectors of a proving key that every proof reads and none writes (plonk.rs:226-240 under `hip`: coefficient forms):
-/// `fixed_polys`, `permutation.polys`, `l0`, `l_last`, `l_active_row`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
+/// `fixed_polys`, `permutation.polys`, `permutation.permutations`, `l0`, `l_last`, `l_active_row`.  Called at the end of `keygen_pk` / `keygen_pk_from_info`
 /// (plonk/keygen.rs:442-455, :540-553); `ProvingKey`'s `Drop` (added by the patch) unregisters before the vectors go.
 /// A proving key is not moved out of its `Vec`s after keygen: the registered addresses are those of the heap buffers.
 pub fn proving_key_polys<'a, C: CurveAffine>(pk: &'a crate::plonk::ProvingKey<C>) -> Vec<&'a [C::Scalar]> {
@@ -600,6 +658,9 @@ pub fn proving_key_polys<'a, C: CurveAffine>(pk: &'a crate::plonk::ProvingKey<C>
     }
     for p in pk.permutation.polys.iter() {
         out.push(&p.values[..]);
+    }
+    for p in pk.permutation.permutations.iter() {
+        out.push(&p.values[..]); // the sigma columns' values: `permutation_product` reads them in every proof
     }
     out.push(&pk.l0.values[..]);
     out.push(&pk.l_last.values[..]);

@@ -48,8 +48,16 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
         first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None)
         assert len(got) == len(want) and first is None, "host-slice proof differs at byte %s" % first
     calls = H.L.calls
-    assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_terms"] >= 2
-    assert not any(name.startswith("oracle") for name in calls)
+    assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
+    assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
+    assert "h2_permutation_terms" not in calls and not any(name.startswith("oracle") for name in calls)
+    # the permutation products step by step (h2_permutation_terms, the shared batch inversion, h2_eval_op, h2_prefix_product):
+    # the same bytes
+    S = host_api.HostApiDevice(fused_permutation=False)
+    sparams = host_api.params_like(S, params)
+    spk = prover.keygen(S, sparams, cs, fixed, copies)
+    assert prover.create_proof_ext(S, sparams, spk, adv, ProverRng(2), True, instances=inst) == want
+    assert S.L.calls["h2_permutation_terms"] >= 1 and "h2_permutation_product" not in S.L.calls
     if which == "mini" and k == 9:          # two circuit instances in one proof
         adv2 = circuits.mini_plonk_synthesize(k, a=9)[0]
         want = prover.create_proof_ext(device, params, pk, [adv, adv2], ProverRng(5), False, instances=[(), ()])
@@ -239,7 +247,7 @@ def test_host_slice_proof_at_a_pipelined_size(oracle, device, register):
     cs, (adv, fixed, copies) = circuits.mini_plonk(), circuits.mini_plonk_synthesize(k)
     params = prover.Params.unsafe_setup(device, k, 0x1D0C5F0A3B7E91C2A4D6F8091B2C3D4E5F60718293A4B5C6D7E8F9010203)
     pk = prover.keygen(device, params, cs, fixed, copies)
-    H = host_api.HostApiDevice(pinned=register, register_polys=register)
+    H = host_api.HostApiDevice(pinned=register, register_polys=register, fused_permutation=register)
     hparams = host_api.params_like(H, params)
     hpk = prover.keygen(H, hparams, cs, fixed, copies)
     for seed, gwc in ((3, False), (4, True)):
@@ -292,3 +300,54 @@ def test_two_threads_through_the_chunk_pipeline_at_once(oracle):
         assert not errors, errors
     finally:
         pool.free()
+
+
+@pytest.mark.parametrize("n,count,registered", [(1, 1, False), (2, 2, False), (4097, 3, False), ((1 << 21) + 5, 2, True)])
+def test_permutation_product_in_one_call(oracle, n, count, registered):
+    """h2_permutation_product (one grand-product column of the permutation argument: the per-column products, the batch inversion,
+    the product and the running product on the device, the set's columns up once and z down once) against the oracle's
+    steps taken one by one (permutation/prover.rs:72-165); sigma columns registered with h2_poly_register are read on the device"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from h2util import R_MOD, fr_mont
+
+    L = h2.lib()
+    values = [oracle.random_fr(9800 + j, n) for j in range(count)]
+    sigmas = [oracle.random_fr(9810 + j, n) for j in range(count)]
+    beta, gamma, init = oracle.random_fr(9820, 3)
+    delta = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
+    omega = fr_mont(pow(0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C, 1 << (28 - 22), R_MOD))
+    first_col = 4
+    num, den = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+    for j in range(count):
+        dpow = fr_mont(pow(delta, first_col + j, R_MOD))
+        oracle.lib.oracle_permutation_terms(_ptr(num), _ptr(den), _ptr(values[j]), _ptr(sigmas[j]), n, _ptr(beta), _ptr(gamma), _ptr(dpow),
+                                            _ptr(omega), 1 if j == 0 else 0)
+    oracle.lib.oracle_batch_invert(_ptr(den), n)
+    import halo2_gpu_specific_amd.arithmetic as ar
+
+    f = oracle.eval_op(ar.OP_MUL, num, den, 0, 0, None)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    want[0] = init
+    if n > 1:
+        from oracle_prover import OracleLib
+
+        OracleLib().O.oracle_prefix_product(_ptr(f), n, _ptr(init), _ptr(want))
+    if registered:
+        for sg in sigmas:
+            assert L.h2_poly_register(_ptr(sg), n) == 0
+    try:
+        z = np.empty((n, 4), dtype=np.uint64)
+        vp = (ctypes.c_void_p * count)(*[v.ctypes.data for v in values])
+        sp = (ctypes.c_void_p * count)(*[v.ctypes.data for v in sigmas])
+        for _ in range(2 if registered else 1):            # (the second call finds the device copies)
+            z[:] = 0
+            assert L.h2_permutation_product(_ptr(z), vp, sp, count, n, _ptr(beta), _ptr(gamma), _ptr(fr_mont(pow(delta, first_col, R_MOD))),
+                                            _ptr(fr_mont(delta)), _ptr(omega), _ptr(init)) == 0
+            assert np.array_equal(z, want)
+    finally:
+        if registered:
+            for sg in sigmas:
+                assert L.h2_poly_unregister(_ptr(sg)) == 0
+    assert L.h2_permutation_product(_ptr(z), vp, None, count, n, _ptr(beta), _ptr(gamma), _ptr(init), _ptr(init), _ptr(omega), _ptr(init)) != 0

@@ -32,6 +32,51 @@ FILES = ["halo2_proofs/Cargo.toml", "halo2_proofs/build.rs", "halo2_proofs/src/l
 NEW_FILES = {"halo2_proofs/src/hip.rs": "hip.rs", "halo2_proofs/src/plonk/evaluation_hip.rs": "evaluation_hip.rs",
              "halo2_proofs/src/hip_resident.rs": "hip_resident.rs"}
 
+PERMUTATION_HIP = '''        #[cfg(feature = "hip")]
+        {
+            let mut last_z = C::Scalar::one();
+            for (i, (columns, permutations)) in self
+                .columns
+                .chunks(chunk_len)
+                .zip(pkey.permutations.chunks(chunk_len))
+                .enumerate()
+            {
+                let values: Vec<&[C::Scalar]> = columns
+                    .iter()
+                    .map(|&column| {
+                        let values = match column.column_type() {
+                            Any::Advice => advice,
+                            Any::Fixed => fixed,
+                            Any::Instance => instance,
+                        };
+                        &values[column.index()][..]
+                    })
+                    .collect();
+                let sigmas: Vec<&[C::Scalar]> = permutations.iter().map(|p| &p[..]).collect();
+                let z = crate::hip::permutation_product(
+                    &values,
+                    &sigmas,
+                    &*beta,
+                    &*gamma,
+                    &C::Scalar::DELTA.pow(&[i as u64 * chunk_len as u64, 0, 0, 0]),
+                    &C::Scalar::DELTA,
+                    &domain.get_omega(),
+                    &last_z,
+                );
+                let mut z = domain.lagrange_from_vec(z);
+                // Set blinding factors
+                for z in &mut z[params.n as usize - blinding_factors..] {
+                    *z = C::Scalar::random(&mut rng);
+                }
+                // Set new last_z
+                last_z = z[params.n as usize - (blinding_factors + 1)];
+                sets.push(z);
+            }
+            return Ok(sets);
+        }
+
+'''
+
 HIP_FUNCTIONS = '''#[cfg(feature = "hip")]
 pub fn gpu_multiexp_single_gpu_with_bound<C: CurveAffine>(
     coeffs: &[C::Scalar],
@@ -443,6 +488,10 @@ def edit(rel, text):
     if rel.endswith("permutation/keygen.rs"):
         return switch_shape(text, 2)
     if rel.endswith("permutation/prover.rs"):
+        # the grand products of the permutation argument: one device call per set of columns instead of three rayon passes over n
+        # rows, a batch inversion and a serial running product on the host (the sets stay sequential: each starts from the last)
+        text = replace_once(text, "        let mut sets = vec![];\n\n        let raw_zs = self\n", "        let mut sets = vec![];\n\n" + PERMUTATION_HIP +
+                            "        let raw_zs = self\n", "permutation commit")
         return switch_shape(text, 1)
     if rel.endswith("plonk/prover.rs"):
         text = replace_once(text, N_GPU_CUDA, N_GPU_HIP, "N_GPU default")
