@@ -1139,6 +1139,109 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
     });
 }
 
+// The quotient contributions of a multi-point opening in ONE call (poly/multiopen/shplonk/prover.rs:95-153: every rotation set's
+// linear combination, minus its low-degree remainder polynomial, divided by the set's vanishing polynomial, the sets folded by
+// powers of v; and :205-219 with n_sets = 1: the final quotient l(X) / (X - u)):
+//   out = sum_s  (sum_i coeffs[s][i] * polys[s][i](X)  -  low_s(X)) / prod_j (X - points[s][j])
+// The caller multiplies v^(R-1-s) into set s's coeffs and low (division is linear: the same field elements).  Operands inside
+// a range registered with h2_poly_register are read where they lie on the device, the others go up once; every combination,
+// subtraction and synthetic division stays on the device; `out` (n coefficients) comes down once.  `remainders` (optional):
+// what each division left, in order -- the value of its dividend at the point (the reference's must_be_zero check, :213-214).
+int h2_quotient_sum(uint64_t* out, size_t n, size_t n_sets, const size_t* counts, const uint64_t* const* polys, const uint64_t* coeffs,
+                    const size_t* low_counts, const uint64_t* low, const size_t* point_counts, const uint64_t* points,
+                    uint64_t* remainders) {
+    if (!out || (n_sets && (!counts || !polys || !coeffs || !low_counts || !point_counts))) return bad("h2_quotient_sum: null argument");
+    size_t total = 0, total_low = 0, total_points = 0;
+    for (size_t s = 0; s < n_sets; s++) {
+        total += counts[s];
+        total_low += low_counts[s];
+        total_points += point_counts[s];
+        if (low_counts[s] > n) return bad("h2_quotient_sum: more low coefficients than coefficients");
+    }
+    if ((total_low && !low) || (total_points && !points)) return bad("h2_quotient_sum: null argument");
+    for (size_t i = 0; i < total; i++)
+        if (!polys[i]) return bad("h2_quotient_sum: null operand");
+    return guarded([&] {
+        const size_t bytes = n * sizeof(Fr);
+        if (n == 0) return (int)H2_OK;
+        if (n_sets == 0) {
+            memset(out, 0, bytes);
+            return (int)H2_OK;
+        }
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(out, bytes);
+        size_t max_staged = 0, max_low = 0;
+        {
+            size_t at = 0;
+            for (size_t s = 0; s < n_sets; s++) {
+                size_t st = 0;
+                for (size_t i = 0; i < counts[s]; i++)
+                    if (!resident_operand(ctx, polys[at + i], n)) st++;
+                max_staged = std::max(max_staged, st);
+                max_low = std::max(max_low, low_counts[s]);
+                at += counts[s];
+            }
+        }
+        Fr* d_up = max_staged ? (Fr*)ctx->buf_a.get(bytes * max_staged) : nullptr;
+        Fr* cur = (Fr*)ctx->buf_b.get(bytes);
+        Fr* nxt = (Fr*)ctx->buf_c.get(bytes);
+        // one block: the running sum, the synthetic divisions' scratch, a set's low coefficients
+        const size_t tmp_elems = std::max(scan_tmp_elems(n), eval_polynomial_tmp_elems(n));
+        Fr* acc = (Fr*)ctx->buf_d.get((n + tmp_elems + max_low) * sizeof(Fr));
+        Fr* tmp = acc + n;
+        Fr* d_low = tmp + tmp_elems;
+        H2_HIP(hipMemsetAsync(acc, 0, bytes, ctx->stream));
+        size_t at = 0, at_low = 0, at_pt = 0;
+        for (size_t s = 0; s < n_sets; s++) {
+            const size_t count = counts[s];
+            std::vector<const Fr*> ptrs(count);
+            size_t st = 0;
+            for (size_t i = 0; i < count; i++) {
+                ptrs[i] = resident_operand(ctx, polys[at + i], n);
+                if (!ptrs[i]) {
+                    H2_HIP(hipMemcpyAsync(d_up + st * n, polys[at + i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                    ptrs[i] = d_up + st * n;
+                    st++;
+                }
+            }
+            int rc = H2_OK;
+            if (count)
+                rc = lincomb_launch(cur, ptrs.data(), coeffs + 4 * at, count, n, ctx->stream);
+            else
+                H2_HIP(hipMemsetAsync(cur, 0, bytes, ctx->stream));
+            if (rc != H2_OK) return rc;
+            if (low_counts[s]) {
+                H2_HIP(hipMemcpyAsync(d_low, low + 4 * at_low, low_counts[s] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+                rc = eval_op_launch(H2_OP_SUB, cur, cur, d_low, 0, 0, low_counts[s], nullptr, ctx->stream);
+                if (rc != H2_OK) return rc;
+            }
+            for (size_t j = 0; j < point_counts[s]; j++) {
+                const uint64_t* pt = points + 4 * (at_pt + j);
+                if (remainders) {
+                    rc = eval_polynomial_launch(cur, n, pt, tmp, remainders + 4 * (at_pt + j), ctx->stream);
+                    if (rc != H2_OK) return rc;
+                }
+                if (n >= 2) {
+                    rc = kate_division_launch(cur, n, pt, nxt, tmp, ctx->stream);      // n - 1 coefficients
+                    if (rc != H2_OK) return rc;
+                }
+                H2_HIP(hipMemsetAsync(nxt + (n - 1), 0, sizeof(Fr), ctx->stream));    // (resized as shplonk/prover.rs:118)
+                std::swap(cur, nxt);
+            }
+            rc = eval_op_launch(H2_OP_SUM, acc, acc, cur, 0, 0, n, nullptr, ctx->stream);
+            if (rc != H2_OK) return rc;
+            at += count;
+            at_low += low_counts[s];
+            at_pt += point_counts[s];
+        }
+        pf.join();
+        H2_HIP(hipMemcpyAsync(out, acc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
 int h2_dev_permutation_sigma(void* d_out, const void* d_map_col, const void* d_map_row, size_t n,
                              const uint64_t delta[4], const uint64_t omega[4], void* stream) {
     if (n && (!d_out || !d_map_col || !d_map_row || !delta || !omega)) return bad("h2_dev_permutation_sigma: null argument");

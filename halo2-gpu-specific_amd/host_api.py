@@ -339,6 +339,7 @@ class HostApiDevice(P.Device):
         if not fused_permutation:
             self.permutation_product = None                          # the permutation products step by step (rounds 4-6)
             self.commit_lagrange_and_ifft = None                     # ... and h2_msm + h2_intt for the product columns
+            self.quotient_sum = None                                 # ... and the multiopen's folds and divisions one by one
         import torch
 
         if not torch.cuda.is_available():
@@ -420,6 +421,32 @@ class HostApiDevice(P.Device):
         scalars = [_fr(v) for v in (beta, gamma, delta_pow, DELTA, omega, init)]       # (alive until the call has returned)
         check(self.L.R.h2_permutation_product(z.data_ptr(), vp, sp, len(values), n, *[_addr(v) for v in scalars]), "h2_permutation_product")
         return z, self.get_rows(z, probe, 1)[0]
+
+    def quotient_sum(self, n, sets, remainders=False):
+        """sum over `sets` = [(polys, coeffs, low, points)] of (sum_i coeffs[i] polys[i] - low) / prod_j (X - points[j]) by ONE
+        host-slice call (h2_quotient_sum; poly/multiopen/shplonk/prover.rs:95-153, :205-219) -> (the n coefficients, the
+        remainders of the divisions as integers or None)"""
+        from .prover import R_MOD, fr_from_mont_limbs, fr_to_mont_limbs
+
+        def flat(values):
+            return np.array([fr_to_mont_limbs(v % R_MOD) for v in values], dtype=np.uint64).reshape(-1, 4)
+
+        sz = ctypes.c_size_t
+        counts = (sz * len(sets))(*[len(p) for p, _, _, _ in sets])
+        lows = (sz * len(sets))(*[len(lo) for _, _, lo, _ in sets])
+        pts = (sz * len(sets))(*[len(pt) for _, _, _, pt in sets])
+        tensors = [t for p, _, _, _ in sets for t in p]
+        ptrs = (_vp * len(tensors))(*[t.data_ptr() for t in tensors])
+        coeffs = flat([c for _, cs, _, _ in sets for c in cs])
+        low = flat([c for _, _, lo, _ in sets for c in lo])
+        points = flat([c for _, _, _, pt in sets for c in pt])
+        rem = np.zeros((max(len(points), 1), 4), dtype=np.uint64) if remainders else None
+        out = self.empty(n)
+        self.L._count("h2_quotient_sum")
+        check(self.L.R.h2_quotient_sum(out.data_ptr(), n, len(sets), counts, ptrs, coeffs.ctypes.data, lows, low.ctypes.data if len(low) else None,
+                                       pts, points.ctypes.data if len(points) else None, rem.ctypes.data if remainders else None),
+              "h2_quotient_sum")
+        return out, ([fr_from_mont_limbs(r) for r in rem[:len(points)]] if remainders else None)
 
     def commit_lagrange_and_ifft(self, cols, bases, dom):
         """Params::commit_lagrange_and_ifft (poly/commitment.rs:144-197 -> gpu_multiexp_bound_and_fft, arithmetic.rs:375-410):

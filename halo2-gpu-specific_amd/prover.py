@@ -2175,15 +2175,24 @@ def _shplonk(D, params, transcript, queries, polys, n):
     for rs in sets:
         rs["low"] = [_lagrange_interpolate(rs["points"], e) for _, e in rs["commitments"]]
     v = transcript.squeeze_challenge_scalar()
+    R = len(sets)
+    vpow = [pow(v, R - 1 - r, R_MOD) for r in range(R)]
+    # a device whose vectors live on the HOST computes the whole sum in one call (h2_quotient_sum: the combinations, the
+    # subtractions and the synthetic divisions stay on the device, h(X) crosses PCIe once)
+    quotient_sum = getattr(D, "quotient_sum", None) if D.row_range(n) == (0, n) else None
     # quotient contribution of every rotation set: (sum_i y^(m-1-i) (p_i - r_i)) / prod (X - point)
-    quotients = []
+    quotients, fused_sets = [], []
     ping, pong = D.empty(n), D.empty(n)
-    for rs in sets:
+    for r, rs in enumerate(sets):
         m = len(rs["commitments"])
         ypow = [pow(y, m - 1 - i, R_MOD) for i in range(m)]
-        n_x = D.lincomb_range(D.empty(n), [polys[key] for key, _ in rs["commitments"]], ypow, n)
         width = len(rs["points"])
         low = [sum(ypow[i] * rs["low"][i][j] for i in range(m)) % R_MOD for j in range(width)]
+        if quotient_sum:        # v^(R-1-r) goes into the set's coefficients: division is linear, the field elements are the same
+            fused_sets.append(([polys[key] for key, _ in rs["commitments"]], [vpow[r] * c % R_MOD for c in ypow],
+                               [vpow[r] * c % R_MOD for c in low], rs["points"]))
+            continue
+        n_x = D.lincomb_range(D.empty(n), [polys[key] for key, _ in rs["commitments"]], ypow, n)
         D.sub_low_range(n_x, low, n)
         cur = n_x
         for pt in rs["points"]:
@@ -2191,9 +2200,10 @@ def _shplonk(D, params, transcript, queries, polys, n):
             D.kate_division_ranges(cur, n, pt, nxt)
             cur = nxt
         quotients.append(D.clone(cur))
-    R = len(sets)
-    vpow = [pow(v, R - 1 - r, R_MOD) for r in range(R)]
-    h_x = D.lincomb_range(D.empty(n), quotients, vpow, n)
+    if quotient_sum:
+        h_x, _ = quotient_sum(n, fused_sets)
+    else:
+        h_x = D.lincomb_range(D.empty(n), quotients, vpow, n)
     del quotients
     transcript.write_point(D.msm(h_x, params.g, n))
     u = transcript.squeeze_challenge_scalar()
@@ -2211,9 +2221,14 @@ def _shplonk(D, params, transcript, queries, polys, n):
             const = (const + c * _horner(rs["low"][i], u)) % R_MOD
     lin_polys.append(h_x)
     lin_coeffs.append((-zt_eval * scale) % R_MOD)
-    l_x = D.lincomb_range(ping, lin_polys, lin_coeffs, n)
-    D.sub_low_range(l_x, [const], n)
-    if D.eval_polynomial_ranges([l_x], n, [u])[0] != 0:
-        raise AssertionError("shplonk: l(u) != 0")   # the reference's must_be_zero (prover.rs:204-207)
-    D.kate_division_ranges(l_x, n, u, pong)
+    if quotient_sum:
+        pong, rem = quotient_sum(n, [(lin_polys, lin_coeffs, [const], [u])], remainders=True)
+        if rem[0] != 0:
+            raise AssertionError("shplonk: l(u) != 0")
+    else:
+        l_x = D.lincomb_range(ping, lin_polys, lin_coeffs, n)
+        D.sub_low_range(l_x, [const], n)
+        if D.eval_polynomial_ranges([l_x], n, [u])[0] != 0:
+            raise AssertionError("shplonk: l(u) != 0")   # the reference's must_be_zero (prover.rs:213-214)
+        D.kate_division_ranges(l_x, n, u, pong)
     transcript.write_point(D.msm(pong, params.g, n))

@@ -194,6 +194,19 @@ int h2_dev_lincomb(void *d_res, const void *const *d_polys, const uint64_t *coef
  * eval_mul_c / eval_sum pair): polys = host array of `count` host pointers; one upload per operand, one fused pass. */
 int h2_lincomb(uint64_t *res, const uint64_t *const *polys, const uint64_t *coeffs, size_t count, size_t size);
 
+/* The quotient contributions of a multi-point opening in one call (poly/multiopen/shplonk/prover.rs:95-153: every rotation
+ * set's linear combination minus its low-degree remainder polynomial, divided by the set's vanishing polynomial, the sets
+ * folded by powers of v -- and :205-219 with n_sets = 1: the final quotient l(X) / (X - u)):
+ *   out = sum_s (sum_i coeffs[s][i] * polys[s][i](X) - low_s(X)) / prod_j (X - points[s][j])
+ * counts / low_counts / point_counts: per set; polys (host pointers to n coefficients each), coeffs, low, points: the sets'
+ * entries one after the other.  The caller multiplies v^(R-1-s) into set s's coeffs and low (division is linear).  Operands
+ * registered with h2_poly_register are read on the device; everything else stays there too: `out` (n coefficients, the top
+ * ones zero as the reference resizes them, :118) crosses PCIe once.  remainders (may be NULL): 4 words per point, what each
+ * division left (the value of its dividend at the point: the reference's must_be_zero, :213-214). */
+int h2_quotient_sum(uint64_t *out, size_t n, size_t n_sets, const size_t *counts, const uint64_t *const *polys,
+                    const uint64_t *coeffs, const size_t *low_counts, const uint64_t *low, const size_t *point_counts,
+                    const uint64_t *points, uint64_t *remainders);
+
 /* Permutation argument, the elementwise work on either side of the grand-product scan.
  * keygen (plonk/permutation/keygen.rs:197-238): out[j] = DELTA^{map_col[j]} * omega^{map_row[j]} -- one sigma column
  * in Lagrange form from the cycle mapping (u32 device arrays of n entries). */

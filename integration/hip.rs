@@ -262,6 +262,19 @@ extern "C" {
     pub fn h2_lincomb(res: *mut u64, polys: *const *const u64, coeffs: *const u64, count: usize, size: usize) -> c_int;
     pub fn h2_eval_polynomial(poly: *const u64, n: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
+    pub fn h2_quotient_sum(
+        out: *mut u64,
+        n: usize,
+        n_sets: usize,
+        counts: *const usize,
+        polys: *const *const u64,
+        coeffs: *const u64,
+        low_counts: *const usize,
+        low: *const u64,
+        point_counts: *const usize,
+        points: *const u64,
+        remainders: *mut u64,
+    ) -> c_int;
     pub fn h2_permutation_product(
         z: *mut u64,
         values: *const *const u64,
@@ -547,6 +560,61 @@ where
     };
     check(rc, "permutation_product");
     z
+}
+
+/// One rotation set of a multi-point opening as `quotient_sum` takes it: the polynomials that share the set's points, the
+/// coefficient of each in the set's linear combination (the caller folds `v^(R-1-s)` in), the low coefficients subtracted from
+/// the combination (the combined low-degree equivalents `r_i(X)`, same factor folded in) and the points to divide by.
+pub struct QuotientSet<'a, F> {
+    pub polys: Vec<&'a [F]>,
+    pub coeffs: Vec<F>,
+    pub low: Vec<F>,
+    pub points: Vec<F>,
+}
+
+/// `sum_s (sum_i coeffs[s][i] polys[s][i](X) - low_s(X)) / prod_j (X - points[s][j])` in one device call
+/// (poly/multiopen/shplonk/prover.rs:95-153 -- `quotient_contribution` of every rotation set folded by powers of `v` -- and
+/// :205-219 with one set: `div_by_vanishing(l_x, &[u])`).  Returns the n coefficients and, when asked, what every division left
+/// (the reference's `must_be_zero`).  Polynomials registered with `register_polys` are read on the device.
+pub fn quotient_sum<F>(n: usize, sets: &[QuotientSet<F>], want_remainders: bool) -> (Vec<F>, Vec<F>)
+where
+    F: Copy + Default,
+{
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    let counts: Vec<usize> = sets.iter().map(|s| s.polys.len()).collect();
+    let low_counts: Vec<usize> = sets.iter().map(|s| s.low.len()).collect();
+    let point_counts: Vec<usize> = sets.iter().map(|s| s.points.len()).collect();
+    let mut ptrs: Vec<*const u64> = Vec::new();
+    let (mut coeffs, mut low, mut points): (Vec<F>, Vec<F>, Vec<F>) = (Vec::new(), Vec::new(), Vec::new());
+    for s in sets.iter() {
+        assert_eq!(s.polys.len(), s.coeffs.len());
+        for p in s.polys.iter() {
+            assert_eq!(p.len(), n);
+            ptrs.push(p.as_ptr() as *const u64);
+        }
+        coeffs.extend_from_slice(&s.coeffs);
+        low.extend_from_slice(&s.low);
+        points.extend_from_slice(&s.points);
+    }
+    let mut out = vec![F::default(); n];
+    let mut remainders = vec![F::default(); if want_remainders { points.len() } else { 0 }];
+    let rc = unsafe {
+        h2_quotient_sum(
+            out.as_mut_ptr() as *mut u64,
+            n,
+            sets.len(),
+            counts.as_ptr(),
+            ptrs.as_ptr(),
+            coeffs.as_ptr() as *const u64,
+            low_counts.as_ptr(),
+            low.as_ptr() as *const u64,
+            point_counts.as_ptr(),
+            points.as_ptr() as *const u64,
+            if want_remainders { remainders.as_mut_ptr() as *mut u64 } else { std::ptr::null_mut() },
+        )
+    };
+    check(rc, "quotient_sum");
+    (out, remainders)
 }
 
 /// `h2_evaluate_h_coeff` / `h2_evaluate_h`: `values` receives 2^extended_k scalars.  The descriptor's pointers must

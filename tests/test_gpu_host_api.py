@@ -50,6 +50,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
     calls = H.L.calls
     assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
     assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
+    assert calls["h2_quotient_sum"] == 2               # (the SHPLONK proof: the rotation sets' quotients, the final quotient)
     assert "h2_permutation_terms" not in calls and not any(name.startswith("oracle") for name in calls)
     # the permutation products step by step (h2_permutation_terms, the shared batch inversion, h2_eval_op, h2_prefix_product):
     # the same bytes
@@ -57,7 +58,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
     sparams = host_api.params_like(S, params)
     spk = prover.keygen(S, sparams, cs, fixed, copies)
     assert prover.create_proof_ext(S, sparams, spk, adv, ProverRng(2), True, instances=inst) == want
-    assert S.L.calls["h2_permutation_terms"] >= 1 and "h2_permutation_product" not in S.L.calls
+    assert S.L.calls["h2_permutation_terms"] >= 1 and "h2_permutation_product" not in S.L.calls and "h2_quotient_sum" not in S.L.calls
     if which == "mini" and k == 9:          # two circuit instances in one proof
         adv2 = circuits.mini_plonk_synthesize(k, a=9)[0]
         want = prover.create_proof_ext(device, params, pk, [adv, adv2], ProverRng(5), False, instances=[(), ()])
@@ -351,3 +352,66 @@ def test_permutation_product_in_one_call(oracle, n, count, registered):
             for sg in sigmas:
                 assert L.h2_poly_unregister(_ptr(sg)) == 0
     assert L.h2_permutation_product(_ptr(z), vp, None, count, n, _ptr(beta), _ptr(gamma), _ptr(init), _ptr(init), _ptr(omega), _ptr(init)) != 0
+
+
+@pytest.mark.parametrize("n,registered", [(1, False), (2, False), (4099, False), ((1 << 21) + 3, True)])
+def test_quotient_sum_in_one_call(oracle, n, registered):
+    """h2_quotient_sum (a multi-point opening's quotient contributions: per rotation set a linear combination, minus a few low
+    coefficients, divided by the set's points one after the other; the sets summed; everything on the device, one vector down)
+    against the oracle's lincomb / subtraction / Kate divisions taken step by step (shplonk/prover.rs:95-153, :205-219), and the
+    remainders it reports against the oracle's Horner evaluations of the dividends"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    from oracle_prover import OracleLib
+
+    L, O = h2.lib(), OracleLib().O
+    polys = [oracle.random_fr(9900 + j, n) for j in range(4)]
+    sets = [([0, 1, 2], oracle.random_fr(9910, 3), oracle.random_fr(9911, min(2, n)), oracle.random_fr(9912, 2)),
+            ([3], oracle.random_fr(9913, 1), np.zeros((0, 4), dtype=np.uint64), oracle.random_fr(9915, 1)),
+            ([1, 3], oracle.random_fr(9916, 2), oracle.random_fr(9917, min(1, n)), oracle.random_fr(9918, 3))]
+    import halo2_gpu_specific_amd.arithmetic as ar
+
+    want, want_rem = np.zeros((n, 4), dtype=np.uint64), []
+    for idx, coeffs, low, points in sets:
+        cur = np.zeros((n, 4), dtype=np.uint64)
+        ptrs = (ctypes.c_void_p * len(idx))(*[polys[i].ctypes.data for i in idx])
+        O.oracle_lincomb(_ptr(cur), ptrs, _ptr(coeffs), len(idx), n)
+        if len(low):
+            cur[:len(low)] = oracle.eval_op(ar.OP_SUB, cur[:len(low)].copy(), low, 0, 0, None)
+        for pt in points:
+            rem = np.zeros(4, dtype=np.uint64)
+            oracle.lib.oracle_eval_polynomial(_ptr(cur), n, _ptr(pt), _ptr(rem))
+            want_rem.append(rem)
+            q = np.zeros((n, 4), dtype=np.uint64)
+            if n >= 2:
+                O.oracle_kate_division(_ptr(cur), n, _ptr(pt), _ptr(q))
+            cur = q
+        want = oracle.eval_op(ar.OP_SUM, want, cur, 0, 0, None)
+    sz = ctypes.c_size_t
+    counts = (sz * 3)(*[len(s_[0]) for s_ in sets])
+    lows = (sz * 3)(*[len(s_[2]) for s_ in sets])
+    pts = (sz * 3)(*[len(s_[3]) for s_ in sets])
+    ptrs = (ctypes.c_void_p * 6)(*[polys[i].ctypes.data for s_ in sets for i in s_[0]])
+    coeffs = np.concatenate([s_[1] for s_ in sets])
+    low = np.concatenate([s_[2].reshape(-1, 4) for s_ in sets])
+    points = np.concatenate([s_[3] for s_ in sets])
+    if registered:
+        for p_ in polys[:3]:
+            assert L.h2_poly_register(_ptr(p_), n) == 0
+    try:
+        for _ in range(2 if registered else 1):
+            out, rem = np.empty((n, 4), dtype=np.uint64), np.zeros((6, 4), dtype=np.uint64)
+            assert L.h2_quotient_sum(_ptr(out), n, 3, counts, ptrs, _ptr(coeffs), lows, _ptr(low), pts, _ptr(points), _ptr(rem)) == 0
+            assert np.array_equal(out, want)
+            assert np.array_equal(rem, np.array(want_rem))
+            out2 = np.empty((n, 4), dtype=np.uint64)
+            assert L.h2_quotient_sum(_ptr(out2), n, 3, counts, ptrs, _ptr(coeffs), lows, _ptr(low), pts, _ptr(points), None) == 0
+            assert np.array_equal(out2, want)
+    finally:
+        if registered:
+            for p_ in polys[:3]:
+                assert L.h2_poly_unregister(_ptr(p_)) == 0
+    assert L.h2_quotient_sum(_ptr(out), n, 3, counts, None, _ptr(coeffs), lows, _ptr(low), pts, _ptr(points), None) != 0
+    zero = np.ones((n, 4), dtype=np.uint64)
+    assert L.h2_quotient_sum(_ptr(zero), n, 0, None, None, None, None, None, None, None, None) == 0 and not zero.any()
