@@ -103,6 +103,7 @@ SYMBOLS = {
     "h2_dev_permutation_terms": (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     "h2_permutation_terms": (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "h2_permutation_product": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "h2_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "h2_quotient_sum": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2_dev_random_fr": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_distribute_powers": (ctypes.c_int, [_vp, _sz, _vp, _vp]),

@@ -979,6 +979,42 @@ int h2_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], 
     });
 }
 
+// `count` evaluations, polynomial j at point j, in one call (plonk/prover.rs:700-790 evaluates every committed polynomial at x,
+// omega x, ... in a rayon par_iter over eval_polynomial_st): every level of the folds is ONE launch over all of them and the
+// values come back in one copy, instead of `count` latency-bound calls.  A polynomial inside a registered range is read on
+// the device; one that is not goes up once however many points it is evaluated at.
+int h2_eval_polynomial_batch(const uint64_t* const* polys, size_t count, size_t n, const uint64_t* points, uint64_t* out) {
+    if (count && (!polys || !points || !out)) return bad("h2_eval_polynomial_batch: null argument");
+    for (size_t j = 0; n && j < count; j++)
+        if (!polys[j]) return bad("h2_eval_polynomial_batch: null polynomial");
+    return guarded([&] {
+        if (count == 0) return (int)H2_OK;
+        if (n == 0) {
+            memset(out, 0, 32 * count);
+            return (int)H2_OK;
+        }
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        std::vector<const Fr*> d(count);
+        std::map<const uint64_t*, size_t> staged;        // host vector -> its slot in the upload block
+        for (size_t j = 0; j < count; j++) {
+            d[j] = resident_operand(ctx, polys[j], n);
+            if (!d[j] && !staged.count(polys[j])) {
+                const size_t slot = staged.size();
+                staged[polys[j]] = slot;
+            }
+        }
+        if (!staged.empty()) {
+            Fr* up = (Fr*)ctx->buf_a.get(staged.size() * n * sizeof(Fr));
+            for (auto& kv : staged) H2_HIP(hipMemcpyAsync(up + kv.second * n, kv.first, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            for (size_t j = 0; j < count; j++)
+                if (!d[j]) d[j] = up + staged[polys[j]] * n;
+        }
+        Fr* tmp = (Fr*)ctx->buf_d.get(eval_polynomial_batch_tmp_bytes(count, n));
+        return eval_polynomial_batch_launch(d.data(), count, n, points, tmp, out, ctx->stream);
+    });
+}
+
 int h2_dev_batch_invert(void* d_a, void* d_tmp, size_t n, void* stream) {
     if (n && (!d_a || !d_tmp)) return bad("h2_dev_batch_invert: null argument");
     return guarded([&] {

@@ -211,8 +211,8 @@ class HostSliceLib:
         return self.R.h2_eval_polynomial(poly, n, _addr(point), _addr(out))
 
     def h2_dev_eval_polynomial_batch(self, ptrs, count, n, points, out, stream):
-        return self._each(lambda i: self.h2_dev_eval_polynomial(ptrs[i], n, points + 32 * i, out + 32 * i, stream),
-                          list(range(count)))
+        self._count("h2_eval_polynomial_batch")
+        return self.R.h2_eval_polynomial_batch(ptrs, count, n, points, out)
 
     def h2_dev_kate_division(self, a, n, b, q, stream):
         self._count("h2_kate_division")

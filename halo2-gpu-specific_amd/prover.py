@@ -2150,6 +2150,7 @@ def _gwc(D, params, transcript, queries, polys, n):
     eval_sum pair; here they never left the device and one lincomb forms the batch.  One proof over several ranks: every
     vector pass runs on the rank's coefficient range (Device.*_range(s)); the commitments are range-split anyway."""
     v = transcript.squeeze_challenge_scalar()
+    quotient_sum = getattr(D, "quotient_sum", None) if D.row_range(n) == (0, n) else None
     groups = {}
     for qu in queries:
         groups.setdefault(qu[1], []).append(qu)          # BTreeMap<Rotation, Vec<Q>> (gwc.rs:40-49)
@@ -2158,8 +2159,12 @@ def _gwc(D, params, transcript, queries, polys, n):
         group = groups[rot]
         z, m = group[0][2], len(group)
         vpow = [pow(v, m - 1 - i, R_MOD) for i in range(m)]
+        at_z = sum(c * e for c, (_, _, _, e) in zip(vpow, group)) % R_MOD                       # = batch(z)
+        if quotient_sum:                   # (host vectors: the fold, the subtraction and the division in one call)
+            witnesses.append(quotient_sum(n, [([polys[key] for key, _, _, _ in group], vpow, [at_z], [z])])[0])
+            continue
         batch = D.lincomb_range(D.empty(n), [polys[key] for key, _, _, _ in group], vpow, n)
-        D.sub_low_range(batch, [sum(c * e for c, (_, _, _, e) in zip(vpow, group)) % R_MOD], n)   # = batch(z)
+        D.sub_low_range(batch, [at_z], n)
         witnesses.append(D.kate_division_ranges(batch, n, z, D.empty(n)))
     for P in D.msm_batch(witnesses, params.g, n, 254):
         transcript.write_point(P)

@@ -165,6 +165,10 @@ int h2_divide_by_vanishing_poly(uint64_t *a, size_t size, const uint64_t *t_eval
 /* eval_polynomial: arithmetic.rs:714-735 (Horner; prover.rs:731-737 evaluates every committed polynomial
  * at x).  out = sum_i poly[i] * point^i.  Synchronous (the result is host memory). */
 int h2_eval_polynomial(const uint64_t *poly, size_t n, const uint64_t point[4], uint64_t out[4]);
+/* `count` evaluations in one call, polynomial j (n coefficients) at points[4j..4j+4] -> out[4j..4j+4]: what
+ * plonk/prover.rs:700-790 computes in a rayon par_iter over eval_polynomial_st.  One launch per fold level over all of them,
+ * one copy back; registered polynomials are read on the device, the others go up once each. */
+int h2_eval_polynomial_batch(const uint64_t *const *polys, size_t count, size_t n, const uint64_t *points, uint64_t *out);
 int h2_dev_eval_polynomial(const void *d_poly, size_t n, const uint64_t point[4], uint64_t out[4], void *stream);
 /* `count` evaluations, polynomial j (n coefficients, device) at points[4 j .. 4 j + 3], enqueued back to back with one
  * read-back: the rayon `par_iter` over eval_polynomial_st of plonk/prover.rs:731-737.  d_polys: HOST array of device

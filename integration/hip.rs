@@ -261,6 +261,7 @@ extern "C" {
     // gwc/prover.rs:57-151: res = sum_j coeffs[j] * polys[j]
     pub fn h2_lincomb(res: *mut u64, polys: *const *const u64, coeffs: *const u64, count: usize, size: usize) -> c_int;
     pub fn h2_eval_polynomial(poly: *const u64, n: usize, point: *const u64, out: *mut u64) -> c_int;
+    pub fn h2_eval_polynomial_batch(polys: *const *const u64, count: usize, n: usize, points: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
     pub fn h2_quotient_sum(
         out: *mut u64,
@@ -560,6 +561,31 @@ where
     };
     check(rc, "permutation_product");
     z
+}
+
+/// `polys[j](points[j])` for every j in one device call (plonk/prover.rs:700-790: the evaluations of every committed polynomial
+/// at x, omega x, ... -- a rayon `par_iter` over `eval_polynomial_st` in the reference).
+pub fn eval_polynomial_batch<F>(polys: &[&[F]], points: &[F]) -> Vec<F>
+where
+    F: Copy + Default,
+{
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    assert_eq!(polys.len(), points.len());
+    let n = polys.first().map(|p| p.len()).unwrap_or(0);
+    assert!(polys.iter().all(|p| p.len() == n));
+    let ptrs: Vec<*const u64> = polys.iter().map(|p| p.as_ptr() as *const u64).collect();
+    let mut out = vec![F::default(); polys.len()];
+    let rc = unsafe {
+        h2_eval_polynomial_batch(
+            ptrs.as_ptr(),
+            polys.len(),
+            n,
+            points.as_ptr() as *const u64,
+            out.as_mut_ptr() as *mut u64,
+        )
+    };
+    check(rc, "eval_polynomial_batch");
+    out
 }
 
 /// One rotation set of a multi-point opening as `quotient_sum` takes it: the polynomials that share the set's points, the

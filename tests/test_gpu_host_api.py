@@ -50,7 +50,8 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
     calls = H.L.calls
     assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
     assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
-    assert calls["h2_quotient_sum"] == 2               # (the SHPLONK proof: the rotation sets' quotients, the final quotient)
+    assert calls["h2_quotient_sum"] >= 3               # (SHPLONK: the rotation sets' quotients + the final one; GWC: one per point)
+    assert "h2_kate_division" not in calls
     assert "h2_permutation_terms" not in calls and not any(name.startswith("oracle") for name in calls)
     # the permutation products step by step (h2_permutation_terms, the shared batch inversion, h2_eval_op, h2_prefix_product):
     # the same bytes
@@ -415,3 +416,29 @@ def test_quotient_sum_in_one_call(oracle, n, registered):
     assert L.h2_quotient_sum(_ptr(out), n, 3, counts, None, _ptr(coeffs), lows, _ptr(low), pts, _ptr(points), None) != 0
     zero = np.ones((n, 4), dtype=np.uint64)
     assert L.h2_quotient_sum(_ptr(zero), n, 0, None, None, None, None, None, None, None, None) == 0 and not zero.any()
+
+
+@pytest.mark.parametrize("n", [1, 5, 4097, (1 << 20) + 9])
+def test_eval_polynomial_batch_on_host_vectors(oracle, n):
+    """h2_eval_polynomial_batch: polynomial j at point j in one call -- a polynomial evaluated at several points goes up once,
+    a registered one not at all -- against the oracle's Horner, value by value"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+
+    L = h2.lib()
+    polys = [oracle.random_fr(9950 + j, n) for j in range(3)]
+    which = [0, 1, 0, 2, 2, 0, 1]
+    points = oracle.random_fr(9960, len(which))
+    want = np.array([_oracle_evalpoly(oracle, polys[w], points[j]) for j, w in enumerate(which)])
+    ptrs = (ctypes.c_void_p * len(which))(*[polys[w].ctypes.data for w in which])
+    assert L.h2_poly_register(_ptr(polys[1]), n) == 0
+    try:
+        for _ in range(2):
+            out = np.zeros((len(which), 4), dtype=np.uint64)
+            assert L.h2_eval_polynomial_batch(ptrs, len(which), n, _ptr(points), _ptr(out)) == 0
+            assert np.array_equal(out, want)
+    finally:
+        assert L.h2_poly_unregister(_ptr(polys[1])) == 0
+    assert L.h2_eval_polynomial_batch(ptrs, 0, n, None, None) == 0
+    assert L.h2_eval_polynomial_batch(None, 2, n, _ptr(points), _ptr(out)) != 0
