@@ -124,6 +124,7 @@ SYMBOLS = {
     "h2_evalh_generated_launches": (ctypes.c_uint64, []),
     "h2_evaluate_h": (ctypes.c_int, [_vp, _vp]),
     "h2_evaluate_h_coeff": (ctypes.c_int, [_vp, _vp]),
+    "h2_quotient_poly_coeff": (ctypes.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz]),
     "h2_lincomb": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz]),
     "h2_dev_evaluate_h": (ctypes.c_int, [_vp, _vp, _vp]),
     "h2_timer_start": (ctypes.c_int, [_vp]),

@@ -1557,6 +1557,53 @@ int h2_evaluate_h_coeff(const h2_evalh_desc* desc, uint64_t* values) {
     });
 }
 
+// The vanishing argument's quotient, from coefficient forms to coefficient form, in ONE call: what the reference's cuda path does
+// in three steps on host vectors of 2^extended_k elements -- Evaluator::evaluate_h (plonk/evaluation.rs:1229-1985), then
+// divide_by_vanishing_poly (poly/domain.rs:354-373) and extended_to_coeff (:328-350) in vanishing::Argument::construct
+// (plonk/vanishing/prover.rs:69-112).  The 2^extended_k values of the numerator stay on the device: divided there, taken back
+// to coefficients there, and only the out_len = n * quotient_poly_degree coefficients of h(X) cross PCIe (k = 22, degree 4:
+// 384 MiB down instead of 512 MiB down + up + down + up + 384 MiB down, and two 512 MiB host vectors that never exist).
+// With several devices in the pool the cosets are dealt over them as h2_evaluate_h_coeff does and the two other steps follow
+// through a host vector of the call's own.
+int h2_quotient_poly_coeff(const h2_evalh_desc* desc, const uint64_t* t_evaluations, size_t t_len, const uint64_t g_coset[4],
+                           const uint64_t g_coset_inv[4], const uint64_t extended_omega_inv[4],
+                           const uint64_t extended_ifft_divisor[4], uint64_t* out, size_t out_len) {
+    if (!desc || !t_evaluations || !t_len || !g_coset || !g_coset_inv || !extended_omega_inv || !extended_ifft_divisor || !out)
+        return bad("h2_quotient_poly_coeff: null argument");
+    if (desc->extended_k < desc->k || desc->extended_k > 28) return bad("h2_quotient_poly_coeff: bad k / extended_k");
+    const size_t size = (size_t)1 << desc->extended_k;
+    if (out_len > size) return bad("h2_quotient_poly_coeff: out_len exceeds the extended domain");
+    if (size % t_len) return bad("h2_quotient_poly_coeff: t_len does not divide the extended domain");
+    return guarded([&] {
+        Prefault pf(out, out_len * sizeof(Fr));
+        const uint32_t ek = desc->extended_k;
+        EvalhFinish finish = [&](DeviceCtx* ctx, Fr* d_values, hipStream_t s) -> int {
+            Fr* d_t = (Fr*)ctx->buf_c.get(t_len * sizeof(Fr));
+            H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+            int rc = divide_by_vanishing_launch(d_values, size, d_t, t_len, s);
+            if (rc != H2_OK) return rc;
+            Fr* d_tmp = (Fr*)ctx->buf_b.get(size * sizeof(Fr));
+            rc = dev_extended_to_coeff_impl(ctx, d_values, d_tmp, ek, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor, s, true);
+            if (rc != H2_OK) return rc;
+            pf.join();
+            H2_HIP(hipMemcpyAsync(out, d_values, out_len * sizeof(Fr), hipMemcpyDeviceToHost, s));
+            return (int)H2_OK;
+        };
+        if (evalh_host_workers(desc) <= 1) {
+            bool finished = false;
+            int rc = evalh_host_coeffs(desc, nullptr, &finish, &finished);
+            if (rc == H2_OK && !finished) return bad("h2_quotient_poly_coeff: the evaluation did not hand its values over");
+            return rc;
+        }
+        std::vector<uint64_t> values(4 * size);
+        int rc = evalh_host_coeffs(desc, values.data());
+        if (rc != H2_OK) return rc;
+        rc = h2_divide_by_vanishing_poly(values.data(), size, t_evaluations, t_len);
+        if (rc != H2_OK) return rc;
+        return h2_extended_to_coeff(values.data(), out, out_len, ek, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor);
+    });
+}
+
 int h2_dev_evaluate_h(const h2_evalh_desc* desc, void* d_values, void* stream) {
     if (!desc || !d_values) return bad("h2_dev_evaluate_h: null argument");
     return guarded([&] {

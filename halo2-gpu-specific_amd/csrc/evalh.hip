@@ -904,7 +904,8 @@ __global__ void __launch_bounds__(256) k_coset_scatter(const Fr* in, Fr* out, si
 // are scattered to their stride-c positions on the device and come back in one transfer; otherwise each coset's n values
 // come back through the slot's pinned buffer and this thread writes them to values[c i + j] (the workers of the other
 // devices do the same for their cosets at the same time: disjoint 32-byte cells of the caller's vector).
-static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values, uint32_t first, uint32_t step, bool whole) {
+static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values, uint32_t first, uint32_t step, bool whole,
+                               const EvalhFinish* finish = nullptr) {
     const uint32_t log_c = d->extended_k - d->k, c = 1u << log_c;
     const size_t n = (size_t)1 << d->k, size = (size_t)1 << d->extended_k;
     const size_t nbytes = n * sizeof(Fr), ebytes = size * sizeof(Fr);
@@ -1080,10 +1081,14 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
             g = fp_mul(g, w_step);
         }
         H2_HIP(hipGetLastError());
-        if (whole) H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
+        int frc = H2_OK;
+        if (whole && finish)
+            frc = (*finish)(ctx, d_values, stream);          // (what follows the evaluation, on the device: capi.hip)
+        else if (whole)
+            H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
         H2_HIP(hipStreamSynchronize(stream));
         cleanup();
-        return H2_OK;
+        return frc;
     } catch (...) {
         (void)hipStreamSynchronize(stream);
         cleanup();
@@ -1096,8 +1101,17 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
 // coset of the extended domain -- the work per coset is the same and nothing is exchanged between cosets: P = min(pool
 // size, cosets) threads lease a device each (acquire_gpu, arithmetic.rs:314-321), upload the coefficient vectors once per
 // device and take the cosets p, p + P, ...; with one device (or one coset) the caller's thread does it all.
-int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values) {
-    if (!d || !values) {
+uint32_t evalh_host_workers(const h2_evalh_desc* d) {
+    if (!d || d->extended_k < d->k || d->extended_k > 28) return 1;
+    const uint32_t c = 1u << (d->extended_k - d->k);
+    return (uint32_t)std::max(1, std::min<int>(device_count(), (int)c));
+}
+
+int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values) { return evalh_host_coeffs(d, values, nullptr, nullptr); }
+
+int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values, const EvalhFinish* finish, bool* finished) {
+    if (finished) *finished = false;
+    if (!d || (!values && !(finish && evalh_host_workers(d) <= 1))) {
         set_last_error("h2_evaluate_h_coeff: null argument");
         return H2_ERR_INVALID;
     }
@@ -1113,7 +1127,8 @@ int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values) {
     const uint32_t workers = (uint32_t)std::max(1, std::min<int>(device_count(), (int)c));
     if (workers <= 1) {
         DeviceLease lease;
-        return evalh_coeffs_worker(lease.ctx, d, values, 0, 1, true);
+        if (finished) *finished = finish != nullptr;
+        return evalh_coeffs_worker(lease.ctx, d, values, 0, 1, true, finish);
     }
     std::vector<int> rcs(workers, H2_OK);
     std::vector<std::string> errs(workers);

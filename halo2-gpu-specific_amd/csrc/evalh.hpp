@@ -1,5 +1,7 @@
 // evalh.hpp -- evaluate_h drivers (evalh.hip)
 #pragma once
+#include <functional>
+
 #include "common.hpp"
 #include "evalh_gen.hpp"
 
@@ -11,6 +13,13 @@ int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values);
 // host memory, columns as COEFFICIENT vectors of 2^k elements (l_active_row extended): the cuda evaluate_h's shape; leases
 // its devices itself -- the cosets of the extended domain are dealt over the pool (HALO2_PROOFS_N_GPU)
 int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values);
+// the same, with what follows the evaluation kept on the device: when ONE device does all the cosets, `finish` is handed the
+// 2^extended_k values where they lie (under the slot's lease, on its stream) instead of their being copied to `values`
+// (which may then be null) and *finished is set; with several devices the values go to `values` as above
+typedef std::function<int(DeviceCtx*, Fr*, hipStream_t)> EvalhFinish;
+int evalh_host_coeffs(const h2_evalh_desc* d, uint64_t* values, const EvalhFinish* finish, bool* finished);
+// the devices evalh_host_coeffs would deal the cosets of this descriptor over
+uint32_t evalh_host_workers(const h2_evalh_desc* d);
 
 // ---- the generated form (evalh_gen.cpp builds it, evalh.hip loads and launches it)
 struct EvalhPlan;  // the loaded kernels of one program on one device

@@ -340,6 +340,7 @@ class HostApiDevice(P.Device):
             self.permutation_product = None                          # the permutation products step by step (rounds 4-6)
             self.commit_lagrange_and_ifft = None                     # ... and h2_msm + h2_intt for the product columns
             self.quotient_sum = None                                 # ... and the multiopen's folds and divisions one by one
+            self.quotient_poly_coeff = None                          # ... and evaluate_h / divide / extended_to_coeff as three calls
         import torch
 
         if not torch.cuda.is_available():
@@ -421,6 +422,20 @@ class HostApiDevice(P.Device):
         scalars = [_fr(v) for v in (beta, gamma, delta_pow, DELTA, omega, init)]       # (alive until the call has returned)
         check(self.L.R.h2_permutation_product(z.data_ptr(), vp, sp, len(values), n, *[_addr(v) for v in scalars]), "h2_permutation_product")
         return z, self.get_rows(z, probe, 1)[0]
+
+    def quotient_poly_coeff(self, desc, dom, t_evaluations):
+        """h(X) in coefficient form by ONE host-slice call (h2_quotient_poly_coeff: evaluate_h from coefficient forms, the
+        division by the vanishing polynomial and extended_to_coeff on the device; only n * quotient_poly_degree coefficients
+        cross PCIe)"""
+        from .prover import _fr
+
+        out_len = dom.n * dom.quotient_poly_degree
+        out = self.empty(out_len)
+        scalars = [_fr(v) for v in (dom.g_coset, dom.g_coset_inv, dom.extended_omega_inv, dom.extended_ifft_divisor)]
+        self.L._count("h2_quotient_poly_coeff")
+        check(self.L.R.h2_quotient_poly_coeff(ctypes.byref(desc), t_evaluations.data_ptr(), len(dom.t_evaluations),
+                                              *[_addr(v) for v in scalars], out.data_ptr(), out_len), "h2_quotient_poly_coeff")
+        return out
 
     def quotient_sum(self, n, sets, remainders=False):
         """sum over `sets` = [(polys, coeffs, low, points)] of (sum_i coeffs[i] polys[i] - low) / prod_j (X - points[j]) by ONE

@@ -1890,19 +1890,20 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                          sum(2 * len(st["z_polys"]) + 1 for st in circuits[0]["lookups"]) + 3 * len(circuits[0]["shuffle_polys"]))
     y_step = pow(y, terms_per_circuit, R_MOD)
 
-    def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size, rows=None):
-        """`rows` = (first, count): only these rows of the domain are evaluated (and valid in the result)"""
+    def evaluate_quotient(points_of, tables, k_domain, zeta_, omega_, size, rows=None, fused=None):
+        """`rows` = (first, count): only these rows of the domain are evaluated (and valid in the result).  `fused` (host
+        vectors, one circuit instance): the device's h2_quotient_poly_coeff -- the result is h(X) in COEFFICIENT form"""
         total = None
         lo_, cnt_ = rows if rows is not None else (0, size)
         for C in circuits:
-            h_c = evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows)
+            h_c = evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows, fused)
             if total is None:
                 total = h_c
             else:                                                                           # H2_OP_LCTHETA: l * c + r
                 D.eval_op(5, total[lo_:lo_ + cnt_], total[lo_:lo_ + cnt_], h_c[lo_:lo_ + cnt_], c=y_step, size=cnt_)
         return total
 
-    def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows=None):
+    def evaluate_quotient_of(C, points_of, tables, k_domain, zeta_, omega_, size, rows=None, fused=None):
         """the fused evaluator over one evaluation domain: `points_of` maps a list of coefficient vectors to their values there"""
         lookups = C["lookups"]
         if points_of is None:
@@ -1923,6 +1924,10 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 y=fr_to_mont_limbs(y), beta=fr_to_mont_limbs(beta), gamma=fr_to_mont_limbs(gamma), theta=fr_to_mont_limbs(theta),
                 delta=fr_to_mont_limbs(DELTA), zeta=fr_to_mont_limbs(zeta_), extended_omega=fr_to_mont_limbs(omega_),
                 flags=0 if pk.evalh_stats else ev.EVALH_INTERPRET)
+            if fused:           # ... divided by the vanishing polynomial and taken back to coefficients in the same call
+                out = fused(b.desc, dom, pk.t_evaluations)
+                mark("evaluate_h")
+                return out
             out = D.empty(size)
             check(L.h2_evaluate_h_coeff(ctypes.byref(b.desc), out.data_ptr()), "h2_evaluate_h_coeff")
             mark("evaluate_h")
@@ -1980,12 +1985,15 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         tables = {"fixed": pk.fixed_cosets, "sigma": pk.sigma_cosets, "l0": pk.l0, "l_last": pk.l_last,
                   "l_active_row": pk.l_active_row}
         from_coeffs = getattr(D, "quotient_from_coeffs", False)
+        # (host vectors, one circuit instance: the three steps in one call, the 2^extended_k values never leave the device)
+        fused = getattr(D, "quotient_poly_coeff", None) if from_coeffs and len(circuits) == 1 else None
         h = evaluate_quotient(None if from_coeffs else (lambda ts: D.coeffs_to_extended(ts, dom)), tables, ek, ZETA,
-                              dom.extended_omega, en)
-        # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
-        check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
-                                                D.stream), "h2_dev_divide_by_vanishing_poly")
-        D.extended_to_coeff(h, dom)
+                              dom.extended_omega, en, fused=fused)
+        if not fused:
+            # vanishing construct: divide, back to coefficients (vanishing/prover.rs:69-112)
+            check(L.h2_dev_divide_by_vanishing_poly(h.data_ptr(), en, pk.t_evaluations.data_ptr(), len(dom.t_evaluations),
+                                                    D.stream), "h2_dev_divide_by_vanishing_poly")
+            D.extended_to_coeff(h, dom)
         pieces = [h[i * n:(i + 1) * n] for i in range(dom.quotient_poly_degree)]
     else:
         # ---- one proof over several ranks: the extended domain by coset.  On coset j (points

@@ -377,6 +377,16 @@ int h2_evaluate_h(const h2_evalh_desc *desc, uint64_t *values);
  * time, so device memory is (distinct columns) x 2 x 2^k x 32 B + two extended vectors whatever extended_k is -- the
  * memory-bounded route (the reference bounds it with a 5-entry cache of extended FFTs, evaluation_gpu.rs:335-468). */
 int h2_evaluate_h_coeff(const h2_evalh_desc *desc, uint64_t *values);
+/* The vanishing argument's quotient h(X) in COEFFICIENT form from coefficient forms, in one call: the three steps the
+ * reference's cuda path takes on host vectors of 2^extended_k elements -- Evaluator::evaluate_h (plonk/evaluation.rs:1229-1985,
+ * the descriptor as for h2_evaluate_h_coeff), EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:354-373) and
+ * extended_to_coeff (:328-350), the latter two in vanishing::Argument::construct (plonk/vanishing/prover.rs:69-112) -- with the
+ * numerator's values never leaving the device.  out: out_len = n * quotient_poly_degree coefficients (the truncation of
+ * domain.rs:346-347); t_evaluations / t_len as h2_divide_by_vanishing_poly, the scalars as h2_extended_to_coeff. */
+int h2_quotient_poly_coeff(const h2_evalh_desc *desc, const uint64_t *t_evaluations, size_t t_len,
+                           const uint64_t g_coset[4], const uint64_t g_coset_inv[4],
+                           const uint64_t extended_omega_inv[4], const uint64_t extended_ifft_divisor[4],
+                           uint64_t *out, size_t out_len);
 /* Column / table pointers inside `desc` are DEVICE pointers (the descriptor itself and its program
  * arrays -- constants, rotations, calculations, ... and the pointer tables -- stay in host memory).
  * d_values: 2^extended_k Fr on the device.  Work space is taken from the library's arena. */

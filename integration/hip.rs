@@ -295,6 +295,17 @@ extern "C" {
     // (the cuda shape, :1229-1241); evaluate_with_theta is h2_evaluate_h with y := theta, extended_k := k
     pub fn h2_evaluate_h(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
     pub fn h2_evaluate_h_coeff(desc: *const H2EvalhDesc, values: *mut u64) -> c_int;
+    pub fn h2_quotient_poly_coeff(
+        desc: *const H2EvalhDesc,
+        t_evaluations: *const u64,
+        t_len: usize,
+        g_coset: *const u64,
+        g_coset_inv: *const u64,
+        extended_omega_inv: *const u64,
+        extended_ifft_divisor: *const u64,
+        out: *mut u64,
+        out_len: usize,
+    ) -> c_int;
     // The library turns a descriptor's program into generated kernels (hipRTC, cached by program hash in memory and on
     // disk) the first time it sees it; h2_evalh_prepare does that ahead of the first proof, e.g. from keygen_pk
     pub fn h2_evalh_prepare(desc: *const H2EvalhDesc, info: *mut H2EvalhInfo) -> c_int;
@@ -561,6 +572,39 @@ where
     };
     check(rc, "permutation_product");
     z
+}
+
+/// `h2_quotient_poly_coeff`: h(X) in coefficient form (`out_len = n * quotient_poly_degree` scalars) from the descriptor
+/// `evaluate_h` takes -- `Evaluator::evaluate_h` (plonk/evaluation.rs:1229-1985), `divide_by_vanishing_poly`
+/// (poly/domain.rs:354-373) and `extended_to_coeff` (:328-350) without the 2^extended_k values leaving the device.
+/// Optional: the patch keeps the reference's three steps (`vanishing::Argument::construct` takes the extended values).
+pub fn quotient_poly_coeff<F: Copy + Default>(
+    desc: &H2EvalhDesc,
+    t_evaluations: &[F],
+    g_coset: &F,
+    g_coset_inv: &F,
+    extended_omega_inv: &F,
+    extended_ifft_divisor: &F,
+    out_len: usize,
+) -> Vec<F> {
+    assert_eq!(std::mem::size_of::<F>(), 32);
+    let mut out = vec![F::default(); out_len];
+    let (g, gi, wi, dv) = (limbs(g_coset), limbs(g_coset_inv), limbs(extended_omega_inv), limbs(extended_ifft_divisor));
+    let rc = unsafe {
+        h2_quotient_poly_coeff(
+            desc as *const H2EvalhDesc,
+            t_evaluations.as_ptr() as *const u64,
+            t_evaluations.len(),
+            g.as_ptr(),
+            gi.as_ptr(),
+            wi.as_ptr(),
+            dv.as_ptr(),
+            out.as_mut_ptr() as *mut u64,
+            out_len,
+        )
+    };
+    check(rc, "quotient_poly_coeff");
+    out
 }
 
 /// `polys[j](points[j])` for every j in one device call (plonk/prover.rs:700-790: the evaluations of every committed polynomial

@@ -151,6 +151,24 @@ def test_evaluate_h_from_coefficient_forms(oracle, seed, j, k, kwargs):
     got = ev.evaluate_h_coeff(ev.Builder().build(**coeff))
     assert np.array_equal(got, want)
     assert np.array_equal(ev.evaluate_h(ev.Builder().build(**ext)), want)            # the extended-coset entry point agrees
+    # h2_quotient_poly_coeff: the same evaluation, divided by the vanishing polynomial and taken back to coefficient form without
+    # leaving the device -- against the oracle's divide_by_vanishing_poly (poly/domain.rs:354-373) and extended_to_coeff
+    # (:328-350) applied to the oracle's numerator
+    import ctypes
+
+    from halo2_gpu_specific_amd._lib import lib
+
+    _, t = oracle.domain(j, k)
+    divided = want.copy()
+    oracle.lib.oracle_divide_by_vanishing_poly(divided.ctypes.data, len(divided), t.ctypes.data, len(t), 8)
+    want_coeff = oracle.extended_to_coeff(divided, d, threads=8)
+    b = ev.Builder().build(**coeff)
+    out = np.empty((len(want_coeff), 4), dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)                                  # noqa: E731
+    scal = [d.fr(name) for name in ("g_coset", "g_coset_inv", "extended_omega_inv", "extended_ifft_divisor")]
+    assert lib().h2_quotient_poly_coeff(ctypes.byref(b.desc), vp(t), len(t), *[vp(v) for v in scal], vp(out), len(out)) == 0
+    assert np.array_equal(out, want_coeff)
+    assert lib().h2_quotient_poly_coeff(ctypes.byref(b.desc), vp(t), 3, *[vp(v) for v in scal], vp(out), len(out)) != 0   # t_len must divide
 
 
 def test_host_lincomb(oracle):

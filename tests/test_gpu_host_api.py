@@ -48,7 +48,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
         first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None)
         assert len(got) == len(want) and first is None, "host-slice proof differs at byte %s" % first
     calls = H.L.calls
-    assert calls["h2_evaluate_h_coeff"] == 2 and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
+    assert calls["h2_quotient_poly_coeff"] == 2 and "h2_evaluate_h_coeff" not in calls and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
     assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
     assert calls["h2_quotient_sum"] >= 3               # (SHPLONK: the rotation sets' quotients + the final one; GWC: one per point)
     assert "h2_kate_division" not in calls
@@ -60,6 +60,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
     spk = prover.keygen(S, sparams, cs, fixed, copies)
     assert prover.create_proof_ext(S, sparams, spk, adv, ProverRng(2), True, instances=inst) == want
     assert S.L.calls["h2_permutation_terms"] >= 1 and "h2_permutation_product" not in S.L.calls and "h2_quotient_sum" not in S.L.calls
+    assert S.L.calls["h2_evaluate_h_coeff"] == 1 and S.L.calls["h2_divide_by_vanishing_poly"] == 1 and S.L.calls["h2_extended_to_coeff"] == 1
     if which == "mini" and k == 9:          # two circuit instances in one proof
         adv2 = circuits.mini_plonk_synthesize(k, a=9)[0]
         want = prover.create_proof_ext(device, params, pk, [adv, adv2], ProverRng(5), False, instances=[(), ()])
