@@ -106,6 +106,7 @@ SYMBOLS = {
     "h2_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "h2_quotient_sum": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2_dev_random_fr": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_random_fr": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_dev_distribute_powers": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_dev_g1_fold": (ctypes.c_int, [_vp, _u32, _u32, _vp, _vp]),
     "h2_dev_prefix_sum": (ctypes.c_int, [_vp, _sz, _vp, _vp, _vp]),

@@ -893,6 +893,25 @@ int h2_dev_random_fr(const uint8_t key[32], size_t n, void* d_out, void* stream)
     });
 }
 
+// the same into a host vector (the reference fills its `random_poly` on the host, plonk/vanishing/prover.rs:47-61: a host that
+// wants the device's keyed stream in a `Vec` gets it with one copy down)
+int h2_random_fr(const uint8_t key[32], size_t n, uint64_t* out) {
+    if ((!out && n) || !key) return bad("h2_random_fr: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(out, n * sizeof(Fr));
+        uint64_t* d = (uint64_t*)ctx->buf_a.get(n * sizeof(Fr));
+        int rc = random_fr_launch(key, n, d, ctx->stream);
+        if (rc != H2_OK) return rc;
+        pf.join();
+        H2_HIP(hipMemcpyAsync(out, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
 int h2_dev_eval_op(int op, void* d_res, const void* d_l, const void* d_r, int32_t l_rot, int32_t r_rot, size_t size,
                    const uint64_t c[4], void* stream) {
     return guarded([&] {

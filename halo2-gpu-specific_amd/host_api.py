@@ -22,8 +22,7 @@ from . import prover as P
 from ._lib import check, lib
 
 _vp = ctypes.c_void_p
-STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity",
-          "h2_dev_random_fr", "h2_dev_distribute_powers")
+STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity", "h2_dev_distribute_powers")
 
 
 def _addr(x):
@@ -261,12 +260,8 @@ class HostSliceLib:
         return rc
 
     def h2_dev_random_fr(self, key, n, out, stream):
-        self._count("h2_dev_random_fr (staged)")
-        t = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
-        rc = self.R.h2_dev_random_fr(key, n, t.data_ptr(), None)
-        self._sync()
-        self._down(t, out, 32 * n)
-        return rc
+        self._count("h2_random_fr")
+        return self.R.h2_random_fr(key, n, out)
 
     # -- the quotient numerator ---------------------------------------------------------------------------------------
     def h2_dev_evaluate_h(self, desc, out, stream):
@@ -390,7 +385,12 @@ class HostApiDevice(P.Device):
         return [np.zeros((n,) if compact else (n, 4), dtype=np.uint64) for _ in range(count)]
 
     def max_scalar_bits_many(self, cols, n):
-        return [P.max_scalar_bits(c[:n].numpy().view(np.uint64)) for c in cols]
+        """find_max_scalar_bits (plonk/prover.rs:237-254: a rayon fold over the column there) per column, the columns on the
+        worker threads (numpy's reductions release the interpreter lock)"""
+        one = lambda c: P.max_scalar_bits(c[:n].numpy().view(np.uint64))       # noqa: E731
+        if self.L.pool is None or len(cols) < 2:
+            return [one(c) for c in cols]
+        return list(self.L.pool.map(one, cols))
 
     def residency(self, cs, dom, instances=1):
         return "extended", None

@@ -247,6 +247,8 @@ int h2_dev_permutation_terms(void *d_num, void *d_den, const void *d_value, cons
  * (halo2-gpu-specific_amd/rng.py draws it from os.urandom; its seeded mode is for tests); rng.py also holds the host
  * twin the reference prover of the tests draws from. */
 int h2_dev_random_fr(const uint8_t key[32], size_t n, void *d_out, void *stream);
+/* the same stream of elements into a host vector (one copy down) */
+int h2_random_fr(const uint8_t key[32], size_t n, uint64_t *out);
 
 /* a[i] *= g^i for i < n (n <= 2^28): distribute_powers_zeta (poly/domain.rs:382-398) for an arbitrary generator.  With
  * g = zeta * extended_omega^j followed by an n-point h2_dev_ntt it evaluates a coefficient vector on coset j of the

@@ -263,6 +263,7 @@ extern "C" {
     pub fn h2_eval_polynomial(poly: *const u64, n: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn h2_eval_polynomial_batch(polys: *const *const u64, count: usize, n: usize, points: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
+    pub fn h2_random_fr(key: *const u8, n: usize, out: *mut u64) -> c_int;
     pub fn h2_quotient_sum(
         out: *mut u64,
         n: usize,

@@ -443,3 +443,24 @@ def test_eval_polynomial_batch_on_host_vectors(oracle, n):
         assert L.h2_poly_unregister(_ptr(polys[1])) == 0
     assert L.h2_eval_polynomial_batch(ptrs, 0, n, None, None) == 0
     assert L.h2_eval_polynomial_batch(None, 2, n, _ptr(points), _ptr(out)) != 0
+
+
+def test_random_fr_into_a_host_vector():
+    """h2_random_fr: the keyed stream of h2_dev_random_fr (the vanishing argument's blinding polynomial) in a host vector"""
+    import ctypes
+
+    import torch
+
+    import halo2_gpu_specific_amd as h2
+
+    L = h2.lib()
+    key = (ctypes.c_uint8 * 32)(*range(7, 39))
+    for n in (1, 4097, (1 << 18) + 3):
+        dev = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()                      # (torch's fill runs on torch's stream, the generator on the library's)
+        assert L.h2_dev_random_fr(key, n, dev.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        host = np.zeros((n, 4), dtype=np.uint64)
+        assert L.h2_random_fr(key, n, _ptr(host)) == 0
+        assert np.array_equal(host, dev.cpu().numpy().view(np.uint64))
+    assert L.h2_random_fr(None, 4, _ptr(host)) != 0
