@@ -672,6 +672,9 @@ def main():
                                 "(no CPU arithmetic here).  `pageable`: the vectors in ordinary memory (a Rust Vec); `pinned`: in "
                                 "page-locked memory (an allocator over h2_host_alloc_pinned): the same calls, DMA transfers"}
             for mode in ("pageable", "pinned"):
+                import gc
+
+                gc.collect()
                 H = ha.HostApiDevice(local_rank, pinned=(mode == "pinned"))
                 hparams = ha.params_like(H, params)
                 hpk = prover.keygen(H, hparams, circuits.mini_plonk(), fixed, copies)
@@ -684,7 +687,10 @@ def main():
                 in_lib, by_call = H.L.R.busy_seconds, {n: round(v * 1e3, 2) for n, v in sorted(H.L.R.by_call.items())}
                 calls = dict(sorted(H.L.calls.items()))
                 hphases = {}
+                H.L.R.reset()
                 prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1), timings=hphases)
+                if os.environ.get("H2_BENCH_DEBUG"):
+                    sys.stderr.write("%s phases run, library ms by call: %s\n" % (mode, {n: round(v * 1e3, 1) for n, v in sorted(H.L.R.by_call.items())}))
                 host_api[mode] = {
                     "seconds": hsec, "proof_bytes_equal": bool(hproof == proof), "ratio_to_resident": hsec / (pelapsed / steps),
                     # wall time with at least one C-ABI call executing; the rest is the host's own handling of its vectors
@@ -695,6 +701,11 @@ def main():
                 }
                 assert hproof == proof, "the host-slice data flow changed the proof"
                 del hpk, hparams, H
+                # (the leg's objects sit in reference cycles: collected NOW -- their finalizers unregister and free ~40 host and
+                # device vectors -- not in the middle of the next leg's proofs)
+                import gc
+
+                gc.collect()
         return {
             "k": pk_k,
             "compact_witness": compact,

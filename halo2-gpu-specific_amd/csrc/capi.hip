@@ -306,11 +306,12 @@ int h2_release_plans(void) {
         } restore;
         for (DeviceCtx* ctx : existing_contexts()) {
             std::vector<NttPlan*> gone;
+            H2_HIP(hipSetDevice(ctx->device));
             {
                 std::lock_guard<std::mutex> g(ctx->mu);      // no transform of this context is between lookup and launch
                 ntt_detach_idle_plans(ctx, gone);
+                ctx->coeff_arena.release();                   // (no call of the slot is running: its block of column vectors goes too)
             }
-            H2_HIP(hipSetDevice(ctx->device));
             ntt_free_plans(gone);                             // synchronises and frees with no lock held
         }
         return (int)H2_OK;
@@ -333,7 +334,7 @@ size_t h2_library_memory_bytes(void) {
         for (DeviceCtx* c : existing_contexts()) {                        // ... plus every slot's own buffers
             if (c->device != ctx->device) continue;
             std::lock_guard<std::mutex> g(c->mu);
-            total += c->buf_a.cap + c->buf_b.cap + c->buf_c.cap + c->buf_d.cap + c->msm_scratch.cap + c->evalh_scratch.cap;
+            total += c->buf_a.cap + c->buf_b.cap + c->buf_c.cap + c->buf_d.cap + c->msm_scratch.cap + c->evalh_scratch.cap + c->coeff_arena.cap;
         }
         return (int)H2_OK;
     });

@@ -87,6 +87,7 @@ struct DeviceCtx {
     DevBuf buf_a, buf_b, buf_c, buf_d; // staging / ping-pong scratch
     DevBuf msm_scratch;
     DevBuf evalh_scratch;
+    DevBuf coeff_arena;                // h2_evaluate_h_coeff / h2_quotient_poly_coeff: the columns' coefficient and coset vectors of a call
     PinnedBuf pinned;
     DeviceShared* shared;
     std::map<const void*, ResidentCopy>& resident;

@@ -916,7 +916,9 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
     };
     // ONE device block for the call, handed out piece by piece (a call used to make ~2 x columns + 5 hipMalloc / hipFree pairs,
     // every hipFree a device synchronisation); sized from the distinct vectors of the descriptor, individual allocations if the
-    // block cannot be had or turns out short
+    // block cannot be had or turns out short.  The block belongs to the slot (ctx->coeff_arena, grow-only, given back by
+    // h2_release_plans): a hipMalloc of 6.4 GiB per call (k = 22, 16 columns) took 0.3 ms when the runtime still had the range
+    // of the previous call and 160 ms when it did not -- one proof in three of the literal drop-in's measured sequence.
     char* arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
     auto dmalloc = [&](size_t bytes) -> void* {
@@ -947,12 +949,11 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
             if (d->l_last) distinct.insert(d->l_last);
             const size_t width = std::max<size_t>(1, std::min<size_t>(16, ((size_t)1 << 30) / nbytes));
             arena_bytes = (2 * distinct.size() + 2 + width) * (nbytes + 256) + (whole ? 2 * (ebytes + 256) : 0);
-            void* q = nullptr;
-            if (hipMalloc(&q, arena_bytes) == hipSuccess) {
-                arena = (char*)q;
-                owned.push_back(q);
-            } else {
+            try {
+                arena = (char*)ctx->coeff_arena.get(arena_bytes);
+            } catch (const HipError&) {
                 (void)hipGetLastError();
+                arena = nullptr;
                 arena_bytes = 0;
             }
         }

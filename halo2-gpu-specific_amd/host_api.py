@@ -385,12 +385,19 @@ class HostApiDevice(P.Device):
         return [np.zeros((n,) if compact else (n, 4), dtype=np.uint64) for _ in range(count)]
 
     def max_scalar_bits_many(self, cols, n):
-        """find_max_scalar_bits (plonk/prover.rs:237-254: a rayon fold over the column there) per column, the columns on the
-        worker threads (numpy's reductions release the interpreter lock)"""
-        one = lambda c: P.max_scalar_bits(c[:n].numpy().view(np.uint64))       # noqa: E731
-        if self.L.pool is None or len(cols) < 2:
-            return [one(c) for c in cols]
-        return list(self.L.pool.map(one, cols))
+        """find_max_scalar_bits (plonk/prover.rs:237-254: a rayon fold over the column there) per column, each column cut into
+        row ranges for the worker threads (numpy's reductions release the interpreter lock)"""
+        parts = self.workers if self.L.pool is not None and n >= (1 << 16) else 1
+        step = (n + parts - 1) // parts
+        # (a job carries an address, not a tensor: a pool thread keeps its last job alive until the next one arrives, and a
+        # page-locked block that cannot go back to the allocator's cache costs the next proof a fresh hipHostMalloc)
+        jobs = [(ci, c.data_ptr() + 32 * lo, min(step, n - lo)) for ci, c in enumerate(cols) for lo in range(0, n, step)]
+        one = lambda job: (job[0], P.max_scalar_bits(_bytes_at(job[1], 32 * job[2]).view(np.uint64).reshape(-1, 4)))       # noqa: E731
+        done = [one(j) for j in jobs] if parts == 1 else list(self.L.pool.map(one, jobs))
+        bits = [0] * len(cols)
+        for ci, b in done:
+            bits[ci] = max(bits[ci], b)
+        return bits
 
     def residency(self, cs, dom, instances=1):
         return "extended", None
@@ -473,10 +480,11 @@ class HostApiDevice(P.Device):
             return []
         out = np.zeros((len(cols), 12), dtype=np.uint64)
         wi, dv = _fr(dom.omega_inv), _fr(dom.ifft_divisor)
+        ptrs, bp, n_, k_ = [c.data_ptr() for c in cols], bases.data_ptr(), dom.n, dom.k     # (addresses: see max_scalar_bits_many)
 
         def one(i):
             self.L._count("h2_msm_intt")
-            return self.L.R.h2_msm_intt(cols[i].data_ptr(), bases.data_ptr(), dom.n, 254, _addr(wi), _addr(dv), dom.k, out[i].ctypes.data)
+            return self.L.R.h2_msm_intt(ptrs[i], bp, n_, 254, _addr(wi), _addr(dv), k_, out[i].ctypes.data)
 
         check(self.L._each(one, list(range(len(cols)))), "h2_msm_intt")
         return jacobians_to_affine(out)
