@@ -65,7 +65,9 @@ int h2_synchronize(void);
  *    suffixes) or h2_set_table_budget; default 1/32 of the device's memory.  When a new table would exceed it, idle
  *    tables leave in least-recently-used order; a transform without a table composes its twiddles (same values).
  *  - h2_release_plans frees every plan (and its tables) that no call is using, on every device: for callers that
- *    cycle through domains or coset generators.  Synchronises the devices.
+ *    cycle through domains or coset generators.  Synchronises the devices.  It also gives back every slot's block of
+ *    column vectors of h2_evaluate_h_coeff / h2_quotient_poly_coeff ((2 x distinct columns + a few) x 2^k x 32 B plus two
+ *    extended vectors: 6.4 GiB for 16 columns at k = 22; kept between calls because allocating it cost up to 160 ms).
  *  - h2_library_memory_bytes: what the library holds on the current device right now. */
 int h2_release_plans(void);
 int h2_set_table_budget(size_t bytes);
