@@ -9,7 +9,8 @@ a proof is a deterministic function of (key, witness, randomness) whether or not
 divides pointwise on the extended domain either way -- so unsatisfied gates and copies exercise the same arithmetic;
 only what the prover itself checks is made true (lookup inputs come from the table, the shuffle is a permutation).
 
-usage: [H2_FUZZ_KMAX=14] python tools/prover_fuzz.py [seconds] [first seed] [satisfiable]
+usage: [H2_FUZZ_KMAX=14] [H2_FUZZ_HOST_API=1] python tools/prover_fuzz.py [seconds] [first seed] [satisfiable]
+(H2_FUZZ_HOST_API=1: every circuit is also proved through the host-slice entry points, halo2-gpu-specific_amd/host_api.py)
 """
 import os
 import random
@@ -236,6 +237,20 @@ def compare(device, case, seed, cache={}, satisfiable=False, several=True):
             first = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
             raise AssertionError("seed %d (%s): proof differs at byte %d of %d / %d" % (
                 seed, "gwc" if use_gwc else "shplonk", first, len(got), len(want)))
+    if os.environ.get("H2_FUZZ_HOST_API") == "1":
+        # the literal drop-in's data flow on the same circuit (host vectors, the fused host-slice entry points:
+        # h2_permutation_product, h2_msm_intt, h2_quotient_poly_coeff, h2_eval_polynomial_batch, h2_quotient_sum): the same bytes
+        from halo2_gpu_specific_amd import host_api
+
+        if ("host", k) not in cache:
+            H = host_api.HostApiDevice(pinned=(seed % 2 == 0))
+            cache[("host", k)] = (H, host_api.params_like(H, params))
+        H, hparams = cache[("host", k)]
+        hpk = prover.keygen(H, hparams, cs, fixed, copies)
+        for use_gwc in (False, True):
+            want_h = prover.create_proof_ext(device, params, pk, advice, ProverRng(seed + 7), use_gwc, instances=instances)
+            got_h = prover.create_proof_ext(H, hparams, hpk, advice, ProverRng(seed + 7), use_gwc, instances=instances)
+            assert got_h == want_h, "seed %d (%s): the host-slice data flow changed the proof" % (seed, "gwc" if use_gwc else "shplonk")
     if several and not satisfiable and seed % 4 == 0:
         # several circuit instances in one proof (plonk/prover.rs:206-232): two more witnesses of the same circuit
         advs, insts = [advice], [instances]
