@@ -1132,6 +1132,8 @@ def main():
             ("create_proof_k%d_evalh_alu_frac" % args.prove_k, "create_proof", ("evaluate_h", "roofline", "alu", "frac")),
             ("create_proof_k%d_host_slice_pinned_s" % args.prove_k, "create_proof", ("host_slice_api", "pinned", "seconds")),
             ("create_proof_k%d_host_slice_pageable_s" % args.prove_k, "create_proof", ("host_slice_api", "pageable", "seconds")),
+            ("create_proof_k%d_host_slice_pinned_in_library_s" % args.prove_k, "create_proof", ("host_slice_api", "pinned", "seconds_inside_library_calls")),
+            ("create_proof_k%d_host_slice_pageable_in_library_s" % args.prove_k, "create_proof", ("host_slice_api", "pageable", "seconds_inside_library_calls")),
             ("create_proof_k%d_h2prove_cxx_s" % args.prove_k, "create_proof", ("h2prove_cxx", "seconds")),
             ("create_proof_k%d_cpu_s" % args.cpu_prove_k, "create_proof", ("cpu_baseline", "seconds")),
             ("create_proof_k24_s", "create_proof_k24", ("seconds",)),
