@@ -464,3 +464,52 @@ def test_random_fr_into_a_host_vector():
         assert L.h2_random_fr(key, n, _ptr(host)) == 0
         assert np.array_equal(host, dev.cpu().numpy().view(np.uint64))
     assert L.h2_random_fr(None, 4, _ptr(host)) != 0
+
+
+def test_fused_entry_points_from_two_threads_at_once(oracle):
+    """two threads, each with its own vectors, inside h2_permutation_product / h2_quotient_sum / h2_eval_polynomial_batch at the same
+    time (the two host-API slots of the device): every result equals the one the same call gives alone"""
+    import ctypes
+    import threading
+
+    import halo2_gpu_specific_amd as h2
+    from h2util import R_MOD, fr_mont
+
+    L = h2.lib()
+    n = (1 << 19) + 11
+    delta = fr_mont(0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2)
+    omega = fr_mont(pow(0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C, 1 << (28 - 20), R_MOD))
+    sz = ctypes.c_size_t
+
+    def calls(t):
+        vals = [oracle.random_fr(9980 + 10 * t + j, n) for j in range(3)]
+        sc = oracle.random_fr(9990 + t, 8)
+        vp = (ctypes.c_void_p * 2)(vals[0].ctypes.data, vals[1].ctypes.data)
+        sp = (ctypes.c_void_p * 2)(vals[1].ctypes.data, vals[2].ctypes.data)
+        z = np.empty((n, 4), dtype=np.uint64)
+        assert L.h2_permutation_product(_ptr(z), vp, sp, 2, n, _ptr(sc[0]), _ptr(sc[1]), _ptr(delta), _ptr(delta), _ptr(omega), _ptr(sc[2])) == 0
+        q = np.empty((n, 4), dtype=np.uint64)
+        ptrs = (ctypes.c_void_p * 3)(*[v.ctypes.data for v in vals])
+        assert L.h2_quotient_sum(_ptr(q), n, 2, (sz * 2)(2, 1), ptrs, _ptr(sc[:3]), (sz * 2)(1, 0), _ptr(sc[3:4]), (sz * 2)(2, 1), _ptr(sc[4:7]), None) == 0
+        ev = np.zeros((3, 4), dtype=np.uint64)
+        assert L.h2_eval_polynomial_batch(ptrs, 3, n, _ptr(sc[:3]), _ptr(ev)) == 0
+        return z, q, ev
+
+    alone = [calls(t) for t in range(2)]
+    got, errors = [None, None], []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = calls(t)
+                for a, b in zip(got[t], alone[t]):
+                    assert np.array_equal(a, b)
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
