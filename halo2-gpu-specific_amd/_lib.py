@@ -104,6 +104,10 @@ SYMBOLS = {
     "h2_permutation_terms": (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "h2_permutation_product": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "h2_prefix_sum": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
+    "h2_distribute_powers": (ctypes.c_int, [_vp, _sz, _vp]),
+    "h2_permutation_sigma": (ctypes.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "h2_logup_multiplicity": (ctypes.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "h2_quotient_sum": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2_dev_random_fr": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_random_fr": (ctypes.c_int, [_vp, _sz, _vp]),

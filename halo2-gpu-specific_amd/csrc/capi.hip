@@ -1451,6 +1451,120 @@ int h2_dev_prefix_sum(const void* d_f, size_t n, const uint64_t init[4], void* d
 
 size_t h2_logup_scratch_bytes(size_t n) { return logup_scratch_bytes(n); }
 
+// ---- host-vector twins of the remaining steps of a proof with lookups (the reference runs them as host loops: scan
+// plonk/logup/prover.rs:353-367, multiplicities :104-180, sigma columns plonk/permutation/keygen.rs:197-238,
+// distribute_powers_zeta poly/domain.rs:382-398): a host that keeps its vectors in memory needs no device pointer for any of them
+int h2_prefix_sum(const uint64_t* f, size_t n, const uint64_t init[4], uint64_t* z) {
+    if (!init || (n && !z) || (n > 1 && !f)) return bad("h2_prefix_sum: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf((const void*)z == (const void*)f ? nullptr : z, n * sizeof(Fr));
+        Fr* d_f = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        Fr* d_z = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
+        Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
+        if (n > 1) H2_HIP(hipMemcpyAsync(d_f, f, (n - 1) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = prefix_sum_launch(d_f, n, init, d_z, tmp, ctx->stream);
+        if (rc != H2_OK) return rc;
+        pf.join();
+        H2_HIP(hipMemcpyAsync(z, d_z, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_distribute_powers(uint64_t* a, size_t n, const uint64_t g[4]) {
+    if ((n && !a) || !g) return bad("h2_distribute_powers: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Fr* d = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        H2_HIP(hipMemcpyAsync(d, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        int rc = distribute_powers_launch(d, n, g, ctx->stream);
+        if (rc != H2_OK) return rc;
+        H2_HIP(hipMemcpyAsync(a, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+int h2_permutation_sigma(uint64_t* out, const uint32_t* map_col, const uint32_t* map_row, size_t n, const uint64_t delta[4],
+                         const uint64_t omega[4]) {
+    if (n && (!out || !map_col || !map_row || !delta || !omega)) return bad("h2_permutation_sigma: null argument");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(out, n * sizeof(Fr));
+        Fr* d_out = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
+        uint32_t* d_col = (uint32_t*)ctx->buf_b.get(2 * n * sizeof(uint32_t));
+        uint32_t* d_row = d_col + n;
+        H2_HIP(hipMemcpyAsync(d_col, map_col, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        H2_HIP(hipMemcpyAsync(d_row, map_row, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        int rc = perm_sigma_launch(d_out, d_col, d_row, n, delta, omega, ctx->stream);
+        if (rc != H2_OK) return rc;
+        pf.join();
+        H2_HIP(hipMemcpyAsync(out, d_out, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+// table and inputs: host vectors of n elements (registered ones are read on the device); m: n elements out; *max_bits_out
+// (optional): the bit length of the largest multiplicity
+int h2_logup_multiplicity(const uint64_t* table, const uint64_t* const* inputs, size_t n_inputs, size_t usable_rows, size_t n,
+                          uint64_t* m, uint32_t* max_bits_out) {
+    if (n && (!table || !m || (n_inputs && !inputs))) return bad("h2_logup_multiplicity: null argument");
+    for (size_t i = 0; n && i < n_inputs; i++)
+        if (!inputs[i]) return bad("h2_logup_multiplicity: null input");
+    if (usable_rows > n) return bad("h2_logup_multiplicity: usable_rows > n");
+    return guarded([&] {
+        if (max_bits_out) *max_bits_out = 0;
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(m, n * sizeof(Fr));
+        const size_t bytes = n * sizeof(Fr), sbytes = logup_scratch_bytes(n);
+        std::vector<const Fr*> d_in(n_inputs);
+        size_t staged = 0;
+        const Fr* d_table = resident_operand(ctx, table, n);
+        for (size_t i = 0; i < n_inputs; i++) {
+            d_in[i] = resident_operand(ctx, inputs[i], n);
+            if (!d_in[i]) staged++;
+        }
+        Fr* up = (Fr*)ctx->buf_a.get((staged + (d_table ? 0 : 1)) * bytes + 256);
+        size_t at = 0;
+        if (!d_table) {
+            H2_HIP(hipMemcpyAsync(up, table, bytes, hipMemcpyHostToDevice, ctx->stream));
+            d_table = up;
+            at = 1;
+        }
+        for (size_t i = 0; i < n_inputs; i++)
+            if (!d_in[i]) {
+                H2_HIP(hipMemcpyAsync(up + at * n, inputs[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                d_in[i] = up + at * n;
+                at++;
+            }
+        Fr* d_m = (Fr*)ctx->buf_b.get(bytes);
+        void* d_scratch = ctx->buf_c.get(sbytes);
+        uint32_t max_count = 0;
+        int rc = logup_multiplicity_launch(d_table, d_in.data(), n_inputs, usable_rows, n, d_m, d_scratch, sbytes, ctx->stream, &max_count);
+        if (rc != H2_OK) return rc;
+        if (max_bits_out) {
+            uint32_t bits = 0;
+            while (bits < 32 && (max_count >> bits)) bits++;
+            *max_bits_out = bits;
+        }
+        pf.join();
+        H2_HIP(hipMemcpyAsync(m, d_m, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
+
 int h2_dev_logup_counts(const void* d_table, const void* const* d_inputs, size_t n_inputs, size_t usable_rows, size_t n,
                         size_t row_begin, size_t row_end, void* d_counts, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!d_table || !d_counts || !d_scratch || (n_inputs && !d_inputs)) return bad("h2_dev_logup_counts: null argument");

@@ -8,11 +8,13 @@ y := theta (evaluate_with_theta, :2330-2398), `h2_lincomb` (gwc/prover.rs:57-151
 
 This is a MEASUREMENT device (bench.py: `create_proof.host_slice_api`; INTEGRATION.md states the ratio to the
 device-resident flow), built from product code only: there is no CPU arithmetic in it.  The passes the reference leaves
-to rayon between its GPU calls (permutation terms, batch inversion, grand products / sums, Horner evaluations, Kate
-division, the SHPLONK folds) also go through host-slice entry points where the library has them (`h2_batch_invert`,
-`h2_prefix_product`, `h2_eval_polynomial`, `h2_kate_division`, `h2_eval_op`, `h2_lincomb`); the few without a host-slice
-twin (`STAGED` below) are staged through device memory by hand -- upload, `h2_dev_*`, download, synchronise: the same
-round trip -- and counted in `HostSliceLib.calls`.  The proof bytes are those of the resident prover.
+to rayon between its GPU calls also go through host-slice entry points: whole steps where the library has them
+(`h2_permutation_product`, `h2_msm_intt`, `h2_quotient_poly_coeff`, `h2_eval_polynomial_batch`, `h2_quotient_sum`; the
+step-by-step forms `h2_permutation_terms`, `h2_batch_invert`, `h2_prefix_product`, `h2_eval_polynomial`, `h2_kate_division`,
+`h2_eval_op`, `h2_lincomb` with `fused_permutation=False`), single passes otherwise (`h2_prefix_sum`,
+`h2_logup_multiplicity`, `h2_permutation_sigma`, `h2_distribute_powers`, `h2_random_fr`).  Every call is counted in
+`HostSliceLib.calls`; nothing is staged through device tensors by hand any more (`STAGED` is empty).  The proof bytes are
+those of the resident prover.
 """
 import ctypes
 
@@ -22,7 +24,7 @@ from . import prover as P
 from ._lib import check, lib
 
 _vp = ctypes.c_void_p
-STAGED = ("h2_dev_prefix_sum", "h2_dev_permutation_sigma", "h2_dev_logup_multiplicity", "h2_dev_distribute_powers")
+STAGED = ()
 
 
 def _addr(x):
@@ -110,18 +112,6 @@ class HostSliceLib:
     def _count(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1      # (dict updates of the worker threads: GIL-atomic enough for a tally)
 
-    # -- staging for the entry points without a host-slice twin -------------------------------------------------------
-    def _up(self, addr, nbytes):
-        t = self.torch.from_numpy(_bytes_at(addr, nbytes)).to(self.dev)
-        self.torch.cuda.synchronize(self.dev)      # torch's stream is not the library's: the operand has landed
-        return t
-
-    def _down(self, t, addr, nbytes):
-        _bytes_at(addr, nbytes)[:] = t.cpu().numpy()
-
-    def _sync(self):
-        self.torch.cuda.synchronize(self.dev)
-
     # -- transforms ----------------------------------------------------------------------------------------------------
     def h2_dev_ntt(self, a, tmp, omega, k, stream):
         self._count("h2_ntt")
@@ -151,12 +141,8 @@ class HostSliceLib:
         return self.R.h2_divide_by_vanishing_poly(a, size, t_evals, t_len)
 
     def h2_dev_distribute_powers(self, a, n, g, stream):
-        self._count("h2_dev_distribute_powers (staged)")
-        t = self._up(a, 32 * n)
-        rc = self.R.h2_dev_distribute_powers(t.data_ptr(), n, _addr(g), None)
-        self._sync()
-        self._down(t, a, 32 * n)
-        return rc
+        self._count("h2_distribute_powers")
+        return self.R.h2_distribute_powers(a, n, _addr(g))
 
     # -- commitments: the SRS is registered once (Params below), each call ships the scalars ----------------------------
     def h2_msm_scratch_bytes(self, n, bits):
@@ -226,38 +212,24 @@ class HostSliceLib:
         return self.R.h2_batch_invert(a, n)
 
     def h2_dev_prefix_sum(self, f, n, init, z, stream):
-        self._count("h2_dev_prefix_sum (staged)")
-        tf = self._up(f, 32 * (n - 1 if n else 0))
-        tz = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
-        rc = self.R.h2_dev_prefix_sum(tf.data_ptr(), n, _addr(init), tz.data_ptr(), None)
-        self._sync()
-        self._down(tz, z, 32 * n)
-        return rc
+        self._count("h2_prefix_sum")
+        return self.R.h2_prefix_sum(f, n, _addr(init), z)
 
     def h2_dev_permutation_terms(self, num, den, value, sigma, n, beta, gamma, delta_pow, omega, first, stream):
         self._count("h2_permutation_terms")
         return self.R.h2_permutation_terms(num, den, value, sigma, n, _addr(beta), _addr(gamma), _addr(delta_pow), _addr(omega), first)
 
     def h2_dev_permutation_sigma(self, out, map_col, map_row, n, delta, omega, stream):
-        self._count("h2_dev_permutation_sigma (staged)")
-        to = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
-        mc, mr = self._up(map_col, 4 * n), self._up(map_row, 4 * n)
-        rc = self.R.h2_dev_permutation_sigma(to.data_ptr(), mc.data_ptr(), mr.data_ptr(), n, _addr(delta), _addr(omega), None)
-        self._sync()
-        self._down(to, out, 32 * n)
-        return rc
+        self._count("h2_permutation_sigma")
+        return self.R.h2_permutation_sigma(out, map_col, map_row, n, _addr(delta), _addr(omega))
 
     def h2_dev_logup_multiplicity(self, table, ptrs, n_inputs, usable, n, m, scratch, nbytes, stream):
-        self._count("h2_dev_logup_multiplicity (staged)")
-        tt = self._up(table, 32 * n)
-        ins = [self._up(ptrs[i], 32 * n) for i in range(n_inputs)]
-        tm = self.torch.empty(32 * n, dtype=self.torch.uint8, device=self.dev)
-        sc = self.torch.empty(max(nbytes, 256), dtype=self.torch.uint8, device=self.dev)
-        dptrs = (_vp * n_inputs)(*[t.data_ptr() for t in ins])
-        rc = self.R.h2_dev_logup_multiplicity(tt.data_ptr(), dptrs, n_inputs, usable, n, tm.data_ptr(), sc.data_ptr(), nbytes, None)
-        self._sync()
-        self._down(tm, m, 32 * n)
-        return rc
+        self._count("h2_logup_multiplicity")
+        return self.R.h2_logup_multiplicity(table, ptrs, n_inputs, usable, n, m, None)
+
+    def h2_dev_logup_multiplicity_bits(self, table, ptrs, n_inputs, usable, n, m, scratch, nbytes, bits_out, stream):
+        self._count("h2_logup_multiplicity")
+        return self.R.h2_logup_multiplicity(table, ptrs, n_inputs, usable, n, m, bits_out)
 
     def h2_dev_random_fr(self, key, n, out, stream):
         self._count("h2_random_fr")

@@ -267,6 +267,15 @@ int h2_dev_prefix_sum(const void *d_f, size_t n, const uint64_t init[4], void *d
  * duplicate; the argument is indifferent).  d_inputs: HOST array of n_inputs device pointers.  Returns H2_ERR_INVALID
  * when an input value is absent from the table (the reference panics).  Synchronous. */
 size_t h2_logup_scratch_bytes(size_t n);
+/* Host-vector twins (the reference runs these steps as host loops between its GPU calls): the grand-sum scan, a[i] *= g^i,
+ * one sigma column from the cycle mapping (u32 host arrays of n entries), the multiplicity column of a lookup (table and
+ * inputs: host vectors of n elements, read on the device when registered with h2_poly_register; max_bits_out may be NULL). */
+int h2_prefix_sum(const uint64_t *f, size_t n, const uint64_t init[4], uint64_t *z);
+int h2_distribute_powers(uint64_t *a, size_t n, const uint64_t g[4]);
+int h2_permutation_sigma(uint64_t *out, const uint32_t *map_col, const uint32_t *map_row, size_t n,
+                         const uint64_t delta[4], const uint64_t omega[4]);
+int h2_logup_multiplicity(const uint64_t *table, const uint64_t *const *inputs, size_t n_inputs, size_t usable_rows,
+                          size_t n, uint64_t *m, uint32_t *max_bits_out);
 int h2_dev_logup_multiplicity(const void *d_table, const void *const *d_inputs, size_t n_inputs, size_t usable_rows,
                               size_t n, void *d_m, void *d_scratch, size_t scratch_bytes, void *stream);
 /* h2_dev_logup_multiplicity that also returns the bit length of the LARGEST multiplicity (0 when every count is zero): the

@@ -264,6 +264,25 @@ extern "C" {
     pub fn h2_eval_polynomial_batch(polys: *const *const u64, count: usize, n: usize, points: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
     pub fn h2_random_fr(key: *const u8, n: usize, out: *mut u64) -> c_int;
+    pub fn h2_prefix_sum(f: *const u64, n: usize, init: *const u64, z: *mut u64) -> c_int;
+    pub fn h2_distribute_powers(a: *mut u64, n: usize, g: *const u64) -> c_int;
+    pub fn h2_permutation_sigma(
+        out: *mut u64,
+        map_col: *const u32,
+        map_row: *const u32,
+        n: usize,
+        delta: *const u64,
+        omega: *const u64,
+    ) -> c_int;
+    pub fn h2_logup_multiplicity(
+        table: *const u64,
+        inputs: *const *const u64,
+        n_inputs: usize,
+        usable_rows: usize,
+        n: usize,
+        m: *mut u64,
+        max_bits_out: *mut u32,
+    ) -> c_int;
     pub fn h2_quotient_sum(
         out: *mut u64,
         n: usize,

@@ -513,3 +513,69 @@ def test_fused_entry_points_from_two_threads_at_once(oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n", [1, 2, 4099, (1 << 18) + 5])
+def test_host_vector_twins_of_the_lookup_steps(oracle, n):
+    """h2_prefix_sum, h2_distribute_powers, h2_permutation_sigma, h2_logup_multiplicity on host vectors against the device entry
+    points they wrap (each of those is checked against the oracle in tests/test_gpu_numerics.py)"""
+    import ctypes
+
+    import torch
+
+    import halo2_gpu_specific_amd as h2
+    from h2util import R_MOD, fr_mont
+
+    L = h2.lib()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()            # noqa: E731
+    host = lambda t: t.cpu().numpy().view(np.uint64)                                           # noqa: E731
+    f, init, g = oracle.random_fr(9970, n), oracle.random_fr(9971, 1)[0], oracle.random_fr(9972, 1)[0]
+    # grand sum
+    z = np.empty((n, 4), dtype=np.uint64)
+    assert L.h2_prefix_sum(_ptr(f), n, _ptr(init), _ptr(z)) == 0
+    d_f, d_z = dev(f), torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert L.h2_dev_prefix_sum(d_f.data_ptr(), n, _ptr(init), d_z.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(z, host(d_z))
+    # a[i] *= g^i
+    a = f.copy()
+    assert L.h2_distribute_powers(_ptr(a), n, _ptr(g)) == 0
+    d_a = dev(f)
+    torch.cuda.synchronize()
+    assert L.h2_dev_distribute_powers(d_a.data_ptr(), n, _ptr(g), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(a, host(d_a))
+    # one sigma column
+    rng = np.random.default_rng(n)
+    mc, mr = rng.integers(0, 5, size=n, dtype=np.uint32), rng.integers(0, n, size=n, dtype=np.uint32)
+    delta = fr_mont(0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2)
+    omega = fr_mont(pow(0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C, 1 << (28 - 19), R_MOD))
+    sig = np.empty((n, 4), dtype=np.uint64)
+    assert L.h2_permutation_sigma(_ptr(sig), _ptr(mc), _ptr(mr), n, _ptr(delta), _ptr(omega)) == 0
+    d_mc, d_mr = torch.from_numpy(mc.view(np.int32)).cuda(), torch.from_numpy(mr.view(np.int32)).cuda()
+    d_sig = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert L.h2_dev_permutation_sigma(d_sig.data_ptr(), d_mc.data_ptr(), d_mr.data_ptr(), n, _ptr(delta), _ptr(omega), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(sig, host(d_sig))
+    # multiplicities: a table of distinct values, two input columns drawn from it
+    usable = max(n - 3, 1) if n > 4 else n
+    table = oracle.random_fr(9973, n)
+    table[usable:] = table[0]
+    ins = [table[rng.integers(0, usable, size=n)] for _ in range(2)]
+    m, bits = np.empty((n, 4), dtype=np.uint64), ctypes.c_uint32(99)
+    ptrs = (ctypes.c_void_p * 2)(*[c.ctypes.data for c in ins])
+    assert L.h2_logup_multiplicity(_ptr(table), ptrs, 2, usable, n, _ptr(m), ctypes.byref(bits)) == 0
+    d_t, d_ins = dev(table), [dev(c) for c in ins]
+    d_m = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    nbytes = L.h2_logup_scratch_bytes(n)
+    d_sc = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    dptrs, dbits = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in d_ins]), ctypes.c_uint32(0)
+    assert L.h2_dev_logup_multiplicity_bits(d_t.data_ptr(), dptrs, 2, usable, n, d_m.data_ptr(), d_sc.data_ptr(), nbytes, ctypes.byref(dbits), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(m, host(d_m)) and bits.value == dbits.value
+    absent = [oracle.random_fr(9974, n)]
+    ptr1 = (ctypes.c_void_p * 1)(absent[0].ctypes.data)
+    assert L.h2_logup_multiplicity(_ptr(table), ptr1, 1, usable, n, _ptr(m), None) != 0          # a value that is not in the table
