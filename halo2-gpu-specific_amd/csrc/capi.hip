@@ -122,15 +122,6 @@ bool pipeline_enabled() {
 // page-locked host memory (hipHostMalloc / h2_host_alloc_pinned / hipHostRegister)?  Only then are the chunk copies asynchronous
 // DMA; from ordinary memory every hipMemcpyAsync stages and blocks, and sixteen small blocking copies are slower than one large
 // one (measured: the k = 22 drop-in proof from ordinary memory 1.25 -> 1.52 s with the pipeline forced on): single shot there.
-bool host_pinned(const void* p) {
-    if (!p) return true;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
-}
 bool use_pipeline(size_t size, std::initializer_list<const void*> host) {
     if (!pipeline_enabled() || size < PIPE_MIN) return false;
     for (const void* p : host)
@@ -279,7 +270,7 @@ int h2_stream_synchronize(void* stream) {
 int h2_dev_upload(void* d_dst, const void* src, size_t bytes, void* stream) {
     if (bytes && (!d_dst || !src)) return bad("h2_dev_upload: null argument");
     return guarded([&] {
-        if (bytes) H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, pick_stream(current_ctx(), stream)));
+        if (bytes) host_upload(d_dst, src, bytes, pick_stream(current_ctx(), stream));
         return (int)H2_OK;
     });
 }
@@ -288,7 +279,7 @@ int h2_dev_download(void* dst, const void* d_src, size_t bytes, void* stream) {
     if (bytes && (!dst || !d_src)) return bad("h2_dev_download: null argument");
     return guarded([&] {
         hipStream_t s = pick_stream(current_ctx(), stream);
-        if (bytes) H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        if (bytes) host_download(dst, d_src, bytes, s);
         H2_HIP(hipStreamSynchronize(s));
         return (int)H2_OK;
     });
@@ -350,10 +341,10 @@ int h2_ntt(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
         size_t bytes = sizeof(Fr) << log_n;
         Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
         Fr* d_t = (Fr*)ctx->buf_b.get(bytes);
-        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_a, a, bytes, ctx->stream);
         int rc = dev_ntt_impl(ctx, d_a, d_a, d_t, 1u << log_n, omega, log_n, nullptr, nullptr, ctx->stream, true);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d_a, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -369,10 +360,10 @@ int h2_intt(uint64_t* a, const uint64_t omega_inv[4], const uint64_t divisor[4],
         Fr* d_t = (Fr*)ctx->buf_b.get(bytes);
         Fr d = fr_from_u64x4(divisor);
         Fr post3[3] = {d, d, d};
-        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_a, a, bytes, ctx->stream);
         int rc = dev_ntt_impl(ctx, d_a, d_a, d_t, 1u << log_n, omega_inv, log_n, nullptr, post3, ctx->stream, true);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d_a, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -393,13 +384,13 @@ int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint
         Fr pre3[3] = {fr_from_u64x4(g_coset), fr_from_u64x4(g_coset), fr_from_u64x4(g_coset_inv)};
         const Fr* src = resident_operand(ctx, coeffs, (size_t)1 << k);
         if (!src) {
-            H2_HIP(hipMemcpyAsync(d_in, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(d_in, coeffs, in_bytes, ctx->stream);
             src = d_in;
         }
         int rc = dev_ntt_impl(ctx, src, d_in, d_t, 1u << k, extended_omega, extended_k, pre3, nullptr, ctx->stream, true);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(out, d_in, ext_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(out, d_in, ext_bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -418,12 +409,12 @@ int h2_extended_to_coeff(const uint64_t* a, uint64_t* out, size_t out_len, uint3
         Prefault pf(out == a ? nullptr : out, out_len * sizeof(Fr));
         Fr* d_a = (Fr*)ctx->buf_a.get(ext_bytes);
         Fr* d_t = (Fr*)ctx->buf_b.get(ext_bytes);
-        H2_HIP(hipMemcpyAsync(d_a, a, ext_bytes, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_a, a, ext_bytes, ctx->stream);
         int rc = dev_extended_to_coeff_impl(ctx, d_a, d_t, extended_k, g_coset, g_coset_inv, extended_omega_inv,
                                             extended_ifft_divisor, ctx->stream, true);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(out, d_a, out_len * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(out, d_a, out_len * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -442,22 +433,22 @@ static int host_batch_mont(uint64_t* a, size_t n, bool to_mont) {
             int rc = H2_OK;
             pipeline_chunks(ctx, n,
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                    host_upload(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), st);
                 },
                 [&](size_t, size_t len, int slot, hipStream_t st) {
                     int r = batch_mont_launch(slots + slot * PIPE_CHUNK, len, to_mont, st);
                     if (r != H2_OK) rc = r;
                 },
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                    host_download(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), st);
                 });
             return rc;
         }
         Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
-        H2_HIP(hipMemcpyAsync(d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_a, a, bytes, ctx->stream);
         int rc = batch_mont_launch(d_a, n, to_mont, ctx->stream);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d_a, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d_a, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -484,8 +475,8 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
             int rc = H2_OK;
             pipeline_chunks(ctx, size,
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    if (sl) H2_HIP(hipMemcpyAsync(sl + slot * PIPE_CHUNK, l + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
-                    if (sr) H2_HIP(hipMemcpyAsync(sr + slot * PIPE_CHUNK, r + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                    if (sl) host_upload(sl + slot * PIPE_CHUNK, l + 4 * off, len * sizeof(Fr), st);
+                    if (sr) host_upload(sr + slot * PIPE_CHUNK, r + 4 * off, len * sizeof(Fr), st);
                 },
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
                     const Fr* pl = !l ? nullptr : (res_l ? res_l + off : sl + slot * PIPE_CHUNK);
@@ -494,7 +485,7 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
                     if (rr != H2_OK) rc = rr;
                 },
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(res + 4 * off, so + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                    host_download(res + 4 * off, so + slot * PIPE_CHUNK, len * sizeof(Fr), st);
                 });
             return rc;
         }
@@ -504,18 +495,18 @@ int h2_eval_op(int op, uint64_t* res, const uint64_t* l, const uint64_t* r, int3
         const Fr* d_r = res_r;
         if (l && !d_l) {
             Fr* up = (Fr*)ctx->buf_b.get(bytes);
-            H2_HIP(hipMemcpyAsync(up, l, bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(up, l, bytes, ctx->stream);
             d_l = up;
         }
         if (r && !d_r) {
             Fr* up = (Fr*)ctx->buf_c.get(bytes);
-            H2_HIP(hipMemcpyAsync(up, r, bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(up, r, bytes, ctx->stream);
             d_r = up;
         }
         int rc = eval_op_launch(op, d_res, d_l, d_r, l_rot, r_rot, size, c, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(res, d_res, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -531,29 +522,29 @@ int h2_divide_by_vanishing_poly(uint64_t* a, size_t size, const uint64_t* t_eval
             // a[i] *= t[i % t_len]: a chunk that starts at a multiple of t_len sees the table from its first entry
             Fr* slots = (Fr*)ctx->buf_a.get(2 * PIPE_CHUNK * sizeof(Fr));
             Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
-            H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            host_upload(d_t, t_evaluations, t_len * sizeof(Fr), ctx->stream);
             H2_HIP(hipStreamSynchronize(ctx->stream));
             int rc = H2_OK;
             pipeline_chunks(ctx, size,
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                    host_upload(slots + slot * PIPE_CHUNK, a + 4 * off, len * sizeof(Fr), st);
                 },
                 [&](size_t, size_t len, int slot, hipStream_t st) {
                     int r = divide_by_vanishing_launch(slots + slot * PIPE_CHUNK, len, d_t, t_len, st);
                     if (r != H2_OK) rc = r;
                 },
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                    host_download(a + 4 * off, slots + slot * PIPE_CHUNK, len * sizeof(Fr), st);
                 });
             return rc;
         }
         Fr* d_a = (Fr*)ctx->buf_a.get(size * sizeof(Fr));
         Fr* d_t = (Fr*)ctx->buf_b.get(t_len * sizeof(Fr));
-        H2_HIP(hipMemcpyAsync(d_a, a, size * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_a, a, size * sizeof(Fr), ctx->stream);
+        host_upload(d_t, t_evaluations, t_len * sizeof(Fr), ctx->stream);
         int rc = divide_by_vanishing_launch(d_a, size, d_t, t_len, ctx->stream);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d_a, size * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d_a, size * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -627,7 +618,7 @@ int h2_msm_intt(uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max
         // one upload of the scalars feeds both the MSM and the iNTT (arithmetic.rs:402-404)
         Fr* d_s = (Fr*)ctx->buf_a.get(sbytes);
         Fr* d_t = (Fr*)ctx->buf_b.get(sbytes);
-        H2_HIP(hipMemcpyAsync(d_s, scalars, sbytes, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_s, scalars, sbytes, ctx->stream);
         int rc = H2_OK;
         if (max_bits == 0)
             msm_identity(out_xyz);
@@ -638,7 +629,7 @@ int h2_msm_intt(uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max
         Fr post3[3] = {d, d, d};
         rc = dev_ntt_impl(ctx, d_s, d_s, d_t, (uint32_t)n, omega_inv, log_n, nullptr, post3, ctx->stream, true);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(scalars, d_s, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(scalars, d_s, sbytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -907,7 +898,7 @@ int h2_random_fr(const uint8_t key[32], size_t n, uint64_t* out) {
         int rc = random_fr_launch(key, n, d, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(out, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(out, d, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -992,7 +983,7 @@ int h2_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], 
         const Fr* d = n ? resident_operand(ctx, poly, n) : nullptr;
         if (!d) {
             Fr* up = (Fr*)ctx->buf_a.get((n ? n : 1) * sizeof(Fr));
-            if (n) H2_HIP(hipMemcpyAsync(up, poly, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            if (n) host_upload(up, poly, n * sizeof(Fr), ctx->stream);
             d = up;
         }
         return eval_polynomial_launch(d, n, point, tmp, out, ctx->stream);
@@ -1026,7 +1017,7 @@ int h2_eval_polynomial_batch(const uint64_t* const* polys, size_t count, size_t 
         }
         if (!staged.empty()) {
             Fr* up = (Fr*)ctx->buf_a.get(staged.size() * n * sizeof(Fr));
-            for (auto& kv : staged) H2_HIP(hipMemcpyAsync(up + kv.second * n, kv.first, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            for (auto& kv : staged) host_upload(up + kv.second * n, kv.first, n * sizeof(Fr), ctx->stream);
             for (size_t j = 0; j < count; j++)
                 if (!d[j]) d[j] = up + staged[polys[j]] * n;
         }
@@ -1051,10 +1042,10 @@ int h2_batch_invert(uint64_t* a, size_t n) {
         DeviceCtx* ctx = lease.ctx;
         Fr* d = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         Fr* t = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
-        H2_HIP(hipMemcpyAsync(d, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d, a, n * sizeof(Fr), ctx->stream);
         int rc = batch_invert_launch(d, t, n, ctx->stream);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1082,13 +1073,13 @@ int h2_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t*
         const Fr* d_a = resident_operand(ctx, a, n);
         if (!d_a) {
             Fr* up = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
-            H2_HIP(hipMemcpyAsync(up, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            host_upload(up, a, n * sizeof(Fr), ctx->stream);
             d_a = up;
         }
         int rc = kate_division_launch(d_a, n, b, d_q, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(q, d_q, (n - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(q, d_q, (n - 1) * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1115,11 +1106,11 @@ int h2_prefix_product(const uint64_t* f, size_t n, const uint64_t init[4], uint6
         Fr* d_f = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         Fr* d_z = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
-        if (n > 1) H2_HIP(hipMemcpyAsync(d_f, f, (n - 1) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        if (n > 1) host_upload(d_f, f, (n - 1) * sizeof(Fr), ctx->stream);
         int rc = prefix_product_launch(d_f, n, init, d_z, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(z, d_z, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(z, d_z, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1175,7 +1166,7 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
                     if (r != H2_OK) rc = r;
                 },
                 [&](size_t off, size_t len, int slot, hipStream_t st) {
-                    H2_HIP(hipMemcpyAsync(res + 4 * off, sout + slot * PIPE_CHUNK, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+                    host_download(res + 4 * off, sout + slot * PIPE_CHUNK, len * sizeof(Fr), st);
                 });
             return rc;
         }
@@ -1184,12 +1175,12 @@ int h2_lincomb(uint64_t* res, const uint64_t* const* polys, const uint64_t* coef
         Fr* d_res = (Fr*)ctx->buf_b.get(bytes);
         for (size_t j = 0; j < staged.size(); j++) {
             ptrs[staged[j]] = d_all + j * size;
-            H2_HIP(hipMemcpyAsync(d_all + j * size, polys[staged[j]], bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(d_all + j * size, polys[staged[j]], bytes, ctx->stream);
         }
         int rc = lincomb_launch(d_res, ptrs.data(), coeffs, count, size, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(res, d_res, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(res, d_res, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1256,7 +1247,7 @@ int h2_quotient_sum(uint64_t* out, size_t n, size_t n_sets, const size_t* counts
             for (size_t i = 0; i < count; i++) {
                 ptrs[i] = resident_operand(ctx, polys[at + i], n);
                 if (!ptrs[i]) {
-                    H2_HIP(hipMemcpyAsync(d_up + st * n, polys[at + i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                    host_upload(d_up + st * n, polys[at + i], bytes, ctx->stream);
                     ptrs[i] = d_up + st * n;
                     st++;
                 }
@@ -1268,7 +1259,7 @@ int h2_quotient_sum(uint64_t* out, size_t n, size_t n_sets, const size_t* counts
                 H2_HIP(hipMemsetAsync(cur, 0, bytes, ctx->stream));
             if (rc != H2_OK) return rc;
             if (low_counts[s]) {
-                H2_HIP(hipMemcpyAsync(d_low, low + 4 * at_low, low_counts[s] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+                host_upload(d_low, low + 4 * at_low, low_counts[s] * sizeof(Fr), ctx->stream);
                 rc = eval_op_launch(H2_OP_SUB, cur, cur, d_low, 0, 0, low_counts[s], nullptr, ctx->stream);
                 if (rc != H2_OK) return rc;
             }
@@ -1292,7 +1283,7 @@ int h2_quotient_sum(uint64_t* out, size_t n, size_t n_sets, const size_t* counts
             at_pt += point_counts[s];
         }
         pf.join();
-        H2_HIP(hipMemcpyAsync(out, acc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(out, acc, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1329,11 +1320,11 @@ int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, co
         Fr* s_sig = res_sigma ? nullptr : (Fr*)ctx->buf_d.get(2 * chunk * sizeof(Fr));
         int rc = H2_OK;
         auto up = [&](size_t off, size_t len, int slot, hipStream_t st) {
-            if (s_val) H2_HIP(hipMemcpyAsync(s_val + slot * chunk, value + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
-            if (s_sig) H2_HIP(hipMemcpyAsync(s_sig + slot * chunk, sigma + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+            if (s_val) host_upload(s_val + slot * chunk, value + 4 * off, len * sizeof(Fr), st);
+            if (s_sig) host_upload(s_sig + slot * chunk, sigma + 4 * off, len * sizeof(Fr), st);
             if (!first) {
-                H2_HIP(hipMemcpyAsync(s_num + slot * chunk, num + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
-                H2_HIP(hipMemcpyAsync(s_den + slot * chunk, den + 4 * off, len * sizeof(Fr), hipMemcpyHostToDevice, st));
+                host_upload(s_num + slot * chunk, num + 4 * off, len * sizeof(Fr), st);
+                host_upload(s_den + slot * chunk, den + 4 * off, len * sizeof(Fr), st);
             }
         };
         auto run = [&](size_t off, size_t len, int slot, hipStream_t st) {
@@ -1345,8 +1336,8 @@ int h2_permutation_terms(uint64_t* num, uint64_t* den, const uint64_t* value, co
             if (r != H2_OK) rc = r;
         };
         auto down = [&](size_t off, size_t len, int slot, hipStream_t st) {
-            H2_HIP(hipMemcpyAsync(num + 4 * off, s_num + slot * chunk, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
-            H2_HIP(hipMemcpyAsync(den + 4 * off, s_den + slot * chunk, len * sizeof(Fr), hipMemcpyDeviceToHost, st));
+            host_download(num + 4 * off, s_num + slot * chunk, len * sizeof(Fr), st);
+            host_download(den + 4 * off, s_den + slot * chunk, len * sizeof(Fr), st);
         };
         if (pipe) {
             pipeline_chunks(ctx, n, up, run, down);
@@ -1392,11 +1383,11 @@ int h2_permutation_product(uint64_t* z, const uint64_t* const* values, const uin
             const Fr* value = resident_operand(ctx, values[j], n);
             const Fr* sigma = resident_operand(ctx, sigmas[j], n);
             if (!value) {
-                H2_HIP(hipMemcpyAsync(s_val, values[j], bytes, hipMemcpyHostToDevice, ctx->stream));
+                host_upload(s_val, values[j], bytes, ctx->stream);
                 value = s_val;
             }
             if (!sigma) {
-                H2_HIP(hipMemcpyAsync(s_sig, sigmas[j], bytes, hipMemcpyHostToDevice, ctx->stream));
+                host_upload(s_sig, sigmas[j], bytes, ctx->stream);
                 sigma = s_sig;
             }
             uint64_t dpj[4];
@@ -1412,7 +1403,7 @@ int h2_permutation_product(uint64_t* z, const uint64_t* const* values, const uin
         rc = prefix_product_launch(num, n, init, den, s_sig, ctx->stream);      // z over the inverted denominators' block
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(z, den, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(z, den, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1464,11 +1455,11 @@ int h2_prefix_sum(const uint64_t* f, size_t n, const uint64_t init[4], uint64_t*
         Fr* d_f = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         Fr* d_z = (Fr*)ctx->buf_b.get(n * sizeof(Fr));
         Fr* tmp = (Fr*)ctx->buf_d.get(scan_tmp_elems(n) * sizeof(Fr));
-        if (n > 1) H2_HIP(hipMemcpyAsync(d_f, f, (n - 1) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        if (n > 1) host_upload(d_f, f, (n - 1) * sizeof(Fr), ctx->stream);
         int rc = prefix_sum_launch(d_f, n, init, d_z, tmp, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(z, d_z, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(z, d_z, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1481,10 +1472,10 @@ int h2_distribute_powers(uint64_t* a, size_t n, const uint64_t g[4]) {
         DeviceLease lease;
         DeviceCtx* ctx = lease.ctx;
         Fr* d = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
-        H2_HIP(hipMemcpyAsync(d, a, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d, a, n * sizeof(Fr), ctx->stream);
         int rc = distribute_powers_launch(d, n, g, ctx->stream);
         if (rc != H2_OK) return rc;
-        H2_HIP(hipMemcpyAsync(a, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(a, d, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1501,12 +1492,12 @@ int h2_permutation_sigma(uint64_t* out, const uint32_t* map_col, const uint32_t*
         Fr* d_out = (Fr*)ctx->buf_a.get(n * sizeof(Fr));
         uint32_t* d_col = (uint32_t*)ctx->buf_b.get(2 * n * sizeof(uint32_t));
         uint32_t* d_row = d_col + n;
-        H2_HIP(hipMemcpyAsync(d_col, map_col, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        H2_HIP(hipMemcpyAsync(d_row, map_row, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        host_upload(d_col, map_col, n * sizeof(uint32_t), ctx->stream);
+        host_upload(d_row, map_row, n * sizeof(uint32_t), ctx->stream);
         int rc = perm_sigma_launch(d_out, d_col, d_row, n, delta, omega, ctx->stream);
         if (rc != H2_OK) return rc;
         pf.join();
-        H2_HIP(hipMemcpyAsync(out, d_out, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        host_download(out, d_out, n * sizeof(Fr), ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1537,13 +1528,13 @@ int h2_logup_multiplicity(const uint64_t* table, const uint64_t* const* inputs, 
         Fr* up = (Fr*)ctx->buf_a.get((staged + (d_table ? 0 : 1)) * bytes + 256);
         size_t at = 0;
         if (!d_table) {
-            H2_HIP(hipMemcpyAsync(up, table, bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(up, table, bytes, ctx->stream);
             d_table = up;
             at = 1;
         }
         for (size_t i = 0; i < n_inputs; i++)
             if (!d_in[i]) {
-                H2_HIP(hipMemcpyAsync(up + at * n, inputs[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                host_upload(up + at * n, inputs[i], bytes, ctx->stream);
                 d_in[i] = up + at * n;
                 at++;
             }
@@ -1558,7 +1549,7 @@ int h2_logup_multiplicity(const uint64_t* table, const uint64_t* const* inputs, 
             *max_bits_out = bits;
         }
         pf.join();
-        H2_HIP(hipMemcpyAsync(m, d_m, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        host_download(m, d_m, bytes, ctx->stream);
         H2_HIP(hipStreamSynchronize(ctx->stream));
         return (int)H2_OK;
     });
@@ -1713,14 +1704,14 @@ int h2_quotient_poly_coeff(const h2_evalh_desc* desc, const uint64_t* t_evaluati
         const uint32_t ek = desc->extended_k;
         EvalhFinish finish = [&](DeviceCtx* ctx, Fr* d_values, hipStream_t s) -> int {
             Fr* d_t = (Fr*)ctx->buf_c.get(t_len * sizeof(Fr));
-            H2_HIP(hipMemcpyAsync(d_t, t_evaluations, t_len * sizeof(Fr), hipMemcpyHostToDevice, s));
+            host_upload(d_t, t_evaluations, t_len * sizeof(Fr), s);
             int rc = divide_by_vanishing_launch(d_values, size, d_t, t_len, s);
             if (rc != H2_OK) return rc;
             Fr* d_tmp = (Fr*)ctx->buf_b.get(size * sizeof(Fr));
             rc = dev_extended_to_coeff_impl(ctx, d_values, d_tmp, ek, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor, s, true);
             if (rc != H2_OK) return rc;
             pf.join();
-            H2_HIP(hipMemcpyAsync(out, d_values, out_len * sizeof(Fr), hipMemcpyDeviceToHost, s));
+            host_download(out, d_values, out_len * sizeof(Fr), s);
             return (int)H2_OK;
         };
         if (evalh_host_workers(desc) <= 1) {

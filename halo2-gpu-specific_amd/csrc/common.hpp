@@ -53,6 +53,13 @@ struct PinnedBuf {
     void* get(size_t bytes);
 };
 
+// Bulk copies between the CALLER's host vectors and device memory (hostcopy.hip): hipMemcpyAsync, with the long copies from /
+// into ordinary (pageable) memory taken one at a time per process -- concurrent ones obstruct each other in the runtime.
+// As hipMemcpyAsync on pageable memory: an upload returns when the source has been read, a download when `dst` holds the data.
+bool host_pinned(const void* p);
+void host_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s);
+void host_download(void* dst, const void* d_src, size_t bytes, hipStream_t s);
+
 struct NttPlan;  // ntt.hip
 
 // device copy of a registered host range of SRS points (msm.hip): `gen` is the registration it was uploaded for

@@ -839,7 +839,7 @@ int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
             void* q = nullptr;
             H2_HIP(hipMalloc(&q, bytes));
             owned.push_back(q);
-            H2_HIP(hipMemcpyAsync(q, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+            host_upload(q, h, bytes, ctx->stream);
             up[h] = (const uint64_t*)q;
             return (const uint64_t*)q;
         };
@@ -868,7 +868,7 @@ int evalh_host(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t* values) {
         owned.push_back(d_values);
         int rc = evalh_device(ctx, &dd, (Fr*)d_values, ctx->stream, true);
         if (rc == H2_OK) {
-            H2_HIP(hipMemcpyAsync(values, d_values, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            host_download(values, d_values, bytes, ctx->stream);
             H2_HIP(hipStreamSynchronize(ctx->stream));
         }
         cleanup();
@@ -966,7 +966,7 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
             Fr* dc = const_cast<Fr*>(poly_resident(ctx, h, n));
             if (!dc) {
                 dc = (Fr*)dmalloc(nbytes);
-                H2_HIP(hipMemcpyAsync(dc, h, nbytes, hipMemcpyHostToDevice, stream));
+                host_upload(dc, h, nbytes, stream);
             }
             Fr* dv = (Fr*)dmalloc(nbytes);
             cols[h] = {dc, dv};
@@ -997,7 +997,7 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
                 d_active = const_cast<Fr*>(poly_resident(ctx, d->l_active_row, size));
                 if (!d_active) {
                     d_active = (Fr*)dmalloc(ebytes);
-                    H2_HIP(hipMemcpyAsync(d_active, d->l_active_row, ebytes, hipMemcpyHostToDevice, stream));
+                    host_upload(d_active, d->l_active_row, ebytes, stream);
                 }
             }
             d_values = (Fr*)dmalloc(ebytes);
@@ -1086,7 +1086,7 @@ static int evalh_coeffs_worker(DeviceCtx* ctx, const h2_evalh_desc* d, uint64_t*
         if (whole && finish)
             frc = (*finish)(ctx, d_values, stream);          // (what follows the evaluation, on the device: capi.hip)
         else if (whole)
-            H2_HIP(hipMemcpyAsync(values, d_values, ebytes, hipMemcpyDeviceToHost, stream));
+            host_download(values, d_values, ebytes, stream);
         H2_HIP(hipStreamSynchronize(stream));
         cleanup();
         return frc;

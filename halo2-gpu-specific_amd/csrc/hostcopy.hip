@@ -1,18 +1,24 @@
 // hostcopy.hip -- bulk copies between the CALLER's host vectors and device memory for the host-slice entry points.
 //
 // The reference hands `&[Fr]` slices of ordinary (pageable) memory to its GPU crate from several rayon workers at once
-// (plonk/prover.rs:293-299, 643-646, 731-737; arithmetic.rs:351-352, 391-394, 507-508).  Through hipMemcpyAsync a pageable
-// copy is a BLOCKING operation of the runtime (it pins the range piecewise and feeds the DMA engine from the calling thread),
-// and two of them from two threads do not overlap -- they slow each other down: four concurrent 128 MiB round trips take
-// 38-54 ms against 21 ms one after the other (tools/experiments/pageable_calls_probe.py), so the two host-API slots of a
-// device bought nothing from ordinary memory.
+// (plonk/prover.rs:293-299, 643-646, 731-737; arithmetic.rs:351-352, 391-394, 507-508), and nearly every one of those vectors is
+// NEW: a `Vec` the previous step has just filled.  Through hipMemcpyAsync a pageable copy is a blocking operation of the
+// runtime that registers the caller's pages with the driver piecewise and feeds the DMA engine from the calling thread.  That
+// is fast for a buffer the runtime has seen and whose pages are huge (numpy's allocations: 128 MiB in 2.4 ms, as page-locked
+// memory) and slow and erratic for what a drop-in actually passes -- fresh 4 KiB-paged allocations (malloc / torch / a Rust
+// `Vec`): an h2_intt of a new 32 MiB vector 2.8-3.9 ms against 1.35 ms for the same vector again, single calls of 87-125 ms,
+// sixteen such calls from four threads 97-166 ms against 20 ms (tools/experiments/pageable_intt_probe.py).
 //
-// Here a long pageable copy goes through the library's own page-locked staging instead: a few host threads per transfer, each
-// with a lane of two 8 MiB page-locked blocks, copy their chunks with memcpy and queue ASYNCHRONOUS DMA transfers from / into
-// the blocks on the caller's stream.  The link sees only page-locked memory: transfers of different calls (and of the two
-// directions) interleave freely, and the per-buffer pinning cost is gone.  One 128 MiB vector crosses in 2.9-3.1 ms with four
-// threads (2.4 ms from page-locked memory; tools/experiments/pageable_probe.hip).  Page-locked ranges and short copies keep
-// the plain hipMemcpyAsync.  H2_HOST_COPY_THREADS (default 4; 0 = the runtime's pageable path as before).
+// Long copies from / into ordinary memory therefore go through the library's own page-locked staging: a few threads per
+// transfer (H2_HOST_COPY_THREADS, default 2), each with a lane of two 8 MiB page-locked blocks, memcpy into / out of a block
+// and queue ASYNCHRONOUS DMA from / into it on the caller's stream.  The link only ever sees page-locked memory -- no
+// registration of the caller's pages, transfers of different calls interleave -- at 2.9-3.1 ms per 128 MiB whatever the
+// buffer's history.  The k = 22 drop-in proof from ordinary memory: 0.51-0.54 -> 0.40-0.47 s, alternating on one box
+// (profiles/r6_host_copy_threads_ab.txt); on hugepage-backed buffers that the runtime already knows the staged path is the
+// slower one (5.3 -> 6.6 ms per call: profiles/r6_pageable_calls_probe.txt), which is why it was measured and set aside
+// twice before the fresh-vector case was measured.  H2_HOST_COPY_THREADS=0 selects the runtime's pageable path, whose long
+// copies are then taken one at a time per process (H2_HOST_SERIAL_COPIES=0: not even that).  Page-locked ranges
+// (asynchronous DMA) and copies below 4 MiB always go straight to hipMemcpyAsync.
 //
 // Semantics are those of hipMemcpyAsync on pageable memory: an upload returns when the source has been read (the transfers
 // themselves may still be in flight on the stream), a download returns when the destination holds the data.
@@ -26,7 +32,14 @@
 namespace h2 {
 
 namespace {
+constexpr size_t SERIAL_MIN = (size_t)1 << 20;   // shorter copies are not worth a lock
+std::mutex g_pageable_mu;
+bool serialise() {
+    static const bool on = !(getenv("H2_HOST_SERIAL_COPIES") && atoi(getenv("H2_HOST_SERIAL_COPIES")) == 0);
+    return on;
+}
 
+// ---- the staged path (H2_HOST_COPY_THREADS > 0) ----
 constexpr size_t STAGE_CHUNK = (size_t)8 << 20;   // bytes per staging block (2 per lane)
 constexpr size_t STAGE_MIN = (size_t)4 << 20;     // shorter copies: the runtime's own path
 
@@ -43,7 +56,7 @@ std::vector<Lane*> g_idle_lanes;
 int copy_threads() {
     static const int t = [] {
         const char* e = getenv("H2_HOST_COPY_THREADS");
-        const int v = e ? atoi(e) : 4;
+        const int v = e ? atoi(e) : 2;
         return v < 0 ? 0 : (v > 16 ? 16 : v);
     }();
     return t;
@@ -162,20 +175,31 @@ bool host_pinned(const void* p) {
 
 void host_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
-    if (bytes < STAGE_MIN || !copy_threads() || host_pinned(src)) {
+    if (bytes >= STAGE_MIN && copy_threads() && !host_pinned(src)) {
+        staged_copy(true, d_dst, const_cast<void*>(src), bytes, s);
+        return;
+    }
+    if (bytes < SERIAL_MIN || !serialise() || host_pinned(src)) {
         H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));
         return;
     }
-    staged_copy(true, d_dst, const_cast<void*>(src), bytes, s);
+    std::lock_guard<std::mutex> g(g_pageable_mu);
+    H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));      // returns when the source has been read
 }
 
 void host_download(void* dst, const void* d_src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
-    if (bytes < STAGE_MIN || !copy_threads() || host_pinned(dst)) {
+    if (bytes >= STAGE_MIN && copy_threads() && !host_pinned(dst)) {
+        staged_copy(false, const_cast<void*>(d_src), dst, bytes, s);
+        return;
+    }
+    if (bytes < SERIAL_MIN || !serialise() || host_pinned(dst)) {
         H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
         return;
     }
-    staged_copy(false, const_cast<void*>(d_src), dst, bytes, s);
+    H2_HIP(hipStreamSynchronize(s));                // the kernels before the copy: waited for OUTSIDE the lock
+    std::lock_guard<std::mutex> g(g_pageable_mu);
+    H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));       // returns when `dst` holds the data
 }
 
 }  // namespace h2

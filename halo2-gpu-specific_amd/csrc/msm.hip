@@ -2388,7 +2388,7 @@ static const void* resident_lookup_unit(DeviceCtx* ctx, const uint64_t* bases, s
         c.len = reg.len;
         c.gen = reg.gen;
         H2_HIP(hipMalloc(&c.ptr, reg.len * (size_t)unit));
-        H2_HIP(hipMemcpyAsync(c.ptr, key, reg.len * (size_t)unit, hipMemcpyHostToDevice, ctx->stream));
+        host_upload(c.ptr, key, reg.len * (size_t)unit, ctx->stream);
         rit = ctx->resident.emplace((const void*)key, c).first;
         // a registered SRS is committed against for the life of the process: give its device copy a shifted-base table
         // when that takes less than half of the free memory (H2_MSM_TABLES=0: never)
@@ -2414,7 +2414,7 @@ int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_
     const Affine* d_bases = resident_lookup(ctx, bases, n);
     if (!d_bases) {
         Affine* up = (Affine*)ctx->buf_c.get(n * sizeof(Affine));
-        H2_HIP(hipMemcpyAsync(up, bases, n * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+        host_upload(up, bases, n * sizeof(Affine), ctx->stream);
         d_bases = up;
     }
     size_t sb = msm_scratch_bytes(n, max_bits);
@@ -2425,7 +2425,7 @@ int msm_host_resident_scalars(DeviceCtx* ctx, const Fr* d_scalars, const uint64_
 int msm_host(DeviceCtx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint32_t max_bits,
              uint64_t out_xyz[12]) {
     Fr* d_s = (Fr*)ctx->buf_d.get(n * sizeof(Fr));
-    H2_HIP(hipMemcpyAsync(d_s, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    host_upload(d_s, scalars, n * sizeof(Fr), ctx->stream);
     return msm_host_resident_scalars(ctx, d_s, bases, n, max_bits, out_xyz);
 }
 
