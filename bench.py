@@ -679,20 +679,27 @@ def main():
                 hparams = ha.params_like(H, params)
                 hpk = prover.keygen(H, hparams, circuits.mini_plonk(), fixed, copies)
                 hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))      # warm-up (device copies, tables)
-                H.L.calls.clear()
-                H.L.R.reset()
-                h0 = time.perf_counter()
-                hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))
-                hsec = time.perf_counter() - h0
-                in_lib, by_call = H.L.R.busy_seconds, {n: round(v * 1e3, 2) for n, v in sorted(H.L.R.by_call.items())}
-                calls = dict(sorted(H.L.calls.items()))
+                # three timed proofs, the MEDIAN one reported with its own call times (the host side of this leg allocates and
+                # frees ~30 blocks of 128 MiB per proof: single proofs vary by 10-20 % from run to run)
+                runs = []
+                for _ in range(3):
+                    H.L.calls.clear()
+                    H.L.R.reset()
+                    h0 = time.perf_counter()
+                    hproof = prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1))
+                    hsec = time.perf_counter() - h0
+                    runs.append((hsec, H.L.R.busy_seconds, {n: round(v * 1e3, 2) for n, v in sorted(H.L.R.by_call.items())},
+                                 dict(sorted(H.L.calls.items()))))
+                    assert hproof == proof, "the host-slice data flow changed the proof"
+                hsec, in_lib, by_call, calls = sorted(runs, key=lambda r: r[0])[1]
                 hphases = {}
                 H.L.R.reset()
                 prover.create_proof_with_shplonk(H, hparams, hpk, adv, ProverRng(1), timings=hphases)
                 if os.environ.get("H2_BENCH_DEBUG"):
                     sys.stderr.write("%s phases run, library ms by call: %s\n" % (mode, {n: round(v * 1e3, 1) for n, v in sorted(H.L.R.by_call.items())}))
                 host_api[mode] = {
-                    "seconds": hsec, "proof_bytes_equal": bool(hproof == proof), "ratio_to_resident": hsec / (pelapsed / steps),
+                    "seconds": hsec, "seconds_each": [round(r[0], 4) for r in runs], "proof_bytes_equal": bool(hproof == proof),
+                    "ratio_to_resident": hsec / (pelapsed / steps),
                     # wall time with at least one C-ABI call executing; the rest is the host's own handling of its vectors
                     # (allocating, first-touching, freeing 128 MiB blocks: what the reference's Vecs cost it too)
                     "seconds_inside_library_calls": in_lib, "seconds_host_vector_handling": hsec - in_lib,
