@@ -5,20 +5,20 @@
 // NEW: a `Vec` the previous step has just filled.  Through hipMemcpyAsync a pageable copy is a blocking operation of the
 // runtime that registers the caller's pages with the driver piecewise and feeds the DMA engine from the calling thread.  That
 // is fast for a buffer the runtime has seen and whose pages are huge (numpy's allocations: 128 MiB in 2.4 ms, as page-locked
-// memory) and slow and erratic for what a drop-in actually passes -- fresh 4 KiB-paged allocations (malloc / torch / a Rust
-// `Vec`): an h2_intt of a new 32 MiB vector 2.8-3.9 ms against 1.35 ms for the same vector again, single calls of 87-125 ms,
-// sixteen such calls from four threads 97-166 ms against 20 ms (tools/experiments/pageable_intt_probe.py).
+// memory) and slower for what a drop-in actually passes -- fresh 4 KiB-paged allocations (malloc / torch / a Rust `Vec`): an
+// h2_intt of a new 32 MiB vector 2.3-3.0 ms against 1.34 ms for the same vector again (tools/experiments/pageable_intt_probe.py).
 //
 // Long copies from / into ordinary memory therefore go through the library's own page-locked staging: a few threads per
 // transfer (H2_HOST_COPY_THREADS, default 2), each with a lane of two 8 MiB page-locked blocks, memcpy into / out of a block
 // and queue ASYNCHRONOUS DMA from / into it on the caller's stream.  The link only ever sees page-locked memory -- no
-// registration of the caller's pages, transfers of different calls interleave -- at 2.9-3.1 ms per 128 MiB whatever the
-// buffer's history.  The k = 22 drop-in proof from ordinary memory: 0.51-0.54 -> 0.40-0.47 s, alternating on one box
-// (profiles/r6_host_copy_threads_ab.txt); on hugepage-backed buffers that the runtime already knows the staged path is the
-// slower one (5.3 -> 6.6 ms per call: profiles/r6_pageable_calls_probe.txt), which is why it was measured and set aside
-// twice before the fresh-vector case was measured.  H2_HOST_COPY_THREADS=0 selects the runtime's pageable path, whose long
-// copies are then taken one at a time per process (H2_HOST_SERIAL_COPIES=0: not even that).  Page-locked ranges
-// (asynchronous DMA) and copies below 4 MiB always go straight to hipMemcpyAsync.
+// registration of the caller's pages, transfers of different calls interleave -- at 2.2-2.4 ms per 32 MiB round trip whatever
+// the buffer's history.  Measured on the two drop-in proofs, alternating on one box (profiles/r6_host_copy_threads_ab.txt,
+// r6_host_copy_modes_ab.txt): mini-PLONK k = 22 from ordinary memory 0.46-0.54 -> 0.40-0.47 s, the 64-column circuit at k = 20
+// 1.77-1.90 -> 1.54-1.70 s.  On hugepage-backed buffers that the runtime already knows the staged path is the slower one (5.3 ->
+// 6.6 ms per call: profiles/r6_pageable_calls_probe.txt), which is why it was measured and set aside twice before the
+// fresh-vector case was measured.  H2_HOST_COPY_THREADS=0 selects the runtime's pageable path.  (Taking the runtime's long
+// pageable copies one at a time per process was tried too: nothing on mini-PLONK, 1.8 -> 3.4 s on the 64-column proof.)
+// Page-locked ranges (asynchronous DMA) and copies below 4 MiB always go straight to hipMemcpyAsync.
 //
 // Semantics are those of hipMemcpyAsync on pageable memory: an upload returns when the source has been read (the transfers
 // themselves may still be in flight on the stream), a download returns when the destination holds the data.
@@ -32,13 +32,6 @@
 namespace h2 {
 
 namespace {
-constexpr size_t SERIAL_MIN = (size_t)1 << 20;   // shorter copies are not worth a lock
-std::mutex g_pageable_mu;
-bool serialise() {
-    static const bool on = !(getenv("H2_HOST_SERIAL_COPIES") && atoi(getenv("H2_HOST_SERIAL_COPIES")) == 0);
-    return on;
-}
-
 // ---- the staged path (H2_HOST_COPY_THREADS > 0) ----
 constexpr size_t STAGE_CHUNK = (size_t)8 << 20;   // bytes per staging block (2 per lane)
 constexpr size_t STAGE_MIN = (size_t)4 << 20;     // shorter copies: the runtime's own path
@@ -179,12 +172,7 @@ void host_upload(void* d_dst, const void* src, size_t bytes, hipStream_t s) {
         staged_copy(true, d_dst, const_cast<void*>(src), bytes, s);
         return;
     }
-    if (bytes < SERIAL_MIN || !serialise() || host_pinned(src)) {
-        H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));
-        return;
-    }
-    std::lock_guard<std::mutex> g(g_pageable_mu);
-    H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));      // returns when the source has been read
+    H2_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));
 }
 
 void host_download(void* dst, const void* d_src, size_t bytes, hipStream_t s) {
@@ -193,13 +181,7 @@ void host_download(void* dst, const void* d_src, size_t bytes, hipStream_t s) {
         staged_copy(false, const_cast<void*>(d_src), dst, bytes, s);
         return;
     }
-    if (bytes < SERIAL_MIN || !serialise() || host_pinned(dst)) {
-        H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
-        return;
-    }
-    H2_HIP(hipStreamSynchronize(s));                // the kernels before the copy: waited for OUTSIDE the lock
-    std::lock_guard<std::mutex> g(g_pageable_mu);
-    H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));       // returns when `dst` holds the data
+    H2_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
 }
 
 }  // namespace h2
