@@ -104,6 +104,7 @@ SYMBOLS = {
     "h2_permutation_terms": (ctypes.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "h2_permutation_product": (ctypes.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2_eval_polynomial_batch": (ctypes.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "h2_logup_grand_sum": (ctypes.c_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp]),
     "h2_prefix_sum": (ctypes.c_int, [_vp, _sz, _vp, _vp]),
     "h2_distribute_powers": (ctypes.c_int, [_vp, _sz, _vp]),
     "h2_permutation_sigma": (ctypes.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),

@@ -1465,6 +1465,65 @@ int h2_prefix_sum(const uint64_t* f, size_t n, const uint64_t init[4], uint64_t*
     });
 }
 
+// One grand-sum column of a logup lookup in ONE call (plonk/logup/prover.rs:243-347, `commit_z`, for one set of inputs):
+//   z[0] = init;   z[i + 1] = z[i] + sum_j 1 / (beta + inputs[j][i])  -  m[i] / (beta + table[i])
+// the last term only for the set that carries the table (table != NULL: the first set, :283-290).  The reference makes a
+// vector of beta + f per input, batch-inverts it, adds it in, and scans on the host; here every one of those vectors lives on the
+// device: the inputs (and table, m) go up once -- registered ones not at all -- and z comes down once.
+int h2_logup_grand_sum(uint64_t* z, const uint64_t* const* inputs, size_t count, const uint64_t* table, const uint64_t* m, size_t n,
+                       const uint64_t beta[4], const uint64_t init[4]) {
+    if (n && (!z || !beta || !init || (count && !inputs) || ((table == nullptr) != (m == nullptr))))
+        return bad("h2_logup_grand_sum: null argument");
+    for (size_t j = 0; n && j < count; j++)
+        if (!inputs[j]) return bad("h2_logup_grand_sum: null input");
+    return guarded([&] {
+        if (n == 0) return (int)H2_OK;
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        Prefault pf(z, n * sizeof(Fr));
+        const size_t bytes = n * sizeof(Fr);
+        hipStream_t s = ctx->stream;
+        Fr* up = (Fr*)ctx->buf_a.get(bytes);
+        Fr* term = (Fr*)ctx->buf_b.get(bytes);
+        Fr* tmp = (Fr*)ctx->buf_c.get(bytes);
+        Fr* acc = (Fr*)ctx->buf_d.get((2 * n + scan_tmp_elems(n)) * sizeof(Fr));
+        Fr* d_z = acc + n;
+        Fr* scan_tmp = d_z + n;
+        H2_HIP(hipMemsetAsync(acc, 0, bytes, s));
+        auto operand = [&](const uint64_t* host) -> const Fr* {
+            const Fr* d = resident_operand(ctx, host, n);
+            if (d) return d;
+            host_upload(up, host, bytes, s);
+            return up;
+        };
+        int rc = H2_OK;
+        for (size_t j = 0; j < count; j++) {
+            rc = eval_op_launch(H2_OP_SUM_C, term, operand(inputs[j]), nullptr, 0, 0, n, beta, s);     // beta + f_j
+            if (rc != H2_OK) return rc;
+            rc = batch_invert_launch(term, tmp, n, s);
+            if (rc != H2_OK) return rc;
+            rc = eval_op_launch(H2_OP_SUM, acc, acc, term, 0, 0, n, nullptr, s);
+            if (rc != H2_OK) return rc;
+        }
+        if (table) {
+            rc = eval_op_launch(H2_OP_SUM_C, term, operand(table), nullptr, 0, 0, n, beta, s);         // beta + t
+            if (rc != H2_OK) return rc;
+            rc = batch_invert_launch(term, tmp, n, s);
+            if (rc != H2_OK) return rc;
+            rc = eval_op_launch(H2_OP_MUL, term, term, operand(m), 0, 0, n, nullptr, s);               // m / (beta + t)
+            if (rc != H2_OK) return rc;
+            rc = eval_op_launch(H2_OP_SUB, acc, acc, term, 0, 0, n, nullptr, s);
+            if (rc != H2_OK) return rc;
+        }
+        rc = prefix_sum_launch(acc, n, init, d_z, scan_tmp, s);
+        if (rc != H2_OK) return rc;
+        pf.join();
+        host_download(z, d_z, bytes, s);
+        H2_HIP(hipStreamSynchronize(s));
+        return (int)H2_OK;
+    });
+}
+
 int h2_distribute_powers(uint64_t* a, size_t n, const uint64_t g[4]) {
     if ((n && !a) || !g) return bad("h2_distribute_powers: null argument");
     return guarded([&] {

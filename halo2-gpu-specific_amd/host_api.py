@@ -308,6 +308,7 @@ class HostApiDevice(P.Device):
             self.commit_lagrange_and_ifft = None                     # ... and h2_msm + h2_intt for the product columns
             self.quotient_sum = None                                 # ... and the multiopen's folds and divisions one by one
             self.quotient_poly_coeff = None                          # ... and evaluate_h / divide / extended_to_coeff as three calls
+            self.logup_grand_sum = None                              # ... and the lookups' terms, inversion and scans one by one
         import torch
 
         if not torch.cuda.is_available():
@@ -400,6 +401,19 @@ class HostApiDevice(P.Device):
         self.L._count("h2_permutation_product")
         scalars = [_fr(v) for v in (beta, gamma, delta_pow, DELTA, omega, init)]       # (alive until the call has returned)
         check(self.L.R.h2_permutation_product(z.data_ptr(), vp, sp, len(values), n, *[_addr(v) for v in scalars]), "h2_permutation_product")
+        return z, self.get_rows(z, probe, 1)[0]
+
+    def logup_grand_sum(self, inputs, table, m, n, beta, init, probe):
+        """one grand-sum column of a logup lookup by ONE host-slice call (h2_logup_grand_sum: the set's compressed inputs -- and,
+        for the first set, the table and its multiplicities -- in, z out; plonk/logup/prover.rs:243-347) -> (z, z[probe])"""
+        from .prover import _fr
+
+        z = self.empty(n)
+        ip = (_vp * len(inputs))(*[t.data_ptr() for t in inputs])
+        scalars = [_fr(beta), _fr(init)]
+        self.L._count("h2_logup_grand_sum")
+        check(self.L.R.h2_logup_grand_sum(z.data_ptr(), ip, len(inputs), table.data_ptr() if table is not None else None,
+                                          m.data_ptr() if m is not None else None, n, *[_addr(v) for v in scalars]), "h2_logup_grand_sum")
         return z, self.get_rows(z, probe, 1)[0]
 
     def quotient_poly_coeff(self, desc, dom, t_evaluations):

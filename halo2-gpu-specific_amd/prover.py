@@ -1735,13 +1735,15 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
     rows = lambda t: t[lo_s:hi_s]  # noqa: E731
     omega_lo = pow(dom.omega, lo_s, R_MOD)
     fused_perm = getattr(D, "permutation_product", None) if (lo_s, hi_s) == (0, n) else None
+    fused_lookup = getattr(D, "logup_grand_sum", None) if (lo_s, hi_s) == (0, n) else None
     for C in circuits:
         lookups, shuffles = C["lookups"], C["shuffles"]
         colvals = {"advice": C["advice"], "fixed": pk.fixed_values, "instance": C["instance"]}
         # a device whose vectors live on the HOST makes one call per set instead (h2_permutation_product: terms, inversion,
         # product and scan without num / den crossing PCIe around every step): its sets take no slot here
         pslots = 0 if fused_perm else nsets
-        slots = pslots + sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups) + len(shuffles)
+        lslots = 0 if fused_lookup else sum(len(cols_in) for st in lookups for cols_in in st["inputs"]) + len(lookups)
+        slots = pslots + lslots + len(shuffles)
         nums = D.empty(max(pslots, 1) * m_s)
         inv = D.empty(max(slots, 1) * m_s)
         slot = lambda i, inv=inv: inv[i * m_s:(i + 1) * m_s]  # noqa: E731
@@ -1754,6 +1756,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                                                  D.stream), "h2_dev_permutation_terms")
         at = pslots
         for st in lookups:
+            if fused_lookup:            # (host vectors: h2_logup_grand_sum inverts on the device, set by set, further down)
+                continue
             st["inv_inputs"] = []
             for cols_in in st["inputs"]:
                 st["inv_inputs"].append([])
@@ -1800,7 +1804,11 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
         for st in C["lookups"]:
             st["z"] = []
             last = 0
-            for si, inverted in enumerate(st["inv_inputs"]):
+            for si, cols_in in enumerate(st["inputs"] if fused_lookup else ()):
+                z, last = fused_lookup(cols_in, st["table"] if si == 0 else None, st["m"] if si == 0 else None, n, beta, last, usable)
+                blinding.append((z, n - bf, [rng.fr() for _ in range(bf)]))
+                st["z"].append(z)
+            for si, inverted in enumerate(() if fused_lookup else st["inv_inputs"]):
                 src = inverted[0]                                       # sum_i 1 / (beta + f_i)
                 for other in inverted[1:]:
                     src = D.eval_op(2, num, src, other, size=m_s)       # H2_OP_SUM
@@ -1812,7 +1820,8 @@ def create_proof_ext(device, params, pk, advice, rng, use_gwc, timings=None, ins
                 st["z"].append(z)
             if last != 0:
                 raise ValueError("lookup grand sum does not return to zero")   # sanity-checks feature of the reference
-            del st["inv_inputs"], st["inv_table"]
+            if not fused_lookup:
+                del st["inv_inputs"], st["inv_table"]
     # ---- shuffle products (shuffle/prover.rs:82-150; blinding prover.rs:512-530) -------------------------------
     for C in circuits:
         C["shuffle_z"] = []

@@ -270,6 +270,14 @@ size_t h2_logup_scratch_bytes(size_t n);
 /* Host-vector twins (the reference runs these steps as host loops between its GPU calls): the grand-sum scan, a[i] *= g^i,
  * one sigma column from the cycle mapping (u32 host arrays of n entries), the multiplicity column of a lookup (table and
  * inputs: host vectors of n elements, read on the device when registered with h2_poly_register; max_bits_out may be NULL). */
+/* One grand-sum column of a logup lookup, whole, for one set of `count` compressed input columns (plonk/logup/prover.rs:243-347:
+ * beta + f per input :259-272 / :310-324, batch_invert :266 / :318, the table's term m / (beta + t) :275-290, the scan :330-346):
+ *   z[0] = init;  z[i+1] = z[i] + sum_j 1 / (beta + inputs[j][i]) - m[i] / (beta + table[i]),  i + 1 < n
+ * table and m: both NULL for a set without the table (the extra input sets), both given for the first set.  Every intermediate
+ * stays on the device; registered vectors are read there.  The caller writes its blinding rows into z and carries
+ * z[n - (blinding_factors + 1)] into the next set's init (:333-345). */
+int h2_logup_grand_sum(uint64_t *z, const uint64_t *const *inputs, size_t count, const uint64_t *table, const uint64_t *m,
+                       size_t n, const uint64_t beta[4], const uint64_t init[4]);
 int h2_prefix_sum(const uint64_t *f, size_t n, const uint64_t init[4], uint64_t *z);
 int h2_distribute_powers(uint64_t *a, size_t n, const uint64_t g[4]);
 int h2_permutation_sigma(uint64_t *out, const uint32_t *map_col, const uint32_t *map_row, size_t n,

@@ -264,6 +264,16 @@ extern "C" {
     pub fn h2_eval_polynomial_batch(polys: *const *const u64, count: usize, n: usize, points: *const u64, out: *mut u64) -> c_int;
     pub fn h2_batch_invert(a: *mut u64, n: usize) -> c_int;
     pub fn h2_random_fr(key: *const u8, n: usize, out: *mut u64) -> c_int;
+    pub fn h2_logup_grand_sum(
+        z: *mut u64,
+        inputs: *const *const u64,
+        count: usize,
+        table: *const u64,
+        m: *const u64,
+        n: usize,
+        beta: *const u64,
+        init: *const u64,
+    ) -> c_int;
     pub fn h2_prefix_sum(f: *const u64, n: usize, init: *const u64, z: *mut u64) -> c_int;
     pub fn h2_distribute_powers(a: *mut u64, n: usize, g: *const u64) -> c_int;
     pub fn h2_permutation_sigma(

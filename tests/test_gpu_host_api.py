@@ -52,6 +52,8 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
     assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
     assert calls["h2_quotient_sum"] >= 3               # (SHPLONK: the rotation sets' quotients + the final one; GWC: one per point)
     assert "h2_kate_division" not in calls
+    if which in ("lookup", "wide"):                    # the lookups' grand sums: one call per input set, nothing step by step
+        assert calls["h2_logup_grand_sum"] >= 2 and "h2_prefix_sum" not in calls
     assert "h2_permutation_terms" not in calls and not any(name.startswith("oracle") for name in calls)
     # the permutation products step by step (h2_permutation_terms, the shared batch inversion, h2_eval_op, h2_prefix_product):
     # the same bytes
@@ -579,3 +581,47 @@ def test_host_vector_twins_of_the_lookup_steps(oracle, n):
     absent = [oracle.random_fr(9974, n)]
     ptr1 = (ctypes.c_void_p * 1)(absent[0].ctypes.data)
     assert L.h2_logup_multiplicity(_ptr(table), ptr1, 1, usable, n, _ptr(m), None) != 0          # a value that is not in the table
+
+
+@pytest.mark.parametrize("n,count,with_table,registered", [(1, 1, True, False), (2, 2, False, False), (4099, 3, True, False), ((1 << 20) + 9, 2, True, True)])
+def test_logup_grand_sum_in_one_call(oracle, n, count, with_table, registered):
+    """h2_logup_grand_sum (one grand-sum column of a logup lookup: beta + f per input, the inversions, the table's m / (beta + t)
+    and the running sum on the device; plonk/logup/prover.rs:243-347) against the oracle's steps taken one by one"""
+    import ctypes
+
+    import halo2_gpu_specific_amd as h2
+    import halo2_gpu_specific_amd.arithmetic as ar
+    from oracle_prover import OracleLib
+
+    L, O = h2.lib(), OracleLib().O
+    inputs = [oracle.random_fr(9930 + j, n) for j in range(count)]
+    table, m = oracle.random_fr(9940, n), oracle.random_fr(9941, n)
+    beta, init = oracle.random_fr(9942, 2)
+    if n > 2:
+        inputs[0][1] = oracle.eval_op(ar.OP_SUB, np.zeros((1, 4), dtype=np.uint64), beta.reshape(1, 4), 0, 0, None)[0]   # beta + f = 0: kept 0
+    acc = np.zeros((n, 4), dtype=np.uint64)
+    for f in inputs:
+        t = oracle.eval_op(ar.OP_SUM_C, f, None, 0, 0, beta)
+        oracle.lib.oracle_batch_invert(_ptr(t), n)
+        acc = oracle.eval_op(ar.OP_SUM, acc, t, 0, 0, None)
+    if with_table:
+        t = oracle.eval_op(ar.OP_SUM_C, table, None, 0, 0, beta)
+        oracle.lib.oracle_batch_invert(_ptr(t), n)
+        acc = oracle.eval_op(ar.OP_SUB, acc, oracle.eval_op(ar.OP_MUL, t, m, 0, 0, None), 0, 0, None)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    want[0] = init
+    if n > 1:
+        O.oracle_prefix_sum(_ptr(acc), n, _ptr(init), _ptr(want))
+    ip = (ctypes.c_void_p * count)(*[f.ctypes.data for f in inputs])
+    if registered:
+        assert L.h2_poly_register(_ptr(table), n) == 0 and L.h2_poly_register(_ptr(inputs[0]), n) == 0
+    try:
+        for _ in range(2 if registered else 1):
+            z = np.empty((n, 4), dtype=np.uint64)
+            assert L.h2_logup_grand_sum(_ptr(z), ip, count, _ptr(table) if with_table else None, _ptr(m) if with_table else None, n,
+                                        _ptr(beta), _ptr(init)) == 0
+            assert np.array_equal(z, want)
+    finally:
+        if registered:
+            assert L.h2_poly_unregister(_ptr(table)) == 0 and L.h2_poly_unregister(_ptr(inputs[0])) == 0
+    assert L.h2_logup_grand_sum(_ptr(z), ip, count, _ptr(table), None, n, _ptr(beta), _ptr(init)) != 0        # a table without its m
