@@ -161,6 +161,9 @@ def _process_group_cache(key, make):
     return _PROCESS_GROUPS[(key, world)]
 
 
+_DEVICE_STREAMS = {}        # (GPU index, stream priorities) -> {"compute", "copy", "side"}: see Device.__init__
+
+
 class Device:
     """Buffers (torch) + stream + thin typed wrappers over the h2_dev_* entry points."""
 
@@ -187,8 +190,17 @@ class Device:
 
         pr = _os.environ.get("H2_STREAM_PRIORITY", "")
         self._prio = tuple(int(x) for x in pr.split(",")) if pr else (0, 0)
-        self.tstream = torch.cuda.Stream(device=self.dev, priority=self._prio[0])
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        # The streams belong to the PROCESS, not to the Device object: HIP multiplexes streams onto a few hardware queues
+        # (GPU_MAX_HW_QUEUES) in creation order, and streams that share a queue serialise.  A process that made a Device per
+        # workload kept drawing new streams, and which of them ended up sharing a queue depended on how many had been made before:
+        # the 64-column proof at k = 22 ran 0.344 s as a process's first workload and 0.386 s after the k = 20 legs (its uploads
+        # and commitments no longer overlapped: `advice commit` 170 -> 220 ms).  One set per (GPU, priorities), made once.
+        streams = _DEVICE_STREAMS.setdefault((self.dev.index, self._prio), {})
+        if not streams:
+            streams["compute"] = torch.cuda.Stream(device=self.dev, priority=self._prio[0])
+            streams["copy"] = torch.cuda.Stream(device=self.dev)
+        self._streams = streams
+        self.tstream, self.copy_stream = streams["compute"], streams["copy"]
         self.stream = _vp(self.tstream.cuda_stream)
         self._scratch = None
         self._pinned = {}
@@ -569,6 +581,12 @@ class Device:
                                  self.stream), "h2_dev_intt")
         return t
 
+    def _side_stream(self):
+        """the process's side stream of this GPU (see the streams' note in __init__)"""
+        if "side" not in self._streams:
+            self._streams["side"] = self.torch.cuda.Stream(device=self.dev, priority=self._prio[1])
+        return self._streams["side"]
+
     def intt_on_side_stream(self, cols, dom, extend=False):
         """coefficient forms of `cols` (left untouched) -- and with `extend` their values on the extended domain --
         computed on the side stream, behind what is queued on the compute stream now; returns (copies, extended or None,
@@ -577,7 +595,7 @@ class Device:
         if getattr(self, "_side", None) is None:
             import concurrent.futures
 
-            self._side = (self.torch.cuda.Stream(device=self.dev, priority=self._prio[1]), concurrent.futures.ThreadPoolExecutor(max_workers=1))
+            self._side = (self._side_stream(), concurrent.futures.ThreadPoolExecutor(max_workers=1))
         side = self._side[0]
         ready = self.torch.cuda.Event()
         ready.record(self.tstream)
@@ -673,7 +691,7 @@ class Device:
             fut.set_result(point)
             return fut
         if getattr(self, "_side", None) is None:
-            self._side = (self.torch.cuda.Stream(device=self.dev, priority=self._prio[1]), concurrent.futures.ThreadPoolExecutor(max_workers=1))
+            self._side = (self._side_stream(), concurrent.futures.ThreadPoolExecutor(max_workers=1))
         side, pool = self._side
         ready = self.torch.cuda.Event()
         ready.record(self.tstream)
