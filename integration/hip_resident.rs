@@ -146,7 +146,9 @@ extern "C" {
 }
 
 /// The stream every resident operation of one proof is ordered on (the reference serialises its GPU work per device with
-/// a blocking pool, arithmetic.rs:314-331; here the order is the stream's).
+/// a blocking pool, arithmetic.rs:314-331; here the order is the stream's).  Create it ONCE per process and keep it: HIP hands
+/// hardware queues out in stream-creation order, and a prover that makes a fresh stream per proof ends up sharing a queue --
+/// and serialising -- with streams made earlier.
 pub struct DeviceStream(pub *mut c_void);
 
 impl DeviceStream {
