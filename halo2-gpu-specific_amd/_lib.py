@@ -49,6 +49,7 @@ SYMBOLS = {
     "h2_library_memory_bytes": (_sz, []),
     "h2_ntt": (ctypes.c_int, [_vp, _vp, _u32]),
     "h2_intt": (ctypes.c_int, [_vp, _vp, _vp, _u32]),
+    "h2_intt_to": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32]),
     "h2_coeff_to_extended": (ctypes.c_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "h2_extended_to_coeff": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
     "h2_msm": (ctypes.c_int, [_vp, _vp, _sz, _u32, _vp]),

@@ -369,6 +369,33 @@ int h2_intt(uint64_t* a, const uint64_t omega_inv[4], const uint64_t divisor[4],
     });
 }
 
+// lagrange_to_coeff of a vector the caller KEEPS (plonk/prover.rs:643-646: `domain.lagrange_to_coeff(advice_values.clone())` per
+// column): the values are read where they are, the coefficients written to `out` -- no host copy of the column first
+int h2_intt_to(const uint64_t* a, uint64_t* out, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n) {
+    if (!a || !out || !omega_inv || !divisor) return bad("h2_intt_to: null argument");
+    return guarded([&] {
+        DeviceLease lease;
+        DeviceCtx* ctx = lease.ctx;
+        size_t bytes = sizeof(Fr) << log_n;
+        Prefault pf((const void*)out == (const void*)a ? nullptr : out, bytes);
+        Fr* d_a = (Fr*)ctx->buf_a.get(bytes);
+        Fr* d_t = (Fr*)ctx->buf_b.get(bytes);
+        Fr d = fr_from_u64x4(divisor);
+        Fr post3[3] = {d, d, d};
+        const Fr* src = resident_operand(ctx, a, (size_t)1 << log_n);
+        if (!src) {
+            host_upload(d_a, a, bytes, ctx->stream);
+            src = d_a;
+        }
+        int rc = dev_ntt_impl(ctx, src, d_a, d_t, 1u << log_n, omega_inv, log_n, nullptr, post3, ctx->stream, true);
+        if (rc != H2_OK) return rc;
+        pf.join();
+        host_download(out, d_a, bytes, ctx->stream);
+        H2_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)H2_OK;
+    });
+}
+
 int h2_coeff_to_extended(const uint64_t* coeffs, uint64_t* out, uint32_t k, uint32_t extended_k,
                          const uint64_t g_coset[4], const uint64_t g_coset_inv[4], const uint64_t extended_omega[4]) {
     if (!coeffs || !out || !g_coset || !g_coset_inv || !extended_omega) return bad("h2_coeff_to_extended: null argument");

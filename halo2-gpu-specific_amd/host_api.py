@@ -382,9 +382,34 @@ class HostApiDevice(P.Device):
         fut.set_result(self.msm(scalars, bases, n, max_bits))
         return fut
 
+    def intt(self, t, dom):
+        """lagrange_to_coeff in place (poly/domain.rs:233-266): one h2_intt call (no scratch vector on the host side)"""
+        from .prover import _fr
+
+        check(self.L.h2_dev_intt(t.data_ptr(), None, _fr(dom.omega_inv), _fr(dom.ifft_divisor), dom.k, None), "h2_intt")
+        return t
+
+    def intt_to(self, t, dom):
+        """the coefficient form of a column whose values are kept: h2_intt_to reads `t` and writes a new vector (the reference
+        clones the column and transforms the clone in place, plonk/prover.rs:643-646)"""
+        from .prover import _fr
+
+        out = self.empty(dom.n)
+        wi, dv = _fr(dom.omega_inv), _fr(dom.ifft_divisor)
+        self.L._count("h2_intt_to")
+        check(self.L.R.h2_intt_to(t.data_ptr(), out.data_ptr(), _addr(wi), _addr(dv), dom.k), "h2_intt_to")
+        return out
+
     def intt_on_side_stream(self, cols, dom, extend=False):
-        out = [self.intt(self.clone(t), dom) for t in cols]
-        return out, None, _NullStream()
+        ptrs = [(t.data_ptr(), self.empty(dom.n)) for t in cols]                 # (addresses for the worker threads)
+        wi, dv = P._fr(dom.omega_inv), P._fr(dom.ifft_divisor)
+
+        def one(job):
+            self.L._count("h2_intt_to")
+            return self.L.R.h2_intt_to(job[0], job[1].data_ptr(), _addr(wi), _addr(dv), dom.k)
+
+        check(self.L._each(lambda i: one(ptrs[i]), list(range(len(ptrs)))), "h2_intt_to")
+        return [o for _, o in ptrs], None, _NullStream()
 
     def sync(self):
         pass

@@ -79,6 +79,9 @@ int h2_ntt(uint64_t *a, const uint64_t omega[4], uint32_t log_n);
 /* gpu_ifft: arithmetic.rs:515-534 (EvaluationDomain::ifft, poly/domain.rs:400-414).
  * a <- NTT(a, omega_inv) * divisor. */
 int h2_intt(uint64_t *a, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n);
+/* the same out of place: `a` (2^log_n values the caller keeps: the reference clones the column first, plonk/prover.rs:643-646)
+ * is only read, the coefficients go to `out`. */
+int h2_intt_to(const uint64_t *a, uint64_t *out, const uint64_t omega_inv[4], const uint64_t divisor[4], uint32_t log_n);
 /* EvaluationDomain::coeff_to_extended: poly/domain.rs:270-287 (+ distribute_powers_zeta :382-398).
  * coeffs: 2^k Fr (read only); out: 2^extended_k Fr. */
 int h2_coeff_to_extended(const uint64_t *coeffs, uint64_t *out, uint32_t k, uint32_t extended_k,

@@ -214,6 +214,7 @@ extern "C" {
     // best_fft / gpu_fft (arithmetic.rs:495-512,546-554) and gpu_ifft (:515-534): in place, natural order
     pub fn h2_ntt(a: *mut u64, omega: *const u64, log_n: u32) -> c_int;
     pub fn h2_intt(a: *mut u64, omega_inv: *const u64, divisor: *const u64, log_n: u32) -> c_int;
+    pub fn h2_intt_to(a: *const u64, out: *mut u64, omega_inv: *const u64, divisor: *const u64, log_n: u32) -> c_int;
     // gpu_multiexp_single_gpu_with_bound (:334-367), gpu_multiexp_bound (:413-440), gpu_multiexp_bound_and_fft (:375-410)
     pub fn h2_msm(scalars: *const u64, bases: *const u64, n: usize, max_bits: u32, out_xyz: *mut u64) -> c_int;
     pub fn h2_msm_multi(scalars: *const u64, bases: *const u64, n: usize, max_bits: u32, out_xyz: *mut u64) -> c_int;

@@ -48,7 +48,7 @@ def test_host_slice_api_gives_the_resident_provers_bytes(oracle, device, which, 
         first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None)
         assert len(got) == len(want) and first is None, "host-slice proof differs at byte %s" % first
     calls = H.L.calls
-    assert calls["h2_quotient_poly_coeff"] == 2 and "h2_evaluate_h_coeff" not in calls and calls["h2_msm"] > 10 and calls["h2_intt"] > 3 and calls["h2_permutation_product"] >= 2
+    assert calls["h2_quotient_poly_coeff"] == 2 and "h2_evaluate_h_coeff" not in calls and calls["h2_msm"] > 10 and calls["h2_intt_to"] > 3 and calls["h2_permutation_product"] >= 2
     assert calls["h2_msm_intt"] >= 2                   # the product columns: commitment + coefficient form in one call each
     assert calls["h2_quotient_sum"] >= 3               # (SHPLONK: the rotation sets' quotients + the final one; GWC: one per point)
     assert "h2_kate_division" not in calls
@@ -625,3 +625,27 @@ def test_logup_grand_sum_in_one_call(oracle, n, count, with_table, registered):
         if registered:
             assert L.h2_poly_unregister(_ptr(table)) == 0 and L.h2_poly_unregister(_ptr(inputs[0])) == 0
     assert L.h2_logup_grand_sum(_ptr(z), ip, count, _ptr(table), None, n, _ptr(beta), _ptr(init)) != 0        # a table without its m
+
+
+@pytest.mark.parametrize("k", [3, 12, 20])
+def test_intt_out_of_place(oracle, k):
+    """h2_intt_to: the values are left alone, the coefficients land in another vector -- the same coefficients h2_intt leaves in place"""
+    import halo2_gpu_specific_amd as h2
+    from halo2_gpu_specific_amd import prover
+
+    L = h2.lib()
+    n = 1 << k
+    dom = prover.Domain(k, 3)
+    wi, dv = prover._fr(dom.omega_inv), prover._fr(dom.ifft_divisor)
+    a = oracle.random_fr(9990 + k, n)
+    keep, out = a.copy(), np.empty((n, 4), dtype=np.uint64)
+    assert L.h2_intt_to(_ptr(a), _ptr(out), wi, dv, k) == 0
+    assert np.array_equal(a, keep)
+    assert L.h2_intt(_ptr(a), wi, dv, k) == 0
+    assert np.array_equal(out, a)
+    assert L.h2_poly_register(_ptr(keep), n) == 0            # a registered column is read on the device
+    try:
+        out2 = np.empty((n, 4), dtype=np.uint64)
+        assert L.h2_intt_to(_ptr(keep), _ptr(out2), wi, dv, k) == 0 and np.array_equal(out2, a)
+    finally:
+        assert L.h2_poly_unregister(_ptr(keep)) == 0
